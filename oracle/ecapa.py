@@ -1,0 +1,144 @@
+"""Oracle (test infrastructure): ECAPA-TDNN (``Res2Net2``) restated as pure
+functions over a parameter dict (PyTorch-CPU fp32).
+
+Follows ecapa_tdnn.py:
+
+* ``SEModule.forward`` ....... ecapa_tdnn.py:27-29 (layers :18-25)
+* ``Bottle2neck.forward`` .... ecapa_tdnn.py:64-95 (shapes :33-62)
+* ``Res2Net2.__init__`` ...... ecapa_tdnn.py:99-150
+* ``Res2Net2.forward`` ....... ecapa_tdnn.py:152-198
+
+Ordering is conv -> ReLU -> BN throughout.  Parameter names
+are the reference's ``state_dict`` keys.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _bn_shapes(prefix, c, out):
+    out[prefix + ".weight"] = (c,)
+    out[prefix + ".bias"] = (c,)
+    out[prefix + ".running_mean"] = (c,)
+    out[prefix + ".running_var"] = (c,)
+    out[prefix + ".num_batches_tracked"] = ()
+
+
+def _conv_shapes(prefix, cout, cin, k, out):
+    out[prefix + ".weight"] = (cout, cin, k)
+    out[prefix + ".bias"] = (cout,)
+
+
+def ecapa_shapes(C=512, scale=8, nOut=2, n_mels=60, bottleneck=128, attn_ch=128, context=True):
+    s = OrderedDict()
+    _conv_shapes("conv1", C, n_mels, 5, s)
+    _bn_shapes("bn1", C, s)
+    width = C // scale
+    for li in (1, 2, 3):
+        p = "layer%d" % li
+        _conv_shapes(p + ".conv1", width * scale, C, 1, s)
+        _bn_shapes(p + ".bn1", width * scale, s)
+        for i in range(scale - 1):
+            _conv_shapes(p + ".convs.%d" % i, width, width, 3, s)
+        for i in range(scale - 1):
+            _bn_shapes(p + ".bns.%d" % i, width, s)
+        _conv_shapes(p + ".conv3", C, width * scale, 1, s)
+        _bn_shapes(p + ".bn3", C, s)
+        _conv_shapes(p + ".se.se.1", bottleneck, C, 1, s)
+        _bn_shapes(p + ".se.se.3", bottleneck, s)
+        _conv_shapes(p + ".se.se.4", C, bottleneck, 1, s)
+    _conv_shapes("layer4", 1536, 3 * C, 1, s)
+    _conv_shapes("attention.0", attn_ch, 1536 * (3 if context else 1), 1, s)
+    _bn_shapes("attention.2", attn_ch, s)
+    _conv_shapes("attention.3", 1536, attn_ch, 1, s)
+    _bn_shapes("bn5", 3072, s)
+    s["fc6.weight"] = (256, 3072)
+    s["fc6.bias"] = (256,)
+    s["fc7.weight"] = (nOut, 256)
+    s["fc7.bias"] = (nOut,)
+    _bn_shapes("bn7", nOut, s)
+    return s
+
+
+def _bn(x, p, prefix, training, updates):
+    w, b = p[prefix + ".weight"], p[prefix + ".bias"]
+    rm, rv = p[prefix + ".running_mean"], p[prefix + ".running_var"]
+    if training:
+        rm2, rv2 = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, True, BN_MOMENTUM, BN_EPS)
+        if updates is not None:
+            updates[prefix + ".running_mean"] = rm2
+            updates[prefix + ".running_var"] = rv2
+        return y
+    return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+
+
+def _conv(x, p, prefix, dilation=1, padding=0):
+    return F.conv1d(x, p[prefix + ".weight"], p[prefix + ".bias"], 1, padding, dilation)
+
+
+def se_module(x, p, prefix, training, updates):
+    """ecapa_tdnn.py:18-29: mean over T -> 1x1 -> ReLU -> BN -> 1x1 -> sigmoid; scale."""
+    s = x.mean(dim=2, keepdim=True)
+    s = F.relu(_conv(s, p, prefix + ".se.1"))
+    s = _bn(s, p, prefix + ".se.3", training, updates)
+    s = torch.sigmoid(_conv(s, p, prefix + ".se.4"))
+    return x * s
+
+
+def bottle2neck(x, p, prefix, dilation, scale, training, updates):
+    """ecapa_tdnn.py:64-95."""
+    out = _bn(F.relu(_conv(x, p, prefix + ".conv1")), p, prefix + ".bn1", training, updates)
+    width = out.shape[1] // scale
+    spx = torch.split(out, width, 1)
+    outs = []
+    sp = None
+    for i in range(scale - 1):
+        sp = spx[i] if i == 0 else sp + spx[i]
+        sp = _conv(sp, p, prefix + ".convs.%d" % i, dilation, dilation)  # k=3: pad = dilation (:46)
+        sp = _bn(F.relu(sp), p, prefix + ".bns.%d" % i, training, updates)
+        outs.append(sp)
+    outs.append(spx[scale - 1])
+    out = torch.cat(outs, 1)
+    out = _bn(F.relu(_conv(out, p, prefix + ".conv3")), p, prefix + ".bn3", training, updates)
+    out = se_module(out, p, prefix + ".se", training, updates)
+    return out + x
+
+
+def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context=True, out_bn=True):
+    """Res2Net2.forward (ecapa_tdnn.py:152-198), encoder_type 'ECA', summed=False.
+    x: (B, n_mels, T).  Returns (feat (B,256), out (B,nOut))."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    x = _bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates)  # :159-161
+    x1 = tap("x1", bottle2neck(x, p, "layer1", 2, scale, training, updates))
+    x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates))
+    x3 = tap("x3", bottle2neck(x2, p, "layer3", 4, scale, training, updates))
+    x = F.relu(_conv(torch.cat((x1, x2, x3), 1), p, "layer4"))  # :172-173
+    tap("layer4", x)
+    t = x.shape[-1]
+    if context:  # :177-178
+        gx = torch.cat((x, x.mean(2, keepdim=True).repeat(1, 1, t),
+                        torch.sqrt(x.var(2, keepdim=True).clamp(min=1e-4)).repeat(1, 1, t)), 1)
+    else:
+        gx = x
+    a = _bn(F.relu(_conv(gx, p, "attention.0")), p, "attention.2", training, updates)
+    w = torch.softmax(_conv(a, p, "attention.3"), dim=2)  # :139-145
+    tap("w", w)
+    mu = torch.sum(x * w, dim=2)  # :184
+    sg = torch.sqrt((torch.sum((x ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4))  # :185
+    tap("mu", mu)
+    tap("sg", sg)
+    x = _bn(torch.cat((mu, sg), 1), p, "bn5", training, updates)  # :187-189
+    feat = F.linear(x, p["fc6.weight"], p["fc6.bias"])  # :191
+    out = F.linear(feat, p["fc7.weight"], p["fc7.bias"])  # :193
+    if out_bn:
+        out = _bn(out, p, "bn7", training, updates)  # :195-196
+    return feat, out

@@ -1,0 +1,95 @@
+"""Oracle (test infrastructure): one train step of the hot path.
+
+Restates the inner loop of main_train.py:310-409 for ``--add_loss ang_iso``:
+forward -> AngularIsoLoss -> backward -> Adam(model) + SGD(centre), with the
+step-decay LR of main_train.py:144-147.
+"""
+import numpy as np
+import torch
+
+from . import ecapa as ecapa_oracle
+from . import resnet as resnet_oracle
+from .loss import ocsoftmax_forward
+
+
+def lr_at_epoch(lr0, epoch, lr_decay=0.5, interval=30):
+    """main_train.py:144-147."""
+    return lr0 * (lr_decay ** (epoch // interval))
+
+
+def adam_step_(p, g, m, v, step, lr=5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4):
+    """torch.optim.Adam as configured at main_train.py:175-176 (coupled L2 decay,
+    no amsgrad).  In place on torch tensors; ``step`` is the 1-based count."""
+    g = g + weight_decay * p
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / np.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def sgd_step_(p, g, lr):
+    """torch.optim.SGD(lr) as at main_train.py:272 (no momentum / decay)."""
+    p.add_(g, alpha=-lr)
+
+
+class OracleTrainer:
+    """Functional train loop over a parameter dict (CPU)."""
+
+    def __init__(self, model, params, center, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
+                 weight_loss=1.0):
+        assert model in ("resnet", "ecapa")
+        self.model = model
+        self.params = {k: v.clone() for k, v in params.items()}
+        self.center = center.clone()
+        self.lr = lr
+        self.r_real, self.r_fake, self.alpha = r_real, r_fake, alpha
+        self.weight_loss = weight_loss
+        self.step_count = 0
+        self.m = {}
+        self.v = {}
+
+    def trainable(self):
+        return [k for k, v in self.params.items()
+                if v.dtype.is_floating_point and not resnet_oracle.is_buffer(k)]
+
+    def forward(self, x, training=True, noise=None, updates=None, taps=None):
+        if self.model == "resnet":
+            return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps)
+        return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps)
+
+    def loss_and_grads(self, x, labels, noise=None):
+        names = self.trainable()
+        for k in names:
+            self.params[k] = self.params[k].detach().requires_grad_(True)
+        center = self.center.detach().requires_grad_(True)
+        updates = {}
+        feat, _ = self.forward(x, True, noise, updates)
+        loss, neg_scores = ocsoftmax_forward(feat, center, labels, self.r_real, self.r_fake, self.alpha)
+        (loss * self.weight_loss).backward()  # main_train.py:376, :406
+        grads = {k: self.params[k].grad for k in names}
+        gcenter = center.grad
+        for k in names:
+            self.params[k] = self.params[k].detach()
+        return loss.detach(), neg_scores.detach(), feat.detach(), grads, gcenter, updates
+
+    def step(self, x, labels, noise=None, epoch=0):
+        loss, neg_scores, feat, grads, gcenter, updates = self.loss_and_grads(x, labels, noise)
+        lr = lr_at_epoch(self.lr, epoch)
+        self.step_count += 1
+        with torch.no_grad():
+            for k, g in grads.items():
+                if g is None:  # fc_mu.* (ResNet) / fc7.*, bn7.* (ECAPA) get no grad under ang_iso
+                    continue
+                if k not in self.m:
+                    self.m[k] = torch.zeros_like(self.params[k])
+                    self.v[k] = torch.zeros_like(self.params[k])
+                adam_step_(self.params[k], g, self.m[k], self.v[k], self.step_count, lr)
+            sgd_step_(self.center, gcenter, lr)
+            for k, v in updates.items():
+                self.params[k] = v
+            for k in list(self.params):
+                if k.endswith("num_batches_tracked") and k.rsplit(".", 1)[0] + ".running_mean" in updates:
+                    self.params[k] = self.params[k] + 1
+        return loss, neg_scores, feat, grads, gcenter
