@@ -1,0 +1,86 @@
+"""ctypes binding of the C-ABI in include/air_hip.h (libair_hip.so).
+
+This is the only way the package reaches the GPU kernels.  There is NO CPU or
+PyTorch fallback: if the library is missing or a tensor is not on the GPU the
+call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libair_hip.so")
+_lib = None
+
+ERRORS = {-1: "AIR_EINVAL", -2: "AIR_EUNSUPPORTED", -3: "AIR_ELAUNCH", -4: "AIR_EWORKSPACE"}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class AirError(RuntimeError):
+    pass
+
+
+class AirConv2d(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("B", "Cin", "H", "W", "Cout", "KH", "KW", "sh", "sw", "ph", "pw", "Ho", "Wo")]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libair_hip.so once.  Raises HipExtensionMissing (never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipExtensionMissing(
+                "HIP extension not built: %s is missing. Run `python -m asvspoof2021_air_amd.build` "
+                "(or __graft_entry__.build()). There is no CPU fallback." % _LIB_PATH)
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.air_version.restype = ctypes.c_char_p
+        _lib.air_lfcc_plan_bytes.restype = ctypes.c_size_t
+        _lib.air_preemph_ws_bytes.restype = ctypes.c_size_t
+        for name in ("air_conv2d_ws_bytes", "air_bn_ws_bytes"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = ctypes.c_size_t
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AirError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=torch.float32, allow_none=False):
+    """Device pointer of a contiguous GPU tensor (or NULL)."""
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise AirError("null tensor")
+    if not t.is_cuda:
+        raise AirError("tensor must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise AirError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise AirError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def hptr(t, dtype=torch.float32):
+    """Host pointer of a contiguous CPU tensor."""
+    if t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise AirError("expected contiguous CPU %s tensor" % dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+ci = ctypes.c_int
+cf = ctypes.c_float
+csz = ctypes.c_size_t

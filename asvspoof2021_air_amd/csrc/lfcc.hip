@@ -1,0 +1,541 @@
+// Fused LFCC front-end for gfx950.
+//
+// Replaces LFCC.forward (feature_extraction.py:93-138): pre-emphasis (:105-106)
+// -> framing + periodic Hamming window + 512-point rFFT (torch.stft, :109-111)
+// -> power (:113) -> triangular linear filterbank + log10 (:116-117)
+// -> DCT-II (:120) -> delta / delta-delta (:41-58, :130-133), in ONE launch:
+// PCM is read once from HBM (coalesced), everything in between lives in LDS /
+// registers, and the (B,T,60) rows are written once, fully coalesced.
+//
+// Mapping (wave64): a workgroup of 8 waves owns 60 consecutive output frames
+// of one utterance (+2 halo frames each side for the delta-deltas) and stages
+// their 10,400 pre-emphasised samples in LDS.  Each wave processes 4 frames at
+// a time, 16 lanes per frame.  The 512-point real FFT is a 256-point complex
+// FFT (even/odd packing) done as 16 x 16: every lane runs a 16-point FFT in
+// registers on a stride-16 decimation, the 16x16 transpose goes through a
+// padded (17-column) wave-private LDS tile (conflict-free both ways), a second
+// 16-point FFT finishes it, and the real-FFT untangle pairs bin k with 256-k
+// held by lane (16-q) of the same 16-lane group.  torch.stft centres the
+// 320-tap window inside the 512 frame (offset 96); placing it at offset 0
+// only changes the phase, which |X|^2 discards.
+#include <math.h>
+#include <string.h>
+
+#include "air_common.h"
+
+namespace {
+
+constexpr int FN = 512, FL = 320, FS = 160;
+constexpr int NBIN = FN / 2 + 1;  // 257
+constexpr int MAXF = 32;          // filters supported (2 per lane of a 16-lane group)
+constexpr int MAXW = 32;          // bins per filter supported
+constexpr int NW = 8;             // waves per workgroup
+constexpr int NTHREADS = NW * 64;
+constexpr int GPW = 2;                  // 4-frame groups per wave
+constexpr int FCOMP = NW * GPW * 4;     // 64 frames computed per workgroup
+constexpr int HALO = 2;                 // delta-delta reaches 2 frames each side
+constexpr int FOUT = FCOMP - 2 * HALO;  // 60 frames written per workgroup
+constexpr int NSAMP = FS * (FCOMP + 1); // 10,400 staged samples
+constexpr int XROW = 17;                // padded transpose row (complex elements)
+constexpr int XCH_FLOATS = 4 * 16 * XROW * 2;  // wave-private exchange tile (2176 floats)
+constexpr int PROW = 264;               // power-spectrum row stride (floats)
+constexpr int FBUF_OFF = 4 * PROW;      // filterbank outputs live after the 4 power rows
+
+struct LfccPlan {
+  int nfilt, maxw, fl, fs, fn, nbin, pad0, pad1;
+  float window[FL];
+  float tw256[512];           // e^{-2 pi i n/256}: (re, im), n = 0..255
+  float tw512[32];            // e^{-2 pi i q/512}: (re, im), q = 0..15
+  int lo[MAXF];               // first bin of filter j
+  int cnt[MAXF];              // bins spanned by filter j
+  float fbwT[MAXW * MAXF];    // [i][j] = fb[lo[j]+i][j]
+  float dctT[MAXF * MAXF];    // [j][i] = dct[i][j]
+};
+
+struct cf {
+  float re, im;
+};
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ cf mul_mi(cf a) { return {a.im, -a.re}; }  // * (-i)
+__device__ __forceinline__ cf mul_pi(cf a) { return {-a.im, a.re}; }  // * (+i)
+
+// forward 4-point DFT (w4 = -i), natural order in and out
+__device__ __forceinline__ void fft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+  cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
+  a0 = t0 + t2;
+  a2 = t0 - t2;
+  a1 = t1 + mul_mi(t3);
+  a3 = t1 + mul_pi(t3);
+}
+
+constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
+constexpr float S1 = 0.38268343236508977f;  // sin(pi/8)
+constexpr float R2 = 0.70710678118654752f;  // sqrt(1/2)
+
+// y[m1*4+q2] *= w16^(m1*q2), w16 = e^{-2 pi i/16}
+__device__ __forceinline__ void twiddle16(cf (&y)[16]) {
+  y[5] = cmul(y[5], cf{C1, -S1});                               // w^1
+  y[6] = cf{R2 * (y[6].re + y[6].im), R2 * (y[6].im - y[6].re)};  // w^2
+  y[7] = cmul(y[7], cf{S1, -C1});                               // w^3
+  y[9] = cf{R2 * (y[9].re + y[9].im), R2 * (y[9].im - y[9].re)};  // w^2
+  y[10] = mul_mi(y[10]);                                        // w^4
+  y[11] = cf{R2 * (y[11].im - y[11].re), -R2 * (y[11].re + y[11].im)};  // w^6
+  y[13] = cmul(y[13], cf{S1, -C1});                             // w^3
+  y[14] = cf{R2 * (y[14].im - y[14].re), -R2 * (y[14].re + y[14].im)};  // w^6
+  y[15] = cmul(y[15], cf{-C1, S1});                             // w^9
+}
+
+// 16-point forward DFT, natural order in x[m] and out X[q].
+// m = m1 + 4 m2, q = 4 q1 + q2.  PRUNED: x[10..15] are known zero (a frame has
+// 160 complex samples = 10 per lane) so the first stage skips them.
+template <bool PRUNED>
+__device__ __forceinline__ void fft16(cf (&x)[16]) {
+  cf y[16];
+  if (PRUNED) {
+#pragma unroll
+    for (int m1 = 0; m1 < 2; ++m1) {  // inputs m1, m1+4, m1+8 (m1+12 == 0)
+      cf a0 = x[m1], a1 = x[m1 + 4], a2 = x[m1 + 8];
+      cf t0 = a0 + a2, t1 = a0 - a2;
+      y[m1 * 4 + 0] = t0 + a1;
+      y[m1 * 4 + 2] = t0 - a1;
+      y[m1 * 4 + 1] = t1 + mul_mi(a1);
+      y[m1 * 4 + 3] = t1 + mul_pi(a1);
+    }
+#pragma unroll
+    for (int m1 = 2; m1 < 4; ++m1) {  // inputs m1, m1+4 only
+      cf a0 = x[m1], a1 = x[m1 + 4];
+      y[m1 * 4 + 0] = a0 + a1;
+      y[m1 * 4 + 2] = a0 - a1;
+      y[m1 * 4 + 1] = a0 + mul_mi(a1);
+      y[m1 * 4 + 3] = a0 + mul_pi(a1);
+    }
+  } else {
+#pragma unroll
+    for (int m1 = 0; m1 < 4; ++m1) {
+      cf a0 = x[m1], a1 = x[m1 + 4], a2 = x[m1 + 8], a3 = x[m1 + 12];
+      fft4(a0, a1, a2, a3);
+      y[m1 * 4 + 0] = a0;
+      y[m1 * 4 + 1] = a1;
+      y[m1 * 4 + 2] = a2;
+      y[m1 * 4 + 3] = a3;
+    }
+  }
+  twiddle16(y);
+#pragma unroll
+  for (int q2 = 0; q2 < 4; ++q2) {
+    cf a0 = y[q2], a1 = y[4 + q2], a2 = y[8 + q2], a3 = y[12 + q2];
+    fft4(a0, a1, a2, a3);
+    x[q2] = a0;
+    x[4 + q2] = a1;
+    x[8 + q2] = a2;
+    x[12 + q2] = a3;
+  }
+}
+
+__device__ __constant__ const float W32C[16] = {
+    1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f,
+    0.382683432f, 0.195090322f, 0.000000000f, -0.195090322f, -0.382683432f, -0.555570233f,
+    -0.707106781f, -0.831469612f, -0.923879533f, -0.980785280f};
+__device__ __constant__ const float W32S[16] = {
+    0.000000000f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f,
+    0.923879533f, 0.980785280f, 1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f,
+    0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+
+struct LfccArgs {
+  const float* pcm;
+  float* out;
+  const LfccPlan* plan;
+  const int* start;  // padded mode: per-utterance crop start (may be null)
+  int L, T, tiles, flags, feat_len;
+};
+
+constexpr int FLAG_EMPH = AIR_LFCC_EMPHASIS;
+constexpr int FLAG_DELTA = AIR_LFCC_DELTA;
+constexpr int FLAG_PADDED = 1 << 8;  // internal: (B, D, feat_len) output
+
+__global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_pcm[NSAMP];
+  __shared__ __attribute__((aligned(16))) float s_xch[NW * XCH_FLOATS];
+  __shared__ float s_c[FCOMP * MAXF];
+  __shared__ float s_fbwT[MAXW * MAXF];
+  __shared__ float s_dctT[MAXF * MAXF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int b = blockIdx.x / a.tiles;
+  const int tile = blockIdx.x - b * a.tiles;
+  const int t0 = tile * FOUT;
+  const LfccPlan* __restrict__ plan = a.plan;
+  const int nfilt = plan->nfilt;
+  const int maxw = plan->maxw;
+  const int L = a.L, T = a.T;
+  const float* __restrict__ row = a.pcm + (size_t)b * L;
+
+  // ---- stage tables and pre-emphasised PCM ---------------------------------
+  for (int e = tid; e < MAXW * MAXF; e += NTHREADS) s_fbwT[e] = plan->fbwT[e];
+  for (int e = tid; e < MAXF * MAXF; e += NTHREADS) s_dctT[e] = plan->dctT[e];
+  const long s0 = (long)FS * (t0 - HALO) - FL / 2;  // first staged sample (may be < 0)
+  const bool emph = (a.flags & FLAG_EMPH) != 0;
+  const bool vec_ok = ((((size_t)row) & 15) == 0);
+  for (int e4 = tid; e4 < NSAMP / 4; e4 += NTHREADS) {
+    const long n = s0 + 4 * (long)e4;
+    float v[4];
+    if (vec_ok && n >= 0 && n + 3 < L) {
+      const float4 q = *reinterpret_cast<const float4*>(row + n);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      if (emph) {
+        const float prev = n > 0 ? row[n - 1] : 0.0f;
+        // non-recursive FIR on the ORIGINAL samples, two roundings like the reference
+        v[3] = __fsub_rn(v[3], __fmul_rn(0.97f, v[2]));
+        v[2] = __fsub_rn(v[2], __fmul_rn(0.97f, v[1]));
+        v[1] = __fsub_rn(v[1], __fmul_rn(0.97f, v[0]));
+        if (n > 0) v[0] = __fsub_rn(v[0], __fmul_rn(0.97f, prev));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long m = n + k;
+        float x = 0.0f;
+        if (m >= 0 && m < L) {
+          x = row[m];
+          if (emph && m > 0) x = __fsub_rn(x, __fmul_rn(0.97f, row[m - 1]));
+        }
+        v[k] = x;
+      }
+    }
+    *reinterpret_cast<float4*>(&s_pcm[4 * e4]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+
+  // ---- per-lane constants --------------------------------------------------
+  const int f = lane >> 4;  // frame within the 4-frame group
+  const int g = lane & 15;  // lane within the frame
+  float wre[10], wim[10];
+#pragma unroll
+  for (int m = 0; m < 10; ++m) {
+    wre[m] = plan->window[2 * (g + 16 * m)];
+    wim[m] = plan->window[2 * (g + 16 * m) + 1];
+  }
+  cf tw[16];  // w256^(g*q)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int n = (g * q) & 255;
+    tw[q] = cf{plan->tw256[2 * n], plan->tw256[2 * n + 1]};
+  }
+  const float cq = plan->tw512[2 * g];        //  cos(2 pi g/512)
+  const float sq = -plan->tw512[2 * g + 1];   //  sin(2 pi g/512)
+  const int j0 = g, j1 = g + 16;
+  const int lo0 = plan->lo[j0];
+  const int lo1 = plan->lo[j1 < MAXF ? j1 : 0];
+  const int partner = (lane & 48) | ((16 - g) & 15);
+  float* xch = s_xch + wave * XCH_FLOATS;
+  float2* xch2 = reinterpret_cast<float2*>(xch);
+
+  __syncthreads();
+
+  // ---- frames -> cepstra ---------------------------------------------------
+  for (int gg = 0; gg < GPW; ++gg) {
+    const int gi = wave * GPW + gg;       // group index in the workgroup
+    const int i0 = gi * 4;                // first local frame of the group
+    const int tc_first = t0 - HALO + i0;  // its global frame index
+    if (tc_first + 3 < 0 || tc_first >= T) continue;  // wave-uniform: nothing to compute
+    const int i = i0 + f;
+
+    // windowed even/odd packing: z[n] = w[2n] s[2n] + i w[2n+1] s[2n+1], n = g + 16 m
+    cf x[16];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) {
+      const float2 s = *reinterpret_cast<const float2*>(&s_pcm[FS * i + 2 * (g + 16 * m)]);
+      x[m] = cf{s.x * wre[m], s.y * wim[m]};
+    }
+#pragma unroll
+    for (int m = 10; m < 16; ++m) x[m] = cf{0.0f, 0.0f};
+    fft16<true>(x);  // over m: Y[g][q]
+#pragma unroll
+    for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], tw[q]);
+    // transpose through LDS: row q, column g
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xch2[(f * 16 + q) * XROW + g] = make_float2(x[q].re, x[q].im);
+    air_wave_lds_fence();
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float2 v = xch2[(f * 16 + g) * XROW + l];
+      x[l] = cf{v.x, v.y};
+    }
+    fft16<false>(x);  // over l: Z[g + 16 p] = x[p]
+    air_wave_lds_fence();  // exchange tile is reused for the power rows below
+
+    // real-FFT untangle + power.  Partner lane holds Z[(16-g)%16 + 16 p'].
+    float pnyq = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      // bin k = g + 16 p pairs with 256 - k: lane (16-g)&15, index 15-p  (g != 0)
+      //                                      own lane, index (16-p)&15   (g == 0)
+      const int pp = 15 - p;
+      float bre = __shfl(x[pp].re, partner, 64);
+      float bim = __shfl(x[pp].im, partner, 64);
+      const int p0 = (16 - p) & 15;
+      if (g == 0) {
+        bre = x[p0].re;
+        bim = x[p0].im;
+      }
+      // E2 = A + conj(B), O2 = A - conj(B);  2X = E2 - i w512^k O2
+      const float ere = x[p].re + bre, eim = x[p].im - bim;
+      const float ore = x[p].re - bre, oim = x[p].im + bim;
+      const float c = cq * W32C[p] - sq * W32S[p];  // cos(2 pi k/512)
+      const float s = sq * W32C[p] + cq * W32S[p];  // sin(2 pi k/512)
+      const float xr = ere + c * oim - s * ore;
+      const float xi = eim - c * ore - s * oim;
+      // reference: norm(.,2,-1).pow(2)  (feature_extraction.py:113)
+      const float mag = 0.5f * sqrtf(xr * xr + xi * xi);
+      xch[f * PROW + g + 16 * p] = mag * mag;
+      if (p == 0) {
+        const float ny = x[0].re - x[0].im;  // X[256] = Re Z0 - Im Z0 (real)
+        pnyq = ny * ny;
+      }
+    }
+    if (g == 0) xch[f * PROW + 256] = pnyq;
+    air_wave_lds_fence();
+
+    // sparse triangular filterbank + log10 (feature_extraction.py:116-117)
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int w = 0; w < maxw; ++w) {
+      const int k0 = min(lo0 + w, NBIN - 1), k1 = min(lo1 + w, NBIN - 1);
+      acc0 = fmaf(xch[f * PROW + k0], s_fbwT[w * MAXF + j0], acc0);
+      acc1 = fmaf(xch[f * PROW + k1], s_fbwT[w * MAXF + j1], acc1);
+    }
+    xch[FBUF_OFF + f * MAXF + j0] = log10f(acc0 + 1.1920928955078125e-07f);
+    xch[FBUF_OFF + f * MAXF + j1] = log10f(acc1 + 1.1920928955078125e-07f);
+    air_wave_lds_fence();
+
+    // DCT-II as a 20x20 product (feature_extraction.py:120)
+    float c0 = 0.0f, c1 = 0.0f;
+    for (int j = 0; j < nfilt; ++j) {
+      const float fj = xch[FBUF_OFF + f * MAXF + j];
+      c0 = fmaf(fj, s_dctT[j * MAXF + j0], c0);
+      c1 = fmaf(fj, s_dctT[j * MAXF + j1], c1);
+    }
+    s_c[i * MAXF + j0] = c0;
+    s_c[i * MAXF + j1] = c1;
+    air_wave_lds_fence();  // next group overwrites the exchange tile
+  }
+  __syncthreads();
+
+  // ---- deltas + coalesced store -------------------------------------------
+  const bool with_delta = (a.flags & FLAG_DELTA) != 0;
+  const int D = with_delta ? 3 * nfilt : nfilt;
+  const int base = t0 - HALO;  // global frame of local row 0
+  auto cep = [&](int t, int c) -> float {  // clamped (replicate) access
+    t = min(max(t, 0), T - 1);
+    return s_c[(t - base) * MAXF + c];
+  };
+  auto value = [&](int t, int c) -> float {
+    if (c < nfilt) return cep(t, c);
+    if (c < 2 * nfilt) return cep(t + 1, c - nfilt) - cep(t - 1, c - nfilt);
+    const int cc = c - 2 * nfilt;
+    const int tp = min(t + 1, T - 1), tm = max(t - 1, 0);
+    return (cep(tp + 1, cc) - cep(tp - 1, cc)) - (cep(tm + 1, cc) - cep(tm - 1, cc));
+  };
+  if (!(a.flags & FLAG_PADDED)) {
+    float* __restrict__ orow = a.out + ((size_t)b * T + t0) * D;
+    const int nvalid = min(FOUT, T - t0);
+    for (int e = tid; e < nvalid * D; e += NTHREADS) {
+      const int fo = e / D, c = e - fo * D;
+      orow[e] = value(t0 + fo, c);
+    }
+  } else {
+    // (B, D, feat_len): frame t lands on t' = t - start (+ k T when repeating)
+    const int flen = a.feat_len;
+    const int start = (a.start != nullptr && T > flen) ? a.start[b] : 0;
+    float* __restrict__ obase = a.out + (size_t)b * D * flen;
+    for (int e = tid; e < FOUT * D; e += NTHREADS) {
+      const int c = e / FOUT, fo = e - c * FOUT;
+      const int t = t0 + fo;
+      if (t >= T) continue;
+      const float v = value(t, c);
+      if (T >= flen) {
+        const int tp = t - start;
+        if (tp >= 0 && tp < flen) obase[(size_t)c * flen + tp] = v;
+      } else {
+        for (int tp = t; tp < flen; tp += T) obase[(size_t)c * flen + tp] = v;
+      }
+    }
+  }
+}
+
+// ---- in-place pre-emphasis (the reference mutates its input, :106) ----------
+constexpr int PE_CHUNK = 4096;
+__global__ void preemph_save_kernel(const float* x, int L, int nchunk, int total, float* ws) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*nchunk
+  if (idx >= total) return;
+  const int b = idx / nchunk, c = idx - b * nchunk;
+  const long n = (long)c * PE_CHUNK - 1;
+  ws[idx] = n >= 0 ? x[(size_t)b * L + n] : 0.0f;
+}
+__global__ __launch_bounds__(256) void preemph_apply_kernel(float* x, int L, int nchunk, float coef,
+                                                            const float* ws) {
+  __shared__ float s[PE_CHUNK + 1];
+  const int b = blockIdx.x / nchunk, c = blockIdx.x - b * nchunk;
+  float* row = x + (size_t)b * L;
+  const long n0 = (long)c * PE_CHUNK;
+  const int cnt = (int)min((long)PE_CHUNK, L - n0);
+  if (threadIdx.x == 0) s[0] = ws[blockIdx.x];
+  for (int e = threadIdx.x; e < cnt; e += 256) s[e + 1] = row[n0 + e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < cnt; e += 256) {
+    if (n0 + e == 0) continue;  // y[0] = x[0]
+    row[n0 + e] = __fsub_rn(s[e + 1], __fmul_rn(coef, s[e]));
+  }
+}
+
+// ---- (B,T,D) -> (B,D,feat_len): repeat-pad / chop + transpose ----------------
+__global__ __launch_bounds__(256) void pad_transpose_kernel(const float* feat, int T, int D,
+                                                            float* out, int flen,
+                                                            const int* start) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int tp0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int st = (start != nullptr && T > flen) ? start[b] : 0;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {  // r: frame within tile, tx: coefficient
+    const int tp = tp0 + r, c = c0 + tx;
+    float v = 0.0f;
+    if (tp < flen && c < D) {
+      const int t = (T >= flen) ? tp + st : tp % T;
+      v = feat[((size_t)b * T + t) * D + c];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {  // r: coefficient, tx: frame
+    const int c = c0 + r, tp = tp0 + tx;
+    if (c < D && tp < flen) out[((size_t)b * D + c) * flen + tp] = tile[tx][r];
+  }
+}
+
+int lfcc_launch(const float* pcm, int B, int L, float* out, int feat_len, const int* start,
+                const void* plan_dev, int flags, hipStream_t stream) {
+  if (!pcm || !out || !plan_dev || B <= 0 || L <= 0) return AIR_EINVAL;
+  const int T = 1 + L / FS;
+  LfccArgs a;
+  a.pcm = pcm;
+  a.out = out;
+  a.plan = reinterpret_cast<const LfccPlan*>(plan_dev);
+  a.start = start;
+  a.L = L;
+  a.T = T;
+  a.tiles = (T + FOUT - 1) / FOUT;
+  a.flags = flags;
+  a.feat_len = feat_len;
+  hipLaunchKernelGGL(lfcc_kernel, dim3((unsigned)(B * a.tiles)), dim3(NTHREADS), 0, stream, a);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t air_lfcc_plan_bytes(void) { return sizeof(LfccPlan); }
+
+int air_lfcc_plan_build(const float* fb_host, int nbin, int nfilt, const float* dct_host,
+                        const float* window_host, int fl, int fs, int fn, void* plan_host_out) {
+  if (!fb_host || !dct_host || !plan_host_out) return AIR_EINVAL;
+  if (fl != FL || fs != FS || fn != FN || nbin != NBIN) return AIR_EUNSUPPORTED;
+  if (nfilt < 1 || nfilt > MAXF) return AIR_EUNSUPPORTED;
+  LfccPlan* p = reinterpret_cast<LfccPlan*>(plan_host_out);
+  memset(p, 0, sizeof(LfccPlan));
+  p->nfilt = nfilt;
+  p->fl = fl;
+  p->fs = fs;
+  p->fn = fn;
+  p->nbin = nbin;
+  const double pi = 3.14159265358979323846;
+  for (int n = 0; n < FL; ++n)
+    p->window[n] = window_host ? window_host[n] : (float)(0.54 - 0.46 * cos(2.0 * pi * n / FL));
+  for (int n = 0; n < 256; ++n) {
+    p->tw256[2 * n] = (float)cos(2.0 * pi * n / 256.0);
+    p->tw256[2 * n + 1] = (float)(-sin(2.0 * pi * n / 256.0));
+  }
+  for (int q = 0; q < 16; ++q) {
+    p->tw512[2 * q] = (float)cos(2.0 * pi * q / 512.0);
+    p->tw512[2 * q + 1] = (float)(-sin(2.0 * pi * q / 512.0));
+  }
+  int maxw = 1;
+  for (int j = 0; j < nfilt; ++j) {
+    int first = -1, last = -1;
+    for (int k = 0; k < nbin; ++k) {
+      if (fb_host[(size_t)k * nfilt + j] != 0.0f) {
+        if (first < 0) first = k;
+        last = k;
+      }
+    }
+    if (first < 0) {
+      p->lo[j] = 0;
+      p->cnt[j] = 0;
+      continue;
+    }
+    const int cnt = last - first + 1;
+    if (cnt > MAXW) return AIR_EUNSUPPORTED;  // filter wider than the sparse table
+    p->lo[j] = first;
+    p->cnt[j] = cnt;
+    if (cnt > maxw) maxw = cnt;
+    for (int i = 0; i < cnt; ++i) p->fbwT[i * MAXF + j] = fb_host[(size_t)(first + i) * nfilt + j];
+  }
+  p->maxw = maxw;
+  for (int i = 0; i < nfilt; ++i)
+    for (int j = 0; j < nfilt; ++j) p->dctT[j * MAXF + i] = dct_host[(size_t)i * nfilt + j];
+  return AIR_OK;
+}
+
+int air_lfcc_fwd(const float* pcm, int B, int L, float* out, const void* plan_dev, int flags,
+                 air_stream_t stream) {
+  return lfcc_launch(pcm, B, L, out, 0, nullptr, plan_dev,
+                     flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA), air_stream(stream));
+}
+
+int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len,
+                        const int* start_dev, const void* plan_dev, int flags,
+                        air_stream_t stream) {
+  if (feat_len <= 0) return AIR_EINVAL;
+  return lfcc_launch(pcm, B, L, out, feat_len, start_dev, plan_dev,
+                     (flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA)) | FLAG_PADDED,
+                     air_stream(stream));
+}
+
+size_t air_preemph_ws_bytes(int B, int L) {
+  if (B <= 0 || L <= 0) return 0;
+  const size_t nchunk = ((size_t)L + PE_CHUNK - 1) / PE_CHUNK;
+  return (size_t)B * nchunk * sizeof(float);
+}
+
+int air_preemph_inplace(float* pcm, int B, int L, float coef, void* ws, size_t ws_bytes,
+                        air_stream_t stream) {
+  if (!pcm || !ws || B <= 0 || L <= 0) return AIR_EINVAL;
+  if (ws_bytes < air_preemph_ws_bytes(B, L)) return AIR_EWORKSPACE;
+  const int nchunk = (L + PE_CHUNK - 1) / PE_CHUNK;
+  const int n = B * nchunk;
+  hipLaunchKernelGGL(preemph_save_kernel, dim3((n + 255) / 256), dim3(256), 0, air_stream(stream),
+                     pcm, L, nchunk, n, reinterpret_cast<float*>(ws));
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(preemph_apply_kernel, dim3(n), dim3(256), 0, air_stream(stream), pcm, L,
+                     nchunk, coef, reinterpret_cast<const float*>(ws));
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_pad_transpose(const float* feat, int B, int T, int D, float* out, int feat_len,
+                      const int* start_dev, air_stream_t stream) {
+  if (!feat || !out || B <= 0 || T <= 0 || D <= 0 || feat_len <= 0) return AIR_EINVAL;
+  dim3 grid((feat_len + 63) / 64, (D + 63) / 64, B);
+  hipLaunchKernelGGL(pad_transpose_kernel, grid, dim3(256), 0, air_stream(stream), feat, T, D,
+                     out, feat_len, start_dev);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+/* air_hip.h -- C-ABI of the MI355X (gfx950) hot path of ASVspoof2021_AIR.
+ *
+ * The reference (yzyouzhang/ASVspoof2021_AIR) is pure Python/PyTorch and has no
+ * FFI; the boundary it exposes for this path is the Python module surface
+ * (SURVEY.md §8b).  This header is the C-ABI a binding for that surface calls:
+ * each entry point names the reference function (file:line) whose device work
+ * it replaces.  Conventions:
+ *   - plain pointers and sizes only; device pointers unless suffixed _host
+ *   - no allocation inside: callers pass workspaces (see *_ws_bytes queries)
+ *   - every launch goes to the caller's stream (air_stream_t == hipStream_t)
+ *   - return 0 (AIR_OK) or a negative AIR_E* code; never throws
+ *   - no global state; re-entrant across streams
+ *   - tensors are contiguous fp32, NCHW / (B,C,T) / (B,T,D) as stated per call
+ */
+#ifndef AIR_HIP_H
+#define AIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* air_stream_t; /* hipStream_t */
+
+#define AIR_OK 0
+#define AIR_EINVAL (-1)       /* bad argument (null pointer, non-positive size) */
+#define AIR_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define AIR_ELAUNCH (-3)      /* HIP reported a launch error */
+#define AIR_EWORKSPACE (-4)   /* workspace too small */
+
+/* Library identification: returns "air_hip gfx950 <abi-version>". */
+const char* air_version(void);
+int air_abi_version(void);
+
+/* ------------------------------------------------------------------ LFCC --
+ * Replaces LFCC.forward (feature_extraction.py:93-138) incl. delta (:41-58),
+ * with the filterbank of LFCC.__init__ (:77-86) and the LinearDCT weight
+ * (utils_dsp.py:233-244) folded into a small "plan" blob built on the host.
+ */
+size_t air_lfcc_plan_bytes(void);
+/* fb_host: [nbin][nfilt] row-major (module.lfcc_fb); dct_host: [nfilt][nfilt]
+ * (module.l_dct.weight, y = x @ W^T); window_host: [fl] analysis window
+ * (torch.hamming_window(fl), :110) or NULL for the periodic Hamming closed form.
+ * fl/fs/fn = window / hop / FFT length (this build: 320/160/512, nfilt <= 32).
+ * Writes air_lfcc_plan_bytes() bytes to plan_host_out; the caller uploads it. */
+int air_lfcc_plan_build(const float* fb_host, int nbin, int nfilt, const float* dct_host,
+                        const float* window_host, int fl, int fs, int fn, void* plan_host_out);
+#define AIR_LFCC_EMPHASIS 1 /* pre-emphasis 0.97 (feature_extraction.py:105-106) */
+#define AIR_LFCC_DELTA 2    /* append delta and delta-delta (:130-133) */
+/* pcm: (B, L) fp32, NOT modified.  out: (B, 1 + L/fs, nfilt * (3 if DELTA else 1)). */
+int air_lfcc_fwd(const float* pcm, int B, int L, float* out, const void* plan_dev, int flags,
+                 air_stream_t stream);
+/* Fused variant writing the model-input layout the trainer builds on the host
+ * (dataset.py:66-79 pad/chop + main_train.py:338 transpose): out is
+ * (B, D, feat_len) with frame t' taken from frame (start[b] + t') mod T when
+ * T < feat_len ("repeat" padding, dataset.py:519-522) or start[b] + t' when
+ * T >= feat_len (chop; start_dev may be NULL = 0).  */
+int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len,
+                        const int* start_dev, const void* plan_dev, int flags, air_stream_t stream);
+/* The reference mutates its input (feature_extraction.py:106).  This applies
+ * the same in-place x[n] -= coef*x[n-1] (n>=1).  ws: >= air_preemph_ws_bytes. */
+size_t air_preemph_ws_bytes(int B, int L);
+int air_preemph_inplace(float* pcm, int B, int L, float coef, void* ws, size_t ws_bytes,
+                        air_stream_t stream);
+/* (B,T,D) -> (B,D,feat_len) repeat-pad / chop + transpose (dataset.py:66-79, main_train.py:338). */
+int air_pad_transpose(const float* feat, int B, int T, int D, float* out, int feat_len,
+                      const int* start_dev, air_stream_t stream);
+
+/* --------------------------------------------------------------- conv2d --
+ * Replaces nn.Conv2d forward/backward as used by resnet.py:131,56-61,140
+ * (bias=False everywhere).  NCHW fp32.  Implicit GEMM on f32 MFMA.
+ * Optional fused prologue: per-input-channel y = max(0, x*scale[c]+shift[c])
+ * (BatchNorm apply + ReLU of the pre-activation block, resnet.py:64,67)
+ * applied while staging the input; optional epilogue residual add
+ * (resnet.py:68) and per-output-channel sum / sum-of-squares partials for
+ * the next BatchNorm's batch statistics.
+ */
+typedef struct AirConv2d {
+  int B, Cin, H, W;       /* input */
+  int Cout, KH, KW;       /* filter */
+  int sh, sw, ph, pw;     /* stride, zero padding */
+  int Ho, Wo;             /* output (must equal the conv arithmetic) */
+} AirConv2d;
+
+size_t air_conv2d_ws_bytes(const AirConv2d* p);
+/* y = conv(act(x), w) [+ residual].  in_scale/in_shift NULL = identity prologue.
+ * relu: apply max(0,.) after the affine prologue.  stats: NULL or (2, Cout) fp64
+ * accumulators receiving sum and sum of squares of y (zeroed by the caller). */
+int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
+                   const float* in_scale, const float* in_shift, int relu,
+                   const float* residual, double* stats, void* ws, size_t ws_bytes,
+                   air_stream_t stream);
+/* dx = conv_transpose(dy, w): gradient w.r.t. the (activated) conv input. */
+int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
+                     void* ws, size_t ws_bytes, air_stream_t stream);
+/* dw = correlation(act(x), dy); same prologue as fwd so the activated tensor
+ * is never materialised. */
+int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,
+                     const float* in_scale, const float* in_shift, int relu,
+                     void* ws, size_t ws_bytes, air_stream_t stream);
+
+/* ------------------------------------------------------- batchnorm/relu --
+ * nn.BatchNorm2d/1d (+ F.relu) as used at resnet.py:55-67,132,142 and
+ * ecapa_tdnn.py.  x is (B, C, S) with S = H*W (or T).
+ */
+/* Batch statistics -> mean/invstd, fused scale/shift for the apply, running
+ * stat update (momentum 0.1, unbiased var) when running_* non-NULL.
+ * stats_in: optional (2,C) fp64 sum/sumsq already accumulated by a conv
+ * epilogue; when NULL the kernel reduces x itself. */
+size_t air_bn_ws_bytes(int B, int C, int S);
+int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in,
+                 const float* gamma, const float* beta, float eps, float momentum,
+                 float* running_mean, float* running_var,
+                 float* mean, float* invstd, float* scale, float* shift,
+                 void* ws, size_t ws_bytes, air_stream_t stream);
+/* Eval-mode scale/shift from running stats. */
+int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       air_stream_t stream);
+/* y = x*scale[c] + shift[c], optional ReLU. */
+int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
+                 int relu, float* y, air_stream_t stream);
+/* Backward of y = relu?(bn(x)) in training mode.  dy: grad wrt y.
+ * dx_accum: if non-zero dx += result (gradient joining a residual branch).
+ * dgamma/dbeta: (C,) written. */
+int air_bn_bwd(const float* x, const float* dy, int B, int C, int S,
+               const float* mean, const float* invstd, const float* gamma, const float* beta,
+               int relu, float* dx, int dx_accum, float* dgamma, float* dbeta,
+               void* ws, size_t ws_bytes, air_stream_t stream);
+
+/* ------------------------------------------------------------- pooling ---
+ * SelfAttention.forward (resnet.py:23-46) on x (B, C, T) (the squeezed conv5
+ * output, i.e. BEFORE the permute at resnet.py:185): w_t = <x[:, :, t], a>,
+ * alpha = softmax_T(tanh(w)), weighted = x*alpha, out = [sum_T weighted ,
+ * unbiased std_T(weighted + noise)] -> (B, 2C).
+ * noise: NULL (none) or (B, T, C) already scaled by 1e-5 (reference layout).
+ */
+int air_selfatt_pool_fwd(const float* x, int B, int C, int T, const float* att_w,
+                         const float* noise, float* out, float* alpha_save, air_stream_t stream);
+int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w,
+                         const float* noise, const float* alpha, const float* out,
+                         const float* dout, float* dx, float* datt_partial /*(B,C)*/,
+                         air_stream_t stream);
+
+/* --------------------------------------------------------------- linear ---
+ * nn.Linear (resnet.py:143-144,187-189; ecapa_tdnn.py:148-149): y = x W^T + b.
+ * x (M,K), w (N,K), y (M,N).
+ */
+int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K, int N, float* y,
+                   air_stream_t stream);
+int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K, int N,
+                   float* dx, float* dw, float* db, air_stream_t stream);
+
+/* ----------------------------------------------------------- OC-Softmax ---
+ * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
+ * x (B,D), center (1,D), labels (B,) int64.  loss: scalar; neg_scores (B,).
+ * bwd: dx (B,D), dcenter (1,D) for d(loss*gscale).
+ */
+int air_ocsoftmax_fwd(const float* x, const float* center, const int64_t* labels, int B, int D,
+                      float r_real, float r_fake, float alpha, float* loss, float* neg_scores,
+                      air_stream_t stream);
+int air_ocsoftmax_bwd(const float* x, const float* center, const int64_t* labels, int B, int D,
+                      float r_real, float r_fake, float alpha, const float* gscale_dev,
+                      float* dx, float* dcenter, air_stream_t stream);
+
+/* ------------------------------------------------------------ optimiser ---
+ * torch.optim.Adam as configured at main_train.py:175-176 (coupled L2 weight
+ * decay) and torch.optim.SGD(lr) (main_train.py:272), over flat fp32 buffers.
+ * step is the 1-based step count.  grad_scale multiplies g first (1/world).
+ */
+int air_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  air_stream_t stream);
+int air_sgd_step(float* p, const float* g, size_t n, float lr, float grad_scale,
+                 air_stream_t stream);
+
+/* ------------------------------------------------------------- utility ---- */
+int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream); /* y += x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIR_HIP_H */
