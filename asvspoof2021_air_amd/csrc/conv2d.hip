@@ -1,0 +1,720 @@
+// conv2d forward / dgrad / wgrad for gfx950 as implicit GEMMs on the exact-f32
+// MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TFLOP/s peak).
+//
+// Replaces nn.Conv2d (bias=False) as used by resnet.py:131 (conv1), :56-61
+// (PreActBlock 3x3 / 1x1 shortcut) and :140 (conv5).  NCHW fp32.
+//
+// Forward GEMM:  D[co][px] = sum_k Wp[k][co] * Patch[k][px],  k = (tap, ci).
+//   * M = output channels: a workgroup owns 64 of them (2 MFMA row tiles).
+//   * N = output pixels in "pixel tiles" of 32 consecutive columns of one
+//     output row; pixel tiles are numbered linearly over (b, ho, wo/32) so
+//     ragged widths (750, 375, 188, 94) waste <= 2.4 %.  One wave per pixel
+//     tile, 4 waves per workgroup; MFMA D columns = pixels, so stores are
+//     128-byte coalesced rows of NCHW.
+//   * K is walked in chunks of 8 input channels.  Per chunk the workgroup
+//     stages (a) the packed weight slab [tap][ci][64 co] (shared by its 4
+//     waves) and (b) per wave the input patch [ci][KH rows][31*S+KW cols] in
+//     LDS, so each staged input element feeds all KH*KW taps and all 64
+//     output channels: global/L2 traffic is ~1/9 of an im2col GEMM.
+//   * LDS is double buffered; the next chunk's global loads are issued before
+//     the current chunk's 72 MFMAs and written to LDS after them.
+//   * Optional fused prologue while staging: y = max(0, x*scale[ci]+shift[ci])
+//     (the BatchNorm-apply + ReLU in front of every PreActBlock conv), with
+//     zero padding applied AFTER the activation like F.conv2d on the
+//     activated tensor; optional epilogue residual add (resnet.py:68).
+// dgrad (stride 1) is the same kernel on flipped/transposed packed weights;
+// stride-2 dgrad first zero-upsamples dy.  wgrad is a second implicit GEMM
+// with K = pixels, split over workgroups, reduced deterministically.
+#include "air_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 8;        // input channels per K chunk
+constexpr int BM = 64;       // output channels per workgroup
+constexpr int NWAVE = 4;     // waves (= pixel tiles) per workgroup
+constexpr int PXT = 32;      // output pixels per pixel tile
+
+// ------------------------------------------------------------------ packing
+// forward:  Wp[cot][chunk][tap][cil][col] = W[cot*64+col][chunk*8+cil][tap]
+// dgrad:    roles swapped, taps flipped: Wp[...] = W[chunk*8+cil][cot*64+col][T-1-tap]
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                    int Cin, int taps, int transpose_flip) {
+  // logical (M = "out" role, Kc = "in" role)
+  const int M = transpose_flip ? Cin : Cout;
+  const int Kc = transpose_flip ? Cout : Cin;
+  const int Mpad = (M + BM - 1) / BM * BM;  // channel tiles are zero-padded to 64
+  const size_t total = (size_t)Mpad * Kc * taps;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % BM);
+    size_t r = e / BM;
+    const int cil = (int)(r % CK);
+    r /= CK;
+    const int tap = (int)(r % taps);
+    r /= taps;
+    const int nchunk = Kc / CK;
+    const int chunk = (int)(r % nchunk);
+    const int cot = (int)(r / nchunk);
+    const int m = cot * BM + col, k = chunk * CK + cil;
+    float v = 0.0f;
+    if (m < M) {
+      if (!transpose_flip)
+        v = w[((size_t)m * Cin + k) * taps + tap];
+      else
+        v = w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)];
+    }
+    wp[e] = v;
+  }
+}
+
+// zero-upsample dy (B,C,Ho,Wo) -> (B,C,Hu,Wu) with u[2i][2j] = dy[i][j]
+__global__ void upsample2_kernel(const float* __restrict__ dy, float* __restrict__ up, int Ho,
+                                 int Wo, int Hu, int Wu, size_t planes) {
+  const size_t total = planes * Hu * Wu;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int wu = (int)(e % Wu);
+    const size_t r = e / Wu;
+    const int hu = (int)(r % Hu);
+    const size_t pl = r / Hu;
+    float v = 0.0f;
+    if (!(wu & 1) && !(hu & 1) && (hu >> 1) < Ho && (wu >> 1) < Wo)
+      v = dy[(pl * Ho + (hu >> 1)) * Wo + (wu >> 1)];
+    up[e] = v;
+  }
+}
+
+struct FwdArgs {
+  const float* x;      // (B, Cin, H, W)
+  const float* wp;     // packed weights
+  float* y;            // (B, Cout, Ho, Wo)
+  const float* scale;  // per input channel (may be null)
+  const float* shift;
+  const float* residual;  // same shape as y (may be null)
+  int B, Cin, H, W, Cout, Ho, Wo, ph, pw;
+  int relu;
+  int WT;        // pixel tiles per output row
+  int ntiles;    // B*Ho*WT
+  int npxg;      // pixel-tile groups (ntiles / NWAVE, rounded up)
+  int ncot;      // Cout / 64
+};
+
+// XCD-aware logical block index: hardware places block b on XCD b % 8; give each
+// XCD one contiguous range of logical tiles so neighbours share L2 (bijective).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+template <int KH, int KW, int S>
+struct FwdCfg {
+  static constexpr int TAPS = KH * KW;
+  static constexpr int PW = (PXT - 1) * S + KW;       // patch columns
+  static constexpr int PWP = (S == 2) ? PW + 1 : PW;  // row pitch (even/odd split for S=2)
+  static constexpr int CHS = KH * PWP;                // channel pitch
+  static constexpr int PATCH = CK * CHS;              // floats per wave patch
+  static constexpr int WSLAB = TAPS * CK * BM;        // floats per weight slab
+  static constexpr int NI = (CK * KH * PW + 63) / 64; // patch elements per lane
+  static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);  // float4 per thread
+  static constexpr int BUF = WSLAB + NWAVE * PATCH;   // floats per LDS buffer
+};
+
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
+  using C = FwdCfg<KH, KW, S>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lb % a.ncot;
+  const int pxg = lb / a.ncot;
+  const int nt = pxg * NWAVE + wave;  // this wave's pixel tile
+  const bool tile_ok = nt < a.ntiles;
+  const int wt = nt % a.WT;
+  const int rowid = nt / a.WT;  // b*Ho + ho
+  const int ho = rowid % a.Ho;
+  const int b = rowid / a.Ho;
+  const int wo0 = wt * PXT;
+  const int hi0 = ho * S - a.ph;
+  const int wi0 = wo0 * S - a.pw;
+  const size_t HW = (size_t)a.H * a.W;
+  const float* __restrict__ xb = a.x + (size_t)b * a.Cin * HW;
+  const int nchunk = a.Cin / CK;
+  const float* __restrict__ wslab0 = a.wp + (size_t)cot * nchunk * C::WSLAB;
+  const bool affine = a.scale != nullptr;
+
+  float pv[C::NI];
+  float4 wv[C::NWV];
+
+  auto prefetch = [&](int chunk) {
+    const float* __restrict__ xc = xb + (size_t)chunk * CK * HW;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int e = lane + 64 * i;
+      const int cil = e / (KH * C::PW);
+      const int rem = e - cil * (KH * C::PW);
+      const int r = rem / C::PW;
+      const int c = rem - r * C::PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      float v = 0.0f;
+      if (tile_ok && e < CK * KH * C::PW && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
+        v = xc[(size_t)cil * HW + (size_t)hi * a.W + wi];
+        if (affine) {
+          const int ci = chunk * CK + cil;
+          v = v * a.scale[ci] + a.shift[ci];
+        }
+        if (a.relu) v = fmaxf(v, 0.0f);
+      }
+      pv[i] = v;
+    }
+    const float4* __restrict__ ws4 =
+        reinterpret_cast<const float4*>(wslab0 + (size_t)chunk * C::WSLAB);
+#pragma unroll
+    for (int i = 0; i < C::NWV; ++i) {
+      const int e = tid + NWAVE * 64 * i;
+      wv[i] = (e < C::WSLAB / 4) ? ws4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](int buf) {
+    float* __restrict__ base = lds + buf * C::BUF;
+    float* __restrict__ pl = base + C::WSLAB + wave * C::PATCH;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int e = lane + 64 * i;
+      if (e < CK * KH * C::PW) {
+        const int cil = e / (KH * C::PW);
+        const int rem = e - cil * (KH * C::PW);
+        const int r = rem / C::PW;
+        const int c = rem - r * C::PW;
+        // S == 2: even columns first then odd, so a tap reads 32 contiguous floats
+        const int cm = (S == 2) ? ((c & 1) * ((C::PW + 1) / 2) + (c >> 1)) : c;
+        pl[cil * C::CHS + r * C::PWP + cm] = pv[i];
+      }
+    }
+    float4* __restrict__ wl4 = reinterpret_cast<float4*>(base);
+#pragma unroll
+    for (int i = 0; i < C::NWV; ++i) {
+      const int e = tid + NWAVE * 64 * i;
+      if (e < C::WSLAB / 4) wl4[e] = wv[i];
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+
+  prefetch(0);
+  stage(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int cur = chunk & 1;
+    if (chunk + 1 < nchunk) prefetch(chunk + 1);
+    const float* __restrict__ wl = lds + cur * C::BUF;
+    const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCH;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const int tap = kh * KW + kw;
+        const int cbase = (S == 2) ? ((kw & 1) * ((C::PW + 1) / 2) + (kw >> 1)) : kw;
+#pragma unroll
+        for (int st = 0; st < CK / 2; ++st) {
+          const int cil = 2 * st + half;
+          const float bv = pl[cil * C::CHS + kh * C::PWP + cbase + l31];
+          const float a0 = wl[(tap * CK + cil) * BM + l31];
+          const float a1 = wl[(tap * CK + cil) * BM + 32 + l31];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+        }
+      }
+    }
+    if (chunk + 1 < nchunk) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel
+  if (!tile_ok) return;
+  const int wo = wo0 + l31;
+  if (wo >= a.Wo) return;
+  const size_t HoWo = (size_t)a.Ho * a.Wo;
+  const size_t obase = ((size_t)b * a.Cout + (size_t)cot * BM) * HoWo + (size_t)ho * a.Wo + wo;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const size_t o0 = obase + (size_t)i * HoWo;
+    const size_t o1 = o0 + 32 * HoWo;
+    const int co = cot * BM + i;
+    if (co < a.Cout) {
+      float v0 = acc0[r];
+      if (a.residual != nullptr) v0 += a.residual[o0];
+      a.y[o0] = v0;
+    }
+    if (co + 32 < a.Cout) {
+      float v1 = acc1[r];
+      if (a.residual != nullptr) v1 += a.residual[o1];
+      a.y[o1] = v1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------- wgrad
+// dW[co][ci][tap] = sum_px dy[co][px] * act(x)[ci][px shifted by tap]
+// GEMM M = co (64 per workgroup), N = (ci, tap) with 32-channel MFMA column
+// tiles per tap, K = pixels (pixel tiles of 32).  4 waves = (co half) x (ci
+// half of a 64-channel tile); each wave keeps TAPS accumulators.
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* partial;  // [nsplit][Cout][Cin][taps]
+  const float* scale;
+  const float* shift;
+  int B, Cin, H, W, Cout, Ho, Wo, ph, pw;
+  int relu;
+  int WT, ntiles;
+  int ncot, ncit;  // co tiles (BMW), ci tiles (CT)
+  int nsplit;
+  int tiles_per_split;
+};
+
+// CT = input channels per workgroup (64: waves = 2 co halves x 2 ci halves, 64 co;
+//                                     32: waves = 4 co quarters x 1 ci tile, 128 co)
+template <int KH, int KW, int S, int CT_>
+struct WgCfg {
+  static constexpr int TAPS = KH * KW;
+  static constexpr int CT = CT_;
+  static constexpr int NWCI = CT / 32;                 // waves along ci
+  static constexpr int NWCO = 4 / NWCI;                // waves along co
+  static constexpr int BMW = 32 * NWCO;                // co per workgroup
+  static constexpr int PW = (PXT - 1) * S + KW;
+  static constexpr int CHS = (KH * PW) | 1;            // odd channel pitch: conflict-free ci-strided reads
+  static constexpr int PATCH = CT * CHS;
+  static constexpr int DS = BMW + 1;                   // dy tile pitch [px][co], odd
+  static constexpr int DYT = PXT * DS;
+  static constexpr int BUF = PATCH + DYT;
+  static constexpr int NI = (CT * KH * PW + 255) / 256;  // patch elements per thread
+  static constexpr int ND = (BMW * PXT) / 256;           // dy elements per thread
+};
+
+template <int KH, int KW, int S, int CT_>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  using C = WgCfg<KH, KW, S, CT_>;
+  __shared__ float lds[2 * C::BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave % C::NWCO;  // co sub-tile
+  const int ch = wave / C::NWCO;  // ci sub-tile
+
+  int lb = blockIdx.x;
+  const int split = lb % a.nsplit;
+  lb /= a.nsplit;
+  const int cit = lb % a.ncit;
+  const int cot = lb / a.ncit;
+  const int ci0 = cit * C::CT;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const size_t HW = (size_t)a.H * a.W;
+  const size_t HoWo = (size_t)a.Ho * a.Wo;
+  const bool affine = a.scale != nullptr;
+
+  float pv[C::NI];
+  float dv[C::ND];
+
+  auto prefetch = [&](int nt) {
+    const int wt = nt % a.WT;
+    const int rowid = nt / a.WT;
+    const int ho = rowid % a.Ho;
+    const int b = rowid / a.Ho;
+    const int wo0 = wt * PXT;
+    const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
+    const float* __restrict__ xb = a.x + ((size_t)b * a.Cin + ci0) * HW;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int e = tid + 256 * i;
+      const int cil = e / (KH * C::PW);
+      const int rem = e - cil * (KH * C::PW);
+      const int r = rem / C::PW;
+      const int c = rem - r * C::PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      float v = 0.0f;
+      if (e < C::CT * KH * C::PW && ci0 + cil < a.Cin && hi >= 0 && hi < a.H && wi >= 0 &&
+          wi < a.W) {
+        v = xb[(size_t)cil * HW + (size_t)hi * a.W + wi];
+        if (affine) v = v * a.scale[ci0 + cil] + a.shift[ci0 + cil];
+        if (a.relu) v = fmaxf(v, 0.0f);
+      }
+      pv[i] = v;
+    }
+    const float* __restrict__ dyb =
+        a.dy + ((size_t)b * a.Cout + (size_t)cot * C::BMW) * HoWo + (size_t)ho * a.Wo + wo0;
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int e = tid + 256 * i;
+      const int co = e >> 5, px = e & 31;
+      dv[i] = (wo0 + px < a.Wo) ? dyb[(size_t)co * HoWo + px] : 0.0f;
+    }
+  };
+  auto stage = [&](int buf) {
+    float* __restrict__ pl = lds + buf * C::BUF;
+    float* __restrict__ dl = pl + C::PATCH;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int e = tid + 256 * i;
+      if (e < C::CT * KH * C::PW) {
+        const int cil = e / (KH * C::PW);
+        const int rem = e - cil * (KH * C::PW);
+        pl[cil * C::CHS + rem] = pv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::ND; ++i) {
+      const int e = tid + 256 * i;
+      const int co = e >> 5, px = e & 31;
+      dl[px * C::DS + co] = dv[i];
+    }
+  };
+
+  f32x16 acc[C::TAPS];
+#pragma unroll
+  for (int t = 0; t < C::TAPS; ++t) acc[t] = (f32x16){0};
+
+  if (t_begin < t_end) {
+    prefetch(t_begin);
+    stage(0);
+  }
+  __syncthreads();
+  for (int nt = t_begin; nt < t_end; ++nt) {
+    const int cur = (nt - t_begin) & 1;
+    if (nt + 1 < t_end) prefetch(nt + 1);
+    const float* __restrict__ pl = lds + cur * C::BUF;
+    const float* __restrict__ dl = pl + C::PATCH;
+    const float* __restrict__ pbase = pl + (ch * 32 + l31) * C::CHS;
+#pragma unroll 4
+    for (int st = 0; st < PXT / 2; ++st) {
+      const int px = 2 * st + half;
+      const float av = dl[px * C::DS + mt * 32 + l31];
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const float bv = pbase[kh * C::PW + px * S + kw];
+          acc[kh * KW + kw] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * KW + kw], 0, 0, 0);
+        }
+      }
+    }
+    if (nt + 1 < t_end) stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = co][j = ci] per tap -> partial[split][co][ci][tap]
+  const int ci = ci0 + ch * 32 + l31;
+  if (ci >= a.Cin) return;
+  float* __restrict__ out = a.partial + (size_t)split * a.Cout * a.Cin * C::TAPS;
+#pragma unroll
+  for (int t = 0; t < C::TAPS; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int co = cot * C::BMW + mt * 32 + i;
+      out[((size_t)co * a.Cin + ci) * C::TAPS + t] = acc[t][r];
+    }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                       size_t n, int nsplit) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
+    dw[e] = s;
+  }
+}
+
+// ------------------------------------------------- small-Cin direct kernels
+// conv1 of the ResNet: Cin = 1, Cout = 16, 9x3, stride (3,1), pad (1,1)
+// (resnet.py:131): 0.1 % of the FLOPs, HBM-bound on its 16-channel output.
+struct DirectArgs {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* dy;
+  float* partial;
+  int B, Cin, H, W, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo;
+};
+
+constexpr int DIRECT_MAX_W = 16 * 27;
+
+__global__ __launch_bounds__(256) void conv_direct_fwd_kernel(DirectArgs a) {
+  __shared__ float sw_[DIRECT_MAX_W];
+  const int K = a.Cin * a.KH * a.KW;
+  for (int e = threadIdx.x; e < a.Cout * K; e += 256) sw_[e] = a.w[e];
+  __syncthreads();
+  const size_t npx = (size_t)a.B * a.Ho * a.Wo;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npx; p += (size_t)gridDim.x * 256) {
+    const int wo = (int)(p % a.Wo);
+    const size_t r = p / a.Wo;
+    const int ho = (int)(r % a.Ho);
+    const int b = (int)(r / a.Ho);
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < a.Cin; ++ci)
+      for (int kh = 0; kh < a.KH; ++kh) {
+        const int hi = ho * a.sh - a.ph + kh;
+        if (hi < 0 || hi >= a.H) continue;
+        for (int kw = 0; kw < a.KW; ++kw) {
+          const int wi = wo * a.sw - a.pw + kw;
+          if (wi < 0 || wi >= a.W) continue;
+          const float xv = a.x[(((size_t)b * a.Cin + ci) * a.H + hi) * a.W + wi];
+          const int k = (ci * a.KH + kh) * a.KW + kw;
+#pragma unroll
+          for (int co = 0; co < 16; ++co)
+            if (co < a.Cout) acc[co] = fmaf(xv, sw_[co * K + k], acc[co]);
+        }
+      }
+#pragma unroll
+    for (int co = 0; co < 16; ++co)
+      if (co < a.Cout) a.y[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo] = acc[co];
+  }
+}
+
+// wgrad for the same layer: one block per (b, ho) row slice; block-reduces
+// dy[co][px] * x[patch k] into partial[block][co][k].
+__global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(DirectArgs a) {
+  const int K = a.Cin * a.KH * a.KW;  // <= 27
+  const int row = blockIdx.x;         // b*Ho + ho
+  const int ho = row % a.Ho, b = row / a.Ho;
+  __shared__ float red[4][DIRECT_MAX_W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // each wave owns a subset of (co,k) pairs; lanes stride over wo
+  for (int e = wave; e < a.Cout * K; e += 4) {
+    const int co = e / K, k = e - co * K;
+    const int kw = k % a.KW, kh = (k / a.KW) % a.KH, ci = k / (a.KW * a.KH);
+    const int hi = ho * a.sh - a.ph + kh;
+    float s = 0.0f;
+    if (hi >= 0 && hi < a.H) {
+      const float* __restrict__ dyr = a.dy + (((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo;
+      const float* __restrict__ xr = a.x + (((size_t)b * a.Cin + ci) * a.H + hi) * a.W;
+      for (int wo = lane; wo < a.Wo; wo += 64) {
+        const int wi = wo * a.sw - a.pw + kw;
+        if (wi >= 0 && wi < a.W) s = fmaf(dyr[wo], xr[wi], s);
+      }
+    }
+    s = air_wave_sum(s);
+    if (lane == 0) a.partial[(size_t)row * a.Cout * K + e] = s;
+  }
+  (void)red;
+}
+
+int grid_for(size_t n, int per_block = 256, int cap = 256 * 16) {
+  size_t g = (n + per_block - 1) / per_block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+bool generic_ok(const AirConv2d* p) {
+  const bool k33 = p->KH == 3 && p->KW == 3, k11 = p->KH == 1 && p->KW == 1;
+  const bool s_ok = (p->sh == 1 && p->sw == 1) || (p->sh == 2 && p->sw == 2);
+  return (k33 || k11) && s_ok && p->sh == p->sw && p->Cin % CK == 0 && p->Cout % BM == 0;
+}
+bool direct_ok(const AirConv2d* p) {
+  return p->Cout <= 16 && p->Cout * p->Cin * p->KH * p->KW <= DIRECT_MAX_W;
+}
+bool shape_ok(const AirConv2d* p) {
+  if (p->B <= 0 || p->Cin <= 0 || p->H <= 0 || p->W <= 0 || p->Cout <= 0) return false;
+  if (p->KH <= 0 || p->KW <= 0 || p->sh <= 0 || p->sw <= 0 || p->ph < 0 || p->pw < 0) return false;
+  return p->Ho == (p->H + 2 * p->ph - p->KH) / p->sh + 1 &&
+         p->Wo == (p->W + 2 * p->pw - p->KW) / p->sw + 1 && p->Ho > 0 && p->Wo > 0;
+}
+
+template <int KH, int KW, int S>
+void launch_fwd(const FwdArgs& a, hipStream_t st) {
+  const int nblk = a.npxg * a.ncot;
+  hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+}
+
+// y = conv(act(x), packed w): shared by fwd and stride-1 dgrad
+int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
+            int relu, const float* residual, int B, int Cin, int H, int W, int Cout, int KH, int S,
+            int ph, int pw, int Ho, int Wo, hipStream_t st) {
+  FwdArgs a;
+  a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
+  a.ph = ph; a.pw = pw; a.relu = relu;
+  a.WT = (Wo + PXT - 1) / PXT;
+  a.ntiles = B * Ho * a.WT;
+  a.npxg = (a.ntiles + NWAVE - 1) / NWAVE;
+  a.ncot = (Cout + BM - 1) / BM;
+  if (KH == 3 && S == 1) launch_fwd<3, 3, 1>(a, st);
+  else if (KH == 3 && S == 2) launch_fwd<3, 3, 2>(a, st);
+  else if (KH == 1 && S == 1) launch_fwd<1, 1, 1>(a, st);
+  else if (KH == 1 && S == 2) launch_fwd<1, 1, 2>(a, st);
+  else return AIR_EUNSUPPORTED;
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+// stride-2 3x3 wgrad holds a 65-column patch per channel: use 32-channel tiles there
+int wgrad_ct(const AirConv2d* p) { return (p->sh == 2 && p->Cout % 128 == 0) ? 32 : 64; }
+
+int wgrad_nsplit(const AirConv2d* p) {
+  const int WT = (p->Wo + PXT - 1) / PXT;
+  const int ntiles = p->B * p->Ho * WT;
+  const int ct = wgrad_ct(p);
+  const int ncot = p->Cout / (ct == 32 ? 128 : 64), ncit = (p->Cin + ct - 1) / ct;
+  int target = 1024 / (ncot * ncit);  // ~4 workgroups per CU in total
+  if (target < 1) target = 1;
+  if (target > ntiles) target = ntiles;
+  return target;
+}
+
+size_t packed_dgrad_elems(const AirConv2d* p) {  // dgrad packs with Cin padded to 64
+  return (size_t)((p->Cin + BM - 1) / BM * BM) * p->Cout * p->KH * p->KW;
+}
+
+size_t up_elems(const AirConv2d* p) {  // zero-upsampled dy for stride-2 dgrad
+  if (p->sh == 1) return 0;
+  const int Hu = p->H + 2 * p->ph - p->KH + 1 + 0, Wu = p->W + 2 * p->pw - p->KW + 1;
+  return (size_t)p->B * p->Cout * Hu * Wu;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t air_conv2d_ws_bytes(const AirConv2d* p) {
+  if (!p || !shape_ok(p)) return 0;
+  const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
+  if (direct_ok(p)) return (size_t)p->B * p->Ho * wsz * sizeof(float) + 256;
+  if (!generic_ok(p)) return 0;
+  const size_t fwd = wsz;
+  const size_t dgrad = packed_dgrad_elems(p) + up_elems(p);
+  const size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
+  size_t m = fwd > dgrad ? fwd : dgrad;
+  if (wgrad > m) m = wgrad;
+  return m * sizeof(float) + 256;
+}
+
+int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
+                   const float* in_scale, const float* in_shift, int relu, const float* residual,
+                   double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!p || !x || !w || !y || !shape_ok(p)) return AIR_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
+  if (stats != nullptr) return AIR_EUNSUPPORTED;  // fused BN statistics: not in this build
+  hipStream_t st = air_stream(stream);
+  if (direct_ok(p)) {
+    if (in_scale || relu || residual) return AIR_EUNSUPPORTED;
+    DirectArgs a = {x, w, y, nullptr, nullptr, p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW,
+                    p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
+    hipLaunchKernelGGL(conv_direct_fwd_kernel, dim3(grid_for((size_t)p->B * p->Ho * p->Wo)),
+                       dim3(256), 0, st, a);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
+  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
+  float* wp = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(wsz)), dim3(256), 0, st, w, wp, p->Cout,
+                     p->Cin, p->KH * p->KW, 0);
+  AIR_CHECK_LAUNCH();
+  return run_fwd(x, wp, y, in_scale, in_shift, relu, residual, p->B, p->Cin, p->H, p->W, p->Cout,
+                 p->KH, p->sh, p->ph, p->pw, p->Ho, p->Wo, st);
+}
+
+int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
+                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!p || !dy || !w || !dx || !shape_ok(p)) return AIR_EINVAL;
+  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  hipStream_t st = air_stream(stream);
+  const size_t wsz = packed_dgrad_elems(p);
+  const size_t ups = up_elems(p);
+  if (!ws || ws_bytes < (wsz + ups) * sizeof(float)) return AIR_EWORKSPACE;
+  float* wp = reinterpret_cast<float*>(ws);
+  // roles swap: "input" channels = Cout, "output" channels = Cin; taps flipped
+  if (p->Cout % CK != 0) return AIR_EUNSUPPORTED;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(wsz)), dim3(256), 0, st, w, wp, p->Cout,
+                     p->Cin, p->KH * p->KW, 1);
+  AIR_CHECK_LAUNCH();
+  const float* src = dy;
+  int Hs = p->Ho, Ws = p->Wo;
+  if (p->sh == 2) {
+    // u[2i][2j] = dy[i][j], sized so that a stride-1 conv with pad K-1-p gives (H, W)
+    const int Hu = p->H + 2 * p->ph - p->KH + 1, Wu = p->W + 2 * p->pw - p->KW + 1;
+    float* up = wp + wsz;
+    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(ups)), dim3(256), 0, st, dy, up, p->Ho,
+                       p->Wo, Hu, Wu, (size_t)p->B * p->Cout);
+    AIR_CHECK_LAUNCH();
+    src = up;
+    Hs = Hu;
+    Ws = Wu;
+  }
+  return run_fwd(src, wp, dx, nullptr, nullptr, 0, accumulate, p->B, p->Cout, Hs, Ws, p->Cin,
+                 p->KH, 1, p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W, st);
+}
+
+int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,
+                     const float* in_scale, const float* in_shift, int relu, void* ws,
+                     size_t ws_bytes, air_stream_t stream) {
+  if (!p || !x || !dy || !dw || !shape_ok(p)) return AIR_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
+  hipStream_t st = air_stream(stream);
+  const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
+  if (direct_ok(p)) {
+    if (in_scale || relu) return AIR_EUNSUPPORTED;
+    const int rows = p->B * p->Ho;
+    if (!ws || ws_bytes < (size_t)rows * wsz * sizeof(float)) return AIR_EWORKSPACE;
+    DirectArgs a = {x, nullptr, nullptr, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H,
+                    p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
+    hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
+    AIR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), dw, wsz, rows);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(ws);
+  a.scale = in_scale; a.shift = in_shift;
+  a.B = p->B; a.Cin = p->Cin; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.Ho = p->Ho; a.Wo = p->Wo;
+  a.ph = p->ph; a.pw = p->pw; a.relu = relu;
+  a.WT = (p->Wo + PXT - 1) / PXT;
+  a.ntiles = p->B * p->Ho * a.WT;
+  const int ct = wgrad_ct(p);
+  a.ncot = p->Cout / (ct == 32 ? 128 : 64);
+  a.ncit = (p->Cin + ct - 1) / ct;
+  a.nsplit = wgrad_nsplit(p);
+  a.tiles_per_split = (a.ntiles + a.nsplit - 1) / a.nsplit;
+  if (!ws || ws_bytes < (size_t)a.nsplit * wsz * sizeof(float)) return AIR_EWORKSPACE;
+  const int nblk = a.ncot * a.ncit * a.nsplit;
+  const int KH = p->KH, S = p->sh;
+  if (KH == 3 && S == 1)
+    hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
+  else if (KH == 3 && S == 2 && ct == 32)
+    hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
+  else if (KH == 1 && S == 1)
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
+  else if (KH == 1 && S == 2 && ct == 32)
+    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
+  else
+    return AIR_EUNSUPPORTED;
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+}  // extern "C"

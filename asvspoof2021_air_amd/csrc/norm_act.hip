@@ -1,0 +1,311 @@
+// BatchNorm (+ReLU) forward/backward for gfx950: HBM-bound reductions and
+// elementwise passes over (B, C, S) tensors, S = H*W (BatchNorm2d) or T
+// (BatchNorm1d).  Replaces nn.BatchNorm2d + F.relu at resnet.py:55-67,132,142
+// and nn.BatchNorm1d in ecapa_tdnn.py.
+//
+// Layout: a (b, c) plane is S contiguous floats, so every kernel walks whole
+// planes with consecutive lanes on consecutive addresses (float4 when S % 4 == 0).
+// Reductions are two-stage and deterministic: per-(channel, split) partials in
+// fp64, then one finalize block per launch.  No atomics.
+#include "air_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = air_wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < NT / 64; ++w) r += sh[w];
+  return r;
+}
+
+int splits_for(int B, int C) {
+  int s = 2048 / C;
+  if (s < 1) s = 1;
+  if (s > B) s = B;
+  return s;
+}
+
+// partial[(c*nsplit + split)*2 + {0,1}] = sum, sum of squares over images [b0,b1)
+__global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __restrict__ x, int B,
+                                                              int C, int S, int nsplit,
+                                                              double* __restrict__ partial) {
+  __shared__ double sh[NT / 64];
+  const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
+  const int per = (B + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(B, b0 + per);
+  float s1 = 0.0f, s2 = 0.0f;
+  double d1 = 0.0, d2 = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const float* __restrict__ p = x + ((size_t)b * C + c) * S;
+    if ((S & 3) == 0 && ((((size_t)p) & 15) == 0)) {
+      const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+      for (int i = threadIdx.x; i < S / 4; i += NT) {
+        const float4 v = p4[i];
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += NT) {
+        const float v = p[i];
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    d1 += (double)s1;  // flush the fp32 running sums per image to bound their length
+    d2 += (double)s2;
+    s1 = 0.0f;
+    s2 = 0.0f;
+  }
+  d1 = block_sum_d(d1, sh);
+  d2 = block_sum_d(d2, sh);
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = d1;
+    partial[(size_t)blockIdx.x * 2 + 1] = d2;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nsplit, int C, double N,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += partial[((size_t)c * nsplit + k) * 2];
+    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
+  }
+  const double m = s1 / N;
+  double var = s2 / N - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)m;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = mf;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - mf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, int C, float* scale,
+                                      float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// grid: (B*C planes, chunks of S)
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int C, int S,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      float* __restrict__ y) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float sc = scale[c], sh = shift[c];
+  const float* __restrict__ p = x + (size_t)plane * S;
+  float* __restrict__ q = y + (size_t)plane * S;
+  const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
+  if (i0 >= S) return;
+  if (i0 + 3 < S && ((((size_t)(p + i0)) | ((size_t)(q + i0))) & 15) == 0) {
+    float4 v = *reinterpret_cast<const float4*>(p + i0);
+    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(q + i0) = v;
+  } else {
+    for (int i = i0; i < min(S, i0 + 4); ++i) {
+      float v = p[i] * sc + sh;
+      if (relu) v = fmaxf(v, 0.f);
+      q[i] = v;
+    }
+  }
+}
+
+// backward stage 1: partial[(c*nsplit+split)*2] = sum g, [+1] = sum g*xhat, g = dy*[y>0]
+__global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int B, int C, int S, int nsplit,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    double* __restrict__ partial) {
+  __shared__ double sh[NT / 64];
+  const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
+  const int per = (B + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(B, b0 + per);
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is;
+  const float shf = beta[c] - mu * sc;
+  double d1 = 0.0, d2 = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const float* __restrict__ px = x + ((size_t)b * C + c) * S;
+    const float* __restrict__ pg = dy + ((size_t)b * C + c) * S;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = threadIdx.x; i < S; i += NT) {
+      const float xv = px[i];
+      float g = pg[i];
+      if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+      s1 += g;
+      s2 += g * ((xv - mu) * is);
+    }
+    d1 += (double)s1;
+    d2 += (double)s2;
+  }
+  d1 = block_sum_d(d1, sh);
+  d2 = block_sum_d(d2, sh);
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = d1;
+    partial[(size_t)blockIdx.x * 2 + 1] = d2;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nsplit, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += partial[((size_t)c * nsplit + k) * 2];
+    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+}
+
+// backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, int C, int S, float invN,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
+    float* __restrict__ dx) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is;
+  const float shf = beta[c] - mu * sc;
+  const float k1 = dbeta[c] * invN, k2 = dgamma[c] * invN;
+  const size_t base = (size_t)plane * S;
+  const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
+  for (int i = i0; i < min(S, i0 + 4); ++i) {
+    const float xv = x[base + i];
+    float g = dy[base + i];
+    if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+    const float xh = (xv - mu) * is;
+    float r = sc * (g - k1 - xh * k2);
+    if (accum) r += dx[base + i];
+    dx[base + i] = r;
+  }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] += x[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t air_bn_ws_bytes(int B, int C, int S) {
+  if (B <= 0 || C <= 0 || S <= 0) return 0;
+  return (size_t)C * splits_for(B, C) * 2 * sizeof(double);
+}
+
+int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, const float* gamma,
+                 const float* beta, float eps, float momentum, float* running_mean,
+                 float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                 void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || B <= 0 || C <= 0 || S <= 0)
+    return AIR_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return AIR_EINVAL;
+  if (stats_in != nullptr) return AIR_EUNSUPPORTED;
+  if (!ws || ws_bytes < air_bn_ws_bytes(B, C, S)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  const int nsplit = splits_for(B, C);
+  double* partial = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S,
+                     nsplit, partial);
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C,
+                     (double)B * (double)S, gamma, beta, eps, momentum, running_mean, running_var,
+                     mean, invstd, scale, shift);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       air_stream_t stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0)
+    return AIR_EINVAL;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, air_stream(stream),
+                     gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
+                 int relu, float* y, air_stream_t stream) {
+  if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
+  dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale,
+                     shift, relu, y);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float* mean,
+               const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
+               int dx_accum, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+               air_stream_t stream) {
+  if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 ||
+      C <= 0 || S <= 0)
+    return AIR_EINVAL;
+  if (!ws || ws_bytes < air_bn_ws_bytes(B, C, S)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  const int nsplit = splits_for(B, C);
+  double* partial = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, B, C, S,
+                     nsplit, mean, invstd, gamma, beta, relu, partial);
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit,
+                     C, dgamma, dbeta);
+  AIR_CHECK_LAUNCH();
+  dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, C, S,
+                     (float)(1.0 / ((double)B * (double)S)), mean, invstd, gamma, beta, dgamma,
+                     dbeta, relu, dx_accum, dx);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream) {
+  if (!y || !x) return AIR_EINVAL;
+  if (n == 0) return AIR_OK;
+  size_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)g), dim3(256), 0, air_stream(stream), y, x,
+                     n);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+}  // extern "C"

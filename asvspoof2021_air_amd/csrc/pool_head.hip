@@ -1,0 +1,292 @@
+// Pooling head of the ResNet for gfx950: SelfAttention pooling (resnet.py:23-46)
+// and the two nn.Linear layers (resnet.py:143-144, :187-189; also fc6/fc7 of
+// ecapa_tdnn.py:148-149).  Tiny tensors ((B,256,94), (B,512)): one workgroup per
+// utterance, everything staged in LDS, no intermediate ever reaches HBM.
+#include "air_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = air_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = 0.0f;
+  for (int w = 0; w < NT / 64; ++w) r += sh[w];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = air_wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, sh[w]);
+  return r;
+}
+
+// x: (B, C, T) channel-major (conv5 output after bn5+ReLU, squeezed); the
+// reference works on its (B, T, C) permutation (resnet.py:185) - same numbers.
+// dynamic LDS: xs[C][T+1] + w[T] + alpha[T]
+__global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict__ x, int C, int T,
+                                                         const float* __restrict__ att,
+                                                         const float* __restrict__ noise,
+                                                         float* __restrict__ out,
+                                                         float* __restrict__ alpha_save) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[NT / 64];
+  const int TP = T + 1;
+  float* xs = smem;
+  float* ws = xs + (size_t)C * TP;
+  const int b = blockIdx.x;
+  const float* __restrict__ xb = x + (size_t)b * C * T;
+  for (int e = threadIdx.x; e < C * T; e += NT) {
+    const int c = e / T, t = e - c * T;
+    xs[c * TP + t] = xb[e];
+  }
+  __syncthreads();
+  // w_t = <x[:, t], a>   (torch.bmm, resnet.py:26)
+  for (int t = threadIdx.x; t < T; t += NT) {
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s = fmaf(xs[c * TP + t], att[c], s);
+    ws[t] = tanhf(s);
+  }
+  __syncthreads();
+  // softmax over T of tanh(w)  (resnet.py:28-33)
+  float m = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += NT) m = fmaxf(m, ws[t]);
+  m = block_max(m, red);
+  float se = 0.0f;
+  for (int t = threadIdx.x; t < T; t += NT) se += expf(ws[t] - m);
+  se = block_sum(se, red);
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += NT) {
+    const float al = expf(ws[t] - m) / se;
+    ws[t] = al;
+    alpha_save[(size_t)b * T + t] = al;
+  }
+  __syncthreads();
+  // weighted mean and unbiased std over T (resnet.py:37-42)
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float avg = 0.0f, zs = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      const float wv = xs[c * TP + t] * ws[t];
+      avg += wv;
+      zs += noise ? wv + noise[((size_t)b * T + t) * C + c] : wv;
+    }
+    const float zm = zs / (float)T;
+    float ss = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      float z = xs[c * TP + t] * ws[t];
+      if (noise) z += noise[((size_t)b * T + t) * C + c];
+      const float d = z - zm;
+      ss = fmaf(d, d, ss);
+    }
+    out[(size_t)b * 2 * C + c] = avg;
+    out[(size_t)b * 2 * C + C + c] = sqrtf(ss / (float)(T - 1));
+  }
+}
+
+// backward; dynamic LDS: xs[C][T+1] + alpha[T] + dalpha[T] + dw[T] + zmean[C] + coef[C] + davg[C]
+//   z[t][c] = x[c][t] alpha_t + noise;  G[t][c] = d_avg[c] + d_std[c] (z - mean_z)/((T-1) std)
+//   dalpha_t = sum_c G x;  du = alpha (dalpha - <alpha, dalpha>);  dw = du (1 - tanh^2)
+//   dx[c][t] = G alpha_t + dw_t a_c;  datt[c] = sum_t dw_t x[c][t]
+__global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
+    const float* __restrict__ x, int C, int T, const float* __restrict__ att,
+    const float* __restrict__ noise, const float* __restrict__ alpha,
+    const float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dx,
+    float* __restrict__ datt_partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[NT / 64];
+  const int TP = T + 1;
+  float* xs = smem;
+  float* al = xs + (size_t)C * TP;
+  float* dal = al + T;
+  float* dw = dal + T;
+  float* zm = dw + T;
+  float* coef = zm + C;
+  float* dav = coef + C;
+  const int b = blockIdx.x;
+  const float* __restrict__ xb = x + (size_t)b * C * T;
+  const float* __restrict__ nb = noise ? noise + (size_t)b * T * C : nullptr;
+  for (int e = threadIdx.x; e < C * T; e += NT) {
+    const int c = e / T, t = e - c * T;
+    xs[c * TP + t] = xb[e];
+  }
+  for (int t = threadIdx.x; t < T; t += NT) al[t] = alpha[(size_t)b * T + t];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float zs = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      float z = xs[c * TP + t] * al[t];
+      if (nb) z += nb[(size_t)t * C + c];
+      zs += z;
+    }
+    zm[c] = zs / (float)T;
+    const float sd = out[(size_t)b * 2 * C + C + c];
+    const float dstd = dout[(size_t)b * 2 * C + C + c];
+    coef[c] = sd > 0.0f ? dstd / ((float)(T - 1) * sd) : 0.0f;
+    dav[c] = dout[(size_t)b * 2 * C + c];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += NT) {
+    float acc = 0.0f, s = 0.0f;
+    const float a_t = al[t];
+    for (int c = 0; c < C; ++c) {
+      const float xv = xs[c * TP + t];
+      float z = xv * a_t;
+      if (nb) z += nb[(size_t)t * C + c];
+      const float g = dav[c] + coef[c] * (z - zm[c]);
+      acc = fmaf(g, xv, acc);
+      s = fmaf(xv, att[c], s);
+    }
+    dal[t] = acc;
+    const float u = tanhf(s);
+    dw[t] = 1.0f - u * u;  // finished below once <alpha, dalpha> is known
+  }
+  __syncthreads();
+  float dot = 0.0f;
+  for (int t = threadIdx.x; t < T; t += NT) dot += al[t] * dal[t];
+  dot = block_sum(dot, red);
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += NT) dw[t] = al[t] * (dal[t] - dot) * dw[t];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    const float ac = att[c], cf = coef[c], dv = dav[c], zmc = zm[c];
+    float da = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      const float xv = xs[c * TP + t];
+      float z = xv * al[t];
+      if (nb) z += nb[(size_t)t * C + c];
+      const float g = dv + cf * (z - zmc);
+      dx[((size_t)b * C + c) * T + t] = g * al[t] + dw[t] * ac;
+      da = fmaf(dw[t], xv, da);
+    }
+    datt_partial[(size_t)b * C + c] = da;
+  }
+}
+
+// y[m][n] = sum_k x[m][k] w[n][k] + b[n]; one workgroup per row m, one wave per
+// output n at a time with lanes striding k (coalesced weight rows).
+__global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int K,
+                                                        int N, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const int m = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += NT) xs[k] = x[(size_t)m * K + k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int n = wave; n < N; n += NT / 64) {
+    const float* __restrict__ wr = w + (size_t)n * K;
+    float s = 0.0f;
+    for (int k = lane; k < K; k += 64) s = fmaf(xs[k], wr[k], s);
+    s = air_wave_sum(s);
+    if (lane == 0) y[(size_t)m * N + n] = s + (bias ? bias[n] : 0.0f);
+  }
+}
+
+// dx[m][k] = sum_n dy[m][n] w[n][k]; grid (M), threads over k
+__global__ __launch_bounds__(NT) void linear_dx_kernel(const float* __restrict__ dy,
+                                                       const float* __restrict__ w, int K, int N,
+                                                       float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float ds[];
+  const int m = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += NT) ds[n] = dy[(size_t)m * N + n];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += NT) {
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n) s = fmaf(ds[n], w[(size_t)n * K + k], s);
+    dx[(size_t)m * K + k] = s;
+  }
+}
+
+// dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n]; grid (N), threads over k
+__global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ dy, int M, int K,
+                                                       int N, float* __restrict__ dw,
+                                                       float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float ds[];
+  const int n = blockIdx.x;
+  for (int m = threadIdx.x; m < M; m += NT) ds[m] = dy[(size_t)m * N + n];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += NT) {
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) s = fmaf(ds[m], x[(size_t)m * K + k], s);
+    dw[(size_t)n * K + k] = s;
+  }
+  if (db != nullptr && threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) s += ds[m];
+    db[n] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int air_selfatt_pool_fwd(const float* x, int B, int C, int T, const float* att_w,
+                         const float* noise, float* out, float* alpha_save, air_stream_t stream) {
+  if (!x || !att_w || !out || !alpha_save || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
+  const size_t lds = ((size_t)C * (T + 1) + 2 * (size_t)T) * sizeof(float);
+  if (lds > 150 * 1024) return AIR_EUNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(selfatt_fwd_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return AIR_ELAUNCH;
+  hipLaunchKernelGGL(selfatt_fwd_kernel, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T,
+                     att_w, noise, out, alpha_save);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w,
+                         const float* noise, const float* alpha, const float* out,
+                         const float* dout, float* dx, float* datt_partial, air_stream_t stream) {
+  if (!x || !att_w || !alpha || !out || !dout || !dx || !datt_partial || B <= 0 || C <= 0 ||
+      T <= 1)
+    return AIR_EINVAL;
+  const size_t lds = ((size_t)C * (T + 1) + 3 * (size_t)T + 3 * (size_t)C) * sizeof(float);
+  if (lds > 150 * 1024) return AIR_EUNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(selfatt_bwd_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return AIR_ELAUNCH;
+  hipLaunchKernelGGL(selfatt_bwd_kernel, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T,
+                     att_w, noise, alpha, out, dout, dx, datt_partial);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K, int N, float* y,
+                   air_stream_t stream) {
+  if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return AIR_EINVAL;
+  if ((size_t)K * sizeof(float) > 64 * 1024) return AIR_EUNSUPPORTED;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(M), dim3(NT), (size_t)K * sizeof(float),
+                     air_stream(stream), x, w, b, K, N, y);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K, int N, float* dx,
+                   float* dw, float* db, air_stream_t stream) {
+  if (!x || !w || !dy || M <= 0 || K <= 0 || N <= 0) return AIR_EINVAL;
+  if ((size_t)N * sizeof(float) > 64 * 1024 || (size_t)M * sizeof(float) > 64 * 1024)
+    return AIR_EUNSUPPORTED;
+  if (dx != nullptr) {
+    hipLaunchKernelGGL(linear_dx_kernel, dim3(M), dim3(NT), (size_t)N * sizeof(float),
+                       air_stream(stream), dy, w, K, N, dx);
+    AIR_CHECK_LAUNCH();
+  }
+  if (dw != nullptr) {
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(N), dim3(NT), (size_t)M * sizeof(float),
+                       air_stream(stream), x, dy, M, K, N, dw, db);
+    AIR_CHECK_LAUNCH();
+  }
+  return AIR_OK;
+}
+
+}  // extern "C"

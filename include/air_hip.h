@@ -92,9 +92,11 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
                    const float* in_scale, const float* in_shift, int relu,
                    const float* residual, double* stats, void* ws, size_t ws_bytes,
                    air_stream_t stream);
-/* dx = conv_transpose(dy, w): gradient w.r.t. the (activated) conv input. */
+/* dx = conv_transpose(dy, w) [+ accumulate]: gradient w.r.t. the (activated) conv
+ * input.  accumulate: NULL or a tensor shaped like dx that is added (may alias dx;
+ * used to join the 1x1-shortcut and 3x3 branches of a PreActBlock). */
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
-                     void* ws, size_t ws_bytes, air_stream_t stream);
+                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
 /* dw = correlation(act(x), dy); same prologue as fwd so the activated tensor
  * is never materialised. */
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

@@ -1,0 +1,230 @@
+"""GPU parity of every hand-written kernel (through the C-ABI wrappers in
+asvspoof2021_air_amd.ops) against a PyTorch-CPU fp64 evaluation of the same op
+(these are floating-point kernels: SURVEY.md §8c / task ③ keep a torch
+reference for them).  Tolerances are relative to the output scale: the f32
+MFMA is an exact fmaf chain, so the only difference is summation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loss as o_loss
+from oracle import resnet as o_resnet
+from oracle import train as o_train
+from oracle.filler import synth_feat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from asvspoof2021_air_amd import ops
+    return ops
+
+
+def close(got, want, rtol=2e-5, name=""):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= rtol, "%s: max err %.3g of scale %.3g (rel %.3g > %.3g)" % (
+        name, np.abs(got - want).max(), scale, err, rtol)
+
+
+CONVS = [
+    # (B, Cin, H, W, Cout, k, stride, pad)
+    (2, 16, 18, 75, 64, (3, 3), 1, (1, 1)),     # layer1.0.conv1
+    (2, 64, 6, 70, 64, (3, 3), 1, (1, 1)),      # layer1 3x3
+    (3, 64, 18, 33, 128, (3, 3), 2, (1, 1)),    # layer2.0.conv1 (stride 2, even W... odd Wo)
+    (2, 64, 9, 75, 128, (3, 3), 2, (1, 1)),     # odd H and W
+    (2, 128, 9, 40, 128, (3, 3), 1, (1, 1)),
+    (2, 256, 5, 47, 256, (3, 3), 1, (1, 1)),
+    (1, 512, 3, 94, 512, (3, 3), 1, (1, 1)),    # layer4 3x3
+    (2, 16, 18, 75, 64, (1, 1), 1, (0, 0)),     # layer1.0.shortcut
+    (2, 64, 18, 75, 128, (1, 1), 2, (0, 0)),    # layer2.0.shortcut
+    (2, 256, 5, 47, 512, (1, 1), 2, (0, 0)),    # layer4.0.shortcut-like
+    (2, 512, 3, 94, 256, (3, 3), 1, (0, 1)),    # conv5
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv2d_fwd(ops, cfg, fused):
+    B, Cin, H, W, Cout, k, s, p = cfg
+    x = synth_feat((B, Cin, H, W), 1)
+    w = synth_feat((Cout, Cin) + k, 2, scale=0.1)
+    scale = shift = res = None
+    xa = x.double()
+    if fused:
+        scale = 1.0 + 0.2 * synth_feat((Cin,), 3)
+        shift = 0.3 * synth_feat((Cin,), 4)
+        xa = F.relu(xa * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    want = F.conv2d(xa, w.double(), None, s, p)
+    if fused:
+        res = synth_feat(tuple(want.shape), 5)
+        want = want + res.double()
+    got = ops.conv2d_fwd(x.cuda(), w.cuda(), s, p,
+                         None if scale is None else scale.cuda(), None if shift is None else shift.cuda(),
+                         relu=fused, residual=None if res is None else res.cuda())
+    close(got, want, name="conv2d_fwd")
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_dgrad(ops, cfg):
+    B, Cin, H, W, Cout, k, s, p = cfg
+    x = synth_feat((B, Cin, H, W), 1).double().requires_grad_(True)
+    w = synth_feat((Cout, Cin) + k, 2, scale=0.1)
+    y = F.conv2d(x, w.double(), None, s, p)
+    dy = synth_feat(tuple(y.shape), 6)
+    y.backward(dy.double())
+    got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), s, p)
+    close(got, x.grad, name="conv2d_dgrad")
+    acc = synth_feat((B, Cin, H, W), 7)
+    got2 = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), s, p, accumulate=acc.cuda())
+    close(got2, x.grad + acc.double(), name="conv2d_dgrad+acc")
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv2d_wgrad(ops, cfg, fused):
+    B, Cin, H, W, Cout, k, s, p = cfg
+    x = synth_feat((B, Cin, H, W), 1)
+    w = synth_feat((Cout, Cin) + k, 2, scale=0.1).double().requires_grad_(True)
+    scale = shift = None
+    xa = x.double()
+    if fused:
+        scale = 1.0 + 0.2 * synth_feat((Cin,), 3)
+        shift = 0.3 * synth_feat((Cin,), 4)
+        xa = F.relu(xa * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    y = F.conv2d(xa, w, None, s, p)
+    dy = synth_feat(tuple(y.shape), 6)
+    y.backward(dy.double())
+    got = ops.conv2d_wgrad(x.cuda(), dy.cuda(), tuple(w.shape), s, p,
+                           None if scale is None else scale.cuda(), None if shift is None else shift.cuda(),
+                           relu=fused)
+    close(got, w.grad, name="conv2d_wgrad")
+
+
+def test_conv1_direct(ops):
+    """ResNet conv1: 1->16, 9x3, stride (3,1), pad (1,1) (resnet.py:131)."""
+    x = synth_feat((3, 1, 60, 96), 1)
+    w = synth_feat((16, 1, 9, 3), 2, scale=0.3).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, (3, 1), (1, 1))
+    got = ops.conv2d_fwd(x.cuda(), w.detach().float().cuda(), (3, 1), (1, 1))
+    close(got, y, name="conv1 fwd")
+    dy = synth_feat(tuple(y.shape), 3)
+    y.backward(dy.double())
+    gw = ops.conv2d_wgrad(x.cuda(), dy.cuda(), (16, 1, 9, 3), (3, 1), (1, 1))
+    close(gw, w.grad, name="conv1 wgrad")
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 18, 75), (3, 64, 9, 375), (2, 256, 1, 94), (5, 128, 33)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm(ops, shape, relu):
+    C = shape[1]
+    x = synth_feat(shape, 1) * 2.0 + 0.5
+    gamma = 1.0 + 0.3 * synth_feat((C,), 2)
+    beta = 0.2 * synth_feat((C,), 3)
+    rm = 0.1 * synth_feat((C,), 4)
+    rv = 1.0 + 0.1 * synth_feat((C,), 5).abs()
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(xd, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5)
+    if relu:
+        y = F.relu(y)
+    dy = synth_feat(shape, 6)
+    y.backward(dy.double())
+    rmg, rvg = rm.cuda(), rv.cuda()
+    xg = x.cuda()
+    mean, invstd, scale, shift = ops.bn_stats(xg, gamma.cuda(), beta.cuda(), rmg, rvg)
+    yg = ops.bn_apply(xg, scale, shift, relu)
+    close(yg, y, name="bn fwd")
+    close(rmg, rm_ref, name="running_mean")
+    close(rvg, rv_ref, name="running_var")
+    dx, dg, db = ops.bn_bwd(xg, dy.cuda(), mean, invstd, gamma.cuda(), beta.cuda(), relu)
+    close(dx, xd.grad, rtol=1e-4, name="bn dx")
+    close(dg, gd.grad, rtol=1e-4, name="bn dgamma")
+    close(db, bd.grad, rtol=1e-4, name="bn dbeta")
+    base = synth_feat(shape, 7)
+    dx2, _, _ = ops.bn_bwd(xg, dy.cuda(), mean, invstd, gamma.cuda(), beta.cuda(), relu,
+                           dx=base.cuda(), accumulate=True)
+    close(dx2, xd.grad + base.double(), rtol=1e-4, name="bn dx accumulate")
+    # eval-mode coefficients
+    sc, sh = ops.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda())
+    ye = F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    close(ops.bn_apply(xg, sc, sh, False), ye, name="bn eval")
+
+
+@pytest.mark.parametrize("B,C,T,with_noise", [(3, 256, 94, True), (2, 256, 12, False), (1, 64, 7, True)])
+def test_selfatt_pool(ops, B, C, T, with_noise):
+    x = synth_feat((B, C, T), 1).abs()
+    att = synth_feat((1, C), 2, scale=0.1)
+    noise = 1e-3 * synth_feat((B, T, C), 3) if with_noise else None
+    xd = x.double().requires_grad_(True)
+    ad = att.double().requires_grad_(True)
+    want = o_resnet.self_attention_pool(xd.permute(0, 2, 1), ad, None if noise is None else noise.double())
+    dout = synth_feat((B, 2 * C), 4)
+    want.backward(dout.double())
+    xg, ag = x.cuda(), att.cuda()
+    ng = None if noise is None else noise.cuda()
+    out, alpha = ops.selfatt_pool_fwd(xg, ag, ng)
+    close(out, want, name="selfatt fwd")
+    dx, datt = ops.selfatt_pool_bwd(xg, ag, ng, alpha, out, dout.cuda())
+    close(dx, xd.grad, rtol=1e-4, name="selfatt dx")
+    close(datt.sum(0, keepdim=True), ad.grad, rtol=1e-4, name="selfatt datt")
+
+
+@pytest.mark.parametrize("M,K,N", [(8, 512, 256), (3, 256, 2), (5, 3072, 256)])
+def test_linear(ops, M, K, N):
+    x = synth_feat((M, K), 1)
+    w = synth_feat((N, K), 2, scale=0.05)
+    b = synth_feat((N,), 3)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = F.linear(xd, wd, bd)
+    dy = synth_feat((M, N), 4)
+    y.backward(dy.double())
+    close(ops.linear_fwd(x.cuda(), w.cuda(), b.cuda()), y, name="linear fwd")
+    dx, dw, db = ops.linear_bwd(x.cuda(), w.cuda(), dy.cuda())
+    close(dx, xd.grad, name="linear dx")
+    close(dw, wd.grad, name="linear dw")
+    close(db, bd.grad, name="linear db")
+
+
+@pytest.mark.parametrize("mode", ["mixed", "all0", "all1"])
+def test_ocsoftmax(ops, golden, mode):
+    g = golden("ocsoftmax.npz")
+    x = torch.from_numpy(g["feats_" + mode]).cuda()
+    c = torch.from_numpy(g["center"]).cuda()
+    lab = torch.from_numpy(g["labels_" + mode]).cuda()
+    loss, neg = ops.ocsoftmax_fwd(x, c, lab, 0.9, 0.2, 20.0)
+    np.testing.assert_allclose(loss.item(), g["loss_" + mode], rtol=2e-6)
+    np.testing.assert_allclose(neg.cpu().numpy(), g["negscores_" + mode], atol=1e-6)
+    dx, dc = ops.ocsoftmax_bwd(x, c, lab, 0.9, 0.2, 20.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), g["gfeat_" + mode], atol=2e-7, rtol=1e-4)
+    np.testing.assert_allclose(dc.cpu().numpy(), g["gcenter_" + mode], atol=2e-6, rtol=1e-4)
+    gs = torch.tensor([0.5], device="cuda")
+    dx2, _ = ops.ocsoftmax_bwd(x, c, lab, 0.9, 0.2, 20.0, gscale=gs)
+    np.testing.assert_allclose(dx2.cpu().numpy(), 0.5 * g["gfeat_" + mode], atol=2e-7, rtol=1e-4)
+    # independent fp64 closed form
+    l64, n64, gx, gc = o_loss.ocsoftmax_grads_f64(g["feats_" + mode], g["center"], g["labels_" + mode], 0.9, 0.2, 20.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, atol=2e-7, rtol=1e-4)
+
+
+def test_adam_sgd(ops):
+    n = 100003
+    p = synth_feat((n,), 1)
+    g = synth_feat((n,), 2)
+    pg, m, v = p.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    for step in range(1, 4):
+        gs = g * step
+        ops.adam_step(pg, gs.cuda(), m, v, step)
+        o_train.adam_step_(pr, gs, mr, vr, step)
+        np.testing.assert_allclose(pg.cpu().numpy(), pr.numpy(), atol=2e-7)
+    c = synth_feat((1, 256), 3)
+    cg = c.cuda()
+    ops.sgd_step(cg, g[:256].reshape(1, 256).cuda(), 5e-4)
+    np.testing.assert_allclose(cg.cpu().numpy(), (c - 5e-4 * g[:256].reshape(1, 256)).numpy(), atol=1e-7)
+    ops.sgd_step(cg, g[:256].reshape(1, 256).cuda(), 5e-4, grad_scale=0.5)
