@@ -226,9 +226,77 @@ __global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__
   }
 }
 
+// out[n] = sum_m x[m][n]  (e.g. per-utterance attention-vector partials -> gradient)
+__global__ void sum_rows_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.0f;
+  for (int m = 0; m < M; ++m) s += x[(size_t)m * N + n];
+  out[n] = s;
+}
+
+// Philox4x32-10 counter-based generator -> N(0,1) via Box-Muller, scaled.
+// Replaces the host-side ``1e-5*torch.randn`` of resnet.py:38 (drawn on the CPU
+// and copied every call in the reference) with an on-device draw.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u;
+  k[1] += 0xBB67AE85u;
+}
+
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset,
+                             float scale) {
+  const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 outputs each
+  if (quad * 4 >= n) return;
+  const uint64_t ctr = offset + quad;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  const float inv = 2.3283064365386963e-10f;  // 2^-32
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)c[2 * h] + 1.0f) * inv;  // (0, 1]
+    const float u2 = (float)c[2 * h + 1] * inv;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = r * cs;
+    z[2 * h + 1] = r * sn;
+  }
+  for (int j = 0; j < 4; ++j)
+    if (quad * 4 + j < n) out[quad * 4 + j] = scale * z[j];
+}
+
 }  // namespace
 
 extern "C" {
+
+int air_sum_rows(const float* x, int M, int N, float* out, air_stream_t stream) {
+  if (!x || !out || M <= 0 || N <= 0) return AIR_EINVAL;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, air_stream(stream), x,
+                     M, N, out);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
+              air_stream_t stream) {
+  if (!out) return AIR_EINVAL;
+  if (n == 0) return AIR_OK;
+  const size_t quads = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                     air_stream(stream), out, n, seed, offset, scale);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
 
 int air_selfatt_pool_fwd(const float* x, int B, int C, int T, const float* att_w,
                          const float* noise, float* out, float* alpha_save, air_stream_t stream) {

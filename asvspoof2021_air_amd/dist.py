@@ -1,0 +1,74 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+The reference has no multi-GPU path.  Here utterances are
+sharded across ranks; each rank runs the whole hot path on its shard with its
+own BatchNorm statistics (per-GPU batch == the reference's batch, SURVEY.md
+§8e), and the only exchange is a SUM all-reduce of the gradient arena -- a few
+large buckets in reverse-layer order launched back to back, so RCCL pipelines
+them over the 7 xGMI links -- plus the 256-float loss centre.  The optimiser
+divides by the world size (grad_scale), so no extra pass touches the arena.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+BUCKET_BYTES = 16 << 20  # 49.8 MB of ResNet gradients -> 3-4 buckets
+
+
+def world_size():
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def rank():
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns local rank."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not td.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        td.init_process_group(backend=backend)
+    return local
+
+
+def bucket_slices(n_elems, bucket_bytes=BUCKET_BYTES):
+    """Reverse-order (last layers first) [start, end) slices of a flat arena."""
+    per = max(1, bucket_bytes // 4)
+    out = []
+    end = n_elems
+    while end > 0:
+        start = max(0, end - per)
+        out.append((start, end))
+        end = start
+    return out
+
+
+def allreduce_flat(flat, n_elems, bucket_bytes=BUCKET_BYTES):
+    """SUM all-reduce flat[:n_elems] in buckets, asynchronously; returns the work handles."""
+    works = []
+    for s, e in bucket_slices(n_elems, bucket_bytes):
+        works.append(td.all_reduce(flat[s:e], op=td.ReduceOp.SUM, async_op=True))
+    return works
+
+
+def allreduce_grads(model, loss_module=None):
+    """Sum gradients over ranks: the model's gradient arena (skipping the tail that has
+    no gradient under ang_iso) and the loss centre."""
+    if world_size() == 1:
+        return
+    arena = model.arena()
+    n = arena.total if arena.tail_has_grad else arena.head_total
+    works = allreduce_flat(arena.grad, n)
+    if loss_module is not None:
+        for p in loss_module.parameters():
+            if p.grad is not None:
+                works.append(td.all_reduce(p.grad, op=td.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()

@@ -224,3 +224,18 @@ def add_(y, x):
     _hip.check(_hip.lib().air_add_inplace(dptr(y), dptr(x), csz(y.numel()), stream()),
                "air_add_inplace")
     return y
+
+
+def sum_rows(x, out=None):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_sum_rows(dptr(x), ci(M), ci(N), dptr(out), stream()), "air_sum_rows")
+    return out
+
+
+def randn(shape, device, seed, offset, scale=1.0):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_randn(dptr(out), csz(out.numel()), ctypes.c_uint64(seed),
+                                    ctypes.c_uint64(offset), cf(scale), stream()), "air_randn")
+    return out

@@ -146,6 +146,13 @@ int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w
                          const float* dout, float* dx, float* datt_partial /*(B,C)*/,
                          air_stream_t stream);
 
+/* out[n] = sum_m x[m][n]: folds the per-utterance datt partials over the batch. */
+int air_sum_rows(const float* x, int M, int N, float* out, air_stream_t stream);
+/* scale * N(0,1) from a Philox4x32-10 counter stream (seed, offset): the on-device
+ * replacement for the host-side ``1e-5*torch.randn`` of resnet.py:38. */
+int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
+              air_stream_t stream);
+
 /* --------------------------------------------------------------- linear ---
  * nn.Linear (resnet.py:143-144,187-189; ecapa_tdnn.py:148-149): y = x W^T + b.
  * x (M,K), w (N,K), y (M,N).

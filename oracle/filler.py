@@ -12,35 +12,42 @@ import numpy as np
 import torch
 
 
+def _seed_of(name):
+    h = 2166136261
+    for ch in name.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF  # FNV-1a
+    return h
+
+
 def fill_value(name, shape):
     """Deterministic float32 tensor for parameter ``name`` of ``shape``.
 
-    p.flat[i] = gain * sin(0.37 i + phase(name)); gain follows the fan-in/out
-    scale the reference's initialiser would give (resnet.py:149-157) so
-    activations stay O(1) through the stack.
+    Values come from numpy's PCG64 stream seeded by a hash of the name (bit-stable
+    across platforms), scaled like the reference's initialiser (resnet.py:149-157:
+    kaiming-normal fan_out for convs, kaiming-uniform for linears) so the network
+    is as well conditioned as a freshly initialised one.  (A smooth closed form such
+    as sin(0.37 i) makes the convs cancel catastrophically: fp32 and fp64 CPU
+    evaluations of the same net then differ by 1e-3, which would swamp parity.)
     """
     n = int(np.prod(shape)) if len(shape) else 1
-    phase = (sum(ord(c) * (k + 1) for k, c in enumerate(name)) % 997) * 0.013
-    i = np.arange(n, dtype=np.float64)
-    base = np.sin(0.37 * i + phase)
+    rng = np.random.Generator(np.random.PCG64(_seed_of(name)))
     leaf = name.split(".")[-1]
-    if leaf == "running_mean":
-        v = 0.05 * base
-    elif leaf == "running_var":
-        v = 1.0 + 0.2 * base
-    elif leaf == "num_batches_tracked":
+    if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=torch.long)
-    elif len(shape) >= 3:  # conv weight (Cout, Cin, k...) : kaiming fan_out scale
+    if leaf == "running_mean":
+        v = 0.05 * rng.standard_normal(n)
+    elif leaf == "running_var":
+        v = 1.0 + 0.2 * rng.uniform(-1, 1, n)
+    elif len(shape) >= 3:  # conv weight (Cout, Cin, k...): kaiming normal, fan_out
         fan_out = shape[0] * int(np.prod(shape[2:]))
-        v = math.sqrt(2.0) * math.sqrt(2.0 / fan_out) * base
-        # ECAPA convs are followed by ReLU->BN (no BN before): use fan_in so they stay O(1)
-    elif len(shape) == 2:  # linear weight / attention vector / loss centre
-        fan_in = shape[1]
-        v = math.sqrt(2.0) * math.sqrt(1.0 / fan_in) * base
+        v = math.sqrt(2.0 / fan_out) * rng.standard_normal(n)
+    elif len(shape) == 2:  # linear weight / attention vector / loss centre: uniform, fan_in
+        bound = math.sqrt(3.0 / shape[1])
+        v = rng.uniform(-bound, bound, n)
     elif leaf == "weight":  # BN gamma
-        v = 1.0 + 0.1 * base
+        v = 1.0 + 0.1 * rng.uniform(-1, 1, n)
     else:  # biases, BN beta
-        v = 0.1 * base
+        v = 0.1 * rng.uniform(-1, 1, n)
     return torch.from_numpy(v.astype(np.float32).reshape(shape))
 
 
