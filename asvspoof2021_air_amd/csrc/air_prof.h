@@ -1,0 +1,32 @@
+// Opt-in per-kernel timing with HIP events on the launch stream (bench.py's
+// roofline leg).  Off by default: zero cost on the product path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum AirKernelId {
+  AIR_K_CONV_FWD_331 = 0,  // conv_fwd_kernel<3,3,1>  (forward 3x3 s1 AND every dgrad)
+  AIR_K_CONV_FWD_332,      // conv_fwd_kernel<3,3,2>
+  AIR_K_CONV_FWD_111,      // conv_fwd_kernel<1,1,1>
+  AIR_K_CONV_FWD_112,      // conv_fwd_kernel<1,1,2>
+  AIR_K_CONV_WG_331,       // conv_wgrad_kernel<3,3,1,64>
+  AIR_K_CONV_WG_332,       // conv_wgrad_kernel<3,3,2,32>
+  AIR_K_CONV_WG_111,       // conv_wgrad_kernel<1,1,1,64>
+  AIR_K_CONV_WG_112,       // conv_wgrad_kernel<1,1,2,32>
+  AIR_K_LFCC,              // lfcc_kernel
+  AIR_K_COUNT
+};
+
+bool air_prof_on();
+void air_prof_begin(int kid, double work, hipStream_t st);
+void air_prof_end(hipStream_t st);
+
+struct AirProfScope {
+  hipStream_t st;
+  bool on;
+  AirProfScope(int kid, double work, hipStream_t s) : st(s), on(air_prof_on()) {
+    if (on) air_prof_begin(kid, work, st);
+  }
+  ~AirProfScope() {
+    if (on) air_prof_end(st);
+  }
+};

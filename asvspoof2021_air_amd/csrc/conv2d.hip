@@ -26,6 +26,7 @@
 // stride-2 dgrad first zero-upsamples dy.  wgrad is a second implicit GEMM
 // with K = pixels, split over workgroups, reduced deterministically.
 #include "air_common.h"
+#include "air_prof.h"
 
 namespace {
 
@@ -547,7 +548,7 @@ void launch_fwd(const FwdArgs& a, hipStream_t st) {
 // y = conv(act(x), packed w): shared by fwd and stride-1 dgrad
 int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
             int relu, const float* residual, int B, int Cin, int H, int W, int Cout, int KH, int S,
-            int ph, int pw, int Ho, int Wo, hipStream_t st) {
+            int ph, int pw, int Ho, int Wo, double flops, hipStream_t st) {
   FwdArgs a;
   a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
@@ -556,13 +557,28 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   a.ntiles = B * Ho * a.WT;
   a.npxg = (a.ntiles + NWAVE - 1) / NWAVE;
   a.ncot = (Cout + BM - 1) / BM;
-  if (KH == 3 && S == 1) launch_fwd<3, 3, 1>(a, st);
-  else if (KH == 3 && S == 2) launch_fwd<3, 3, 2>(a, st);
-  else if (KH == 1 && S == 1) launch_fwd<1, 1, 1>(a, st);
-  else if (KH == 1 && S == 2) launch_fwd<1, 1, 2>(a, st);
-  else return AIR_EUNSUPPORTED;
+  if (KH == 3 && S == 1) {
+    AirProfScope ps(AIR_K_CONV_FWD_331, flops, st);
+    launch_fwd<3, 3, 1>(a, st);
+  } else if (KH == 3 && S == 2) {
+    AirProfScope ps(AIR_K_CONV_FWD_332, flops, st);
+    launch_fwd<3, 3, 2>(a, st);
+  } else if (KH == 1 && S == 1) {
+    AirProfScope ps(AIR_K_CONV_FWD_111, flops, st);
+    launch_fwd<1, 1, 1>(a, st);
+  } else if (KH == 1 && S == 2) {
+    AirProfScope ps(AIR_K_CONV_FWD_112, flops, st);
+    launch_fwd<1, 1, 2>(a, st);
+  } else {
+    return AIR_EUNSUPPORTED;
+  }
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+// algorithmic FLOPs (2 * MACs) of the convolution, whatever kernel computes it
+double conv_flops(const AirConv2d* p) {
+  return 2.0 * p->B * p->Cout * p->Ho * p->Wo * (double)p->Cin * p->KH * p->KW;
 }
 
 // stride-2 3x3 wgrad holds a 65-column patch per channel: use 32-channel tiles there
@@ -630,7 +646,7 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
                      p->Cin, p->KH * p->KW, 0);
   AIR_CHECK_LAUNCH();
   return run_fwd(x, wp, y, in_scale, in_shift, relu, residual, p->B, p->Cin, p->H, p->W, p->Cout,
-                 p->KH, p->sh, p->ph, p->pw, p->Ho, p->Wo, st);
+                 p->KH, p->sh, p->ph, p->pw, p->Ho, p->Wo, conv_flops(p), st);
 }
 
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
@@ -661,7 +677,7 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     Ws = Wu;
   }
   return run_fwd(src, wp, dx, nullptr, nullptr, 0, accumulate, p->B, p->Cout, Hs, Ws, p->Cin,
-                 p->KH, 1, p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W, st);
+                 p->KH, 1, p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W, conv_flops(p), st);
 }
 
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,
@@ -700,16 +716,22 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
   if (!ws || ws_bytes < (size_t)a.nsplit * wsz * sizeof(float)) return AIR_EWORKSPACE;
   const int nblk = a.ncot * a.ncit * a.nsplit;
   const int KH = p->KH, S = p->sh;
-  if (KH == 3 && S == 1)
+  const double flops = conv_flops(p);
+  if (KH == 3 && S == 1) {
+    AirProfScope ps(AIR_K_CONV_WG_331, flops, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
-  else if (KH == 3 && S == 2 && ct == 32)
+  } else if (KH == 3 && S == 2 && ct == 32) {
+    AirProfScope ps(AIR_K_CONV_WG_332, flops, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
-  else if (KH == 1 && S == 1)
+  } else if (KH == 1 && S == 1) {
+    AirProfScope ps(AIR_K_CONV_WG_111, flops, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
-  else if (KH == 1 && S == 2 && ct == 32)
+  } else if (KH == 1 && S == 2 && ct == 32) {
+    AirProfScope ps(AIR_K_CONV_WG_112, flops, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
-  else
+  } else {
     return AIR_EUNSUPPORTED;
+  }
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
                      reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit);

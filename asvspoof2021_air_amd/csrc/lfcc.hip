@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "air_common.h"
+#include "air_prof.h"
 
 namespace {
 
@@ -431,7 +432,13 @@ int lfcc_launch(const float* pcm, int B, int L, float* out, int feat_len, const 
   a.tiles = (T + FOUT - 1) / FOUT;
   a.flags = flags;
   a.feat_len = feat_len;
-  hipLaunchKernelGGL(lfcc_kernel, dim3((unsigned)(B * a.tiles)), dim3(NTHREADS), 0, stream, a);
+  {
+    // algorithmic bytes: fp32 PCM in + fp32 features out
+    const int nf = (flags & FLAG_DELTA) ? 3 : 1;
+    const double out_frames = (flags & FLAG_PADDED) ? (double)feat_len : (double)T;
+    AirProfScope ps(AIR_K_LFCC, 4.0 * B * ((double)L + out_frames * nf * 20.0), stream);
+    hipLaunchKernelGGL(lfcc_kernel, dim3((unsigned)(B * a.tiles)), dim3(NTHREADS), 0, stream, a);
+  }
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -1,0 +1,81 @@
+// Per-kernel HIP-event timing (see air_prof.h).  Test/bench instrumentation only.
+#include "air_prof.h"
+
+#include <mutex>
+#include <vector>
+
+#include "air_common.h"
+
+namespace {
+struct Rec {
+  hipEvent_t a, b;
+  int kid;
+  double work;
+};
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+bool g_on = false;
+Rec g_cur;
+const char* const kNames[AIR_K_COUNT] = {
+    "conv_fwd_kernel<3,3,1>", "conv_fwd_kernel<3,3,2>", "conv_fwd_kernel<1,1,1>",
+    "conv_fwd_kernel<1,1,2>", "conv_wgrad_kernel<3,3,1,64>", "conv_wgrad_kernel<3,3,2,32>",
+    "conv_wgrad_kernel<1,1,1,64>", "conv_wgrad_kernel<1,1,2,32>", "lfcc_kernel"};
+}  // namespace
+
+bool air_prof_on() { return g_on; }
+
+void air_prof_begin(int kid, double work, hipStream_t st) {
+  g_cur.kid = kid;
+  g_cur.work = work;
+  if (hipEventCreate(&g_cur.a) != hipSuccess || hipEventCreate(&g_cur.b) != hipSuccess) return;
+  (void)hipEventRecord(g_cur.a, st);
+}
+
+void air_prof_end(hipStream_t st) {
+  (void)hipEventRecord(g_cur.b, st);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_recs.push_back(g_cur);
+}
+
+extern "C" {
+
+int air_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_recs.clear();
+  g_on = on != 0;
+  return AIR_OK;
+}
+
+int air_prof_kernel_count(void) { return AIR_K_COUNT; }
+
+const char* air_prof_kernel_name(int kid) {
+  return (kid >= 0 && kid < AIR_K_COUNT) ? kNames[kid] : "";
+}
+
+/* Totals for kernel id `kid` since air_prof_enable(1): launches, summed event
+ * time (ms) and summed algorithmic work (FLOPs or bytes).  Synchronises. */
+int air_prof_collect(int kid, int* launches, double* total_ms, double* total_work) {
+  if (!launches || !total_ms || !total_work) return AIR_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  double ms = 0.0, work = 0.0;
+  for (auto& r : g_recs) {
+    if (r.kid != kid) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) return AIR_ELAUNCH;
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return AIR_ELAUNCH;
+    ++n;
+    ms += t;
+    work += r.work;
+  }
+  *launches = n;
+  *total_ms = ms;
+  *total_work = work;
+  return AIR_OK;
+}
+
+}  // extern "C"

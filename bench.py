@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/sec through ONE full train step of the hot path
+(BASELINE.json configs[1]): fused HIP LFCC on 4 s @ 16 kHz synthetic PCM (already
+resident in HBM) -> repeat-pad to feat_len 750 -> ResNet-18 forward -> OC-Softmax
+(ang_iso) -> backward -> [RCCL all-reduce] -> Adam + SGD, fp32, batch 64 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  "roofline":     dominant kernel (f32-MFMA implicit-GEMM conv) timed with HIP events on
+                  its launch stream: algorithmic FLOPs / time vs the 157.3 TFLOP/s f32 peak
+  "cpu_baseline": the CPU oracle (a PyTorch-CPU port of the reference path, pinned to the
+                  reference by tests/golden) timed on this box's host cores on a bounded
+                  sample of BASELINE.json configs[0].
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as td
+
+BATCH = 64          # per-GPU batch (the reference's --batch_size, main_train.py:54)
+LENGTH = 64000      # 4 s @ 16 kHz
+FEAT_LEN = 750      # reference default --feat_len (main_train.py:43), padding='repeat'
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(step, rank, device):
+    g = torch.Generator(device=device).manual_seed(688 + rank * 1000 + step)
+    pcm = 0.1 * torch.randn(BATCH, LENGTH, generator=g, device=device, dtype=torch.float32)
+    labels = (torch.rand(BATCH, generator=g, device=device) < 0.9).long()
+    labels[0] = 0
+    labels[1] = 1
+    return pcm, labels
+
+
+def roofline_leg(trainer, batches):
+    """Two extra instrumented steps: every conv / LFCC launch is bracketed by HIP events on
+    the launch stream inside the library (csrc/prof.hip)."""
+    from asvspoof2021_air_amd import _hip
+    lib = _hip.lib()
+    lib.air_prof_kernel_name.restype = ctypes.c_char_p
+    lib.air_prof_enable(1)
+    for pcm, labels in batches[:2]:
+        trainer.step(pcm, labels)
+    torch.cuda.synchronize()
+    rows = []
+    for kid in range(lib.air_prof_kernel_count()):
+        n, ms, work = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _hip.check(lib.air_prof_collect(kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)),
+                   "air_prof_collect")
+        if n.value:
+            rows.append({"kernel": lib.air_prof_kernel_name(kid).decode(), "launches": n.value,
+                         "total_ms": ms.value, "work": work.value})
+    lib.air_prof_enable(0)
+    convs = [r for r in rows if r["kernel"].startswith("conv")]
+    dom = max(convs, key=lambda r: r["total_ms"])
+    achieved = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
+    all_flops = sum(r["work"] for r in convs)
+    all_ms = sum(r["total_ms"] for r in convs)
+    out = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
+           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+           "traffic": None,
+           "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches_per_step": dom["launches"] // 2,
+           "all_conv_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                                "ms_per_step": round(all_ms / 2, 3)}}
+    lf = [r for r in rows if r["kernel"] == "lfcc_kernel"]
+    if lf:
+        gbs = lf[0]["work"] / (lf[0]["total_ms"] * 1e-3) / 1e9
+        out["lfcc_kernel"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(gbs / PEAK_HBM_GBS, 4),
+                              "avg_launch_ms": round(lf[0]["total_ms"] / lf[0]["launches"], 4)}
+    out["per_kernel"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // 2,
+                          "ms_per_step": round(r["total_ms"] / 2, 3),
+                          "rate": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2)} for r in rows]
+    return out
+
+
+def cpu_baseline_leg():
+    """CPU oracle on BASELINE.json configs[0], bounded: per-utterance LFCC loop over 64 seeded
+    4 s wavs (preprocess.py:239-244) + repeat-pad to 750 + ResNet-18/ang_iso train steps at
+    batch 8 (3 warm-up + 5 timed, median)."""
+    import numpy as np
+    from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
+    from oracle.filler import fill_state, fill_value, synth_pcm
+    # PyTorch-CPU's conv backward collapses when oversubscribed (256 threads on a batch-8
+    # problem ran 100x slower than 8 threads): use at most 16 threads and say so in "cores"
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pcm = synth_pcm(64, LENGTH, seed=688)
+    fb, dct = o_lfcc.linear_filterbank(), o_lfcc.dct2_ortho_matrix()
+    t0 = time.perf_counter()
+    feats = [o_lfcc.lfcc_forward(pcm[i:i + 1].numpy().copy(), fb=fb, dct=dct) for i in range(64)]
+    t_lfcc = time.perf_counter() - t0
+    x = torch.stack([o_pad.repeat_pad(torch.from_numpy(f), FEAT_LEN) for f in feats[:8]])
+    x = o_pad.to_model_input(x).contiguous()
+    labels = torch.tensor([0, 1, 1, 1, 0, 1, 1, 1])
+    tr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
+    times = []
+    t_start = time.perf_counter()
+    for it in range(8):
+        t0 = time.perf_counter()
+        tr.step(x, labels, None)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 25.0 and len(times) >= 2:  # bounded sample
+            break
+    warm = min(3, len(times) - 1)
+    step = float(np.median(times[warm:]))
+    per_utt = t_lfcc / 64 + step / 8
+    return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
+                      "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, 3 warm-up + "
+                      "5 timed, median %.3f s/step" % (1e3 * t_lfcc / 64, step),
+            "lfcc_utt_per_s": round(64 / t_lfcc, 1), "train_step_utt_per_s": round(8 / step, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from asvspoof2021_air_amd import dist as air_dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+    local = air_dist.init_from_env("nccl" if world > 1 else None)
+    rank = air_dist.rank()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    torch.manual_seed(688)
+    model = ResNet(3, 256, resnet_type="18", nclasses=2)
+    trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
+                      feat_len=FEAT_LEN, device=device)
+    if world > 1:  # same initial weights everywhere
+        arena = model.arena()
+        td.broadcast(arena.flat, src=0)
+        for p in trainer.loss.parameters():
+            td.broadcast(p.data, src=0)
+
+    nb = max(2, min(4, args.steps + args.warmup))
+    batches = [synth_batch(i, rank, device) for i in range(nb)]  # inputs resident in HBM
+    for i in range(args.warmup):
+        trainer.step(*batches[i % nb])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last, _ = trainer.step(*batches[i % nb])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(last.item())
+
+    if rank == 0:
+        line = {
+            "metric": "utterances/sec (LFCC+ResNet-OCSoftmax train step, 4 s@16 kHz)",
+            "value": round(world * BATCH * args.steps / dt, 2), "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: fused HIP LFCC(320,160,512,20 filters) + ResNet-18 + "
+                                   "OC-Softmax(ang_iso) fp32 train step (fwd+bwd+Adam+SGD), 4 s @ 16 kHz PCM in HBM, "
+                                   "T=401 frames repeat-padded to feat_len=750",
+                       "global_batch": world * BATCH, "per_gpu_batch": BATCH, "feat_len": FEAT_LEN,
+                       "parallelism": "dp%d" % world},
+            "final_loss": round(loss_val, 5),
+        }
+        if not args.no_roofline:
+            line["roofline"] = roofline_leg(trainer, batches)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_leg()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,16 @@ int air_adam_step(float* p, const float* g, float* m, float* v, size_t n, int st
 int air_sgd_step(float* p, const float* g, size_t n, float lr, float grad_scale,
                  air_stream_t stream);
 
+/* ------------------------------------------------- bench instrumentation ---
+ * Opt-in HIP-event timing of the dominant kernels on their launch stream, used
+ * by bench.py's roofline leg only (off by default).  kid indexes the kernel
+ * template instance (air_prof_kernel_name).  work = algorithmic FLOPs (conv) or
+ * bytes (LFCC) summed over the recorded launches. */
+int air_prof_enable(int on);
+int air_prof_kernel_count(void);
+const char* air_prof_kernel_name(int kid);
+int air_prof_collect(int kid, int* launches, double* total_ms, double* total_work);
+
 /* ------------------------------------------------------------- utility ---- */
 int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream); /* y += x */
 
