@@ -31,6 +31,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 8;        // input channels per K chunk
 constexpr int BM = 64;       // output channels per workgroup
@@ -124,10 +125,13 @@ struct FwdCfg {
   static constexpr int BUF = WSLAB + NWAVE * PATCH;   // floats per LDS buffer
 };
 
-template <int KH, int KW, int S>
+constexpr int MAXC = 512;  // channels whose BN scale/shift fit the LDS table
+
+template <int KH, int KW, int S, bool AFFINE>
 __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   using C = FwdCfg<KH, KW, S>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
+  __shared__ float s_scale[AFFINE ? MAXC : 1], s_shift[AFFINE ? MAXC : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -147,60 +151,61 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int hi0 = ho * S - a.ph;
   const int wi0 = wo0 * S - a.pw;
   const size_t HW = (size_t)a.H * a.W;
-  const float* __restrict__ xb = a.x + (size_t)b * a.Cin * HW;
   const int nchunk = a.Cin / CK;
   const float* __restrict__ wslab0 = a.wp + (size_t)cot * nchunk * C::WSLAB;
-  const bool affine = a.scale != nullptr;
 
   float pv[C::NI];
-  float4 wv[C::NWV];
+  f32x4 wv[C::NWV];
 
+  // Staging is split so that NO control flow surrounds the global loads (a branch per load
+  // makes hipcc serialise them behind vmcnt(0) waits):
+  //   prefetch(): unconditional loads from clamped, always-valid addresses -> registers
+  //   stage():    after the chunk's MFMAs, apply BN-affine + ReLU, zero the padding /
+  //               out-of-tile lanes with selects, write LDS.
+  const int HWi = a.H * a.W;
+  const int rowc = min(rowid, a.B * a.Ho - 1);  // clamp so address maths stays in the tensor
+  const float* __restrict__ xbc = a.x + (size_t)(rowc / a.Ho) * a.Cin * HW;
   auto prefetch = [&](int chunk) {
-    const float* __restrict__ xc = xb + (size_t)chunk * CK * HW;
+    const float* __restrict__ xc = xbc + (size_t)chunk * CK * HW;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int e = lane + 64 * i;
-      const int cil = e / (KH * C::PW);
-      const int rem = e - cil * (KH * C::PW);
+      const int cil = min(e / (KH * C::PW), CK - 1);
+      const int rem = e % (KH * C::PW);
       const int r = rem / C::PW;
       const int c = rem - r * C::PW;
-      const int hi = hi0 + r, wi = wi0 + c;
-      float v = 0.0f;
-      if (tile_ok && e < CK * KH * C::PW && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) {
-        v = xc[(size_t)cil * HW + (size_t)hi * a.W + wi];
-        if (affine) {
-          const int ci = chunk * CK + cil;
-          v = v * a.scale[ci] + a.shift[ci];
-        }
-        if (a.relu) v = fmaxf(v, 0.0f);
-      }
-      pv[i] = v;
+      const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
+      pv[i] = xc[cil * HWi + hi * a.W + wi];
     }
-    const float4* __restrict__ ws4 =
-        reinterpret_cast<const float4*>(wslab0 + (size_t)chunk * C::WSLAB);
+    const f32x4* __restrict__ ws4 =
+        reinterpret_cast<const f32x4*>(wslab0 + (size_t)chunk * C::WSLAB);
 #pragma unroll
     for (int i = 0; i < C::NWV; ++i) {
       const int e = tid + NWAVE * 64 * i;
-      wv[i] = (e < C::WSLAB / 4) ? ws4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      wv[i] = ws4[min(e, C::WSLAB / 4 - 1)];
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, int chunk) {
     float* __restrict__ base = lds + buf * C::BUF;
     float* __restrict__ pl = base + C::WSLAB + wave * C::PATCH;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int e = lane + 64 * i;
-      if (e < CK * KH * C::PW) {
-        const int cil = e / (KH * C::PW);
-        const int rem = e - cil * (KH * C::PW);
-        const int r = rem / C::PW;
-        const int c = rem - r * C::PW;
-        // S == 2: even columns first then odd, so a tap reads 32 contiguous floats
-        const int cm = (S == 2) ? ((c & 1) * ((C::PW + 1) / 2) + (c >> 1)) : c;
-        pl[cil * C::CHS + r * C::PWP + cm] = pv[i];
-      }
+      const int cil = min(e / (KH * C::PW), CK - 1);
+      const int rem = e % (KH * C::PW);
+      const int r = rem / C::PW;
+      const int c = rem - r * C::PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      const bool ok = tile_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      float v = pv[i];
+      if (AFFINE) v = v * s_scale[chunk * CK + cil] + s_shift[chunk * CK + cil];
+      v = a.relu ? fmaxf(v, 0.0f) : v;
+      v = ok ? v : 0.0f;  // zero padding applies to the ACTIVATED tensor
+      // S == 2: even columns first then odd, so a tap reads 32 contiguous floats
+      const int cm = (S == 2) ? ((c & 1) * ((C::PW + 1) / 2) + (c >> 1)) : c;
+      if (e < CK * KH * C::PW) pl[cil * C::CHS + r * C::PWP + cm] = v;
     }
-    float4* __restrict__ wl4 = reinterpret_cast<float4*>(base);
+    f32x4* __restrict__ wl4 = reinterpret_cast<f32x4*>(base);
 #pragma unroll
     for (int i = 0; i < C::NWV; ++i) {
       const int e = tid + NWAVE * 64 * i;
@@ -210,8 +215,15 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
 
   f32x16 acc0 = {0}, acc1 = {0};
 
+  if (AFFINE) {
+    for (int e = tid; e < a.Cin; e += NWAVE * 64) {
+      s_scale[e] = a.scale[e];
+      s_shift[e] = a.shift[e];
+    }
+    __syncthreads();
+  }
   prefetch(0);
-  stage(0);
+  stage(0, 0);
   __syncthreads();
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int cur = chunk & 1;
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
         }
       }
     }
-    if (chunk + 1 < nchunk) stage(cur ^ 1);
+    if (chunk + 1 < nchunk) stage(cur ^ 1, chunk + 1);
     __syncthreads();
   }
 
@@ -302,10 +314,11 @@ struct WgCfg {
   static constexpr int ND = (BMW * PXT) / 256;           // dy elements per thread
 };
 
-template <int KH, int KW, int S, int CT_>
+template <int KH, int KW, int S, int CT_, bool AFFINE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   using C = WgCfg<KH, KW, S, CT_>;
   __shared__ float lds[2 * C::BUF];
+  __shared__ float s_scale[AFFINE ? MAXC : 1], s_shift[AFFINE ? MAXC : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -324,11 +337,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
   const size_t HW = (size_t)a.H * a.W;
   const size_t HoWo = (size_t)a.Ho * a.Wo;
-  const bool affine = a.scale != nullptr;
 
   float pv[C::NI];
   float dv[C::ND];
 
+  const int HWi = a.H * a.W;
+  const int HoWoi = a.Ho * a.Wo;
+  // same split as conv_fwd_kernel: prefetch() = unconditional clamped loads,
+  // stage() = affine + ReLU + padding mask + LDS writes
   auto prefetch = [&](int nt) {
     const int wt = nt % a.WT;
     const int rowid = nt / a.WT;
@@ -336,50 +352,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int b = rowid / a.Ho;
     const int wo0 = wt * PXT;
     const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
-    const float* __restrict__ xb = a.x + ((size_t)b * a.Cin + ci0) * HW;
+    const float* __restrict__ xb = a.x + (size_t)b * a.Cin * HW;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int e = tid + 256 * i;
-      const int cil = e / (KH * C::PW);
-      const int rem = e - cil * (KH * C::PW);
+      const int cil = min(e / (KH * C::PW), C::CT - 1);
+      const int rem = e % (KH * C::PW);
       const int r = rem / C::PW;
       const int c = rem - r * C::PW;
-      const int hi = hi0 + r, wi = wi0 + c;
-      float v = 0.0f;
-      if (e < C::CT * KH * C::PW && ci0 + cil < a.Cin && hi >= 0 && hi < a.H && wi >= 0 &&
-          wi < a.W) {
-        v = xb[(size_t)cil * HW + (size_t)hi * a.W + wi];
-        if (affine) v = v * a.scale[ci0 + cil] + a.shift[ci0 + cil];
-        if (a.relu) v = fmaxf(v, 0.0f);
-      }
-      pv[i] = v;
+      const int ci = min(ci0 + cil, a.Cin - 1);
+      const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
+      pv[i] = xb[ci * HWi + hi * a.W + wi];
     }
     const float* __restrict__ dyb =
-        a.dy + ((size_t)b * a.Cout + (size_t)cot * C::BMW) * HoWo + (size_t)ho * a.Wo + wo0;
+        a.dy + ((size_t)b * a.Cout + (size_t)cot * C::BMW) * HoWo + (size_t)ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
       const int e = tid + 256 * i;
       const int co = e >> 5, px = e & 31;
-      dv[i] = (wo0 + px < a.Wo) ? dyb[(size_t)co * HoWo + px] : 0.0f;
+      dv[i] = dyb[co * HoWoi + min(wo0 + px, a.Wo - 1)];
     }
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](int buf, int nt) {
+    const int wt = nt % a.WT;
+    const int rowid = nt / a.WT;
+    const int ho = rowid % a.Ho;
+    const int wo0 = wt * PXT;
+    const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
     float* __restrict__ pl = lds + buf * C::BUF;
     float* __restrict__ dl = pl + C::PATCH;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int e = tid + 256 * i;
-      if (e < C::CT * KH * C::PW) {
-        const int cil = e / (KH * C::PW);
-        const int rem = e - cil * (KH * C::PW);
-        pl[cil * C::CHS + rem] = pv[i];
+      const int cil = min(e / (KH * C::PW), C::CT - 1);
+      const int rem = e % (KH * C::PW);
+      const int r = rem / C::PW;
+      const int c = rem - r * C::PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      const bool ok = ci0 + cil < a.Cin && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      float v = pv[i];
+      if (AFFINE) {
+        const int ci = min(ci0 + cil, a.Cin - 1);
+        v = v * s_scale[ci] + s_shift[ci];
       }
+      v = a.relu ? fmaxf(v, 0.0f) : v;
+      v = ok ? v : 0.0f;
+      if (e < C::CT * KH * C::PW) pl[cil * C::CHS + rem] = v;
     }
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
       const int e = tid + 256 * i;
       const int co = e >> 5, px = e & 31;
-      dl[px * C::DS + co] = dv[i];
+      dl[px * C::DS + co] = (wo0 + px < a.Wo) ? dv[i] : 0.0f;
     }
   };
 
@@ -387,9 +411,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < C::TAPS; ++t) acc[t] = (f32x16){0};
 
+  if (AFFINE) {
+    for (int e = tid; e < a.Cin; e += 256) {
+      s_scale[e] = a.scale[e];
+      s_shift[e] = a.shift[e];
+    }
+    __syncthreads();
+  }
   if (t_begin < t_end) {
     prefetch(t_begin);
-    stage(0);
+    stage(0, t_begin);
   }
   __syncthreads();
   for (int nt = t_begin; nt < t_end; ++nt) {
@@ -412,7 +443,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
       }
     }
-    if (nt + 1 < t_end) stage(cur ^ 1);
+    if (nt + 1 < t_end) stage(cur ^ 1, nt + 1);
     __syncthreads();
   }
 
@@ -542,7 +573,10 @@ bool shape_ok(const AirConv2d* p) {
 template <int KH, int KW, int S>
 void launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
-  hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  if (a.scale != nullptr)
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, true>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, false>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
 }
 
 // y = conv(act(x), packed w): shared by fwd and stride-1 dgrad
@@ -719,16 +753,28 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
   const double flops = conv_flops(p);
   if (KH == 3 && S == 1) {
     AirProfScope ps(AIR_K_CONV_WG_331, flops, st);
-    hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
+    if (a.scale != nullptr)
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, true>), dim3(nblk), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, false>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 3 && S == 2 && ct == 32) {
     AirProfScope ps(AIR_K_CONV_WG_332, flops, st);
-    hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
+    if (a.scale != nullptr)
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, true>), dim3(nblk), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, false>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 1 && S == 1) {
     AirProfScope ps(AIR_K_CONV_WG_111, flops, st);
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64>), dim3(nblk), dim3(256), 0, st, a);
+    if (a.scale != nullptr)
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, true>), dim3(nblk), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, false>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 1 && S == 2 && ct == 32) {
     AirProfScope ps(AIR_K_CONV_WG_112, flops, st);
-    hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32>), dim3(nblk), dim3(256), 0, st, a);
+    if (a.scale != nullptr)
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, true>), dim3(nblk), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, false>), dim3(nblk), dim3(256), 0, st, a);
   } else {
     return AIR_EUNSUPPORTED;
   }
