@@ -25,6 +25,10 @@
 // dgrad (stride 1) is the same kernel on flipped/transposed packed weights;
 // stride-2 dgrad first zero-upsamples dy.  wgrad is a second implicit GEMM
 // with K = pixels, split over workgroups, reduced deterministically.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "air_common.h"
 #include "air_prof.h"
 
@@ -116,26 +120,31 @@ template <int KH, int KW, int S>
 struct FwdCfg {
   static constexpr int TAPS = KH * KW;
   static constexpr int PW = (PXT - 1) * S + KW;       // patch columns
-  static constexpr int PWP = (S == 2) ? PW + 1 : PW;  // row pitch (even/odd split for S=2)
-  static constexpr int CHS = KH * PWP;                // channel pitch
-  static constexpr int PATCH = CK * CHS;              // floats per wave patch
+  static constexpr int CHS = KH * PW;                 // channel pitch (dense: LDS-DMA is lane-linear)
+  static constexpr int NE = CK * CHS;                 // patch elements per wave
+  static constexpr int NI = (NE + 63) / 64;           // DMA instructions (elements per lane)
+  static constexpr int PATCHP = NI * 64;              // padded so the last DMA stays in the wave's region
   static constexpr int WSLAB = TAPS * CK * BM;        // floats per weight slab
-  static constexpr int NI = (CK * KH * PW + 63) / 64; // patch elements per lane
-  static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);  // float4 per thread
-  static constexpr int BUF = WSLAB + NWAVE * PATCH;   // floats per LDS buffer
+  static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);  // 16-byte DMAs per thread
+  static constexpr int BUF = WSLAB + NWAVE * PATCHP;  // floats per LDS buffer
 };
 
 constexpr int MAXC = 512;  // channels whose BN scale/shift fit the LDS table
 
-template <int KH, int KW, int S, bool AFFINE>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
+// operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
+template <int KH, int KW, int S, int MODE>
 __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   using C = FwdCfg<KH, KW, S>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
-  __shared__ float s_scale[AFFINE ? MAXC : 1], s_shift[AFFINE ? MAXC : 1];
+  __shared__ float s_scale[MODE == 1 ? MAXC : 1], s_shift[MODE == 1 ? MAXC : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -151,104 +160,134 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int hi0 = ho * S - a.ph;
   const int wi0 = wo0 * S - a.pw;
   const size_t HW = (size_t)a.H * a.W;
+  const int HWi = a.H * a.W;
   const int nchunk = a.Cin / CK;
   const float* __restrict__ wslab0 = a.wp + (size_t)cot * nchunk * C::WSLAB;
 
-  float pv[C::NI];
-  f32x4 wv[C::NWV];
-
-  // Staging is split so that NO control flow surrounds the global loads (a branch per load
-  // makes hipcc serialise them behind vmcnt(0) waits):
-  //   prefetch(): unconditional loads from clamped, always-valid addresses -> registers
-  //   stage():    after the chunk's MFMAs, apply BN-affine + ReLU, zero the padding /
-  //               out-of-tile lanes with selects, write LDS.
-  const int HWi = a.H * a.W;
-  const int rowc = min(rowid, a.B * a.Ho - 1);  // clamp so address maths stays in the tensor
+  // Staging = LDS-DMA (global_load_lds): no VGPR round trip, no ds_write pass, no branch.
+  // The patch is copied from CLAMPED (always valid) addresses; zero padding and the
+  // activation are applied when the operand is read.  Per-lane source offsets are
+  // chunk-invariant and live in registers.
+  const int rowc = min(rowid, a.B * a.Ho - 1);  // keep address maths inside the tensor
   const float* __restrict__ xbc = a.x + (size_t)(rowc / a.Ho) * a.Cin * HW;
-  auto prefetch = [&](int chunk) {
+  int goff[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int e = lane + 64 * i;
+    const int cil = min(e / C::CHS, CK - 1);
+    const int rem = e % C::CHS;
+    const int r = rem / C::PW;
+    const int c = rem - r * C::PW;
+    const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
+    goff[i] = cil * HWi + hi * a.W + wi;
+  }
+  auto dma = [&](int chunk, int buf) {
+    float* base = lds + buf * C::BUF;
+    float* pl = base + C::WSLAB + wave * C::PATCHP;
     const float* __restrict__ xc = xbc + (size_t)chunk * CK * HW;
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int e = lane + 64 * i;
-      const int cil = min(e / (KH * C::PW), CK - 1);
-      const int rem = e % (KH * C::PW);
-      const int r = rem / C::PW;
-      const int c = rem - r * C::PW;
-      const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
-      pv[i] = xc[cil * HWi + hi * a.W + wi];
-    }
-    const f32x4* __restrict__ ws4 =
-        reinterpret_cast<const f32x4*>(wslab0 + (size_t)chunk * C::WSLAB);
+    for (int i = 0; i < C::NI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(xc + goff[i]), (lptr_t)(pl + 64 * i), 4, 0, 0);
+    const float* __restrict__ ws = wslab0 + (size_t)chunk * C::WSLAB;
 #pragma unroll
     for (int i = 0; i < C::NWV; ++i) {
-      const int e = tid + NWAVE * 64 * i;
-      wv[i] = ws4[min(e, C::WSLAB / 4 - 1)];
+      const int e0 = (wave + NWAVE * i) * 64;  // first float4 of this wave's DMA (wave-uniform)
+      if (e0 < C::WSLAB / 4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ws + 4 * (e0 + lane)), (lptr_t)(base + 4 * e0), 16,
+                                         0, 0);
     }
   };
-  auto stage = [&](int buf, int chunk) {
-    float* __restrict__ base = lds + buf * C::BUF;
-    float* __restrict__ pl = base + C::WSLAB + wave * C::PATCH;
+
+  // padding masks: row validity per kh (wave-uniform), column validity per (kw, lane)
+  bool okm[C::TAPS];
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int e = lane + 64 * i;
-      const int cil = min(e / (KH * C::PW), CK - 1);
-      const int rem = e % (KH * C::PW);
-      const int r = rem / C::PW;
-      const int c = rem - r * C::PW;
-      const int hi = hi0 + r, wi = wi0 + c;
-      const bool ok = tile_ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      float v = pv[i];
-      if (AFFINE) v = v * s_scale[chunk * CK + cil] + s_shift[chunk * CK + cil];
-      v = a.relu ? fmaxf(v, 0.0f) : v;
-      v = ok ? v : 0.0f;  // zero padding applies to the ACTIVATED tensor
-      // S == 2: even columns first then odd, so a tap reads 32 contiguous floats
-      const int cm = (S == 2) ? ((c & 1) * ((C::PW + 1) / 2) + (c >> 1)) : c;
-      if (e < CK * KH * C::PW) pl[cil * C::CHS + r * C::PWP + cm] = v;
-    }
-    f32x4* __restrict__ wl4 = reinterpret_cast<f32x4*>(base);
+  for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
-    for (int i = 0; i < C::NWV; ++i) {
-      const int e = tid + NWAVE * 64 * i;
-      if (e < C::WSLAB / 4) wl4[e] = wv[i];
+    for (int kw = 0; kw < KW; ++kw) {
+      const int hi = hi0 + kh, wi = wi0 + l31 * S + kw;
+      okm[kh * KW + kw] = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
     }
-  };
+
+  // wave-uniform: the whole patch of this pixel tile lies inside the image
+  const bool interior = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 &&
+                        wi0 + (PXT - 1) * S + KW - 1 < a.W;
 
   f32x16 acc0 = {0}, acc1 = {0};
 
-  if (AFFINE) {
+  if (MODE == 1) {
     for (int e = tid; e < a.Cin; e += NWAVE * 64) {
       s_scale[e] = a.scale[e];
       s_shift[e] = a.shift[e];
     }
-    __syncthreads();
   }
-  prefetch(0);
-  stage(0, 0);
+  dma(0, 0);
   __syncthreads();
+  float scn[CK / 2], shn[CK / 2];
+#pragma unroll
+  for (int st = 0; st < CK / 2; ++st) {
+    scn[st] = MODE == 1 ? s_scale[2 * st + half] : 1.0f;
+    shn[st] = MODE == 1 ? s_shift[2 * st + half] : 0.0f;
+  }
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int cur = chunk & 1;
-    if (chunk + 1 < nchunk) prefetch(chunk + 1);
+    if (chunk + 1 < nchunk) dma(chunk + 1, cur ^ 1);
     const float* __restrict__ wl = lds + cur * C::BUF;
-    const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCH;
+    const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCHP;
+    // BN scale/shift of this chunk's channels were fetched during the previous chunk
+    float sc[CK / 2], sh[CK / 2];
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
+    for (int st = 0; st < CK / 2; ++st) {
+      sc[st] = scn[st];
+      sh[st] = shn[st];
+    }
+    if (MODE == 1 && chunk + 1 < nchunk) {
 #pragma unroll
-      for (int kw = 0; kw < KW; ++kw) {
-        const int tap = kh * KW + kw;
-        const int cbase = (S == 2) ? ((kw & 1) * ((C::PW + 1) / 2) + (kw >> 1)) : kw;
-#pragma unroll
-        for (int st = 0; st < CK / 2; ++st) {
-          const int cil = 2 * st + half;
-          const float bv = pl[cil * C::CHS + kh * C::PWP + cbase + l31];
-          const float a0 = wl[(tap * CK + cil) * BM + l31];
-          const float a1 = wl[(tap * CK + cil) * BM + 32 + l31];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
-        }
+      for (int st = 0; st < CK / 2; ++st) {
+        scn[st] = s_scale[(chunk + 1) * CK + 2 * st + half];
+        shn[st] = s_shift[(chunk + 1) * CK + 2 * st + half];
       }
     }
-    if (chunk + 1 < nchunk) stage(cur ^ 1, chunk + 1);
-    __syncthreads();
+    // k-steps of this chunk: (tap, channel pair).  Operands for step n+1 are read from
+    // LDS before the MFMAs of step n are issued.
+    constexpr int NSTEP = C::TAPS * (CK / 2);
+    auto ld = [&](int n, float& a0, float& a1, float& bv) {
+      const int tap = n / (CK / 2), st = n % (CK / 2);
+      const int kh = tap / KW, kw = tap % KW;
+      const int cil = 2 * st + half;
+      bv = pl[cil * C::CHS + kh * C::PW + kw + l31 * S];
+      a0 = wl[(tap * CK + cil) * BM + l31];
+      a1 = wl[(tap * CK + cil) * BM + 32 + l31];
+    };
+    // 3-stage software pipeline per k-step: LDS read (n+2) | activate + mask (n+1) | MFMA (n),
+    // so neither the LDS round trip nor the VALU chain sits between two MFMAs.  A wave issues
+    // about one instruction per 4 cycles, so the per-MFMA instruction count is what bounds
+    // the matrix pipe: interior tiles (no padding in reach) run a mask-free loop.
+    auto steps = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      auto act = [&](int n, float bv) -> float {
+        if (MODE == 1) bv = fmaxf(bv * sc[n % (CK / 2)] + sh[n % (CK / 2)], 0.0f);
+        if (MASKED) bv = okm[n / (CK / 2)] ? bv : 0.0f;  // zero padding of the activated tensor
+        return bv;
+      };
+      float ra0[3], ra1[3], rb[3];
+      ld(0, ra0[0], ra1[0], rb[0]);
+      if (NSTEP > 1) ld(1, ra0[1], ra1[1], rb[1]);
+      rb[0] = act(0, rb[0]);
+#pragma unroll
+      for (int n = 0; n < NSTEP; ++n) {
+        if (n + 2 < NSTEP) ld(n + 2, ra0[(n + 2) % 3], ra1[(n + 2) % 3], rb[(n + 2) % 3]);
+        if (n + 1 < NSTEP) rb[(n + 1) % 3] = act(n + 1, rb[(n + 1) % 3]);
+        __builtin_amdgcn_sched_barrier(0);  // keep reads / VALU ahead of the MFMAs
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[n % 3], rb[n % 3], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[n % 3], rb[n % 3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (interior)
+      steps(std::false_type{});
+    else
+      steps(std::true_type{});
+    __syncthreads();  // drains the DMA (vmcnt) and fences the buffer swap
   }
 
   // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel
@@ -305,24 +344,27 @@ struct WgCfg {
   static constexpr int NWCO = 4 / NWCI;                // waves along co
   static constexpr int BMW = 32 * NWCO;                // co per workgroup
   static constexpr int PW = (PXT - 1) * S + KW;
-  static constexpr int CHS = (KH * PW) | 1;            // odd channel pitch: conflict-free ci-strided reads
-  static constexpr int PATCH = CT * CHS;
-  static constexpr int DS = BMW + 1;                   // dy tile pitch [px][co], odd
-  static constexpr int DYT = PXT * DS;
-  static constexpr int BUF = PATCH + DYT;
-  static constexpr int NI = (CT * KH * PW + 255) / 256;  // patch elements per thread
-  static constexpr int ND = (BMW * PXT) / 256;           // dy elements per thread
+  static constexpr int CHS = KH * PW;                  // dense channel pitch (LDS-DMA is lane-linear)
+  static constexpr int NE = CT * CHS;                  // patch elements per workgroup
+  static constexpr int NI = (NE + 255) / 256;          // patch DMA instructions per wave
+  static constexpr int PATCHP = NI * 256;              // padded to whole instructions
+  static constexpr int DPAIR = 65;                     // pitch of a 2-row (2 x 32 px) dy DMA: odd
+  static constexpr int ND = BMW / 2 / 4;               // dy DMA instructions per wave
+  static constexpr int DYT = (BMW / 2) * DPAIR;
+  static constexpr int BUF = PATCHP + DYT;
 };
 
-template <int KH, int KW, int S, int CT_, bool AFFINE>
+// MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]), applied to the B
+// operand after it is read from LDS (lanes = channels, so scale/shift are two registers).
+// Staging is LDS-DMA from clamped addresses; padding is masked at operand-read time.
+template <int KH, int KW, int S, int CT_, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   using C = WgCfg<KH, KW, S, CT_>;
-  __shared__ float lds[2 * C::BUF];
-  __shared__ float s_scale[AFFINE ? MAXC : 1], s_shift[AFFINE ? MAXC : 1];
+  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int mt = wave % C::NWCO;  // co sub-tile
   const int ch = wave / C::NWCO;  // ci sub-tile
@@ -335,75 +377,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int ci0 = cit * C::CT;
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int HWi = a.H * a.W;
+  const int HoWoi = a.Ho * a.Wo;
   const size_t HW = (size_t)a.H * a.W;
   const size_t HoWo = (size_t)a.Ho * a.Wo;
 
-  float pv[C::NI];
-  float dv[C::ND];
+  // this lane's channel for the B operand
+  const int ci = ci0 + ch * 32 + l31;
+  const bool ci_ok = ci < a.Cin;
+  float sc = 1.0f, sh = 0.0f;
+  if (MODE == 1) {
+    sc = a.scale[min(ci, a.Cin - 1)];
+    sh = a.shift[min(ci, a.Cin - 1)];
+  }
 
-  const int HWi = a.H * a.W;
-  const int HoWoi = a.Ho * a.Wo;
-  // same split as conv_fwd_kernel: prefetch() = unconditional clamped loads,
-  // stage() = affine + ReLU + padding mask + LDS writes
-  auto prefetch = [&](int nt) {
+  // Tile-invariant part of every lane's patch source offset: element e -> (cil, r, c).
+  // For interior tiles the address is just tile_base + eoff[i] (one SGPR base, no VALU).
+  int eoff[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int e = 256 * i + 64 * wave + lane;
+    const int cil = min(e / C::CHS, C::CT - 1);
+    const int rem = e % C::CHS;
+    const int r = rem / C::PW;
+    eoff[i] = min(ci0 + cil, a.Cin - 1) * HWi + r * a.W + (rem - r * C::PW);
+  }
+  auto dma = [&](int nt, int buf) {
     const int wt = nt % a.WT;
     const int rowid = nt / a.WT;
     const int ho = rowid % a.Ho;
     const int b = rowid / a.Ho;
     const int wo0 = wt * PXT;
     const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
+    float* pl = lds + buf * C::BUF;
+    float* dl = pl + C::PATCHP;
     const float* __restrict__ xb = a.x + (size_t)b * a.Cin * HW;
+    const bool inside = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 && wi0 + C::PW - 1 < a.W;
+    if (inside) {  // wave-uniform
+      const float* __restrict__ xt = xb + (hi0 * a.W + wi0);
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int e = tid + 256 * i;
-      const int cil = min(e / (KH * C::PW), C::CT - 1);
-      const int rem = e % (KH * C::PW);
-      const int r = rem / C::PW;
-      const int c = rem - r * C::PW;
-      const int ci = min(ci0 + cil, a.Cin - 1);
-      const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
-      pv[i] = xb[ci * HWi + hi * a.W + wi];
+      for (int i = 0; i < C::NI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xt + eoff[i]), (lptr_t)(pl + 256 * i + 64 * wave),
+                                         4, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i) {
+        const int e = 256 * i + 64 * wave + lane;
+        const int cil = min(e / C::CHS, C::CT - 1);
+        const int rem = e % C::CHS;
+        const int r = rem / C::PW;
+        const int c = rem - r * C::PW;
+        const int cc = min(ci0 + cil, a.Cin - 1);
+        const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + cc * HWi + hi * a.W + wi),
+                                         (lptr_t)(pl + 256 * i + 64 * wave), 4, 0, 0);
+      }
     }
+    // dy rows (co pairs): lane -> (co = 2j + half, px = l31), column clamped to the row
     const float* __restrict__ dyb =
         a.dy + ((size_t)b * a.Cout + (size_t)cot * C::BMW) * HoWo + (size_t)ho * a.Wo;
+    const int dyo = half * HoWoi + min(wo0 + l31, a.Wo - 1);
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
-      const int e = tid + 256 * i;
-      const int co = e >> 5, px = e & 31;
-      dv[i] = dyb[co * HoWoi + min(wo0 + px, a.Wo - 1)];
-    }
-  };
-  auto stage = [&](int buf, int nt) {
-    const int wt = nt % a.WT;
-    const int rowid = nt / a.WT;
-    const int ho = rowid % a.Ho;
-    const int wo0 = wt * PXT;
-    const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
-    float* __restrict__ pl = lds + buf * C::BUF;
-    float* __restrict__ dl = pl + C::PATCH;
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int e = tid + 256 * i;
-      const int cil = min(e / (KH * C::PW), C::CT - 1);
-      const int rem = e % (KH * C::PW);
-      const int r = rem / C::PW;
-      const int c = rem - r * C::PW;
-      const int hi = hi0 + r, wi = wi0 + c;
-      const bool ok = ci0 + cil < a.Cin && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      float v = pv[i];
-      if (AFFINE) {
-        const int ci = min(ci0 + cil, a.Cin - 1);
-        v = v * s_scale[ci] + s_shift[ci];
-      }
-      v = a.relu ? fmaxf(v, 0.0f) : v;
-      v = ok ? v : 0.0f;
-      if (e < C::CT * KH * C::PW) pl[cil * C::CHS + rem] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < C::ND; ++i) {
-      const int e = tid + 256 * i;
-      const int co = e >> 5, px = e & 31;
-      dl[px * C::DS + co] = (wo0 + px < a.Wo) ? dv[i] : 0.0f;
+      const int j = wave + 4 * i;  // row pair
+      __builtin_amdgcn_global_load_lds((gptr_t)(dyb + 2 * j * HoWoi + dyo),
+                                       (lptr_t)(dl + j * C::DPAIR), 4, 0, 0);
     }
   };
 
@@ -411,45 +449,89 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < C::TAPS; ++t) acc[t] = (f32x16){0};
 
-  if (AFFINE) {
-    for (int e = tid; e < a.Cin; e += 256) {
-      s_scale[e] = a.scale[e];
-      s_shift[e] = a.shift[e];
-    }
-    __syncthreads();
-  }
-  if (t_begin < t_end) {
-    prefetch(t_begin);
-    stage(0, t_begin);
-  }
+  if (t_begin < t_end) dma(t_begin, 0);
   __syncthreads();
   for (int nt = t_begin; nt < t_end; ++nt) {
     const int cur = (nt - t_begin) & 1;
-    if (nt + 1 < t_end) prefetch(nt + 1);
+    if (nt + 1 < t_end) dma(nt + 1, cur ^ 1);
+    const int wt = nt % a.WT;
+    const int ho = (nt / a.WT) % a.Ho;
+    const int wo0 = wt * PXT;
+    const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
     const float* __restrict__ pl = lds + cur * C::BUF;
-    const float* __restrict__ dl = pl + C::PATCH;
+    const float* __restrict__ dl = pl + C::PATCHP;
     const float* __restrict__ pbase = pl + (ch * 32 + l31) * C::CHS;
-#pragma unroll 4
-    for (int st = 0; st < PXT / 2; ++st) {
-      const int px = 2 * st + half;
-      const float av = dl[px * C::DS + mt * 32 + l31];
+    const int aco = mt * 32 + l31;
+    const float* __restrict__ abase = dl + (aco >> 1) * C::DPAIR + (aco & 1) * 32;
+    bool rok[KH];
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh) {
+    for (int kh = 0; kh < KH; ++kh) rok[kh] = ci_ok && hi0 + kh >= 0 && hi0 + kh < a.H;
+    // valid patch columns c (= px*S + kw) of this tile: [cmin, cmax]; per lane the test is
+    // done on the compile-time part of c, so fold the lane's half*S into the bounds
+    const int clo = max(0, -wi0) - half * S;
+    const unsigned cspan = (unsigned)(min(C::PW - 1, a.W - 1 - wi0) - half * S - clo);
+    const int pxmax = a.Wo - wo0 - half;  // px = 2 st + half is a real pixel iff 2 st < pxmax
+
+    // 16 k-steps (pixel pairs) x TAPS MFMAs.  Software pipeline, interleaved PER MFMA so the
+    // VALU/LDS work of the following steps issues in the shadow of each 64-cycle MFMA:
+    //   tap t of step n+2: LDS read | tap t of step n+1: activate (+ mask) | tap t of step n: MFMA
+    // One wave issues ~1 instruction per 4 cycles, so instructions per MFMA bound the matrix
+    // pipe: interior tiles (no padding, full row, real channels) take the mask-free loop.
+    const bool interior = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 &&
+                          wi0 + C::PW - 1 < a.W && wo0 + PXT <= a.Wo && ci0 + C::CT <= a.Cin;
+    auto ldb = [&](int st, int t) -> float {
+      const int kh = t / KW, kw = t % KW;
+      return pbase[kh * C::PW + (2 * st + half) * S + kw];
+    };
+    auto steps = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+      auto actb = [&](int st, int t, float v) -> float {
+        const int kh = t / KW, kw = t % KW;
+        if (MODE == 1) v = fmaxf(v * sc + sh, 0.0f);
+        if (MASKED) {
+          const bool ok = rok[kh] && (unsigned)(2 * st * S + kw - clo) <= cspan;
+          v = ok ? v : 0.0f;
+        }
+        return v;
+      };
+      float ra[3], rb[3][C::TAPS];
+      ra[0] = abase[half];
+      ra[1] = abase[2 + half];
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-          const float bv = pbase[kh * C::PW + px * S + kw];
-          acc[kh * KW + kw] =
-              __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * KW + kw], 0, 0, 0);
+      for (int t = 0; t < C::TAPS; ++t) {
+        rb[0][t] = actb(0, t, ldb(0, t));
+        rb[1][t] = ldb(1, t);
+      }
+      if (MASKED) ra[0] = (0 < pxmax) ? ra[0] : 0.0f;
+#pragma unroll
+      for (int st = 0; st < PXT / 2; ++st) {
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+          if (st + 2 < PXT / 2) {
+            if (t == 0) ra[(st + 2) % 3] = abase[2 * (st + 2) + half];
+            rb[(st + 2) % 3][t] = ldb(st + 2, t);
+          }
+          if (st + 1 < PXT / 2) {
+            if (MASKED && t == 0)
+              ra[(st + 1) % 3] = (2 * (st + 1) < pxmax) ? ra[(st + 1) % 3] : 0.0f;
+            rb[(st + 1) % 3][t] = actb(st + 1, t, rb[(st + 1) % 3][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[st % 3], rb[st % 3][t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
-    if (nt + 1 < t_end) stage(cur ^ 1, nt + 1);
-    __syncthreads();
+    };
+    if (interior)
+      steps(std::false_type{});
+    else
+      steps(std::true_type{});
+    __syncthreads();  // drains the DMA (vmcnt) and fences the buffer swap
   }
 
-  // D[i = co][j = ci] per tap -> partial[split][co][ci][tap]
-  const int ci = ci0 + ch * 32 + l31;
-  if (ci >= a.Cin) return;
+  // D[i = co][j = ci] per tap -> partial[split][tap][co][ci]: lanes = consecutive ci, so
+  // every store is a 128-byte row segment (reduce_partials_kernel restores [co][ci][tap])
+  if (!ci_ok) return;
   float* __restrict__ out = a.partial + (size_t)split * a.Cout * a.Cin * C::TAPS;
 #pragma unroll
   for (int t = 0; t < C::TAPS; ++t) {
@@ -457,18 +539,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
       const int co = cot * C::BMW + mt * 32 + i;
-      out[((size_t)co * a.Cin + ci) * C::TAPS + t] = acc[t][r];
+      out[((size_t)t * a.Cout + co) * a.Cin + ci] = acc[t][r];
     }
   }
 }
 
+// dw[e] = sum_k partial[k][e]; with taps > 0 the partials are [tap][co*ci] and dw is [co*ci][tap]
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                       size_t n, int nsplit) {
+                                       size_t n, int nsplit, int taps) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
        e += (size_t)gridDim.x * blockDim.x) {
     float s = 0.0f;
     for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
-    dw[e] = s;
+    if (taps > 1) {
+      const size_t plane = n / taps;  // Cout*Cin
+      const size_t t = e / plane, cc = e - t * plane;
+      dw[cc * taps + t] = s;
+    } else {
+      dw[e] = s;
+    }
   }
 }
 
@@ -574,9 +663,9 @@ template <int KH, int KW, int S>
 void launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
   if (a.scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, true>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, false>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
 }
 
 // y = conv(act(x), packed w): shared by fwd and stride-1 dgrad
@@ -623,7 +712,8 @@ int wgrad_nsplit(const AirConv2d* p) {
   const int ntiles = p->B * p->Ho * WT;
   const int ct = wgrad_ct(p);
   const int ncot = p->Cout / (ct == 32 ? 128 : 64), ncit = (p->Cin + ct - 1) / ct;
-  int target = 1024 / (ncot * ncit);  // ~4 workgroups per CU in total
+  static const int total = getenv("AIR_WGRAD_WGS") ? atoi(getenv("AIR_WGRAD_WGS")) : 256;
+  int target = total / (ncot * ncit);  // workgroups in flight over the whole chip
   if (target < 1) target = 1;
   if (target > ntiles) target = ntiles;
   return target;
@@ -673,6 +763,9 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
     return AIR_OK;
   }
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  // fused prologue = BatchNorm-apply + ReLU together (the pre-activation block), or none
+  if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;
+  if (in_scale != nullptr && p->Cin > MAXC) return AIR_EUNSUPPORTED;
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
   if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
   float* wp = reinterpret_cast<float*>(ws);
@@ -730,11 +823,12 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
     AIR_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(ws), dw, wsz, rows);
+                       reinterpret_cast<const float*>(ws), dw, wsz, rows, 1);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
   }
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;  // BN-apply + ReLU together, or none
   WgradArgs a;
   a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(ws);
   a.scale = in_scale; a.shift = in_shift;
@@ -754,33 +848,33 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
   if (KH == 3 && S == 1) {
     AirProfScope ps(AIR_K_CONV_WG_331, flops, st);
     if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, true>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, 1>), dim3(nblk), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, false>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, 0>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 3 && S == 2 && ct == 32) {
     AirProfScope ps(AIR_K_CONV_WG_332, flops, st);
     if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, true>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, 1>), dim3(nblk), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, false>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, 0>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 1 && S == 1) {
     AirProfScope ps(AIR_K_CONV_WG_111, flops, st);
     if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, true>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, 1>), dim3(nblk), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, false>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, 0>), dim3(nblk), dim3(256), 0, st, a);
   } else if (KH == 1 && S == 2 && ct == 32) {
     AirProfScope ps(AIR_K_CONV_WG_112, flops, st);
     if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, true>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, 1>), dim3(nblk), dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, false>), dim3(nblk), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, 0>), dim3(nblk), dim3(256), 0, st, a);
   } else {
     return AIR_EUNSUPPORTED;
   }
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
-                     reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit);
+                     reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit, p->KH * p->KW);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
