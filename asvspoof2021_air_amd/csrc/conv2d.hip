@@ -37,39 +37,44 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CK = 8;        // input channels per K chunk
 constexpr int BM = 64;       // output channels per workgroup
 constexpr int NWAVE = 4;     // waves (= pixel tiles) per workgroup
 constexpr int PXT = 32;      // output pixels per pixel tile
 
 // ------------------------------------------------------------------ packing
-// forward:  Wp[cot][chunk][tap][cil][col] = W[cot*64+col][chunk*8+cil][tap]
-// dgrad:    roles swapped, taps flipped: Wp[...] = W[chunk*8+cil][cot*64+col][T-1-tap]
+// forward:  Wp[cot][chunk][tap][cil][col] = W[cot*64+col][chunk*ck+cil][sel[tap]]
+// dgrad:    roles swapped:               = W[chunk*ck+cil][cot*64+col][sel[tap]]
+// sel lists the source taps (all taps in order for a forward conv, flipped for a stride-1
+// dgrad, one parity class for a stride-2 dgrad).
+struct TapSel {
+  int n;
+  int idx[9];
+};
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                    int Cin, int taps, int transpose_flip) {
+                                    int Cin, int taps_full, int transpose, int ck, TapSel sel) {
   // logical (M = "out" role, Kc = "in" role)
-  const int M = transpose_flip ? Cin : Cout;
-  const int Kc = transpose_flip ? Cout : Cin;
+  const int M = transpose ? Cin : Cout;
+  const int Kc = transpose ? Cout : Cin;
   const int Mpad = (M + BM - 1) / BM * BM;  // channel tiles are zero-padded to 64
-  const size_t total = (size_t)Mpad * Kc * taps;
+  const size_t total = (size_t)Mpad * Kc * sel.n;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % BM);
     size_t r = e / BM;
-    const int cil = (int)(r % CK);
-    r /= CK;
-    const int tap = (int)(r % taps);
-    r /= taps;
-    const int nchunk = Kc / CK;
+    const int cil = (int)(r % ck);
+    r /= ck;
+    const int tap = (int)(r % sel.n);
+    r /= sel.n;
+    const int nchunk = Kc / ck;
     const int chunk = (int)(r % nchunk);
     const int cot = (int)(r / nchunk);
-    const int m = cot * BM + col, k = chunk * CK + cil;
+    const int m = cot * BM + col, k = chunk * ck + cil;
     float v = 0.0f;
     if (m < M) {
-      if (!transpose_flip)
-        v = w[((size_t)m * Cin + k) * taps + tap];
-      else
-        v = w[((size_t)k * Cin + m) * taps + (taps - 1 - tap)];
+      const int src = sel.idx[tap];
+      v = transpose ? w[((size_t)k * Cin + m) * taps_full + src]
+                    : w[((size_t)m * Cin + k) * taps_full + src];
     }
     wp[e] = v;
   }
@@ -105,6 +110,10 @@ struct FwdArgs {
   int ntiles;    // B*Ho*WT
   int npxg;      // pixel-tile groups (ntiles / NWAVE, rounded up)
   int ncot;      // Cout / 64
+  // output addressing: pixel (ho, wo) -> (ho*oh_mul)*ow_row + wo*ow_mul + o_off in a plane of
+  // oplane floats (a plain conv: 1, Wo, 1, 0, Ho*Wo)
+  int oh_mul, ow_row, ow_mul, o_off;
+  size_t oplane;
 };
 
 // XCD-aware logical block index: hardware places block b on XCD b % 8; give each
@@ -116,15 +125,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + slot;
 }
 
-template <int KH, int KW, int S>
+// CKT = input channels per K chunk (8 for 3x3; more for 1-4 tap kernels so a chunk still
+// holds >= 16 k-steps between barriers)
+template <int KH, int KW, int S, int CKT>
 struct FwdCfg {
   static constexpr int TAPS = KH * KW;
   static constexpr int PW = (PXT - 1) * S + KW;       // patch columns
   static constexpr int CHS = KH * PW;                 // channel pitch (dense: LDS-DMA is lane-linear)
-  static constexpr int NE = CK * CHS;                 // patch elements per wave
+  static constexpr int NE = CKT * CHS;                 // patch elements per wave
   static constexpr int NI = (NE + 63) / 64;           // DMA instructions (elements per lane)
   static constexpr int PATCHP = NI * 64;              // padded so the last DMA stays in the wave's region
-  static constexpr int WSLAB = TAPS * CK * BM;        // floats per weight slab
+  static constexpr int WSLAB = TAPS * CKT * BM;        // floats per weight slab
   static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);  // 16-byte DMAs per thread
   static constexpr int BUF = WSLAB + NWAVE * PATCHP;  // floats per LDS buffer
 };
@@ -136,9 +147,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
 // operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
-template <int KH, int KW, int S, int MODE>
+template <int KH, int KW, int S, int MODE, int CKT>
 __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
-  using C = FwdCfg<KH, KW, S>;
+  using C = FwdCfg<KH, KW, S, CKT>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
   __shared__ float s_scale[MODE == 1 ? MAXC : 1], s_shift[MODE == 1 ? MAXC : 1];
 
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int wi0 = wo0 * S - a.pw;
   const size_t HW = (size_t)a.H * a.W;
   const int HWi = a.H * a.W;
-  const int nchunk = a.Cin / CK;
+  const int nchunk = a.Cin / CKT;
   const float* __restrict__ wslab0 = a.wp + (size_t)cot * nchunk * C::WSLAB;
 
   // Staging = LDS-DMA (global_load_lds): no VGPR round trip, no ds_write pass, no branch.
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
     const int e = lane + 64 * i;
-    const int cil = min(e / C::CHS, CK - 1);
+    const int cil = min(e / C::CHS, CKT - 1);
     const int rem = e % C::CHS;
     const int r = rem / C::PW;
     const int c = rem - r * C::PW;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   auto dma = [&](int chunk, int buf) {
     float* base = lds + buf * C::BUF;
     float* pl = base + C::WSLAB + wave * C::PATCHP;
-    const float* __restrict__ xc = xbc + (size_t)chunk * CK * HW;
+    const float* __restrict__ xc = xbc + (size_t)chunk * CKT * HW;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(xc + goff[i]), (lptr_t)(pl + 64 * i), 4, 0, 0);
@@ -222,9 +233,9 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   }
   dma(0, 0);
   __syncthreads();
-  float scn[CK / 2], shn[CK / 2];
+  float scn[CKT / 2], shn[CKT / 2];
 #pragma unroll
-  for (int st = 0; st < CK / 2; ++st) {
+  for (int st = 0; st < CKT / 2; ++st) {
     scn[st] = MODE == 1 ? s_scale[2 * st + half] : 1.0f;
     shn[st] = MODE == 1 ? s_shift[2 * st + half] : 0.0f;
   }
@@ -234,29 +245,29 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     const float* __restrict__ wl = lds + cur * C::BUF;
     const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCHP;
     // BN scale/shift of this chunk's channels were fetched during the previous chunk
-    float sc[CK / 2], sh[CK / 2];
+    float sc[CKT / 2], sh[CKT / 2];
 #pragma unroll
-    for (int st = 0; st < CK / 2; ++st) {
+    for (int st = 0; st < CKT / 2; ++st) {
       sc[st] = scn[st];
       sh[st] = shn[st];
     }
     if (MODE == 1 && chunk + 1 < nchunk) {
 #pragma unroll
-      for (int st = 0; st < CK / 2; ++st) {
-        scn[st] = s_scale[(chunk + 1) * CK + 2 * st + half];
-        shn[st] = s_shift[(chunk + 1) * CK + 2 * st + half];
+      for (int st = 0; st < CKT / 2; ++st) {
+        scn[st] = s_scale[(chunk + 1) * CKT + 2 * st + half];
+        shn[st] = s_shift[(chunk + 1) * CKT + 2 * st + half];
       }
     }
     // k-steps of this chunk: (tap, channel pair).  Operands for step n+1 are read from
     // LDS before the MFMAs of step n are issued.
-    constexpr int NSTEP = C::TAPS * (CK / 2);
+    constexpr int NSTEP = C::TAPS * (CKT / 2);
     auto ld = [&](int n, float& a0, float& a1, float& bv) {
-      const int tap = n / (CK / 2), st = n % (CK / 2);
+      const int tap = n / (CKT / 2), st = n % (CKT / 2);
       const int kh = tap / KW, kw = tap % KW;
       const int cil = 2 * st + half;
       bv = pl[cil * C::CHS + kh * C::PW + kw + l31 * S];
-      a0 = wl[(tap * CK + cil) * BM + l31];
-      a1 = wl[(tap * CK + cil) * BM + 32 + l31];
+      a0 = wl[(tap * CKT + cil) * BM + l31];
+      a1 = wl[(tap * CKT + cil) * BM + 32 + l31];
     };
     // 3-stage software pipeline per k-step: LDS read (n+2) | activate + mask (n+1) | MFMA (n),
     // so neither the LDS round trip nor the VALU chain sits between two MFMAs.  A wave issues
@@ -265,8 +276,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     auto steps = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
       auto act = [&](int n, float bv) -> float {
-        if (MODE == 1) bv = fmaxf(bv * sc[n % (CK / 2)] + sh[n % (CK / 2)], 0.0f);
-        if (MASKED) bv = okm[n / (CK / 2)] ? bv : 0.0f;  // zero padding of the activated tensor
+        if (MODE == 1) bv = fmaxf(bv * sc[n % (CKT / 2)] + sh[n % (CKT / 2)], 0.0f);
+        if (MASKED) bv = okm[n / (CKT / 2)] ? bv : 0.0f;  // zero padding of the activated tensor
         return bv;
       };
       float ra0[3], ra1[3], rb[3];
@@ -290,17 +301,20 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     __syncthreads();  // drains the DMA (vmcnt) and fences the buffer swap
   }
 
-  // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel
+  // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel.
+  // Output pixel (ho, wo) lands at y[(ho*oh_mul)*ow_row + wo*ow_mul + o_off] of its channel
+  // plane (identity for a plain conv; a parity class of a stride-2 dgrad otherwise).
   if (!tile_ok) return;
   const int wo = wo0 + l31;
   if (wo >= a.Wo) return;
-  const size_t HoWo = (size_t)a.Ho * a.Wo;
-  const size_t obase = ((size_t)b * a.Cout + (size_t)cot * BM) * HoWo + (size_t)ho * a.Wo + wo;
+  const size_t oplane = a.oplane;
+  const size_t obase = ((size_t)b * a.Cout + (size_t)cot * BM) * oplane +
+                       (size_t)(ho * a.oh_mul) * a.ow_row + (size_t)wo * a.ow_mul + a.o_off;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const size_t o0 = obase + (size_t)i * HoWo;
-    const size_t o1 = o0 + 32 * HoWo;
+    const size_t o0 = obase + (size_t)i * oplane;
+    const size_t o1 = o0 + 32 * oplane;
     const int co = cot * BM + i;
     if (co < a.Cout) {
       float v0 = acc0[r];
@@ -647,7 +661,7 @@ int grid_for(size_t n, int per_block = 256, int cap = 256 * 16) {
 bool generic_ok(const AirConv2d* p) {
   const bool k33 = p->KH == 3 && p->KW == 3, k11 = p->KH == 1 && p->KW == 1;
   const bool s_ok = (p->sh == 1 && p->sw == 1) || (p->sh == 2 && p->sw == 2);
-  return (k33 || k11) && s_ok && p->sh == p->sw && p->Cin % CK == 0 && p->Cout % BM == 0;
+  return (k33 || k11) && s_ok && p->sh == p->sw && p->Cin % 8 == 0 && p->Cout % BM == 0;
 }
 bool direct_ok(const AirConv2d* p) {
   return p->Cout <= 16 && p->Cout * p->Cin * p->KH * p->KW <= DIRECT_MAX_W;
@@ -659,42 +673,78 @@ bool shape_ok(const AirConv2d* p) {
          p->Wo == (p->W + 2 * p->pw - p->KW) / p->sw + 1 && p->Ho > 0 && p->Wo > 0;
 }
 
-template <int KH, int KW, int S>
+struct FwdGeom {
+  int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
+  int oh_mul, ow_row, ow_mul, o_off;  // output addressing (see FwdArgs)
+  size_t oplane;
+};
+
+FwdGeom plain_geom(int B, int Cin, int H, int W, int Cout, int KH, int KW, int S, int ph, int pw,
+                   int Ho, int Wo) {
+  FwdGeom g = {B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo, 1, Wo, 1, 0, (size_t)Ho * Wo};
+  return g;
+}
+
+// channels per K chunk: keep >= 16 k-steps between barriers for 1-4 tap kernels
+int pick_ck(int taps, int cin) {
+  if (taps >= 4) return 8;
+  if (taps == 2) return cin % 16 == 0 ? 16 : 8;
+  return cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 8);
+}
+
+template <int KH, int KW, int S, int CKT>
 void launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
   if (a.scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1, CKT>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0, CKT>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
 }
 
-// y = conv(act(x), packed w): shared by fwd and stride-1 dgrad
+// y = conv(act(x), packed w): shared by fwd and every dgrad
 int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
-            int relu, const float* residual, int B, int Cin, int H, int W, int Cout, int KH, int S,
-            int ph, int pw, int Ho, int Wo, double flops, hipStream_t st) {
+            int relu, const float* residual, const FwdGeom& g, int ck, double flops,
+            hipStream_t st) {
   FwdArgs a;
   a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
-  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
-  a.ph = ph; a.pw = pw; a.relu = relu;
-  a.WT = (Wo + PXT - 1) / PXT;
-  a.ntiles = B * Ho * a.WT;
+  a.B = g.B; a.Cin = g.Cin; a.H = g.H; a.W = g.W; a.Cout = g.Cout; a.Ho = g.Ho; a.Wo = g.Wo;
+  a.ph = g.ph; a.pw = g.pw; a.relu = relu;
+  a.WT = (g.Wo + PXT - 1) / PXT;
+  a.ntiles = g.B * g.Ho * a.WT;
   a.npxg = (a.ntiles + NWAVE - 1) / NWAVE;
-  a.ncot = (Cout + BM - 1) / BM;
-  if (KH == 3 && S == 1) {
-    AirProfScope ps(AIR_K_CONV_FWD_331, flops, st);
-    launch_fwd<3, 3, 1>(a, st);
-  } else if (KH == 3 && S == 2) {
-    AirProfScope ps(AIR_K_CONV_FWD_332, flops, st);
-    launch_fwd<3, 3, 2>(a, st);
-  } else if (KH == 1 && S == 1) {
-    AirProfScope ps(AIR_K_CONV_FWD_111, flops, st);
-    launch_fwd<1, 1, 1>(a, st);
-  } else if (KH == 1 && S == 2) {
-    AirProfScope ps(AIR_K_CONV_FWD_112, flops, st);
-    launch_fwd<1, 1, 2>(a, st);
-  } else {
-    return AIR_EUNSUPPORTED;
+  a.ncot = (g.Cout + BM - 1) / BM;
+  a.oh_mul = g.oh_mul; a.ow_row = g.ow_row; a.ow_mul = g.ow_mul; a.o_off = g.o_off;
+  a.oplane = g.oplane;
+  if (g.Cin % ck != 0) return AIR_EUNSUPPORTED;
+  const int key = g.KH * 1000 + g.KW * 100 + g.S * 10;
+#define AIR_FWD_CASE(KH_, KW_, S_, CK_, KID_)                     \
+  if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 && ck == CK_) {      \
+    AirProfScope ps(KID_, flops, st);                              \
+    launch_fwd<KH_, KW_, S_, CK_>(a, st);                          \
+    AIR_CHECK_LAUNCH();                                            \
+    return AIR_OK;                                                 \
   }
+  AIR_FWD_CASE(3, 3, 1, 8, AIR_K_CONV_FWD_331)
+  AIR_FWD_CASE(3, 3, 2, 8, AIR_K_CONV_FWD_332)
+  AIR_FWD_CASE(1, 1, 1, 32, AIR_K_CONV_FWD_111)
+  AIR_FWD_CASE(1, 1, 1, 16, AIR_K_CONV_FWD_111)
+  AIR_FWD_CASE(1, 1, 1, 8, AIR_K_CONV_FWD_111)
+  AIR_FWD_CASE(1, 1, 2, 32, AIR_K_CONV_FWD_112)
+  AIR_FWD_CASE(1, 1, 2, 16, AIR_K_CONV_FWD_112)
+  AIR_FWD_CASE(1, 1, 2, 8, AIR_K_CONV_FWD_112)
+  AIR_FWD_CASE(1, 2, 1, 16, AIR_K_CONV_FWD_CLS)
+  AIR_FWD_CASE(2, 1, 1, 16, AIR_K_CONV_FWD_CLS)
+  AIR_FWD_CASE(2, 2, 1, 8, AIR_K_CONV_FWD_CLS)
+#undef AIR_FWD_CASE
+  return AIR_EUNSUPPORTED;
+}
+
+int pack(const float* w, float* wp, int Cout, int Cin, int taps_full, int transpose, int ck,
+         const TapSel& sel, hipStream_t st) {
+  const int M = transpose ? Cin : Cout, Kc = transpose ? Cout : Cin;
+  const size_t n = (size_t)((M + BM - 1) / BM * BM) * Kc * sel.n;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, wp, Cout, Cin,
+                     taps_full, transpose, ck, sel);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -723,11 +773,6 @@ size_t packed_dgrad_elems(const AirConv2d* p) {  // dgrad packs with Cin padded 
   return (size_t)((p->Cin + BM - 1) / BM * BM) * p->Cout * p->KH * p->KW;
 }
 
-size_t up_elems(const AirConv2d* p) {  // zero-upsampled dy for stride-2 dgrad
-  if (p->sh == 1) return 0;
-  const int Hu = p->H + 2 * p->ph - p->KH + 1 + 0, Wu = p->W + 2 * p->pw - p->KW + 1;
-  return (size_t)p->B * p->Cout * Hu * Wu;
-}
 
 }  // namespace
 
@@ -739,7 +784,7 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   if (direct_ok(p)) return (size_t)p->B * p->Ho * wsz * sizeof(float) + 256;
   if (!generic_ok(p)) return 0;
   const size_t fwd = wsz;
-  const size_t dgrad = packed_dgrad_elems(p) + up_elems(p);
+  const size_t dgrad = packed_dgrad_elems(p);
   const size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (wgrad > m) m = wgrad;
@@ -769,11 +814,17 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
   if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
   float* wp = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(wsz)), dim3(256), 0, st, w, wp, p->Cout,
-                     p->Cin, p->KH * p->KW, 0);
-  AIR_CHECK_LAUNCH();
-  return run_fwd(x, wp, y, in_scale, in_shift, relu, residual, p->B, p->Cin, p->H, p->W, p->Cout,
-                 p->KH, p->sh, p->ph, p->pw, p->Ho, p->Wo, conv_flops(p), st);
+  const int taps = p->KH * p->KW;
+  const int ck = pick_ck(taps, p->Cin);
+  TapSel sel;
+  sel.n = taps;
+  for (int t = 0; t < taps; ++t) sel.idx[t] = t;
+  int rc = pack(w, wp, p->Cout, p->Cin, taps, 0, ck, sel, st);
+  if (rc != AIR_OK) return rc;
+  return run_fwd(x, wp, y, in_scale, in_shift, relu, residual,
+                 plain_geom(p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW, p->sh, p->ph, p->pw,
+                            p->Ho, p->Wo),
+                 ck, conv_flops(p), st);
 }
 
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
@@ -782,29 +833,72 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
   hipStream_t st = air_stream(stream);
   const size_t wsz = packed_dgrad_elems(p);
-  const size_t ups = up_elems(p);
-  if (!ws || ws_bytes < (wsz + ups) * sizeof(float)) return AIR_EWORKSPACE;
+  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
   float* wp = reinterpret_cast<float*>(ws);
-  // roles swap: "input" channels = Cout, "output" channels = Cin; taps flipped
-  if (p->Cout % CK != 0) return AIR_EUNSUPPORTED;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(wsz)), dim3(256), 0, st, w, wp, p->Cout,
-                     p->Cin, p->KH * p->KW, 1);
-  AIR_CHECK_LAUNCH();
-  const float* src = dy;
-  int Hs = p->Ho, Ws = p->Wo;
-  if (p->sh == 2) {
-    // u[2i][2j] = dy[i][j], sized so that a stride-1 conv with pad K-1-p gives (H, W)
-    const int Hu = p->H + 2 * p->ph - p->KH + 1, Wu = p->W + 2 * p->pw - p->KW + 1;
-    float* up = wp + wsz;
-    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for(ups)), dim3(256), 0, st, dy, up, p->Ho,
-                       p->Wo, Hu, Wu, (size_t)p->B * p->Cout);
-    AIR_CHECK_LAUNCH();
-    src = up;
-    Hs = Hu;
-    Ws = Wu;
+  const int taps = p->KH * p->KW;
+  // roles swap: "input" channels = Cout, "output" channels = Cin
+  if (p->sh == 1) {
+    // stride 1: dx = conv(dy, flipped taps) with padding K-1-p
+    const int ck = pick_ck(taps, p->Cout);
+    TapSel sel;
+    sel.n = taps;
+    for (int t = 0; t < taps; ++t) sel.idx[t] = taps - 1 - t;
+    int rc = pack(w, wp, p->Cout, p->Cin, taps, 1, ck, sel, st);
+    if (rc != AIR_OK) return rc;
+    return run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate,
+                   plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, p->KH, p->KW, 1,
+                              p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W),
+                   ck, conv_flops(p), st);
   }
-  return run_fwd(src, wp, dx, nullptr, nullptr, 0, accumulate, p->B, p->Cout, Hs, Ws, p->Cin,
-                 p->KH, 1, p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W, conv_flops(p), st);
+  // stride 2: input pixel (2i+a, 2j+b) only sees the taps with kh = (a+1+ph') parity etc.
+  // Each of the 4 parity classes is a dense stride-1 conv of dy with 1, 2, 2 or 4 taps that
+  // writes its own interleaved quarter of dx: no zero-upsampling, no wasted MFMAs.
+  if (!((p->KH == 3 && p->ph == 1) || (p->KH == 1 && p->ph == 0)) || p->ph != p->pw)
+    return AIR_EUNSUPPORTED;
+  const size_t plane = (size_t)p->H * p->W;
+  const size_t dx_elems = (size_t)p->B * p->Cin * plane;
+  if (p->KH == 1) {
+    // 1x1 stride 2: only even/even pixels receive gradient
+    if (accumulate == nullptr) {
+      if (hipMemsetAsync(dx, 0, dx_elems * sizeof(float), st) != hipSuccess) return AIR_ELAUNCH;
+    } else if (accumulate != dx) {
+      if (hipMemcpyAsync(dx, accumulate, dx_elems * sizeof(float), hipMemcpyDeviceToDevice, st) !=
+          hipSuccess)
+        return AIR_ELAUNCH;
+    }
+    const int ck = pick_ck(1, p->Cout);
+    TapSel sel;
+    sel.n = 1;
+    sel.idx[0] = 0;
+    int rc = pack(w, wp, p->Cout, p->Cin, 1, 1, ck, sel, st);
+    if (rc != AIR_OK) return rc;
+    FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, 1, 1, 1, 0, 0, p->Ho, p->Wo);
+    g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = 0; g.oplane = plane;
+    return run_fwd(dy, wp, dx, nullptr, nullptr, 0, dx, g, ck, conv_flops(p), st);
+  }
+  for (int a = 0; a < 2; ++a) {
+    for (int b = 0; b < 2; ++b) {
+      // class (a, b): rows h = 2i + a.  a == 0: kh = 1 reads dy[i]; a == 1: kh = 2 reads dy[i],
+      // kh = 0 reads dy[i+1].  Same along w.
+      const int nh = a ? 2 : 1, nw = b ? 2 : 1;
+      const int khs[2] = {a ? 2 : 1, 0}, kws[2] = {b ? 2 : 1, 0};
+      const int Hc = (p->H - a + 1) / 2, Wc = (p->W - b + 1) / 2;
+      if (Hc <= 0 || Wc <= 0) continue;
+      TapSel sel;
+      sel.n = nh * nw;
+      for (int i = 0; i < nh; ++i)
+        for (int j = 0; j < nw; ++j) sel.idx[i * nw + j] = khs[i] * 3 + kws[j];
+      const int ck = pick_ck(sel.n, p->Cout);
+      int rc = pack(w, wp, p->Cout, p->Cin, 9, 1, ck, sel, st);
+      if (rc != AIR_OK) return rc;
+      FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, nh, nw, 1, 0, 0, Hc, Wc);
+      g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = a * p->W + b; g.oplane = plane;
+      rc = run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck,
+                   conv_flops(p) * sel.n / 9.0, st);
+      if (rc != AIR_OK) return rc;
+    }
+  }
+  return AIR_OK;
 }
 
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

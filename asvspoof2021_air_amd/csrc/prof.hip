@@ -19,7 +19,8 @@ Rec g_cur;
 const char* const kNames[AIR_K_COUNT] = {
     "conv_fwd_kernel<3,3,1>", "conv_fwd_kernel<3,3,2>", "conv_fwd_kernel<1,1,1>",
     "conv_fwd_kernel<1,1,2>", "conv_wgrad_kernel<3,3,1,64>", "conv_wgrad_kernel<3,3,2,32>",
-    "conv_wgrad_kernel<1,1,1,64>", "conv_wgrad_kernel<1,1,2,32>", "lfcc_kernel"};
+    "conv_wgrad_kernel<1,1,1,64>", "conv_wgrad_kernel<1,1,2,32>",
+    "conv_fwd_kernel<parity class>", "lfcc_kernel"};
 }  // namespace
 
 bool air_prof_on() { return g_on; }
