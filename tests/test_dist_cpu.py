@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient exchange (asvspoof2021_air_amd/dist.py)
+over flat arenas, and the arena layout itself."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from asvspoof2021_air_amd import dist as air_dist
+from asvspoof2021_air_amd.arena import ParamArena
+
+
+def test_bucket_slices_cover_reverse_order():
+    n = 12_450_546
+    sl = air_dist.bucket_slices(n, 16 << 20)
+    assert sl[0][1] == n and sl[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(sl, sl[1:]))  # contiguous, last layers first
+    assert max(e - s for s, e in sl) <= (16 << 20) // 4
+    assert air_dist.bucket_slices(10, 16) == [(6, 10), (2, 6), (0, 2)]
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(7, 5)
+        self.tail = nn.Linear(5, 2)
+        self._arena = None
+
+    def arena(self):
+        if self._arena is None:
+            self._arena = ParamArena(list(self.named_parameters()), tail_names=("tail.weight", "tail.bias"))
+        if not self._arena.bound():
+            self._arena.bind(self.a.weight.device)
+        return self._arena
+
+
+def test_arena_views_and_tail():
+    m = Toy()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ar = m.arena()
+    assert ar.bound()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])  # values preserved
+    # every view 16-byte aligned, tail last
+    offs = {n: o for n, _, o, _ in ar.entries}
+    assert all(o % 4 == 0 for o in offs.values())
+    assert offs["tail.weight"] >= ar.head_total and offs["a.bias"] < ar.head_total
+    m.a.weight.data.add_(1.0)  # writing a parameter writes the arena
+    o = offs["a.weight"]
+    assert torch.equal(ar.flat[o:o + 35].view(5, 7), m.a.weight.data)
+    sd = m.state_dict()
+    m2 = Toy()
+    m2.arena()
+    m2.load_state_dict(sd)  # in-place copy keeps the views bound
+    assert m2.arena().bound() and torch.equal(m2.a.weight, m.a.weight)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    air_dist.init_from_env("gloo")
+    assert air_dist.world_size() == world and air_dist.rank() == rank
+    torch.manual_seed(0)
+    m = Toy()
+    ar = m.arena()
+    # rank-dependent gradients; tail has none (like fc_mu under ang_iso)
+    ar.grad.zero_()
+    ar.grad[:ar.head_total] = float(rank + 1) * torch.arange(ar.head_total, dtype=torch.float32)
+    ar.grad[ar.head_total:] = 123.0 + rank
+    ar.tail_has_grad = False
+    centre = nn.Parameter(torch.zeros(1, 8))
+    centre.grad = torch.full((1, 8), float(rank + 1))
+    holder = nn.Module()
+    holder.center = centre
+    air_dist.BUCKET_BYTES = 64  # force several buckets
+    air_dist.allreduce_grads(m, holder)
+    total = sum(range(1, world + 1))
+    ok = torch.equal(ar.grad[:ar.head_total], total * torch.arange(ar.head_total, dtype=torch.float32))
+    ok &= bool((ar.grad[ar.head_total:] == 123.0 + rank).all())  # tail untouched
+    ok &= bool((centre.grad == total).all())
+    out[rank] = bool(ok)
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_allreduce_grads_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
