@@ -13,6 +13,8 @@ enum AirKernelId {
   AIR_K_CONV_WG_111,       // conv_wgrad_kernel<1,1,1,64>
   AIR_K_CONV_WG_112,       // conv_wgrad_kernel<1,1,2,32>
   AIR_K_CONV_FWD_CLS,      // conv_fwd_kernel<1|2, 1|2, 1>: parity classes of stride-2 dgrad
+  AIR_K_CONV_FWD_1D,       // conv_fwd_kernel<1, 3|5, 1>: ECAPA conv1d layers
+  AIR_K_CONV_WG_1D,        // conv_wgrad_kernel<1, 3|5, 1>: ECAPA conv1d layers
   AIR_K_LFCC,              // lfcc_kernel
   AIR_K_COUNT
 };

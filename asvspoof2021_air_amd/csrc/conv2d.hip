@@ -57,7 +57,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   const int M = transpose ? Cin : Cout;
   const int Kc = transpose ? Cout : Cin;
   const int Mpad = (M + BM - 1) / BM * BM;  // channel tiles are zero-padded to 64
-  const size_t total = (size_t)Mpad * Kc * sel.n;
+  const size_t total = (size_t)Mpad * ((Kc + ck - 1) / ck * ck) * sel.n;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % BM);
@@ -66,12 +66,16 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     r /= ck;
     const int tap = (int)(r % sel.n);
     r /= sel.n;
-    const int nchunk = Kc / ck;
+    const int nchunk = (Kc + ck - 1) / ck;
     const int chunk = (int)(r % nchunk);
     const int cot = (int)(r / nchunk);
-    const int m = cot * BM + col, k = chunk * ck + cil;
+    // ragged Kc: the last chunk covers [Kc-ck, Kc); channels an earlier chunk already
+    // covers get zero weights there
+    const bool last_ragged = chunk == nchunk - 1 && Kc % ck != 0;
+    const int k = last_ragged ? Kc - ck + cil : chunk * ck + cil;
+    const int m = cot * BM + col;
     float v = 0.0f;
-    if (m < M) {
+    if (m < M && !(last_ragged && k < chunk * ck)) {
       const int src = sel.idx[tap];
       v = transpose ? w[((size_t)k * Cin + m) * taps_full + src]
                     : w[((size_t)m * Cin + k) * taps_full + src];
@@ -114,6 +118,11 @@ struct FwdArgs {
   // oplane floats (a plain conv: 1, Wo, 1, 0, Ho*Wo)
   int oh_mul, ow_row, ow_mul, o_off;
   size_t oplane;
+  size_t x_bstride, y_bstride;  // batch strides in floats (channel-slice views of wider tensors)
+  const float* bias;            // per output channel, added in the epilogue (may be null)
+  const float* bias_bc;         // per (batch, output channel) bias (B, Cout) (may be null)
+  int out_relu;                 // epilogue ReLU (conv -> ReLU -> BN ordering of ecapa_tdnn.py)
+  int last_cbase;               // first channel of the last K chunk (Cin - CK when Cin % CK != 0)
 };
 
 // XCD-aware logical block index: hardware places block b on XCD b % 8; give each
@@ -127,10 +136,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // CKT = input channels per K chunk (8 for 3x3; more for 1-4 tap kernels so a chunk still
 // holds >= 16 k-steps between barriers)
-template <int KH, int KW, int S, int CKT>
+template <int KH, int KW, int S, int CKT, int DIL = 1>
 struct FwdCfg {
   static constexpr int TAPS = KH * KW;
-  static constexpr int PW = (PXT - 1) * S + KW;       // patch columns
+  static constexpr int PW = (PXT - 1) * S + (KW - 1) * DIL + 1;  // patch columns (DIL: width dilation)
   static constexpr int CHS = KH * PW;                 // channel pitch (dense: LDS-DMA is lane-linear)
   static constexpr int NE = CKT * CHS;                 // patch elements per wave
   static constexpr int NI = (NE + 63) / 64;           // DMA instructions (elements per lane)
@@ -147,9 +156,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
 // operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
-template <int KH, int KW, int S, int MODE, int CKT>
+template <int KH, int KW, int S, int MODE, int CKT, int DIL = 1>
 __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
-  using C = FwdCfg<KH, KW, S, CKT>;
+  using C = FwdCfg<KH, KW, S, CKT, DIL>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
   __shared__ float s_scale[MODE == 1 ? MAXC : 1], s_shift[MODE == 1 ? MAXC : 1];
 
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int wi0 = wo0 * S - a.pw;
   const size_t HW = (size_t)a.H * a.W;
   const int HWi = a.H * a.W;
-  const int nchunk = a.Cin / CKT;
+  const int nchunk = (a.Cin + CKT - 1) / CKT;
   const float* __restrict__ wslab0 = a.wp + (size_t)cot * nchunk * C::WSLAB;
 
   // Staging = LDS-DMA (global_load_lds): no VGPR round trip, no ds_write pass, no branch.
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   // activation are applied when the operand is read.  Per-lane source offsets are
   // chunk-invariant and live in registers.
   const int rowc = min(rowid, a.B * a.Ho - 1);  // keep address maths inside the tensor
-  const float* __restrict__ xbc = a.x + (size_t)(rowc / a.Ho) * a.Cin * HW;
+  const float* __restrict__ xbc = a.x + (size_t)(rowc / a.Ho) * a.x_bstride;
   int goff[C::NI];
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
@@ -195,7 +204,10 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   auto dma = [&](int chunk, int buf) {
     float* base = lds + buf * C::BUF;
     float* pl = base + C::WSLAB + wave * C::PATCHP;
-    const float* __restrict__ xc = xbc + (size_t)chunk * CKT * HW;
+    // the last chunk of a ragged Cin slides back to [Cin-CK, Cin); its already-covered
+    // channels carry zero weights (pack_weights_kernel)
+    const int cbase = (chunk == nchunk - 1) ? a.last_cbase : chunk * CKT;
+    const float* __restrict__ xc = xbc + (size_t)cbase * HW;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(xc + goff[i]), (lptr_t)(pl + 64 * i), 4, 0, 0);
@@ -215,13 +227,12 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   for (int kh = 0; kh < KH; ++kh)
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw) {
-      const int hi = hi0 + kh, wi = wi0 + l31 * S + kw;
+      const int hi = hi0 + kh, wi = wi0 + l31 * S + kw * DIL;
       okm[kh * KW + kw] = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
     }
 
   // wave-uniform: the whole patch of this pixel tile lies inside the image
-  const bool interior = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 &&
-                        wi0 + (PXT - 1) * S + KW - 1 < a.W;
+  const bool interior = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 && wi0 + C::PW - 1 < a.W;
 
   f32x16 acc0 = {0}, acc1 = {0};
 
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       const int tap = n / (CKT / 2), st = n % (CKT / 2);
       const int kh = tap / KW, kw = tap % KW;
       const int cil = 2 * st + half;
-      bv = pl[cil * C::CHS + kh * C::PW + kw + l31 * S];
+      bv = pl[cil * C::CHS + kh * C::PW + kw * DIL + l31 * S];
       a0 = wl[(tap * CKT + cil) * BM + l31];
       a1 = wl[(tap * CKT + cil) * BM + 32 + l31];
     };
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int wo = wo0 + l31;
   if (wo >= a.Wo) return;
   const size_t oplane = a.oplane;
-  const size_t obase = ((size_t)b * a.Cout + (size_t)cot * BM) * oplane +
+  const size_t obase = (size_t)b * a.y_bstride + (size_t)cot * BM * oplane +
                        (size_t)(ho * a.oh_mul) * a.ow_row + (size_t)wo * a.ow_mul + a.o_off;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -318,12 +329,18 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     const int co = cot * BM + i;
     if (co < a.Cout) {
       float v0 = acc0[r];
+      if (a.bias != nullptr) v0 += a.bias[co];
+      if (a.bias_bc != nullptr) v0 += a.bias_bc[(size_t)b * a.Cout + co];
       if (a.residual != nullptr) v0 += a.residual[o0];
+      if (a.out_relu) v0 = fmaxf(v0, 0.0f);
       a.y[o0] = v0;
     }
     if (co + 32 < a.Cout) {
       float v1 = acc1[r];
+      if (a.bias != nullptr) v1 += a.bias[co + 32];
+      if (a.bias_bc != nullptr) v1 += a.bias_bc[(size_t)b * a.Cout + co + 32];
       if (a.residual != nullptr) v1 += a.residual[o1];
+      if (a.out_relu) v1 = fmaxf(v1, 0.0f);
       a.y[o1] = v1;
     }
   }
@@ -346,18 +363,19 @@ struct WgradArgs {
   int ncot, ncit;  // co tiles (BMW), ci tiles (CT)
   int nsplit;
   int tiles_per_split;
+  size_t x_bstride, dy_bstride;  // batch strides in floats (channel-slice views)
 };
 
 // CT = input channels per workgroup (64: waves = 2 co halves x 2 ci halves, 64 co;
 //                                     32: waves = 4 co quarters x 1 ci tile, 128 co)
-template <int KH, int KW, int S, int CT_>
+template <int KH, int KW, int S, int CT_, int DIL = 1>
 struct WgCfg {
   static constexpr int TAPS = KH * KW;
   static constexpr int CT = CT_;
   static constexpr int NWCI = CT / 32;                 // waves along ci
   static constexpr int NWCO = 4 / NWCI;                // waves along co
   static constexpr int BMW = 32 * NWCO;                // co per workgroup
-  static constexpr int PW = (PXT - 1) * S + KW;
+  static constexpr int PW = (PXT - 1) * S + (KW - 1) * DIL + 1;
   static constexpr int CHS = KH * PW;                  // dense channel pitch (LDS-DMA is lane-linear)
   static constexpr int NE = CT * CHS;                  // patch elements per workgroup
   static constexpr int NI = (NE + 255) / 256;          // patch DMA instructions per wave
@@ -371,9 +389,9 @@ struct WgCfg {
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]), applied to the B
 // operand after it is read from LDS (lanes = channels, so scale/shift are two registers).
 // Staging is LDS-DMA from clamped addresses; padding is masked at operand-read time.
-template <int KH, int KW, int S, int CT_, int MODE>
+template <int KH, int KW, int S, int CT_, int MODE, int DIL = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  using C = WgCfg<KH, KW, S, CT_>;
+  using C = WgCfg<KH, KW, S, CT_, DIL>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
 
   const int tid = threadIdx.x;
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
     float* pl = lds + buf * C::BUF;
     float* dl = pl + C::PATCHP;
-    const float* __restrict__ xb = a.x + (size_t)b * a.Cin * HW;
+    const float* __restrict__ xb = a.x + (size_t)b * a.x_bstride;
     const bool inside = hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 && wi0 + C::PW - 1 < a.W;
     if (inside) {  // wave-uniform
       const float* __restrict__ xt = xb + (hi0 * a.W + wi0);
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
     // dy rows (co pairs): lane -> (co = 2j + half, px = l31), column clamped to the row
     const float* __restrict__ dyb =
-        a.dy + ((size_t)b * a.Cout + (size_t)cot * C::BMW) * HoWo + (size_t)ho * a.Wo;
+        a.dy + (size_t)b * a.dy_bstride + (size_t)cot * C::BMW * HoWo + (size_t)ho * a.Wo;
     const int dyo = half * HoWoi + min(wo0 + l31, a.Wo - 1);
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                           wi0 + C::PW - 1 < a.W && wo0 + PXT <= a.Wo && ci0 + C::CT <= a.Cin;
     auto ldb = [&](int st, int t) -> float {
       const int kh = t / KW, kw = t % KW;
-      return pbase[kh * C::PW + (2 * st + half) * S + kw];
+      return pbase[kh * C::PW + (2 * st + half) * S + kw * DIL];
     };
     auto steps = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
@@ -503,7 +521,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int kh = t / KW, kw = t % KW;
         if (MODE == 1) v = fmaxf(v * sc + sh, 0.0f);
         if (MASKED) {
-          const bool ok = rok[kh] && (unsigned)(2 * st * S + kw - clo) <= cspan;
+          const bool ok = rok[kh] && (unsigned)(2 * st * S + kw * DIL - clo) <= cspan;
           v = ok ? v : 0.0f;
         }
         return v;
@@ -677,28 +695,37 @@ struct FwdGeom {
   int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
   int oh_mul, ow_row, ow_mul, o_off;  // output addressing (see FwdArgs)
   size_t oplane;
+  size_t x_bstride, y_bstride;
+  const float* bias;
+  int out_relu;
+  int dil;
+  const float* bias_bc;
 };
 
 FwdGeom plain_geom(int B, int Cin, int H, int W, int Cout, int KH, int KW, int S, int ph, int pw,
                    int Ho, int Wo) {
-  FwdGeom g = {B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo, 1, Wo, 1, 0, (size_t)Ho * Wo};
+  FwdGeom g = {B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo, 1, Wo, 1, 0, (size_t)Ho * Wo,
+               (size_t)Cin * H * W, (size_t)Cout * Ho * Wo, nullptr, 0, 1, nullptr};
   return g;
 }
 
 // channels per K chunk: keep >= 16 k-steps between barriers for 1-4 tap kernels
 int pick_ck(int taps, int cin) {
+  if (taps == 3) return cin % 16 == 0 ? 16 : 8;  // dilated 1x3 conv1d
   if (taps >= 4) return 8;
   if (taps == 2) return cin % 16 == 0 ? 16 : 8;
   return cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 8);
 }
 
-template <int KH, int KW, int S, int CKT>
+template <int KH, int KW, int S, int CKT, int DIL = 1>
 void launch_fwd(const FwdArgs& a, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
   if (a.scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1, CKT>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1, CKT, DIL>), dim3(nblk), dim3(NWAVE * 64), 0,
+                       st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0, CKT>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0, CKT, DIL>), dim3(nblk), dim3(NWAVE * 64), 0,
+                       st, a);
 }
 
 // y = conv(act(x), packed w): shared by fwd and every dgrad
@@ -715,15 +742,20 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   a.ncot = (g.Cout + BM - 1) / BM;
   a.oh_mul = g.oh_mul; a.ow_row = g.ow_row; a.ow_mul = g.ow_mul; a.o_off = g.o_off;
   a.oplane = g.oplane;
-  if (g.Cin % ck != 0) return AIR_EUNSUPPORTED;
-  const int key = g.KH * 1000 + g.KW * 100 + g.S * 10;
-#define AIR_FWD_CASE(KH_, KW_, S_, CK_, KID_)                     \
-  if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 && ck == CK_) {      \
-    AirProfScope ps(KID_, flops, st);                              \
-    launch_fwd<KH_, KW_, S_, CK_>(a, st);                          \
-    AIR_CHECK_LAUNCH();                                            \
-    return AIR_OK;                                                 \
+  a.x_bstride = g.x_bstride; a.y_bstride = g.y_bstride;
+  a.bias = g.bias; a.out_relu = g.out_relu; a.bias_bc = g.bias_bc;
+  a.last_cbase = (g.Cin % ck != 0) ? g.Cin - ck : (g.Cin / ck - 1) * ck;
+  if (g.Cin < ck) return AIR_EUNSUPPORTED;
+  if (g.Cin % ck != 0 && scale != nullptr) return AIR_EUNSUPPORTED;  // ragged Cin: plain input only
+  const int key = g.KH * 1000 + g.KW * 100 + g.S * 10 + (g.dil - 1);
+#define AIR_FWD_CASE_D(KH_, KW_, S_, CK_, DIL_, KID_)                         \
+  if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 + (DIL_ - 1) && ck == CK_) {      \
+    AirProfScope ps(KID_, flops, st);                                           \
+    launch_fwd<KH_, KW_, S_, CK_, DIL_>(a, st);                                 \
+    AIR_CHECK_LAUNCH();                                                         \
+    return AIR_OK;                                                              \
   }
+#define AIR_FWD_CASE(KH_, KW_, S_, CK_, KID_) AIR_FWD_CASE_D(KH_, KW_, S_, CK_, 1, KID_)
   AIR_FWD_CASE(3, 3, 1, 8, AIR_K_CONV_FWD_331)
   AIR_FWD_CASE(3, 3, 2, 8, AIR_K_CONV_FWD_332)
   AIR_FWD_CASE(1, 1, 1, 32, AIR_K_CONV_FWD_111)
@@ -735,14 +767,20 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   AIR_FWD_CASE(1, 2, 1, 16, AIR_K_CONV_FWD_CLS)
   AIR_FWD_CASE(2, 1, 1, 16, AIR_K_CONV_FWD_CLS)
   AIR_FWD_CASE(2, 2, 1, 8, AIR_K_CONV_FWD_CLS)
+  // ECAPA-TDNN conv1d layers seen as H = 1 images (ecapa_tdnn.py:46,111)
+  AIR_FWD_CASE(1, 5, 1, 8, AIR_K_CONV_FWD_1D)
+  AIR_FWD_CASE_D(1, 3, 1, 16, 2, AIR_K_CONV_FWD_1D)
+  AIR_FWD_CASE_D(1, 3, 1, 16, 3, AIR_K_CONV_FWD_1D)
+  AIR_FWD_CASE_D(1, 3, 1, 16, 4, AIR_K_CONV_FWD_1D)
 #undef AIR_FWD_CASE
+#undef AIR_FWD_CASE_D
   return AIR_EUNSUPPORTED;
 }
 
 int pack(const float* w, float* wp, int Cout, int Cin, int taps_full, int transpose, int ck,
          const TapSel& sel, hipStream_t st) {
   const int M = transpose ? Cin : Cout, Kc = transpose ? Cout : Cin;
-  const size_t n = (size_t)((M + BM - 1) / BM * BM) * Kc * sel.n;
+  const size_t n = (size_t)((M + BM - 1) / BM * BM) * ((Kc + ck - 1) / ck * ck) * sel.n;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, wp, Cout, Cin,
                      taps_full, transpose, ck, sel);
   AIR_CHECK_LAUNCH();
@@ -770,9 +808,66 @@ int wgrad_nsplit(const AirConv2d* p) {
 }
 
 size_t packed_dgrad_elems(const AirConv2d* p) {  // dgrad packs with Cin padded to 64
-  return (size_t)((p->Cin + BM - 1) / BM * BM) * p->Cout * p->KH * p->KW;
+  return (size_t)((p->Cin + BM - 1) / BM * BM) * ((p->Cout + 31) / 32 * 32) * p->KH * p->KW;
 }
 
+
+struct WgradGeom {
+  int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
+  int dil;
+  size_t x_bstride, dy_bstride;
+};
+
+int run_wgrad(const WgradGeom& g, const float* x, const float* dy, float* dw, const float* in_scale,
+              const float* in_shift, int relu, void* ws, size_t ws_bytes, double flops,
+              hipStream_t st) {
+  const size_t wsz = (size_t)g.Cout * g.Cin * g.KH * g.KW;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(ws);
+  a.scale = in_scale; a.shift = in_shift;
+  a.B = g.B; a.Cin = g.Cin; a.H = g.H; a.W = g.W; a.Cout = g.Cout; a.Ho = g.Ho; a.Wo = g.Wo;
+  a.ph = g.ph; a.pw = g.pw; a.relu = relu;
+  a.x_bstride = g.x_bstride; a.dy_bstride = g.dy_bstride;
+  a.WT = (g.Wo + PXT - 1) / PXT;
+  a.ntiles = g.B * g.Ho * a.WT;
+  const int ct = (g.S == 2 && g.Cout % 128 == 0) ? 32 : 64;
+  a.ncot = g.Cout / (ct == 32 ? 128 : 64);
+  a.ncit = (g.Cin + ct - 1) / ct;
+  static const int total = getenv("AIR_WGRAD_WGS") ? atoi(getenv("AIR_WGRAD_WGS")) : 256;
+  int nsplit = total / (a.ncot * a.ncit);  // workgroups in flight over the whole chip
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  a.nsplit = nsplit;
+  a.tiles_per_split = (a.ntiles + a.nsplit - 1) / a.nsplit;
+  if (!ws || ws_bytes < (size_t)a.nsplit * wsz * sizeof(float)) return AIR_EWORKSPACE;
+  const int nblk = a.ncot * a.ncit * a.nsplit;
+  const int key = g.KH * 1000 + g.KW * 100 + g.S * 10 + (g.dil - 1);
+#define AIR_WG_CASE(KH_, KW_, S_, CT_, DIL_, KID_)                                              \
+  if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 + (DIL_ - 1) && ct == CT_) {                       \
+    AirProfScope ps(KID_, flops, st);                                                            \
+    if (a.scale != nullptr)                                                                      \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KH_, KW_, S_, CT_, 1, DIL_>), dim3(nblk), dim3(256), \
+                         0, st, a);                                                              \
+    else                                                                                         \
+      hipLaunchKernelGGL((conv_wgrad_kernel<KH_, KW_, S_, CT_, 0, DIL_>), dim3(nblk), dim3(256), \
+                         0, st, a);                                                              \
+    AIR_CHECK_LAUNCH();                                                                          \
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,            \
+                       reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit, g.KH * g.KW);      \
+    AIR_CHECK_LAUNCH();                                                                          \
+    return AIR_OK;                                                                               \
+  }
+  AIR_WG_CASE(3, 3, 1, 64, 1, AIR_K_CONV_WG_331)
+  AIR_WG_CASE(3, 3, 2, 32, 1, AIR_K_CONV_WG_332)
+  AIR_WG_CASE(1, 1, 1, 64, 1, AIR_K_CONV_WG_111)
+  AIR_WG_CASE(1, 1, 2, 32, 1, AIR_K_CONV_WG_112)
+  AIR_WG_CASE(1, 5, 1, 64, 1, AIR_K_CONV_WG_1D)
+  AIR_WG_CASE(1, 3, 1, 64, 2, AIR_K_CONV_WG_1D)
+  AIR_WG_CASE(1, 3, 1, 64, 3, AIR_K_CONV_WG_1D)
+  AIR_WG_CASE(1, 3, 1, 64, 4, AIR_K_CONV_WG_1D)
+#undef AIR_WG_CASE
+  return AIR_EUNSUPPORTED;
+}
 
 }  // namespace
 
@@ -923,54 +1018,84 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
   }
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
   if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;  // BN-apply + ReLU together, or none
-  WgradArgs a;
-  a.x = x; a.dy = dy; a.partial = reinterpret_cast<float*>(ws);
-  a.scale = in_scale; a.shift = in_shift;
-  a.B = p->B; a.Cin = p->Cin; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.Ho = p->Ho; a.Wo = p->Wo;
-  a.ph = p->ph; a.pw = p->pw; a.relu = relu;
-  a.WT = (p->Wo + PXT - 1) / PXT;
-  a.ntiles = p->B * p->Ho * a.WT;
-  const int ct = wgrad_ct(p);
-  a.ncot = p->Cout / (ct == 32 ? 128 : 64);
-  a.ncit = (p->Cin + ct - 1) / ct;
-  a.nsplit = wgrad_nsplit(p);
-  a.tiles_per_split = (a.ntiles + a.nsplit - 1) / a.nsplit;
-  if (!ws || ws_bytes < (size_t)a.nsplit * wsz * sizeof(float)) return AIR_EWORKSPACE;
-  const int nblk = a.ncot * a.ncit * a.nsplit;
-  const int KH = p->KH, S = p->sh;
-  const double flops = conv_flops(p);
-  if (KH == 3 && S == 1) {
-    AirProfScope ps(AIR_K_CONV_WG_331, flops, st);
-    if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, 1>), dim3(nblk), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 1, 64, 0>), dim3(nblk), dim3(256), 0, st, a);
-  } else if (KH == 3 && S == 2 && ct == 32) {
-    AirProfScope ps(AIR_K_CONV_WG_332, flops, st);
-    if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, 1>), dim3(nblk), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((conv_wgrad_kernel<3, 3, 2, 32, 0>), dim3(nblk), dim3(256), 0, st, a);
-  } else if (KH == 1 && S == 1) {
-    AirProfScope ps(AIR_K_CONV_WG_111, flops, st);
-    if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, 1>), dim3(nblk), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 1, 64, 0>), dim3(nblk), dim3(256), 0, st, a);
-  } else if (KH == 1 && S == 2 && ct == 32) {
-    AirProfScope ps(AIR_K_CONV_WG_112, flops, st);
-    if (a.scale != nullptr)
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, 1>), dim3(nblk), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 32, 0>), dim3(nblk), dim3(256), 0, st, a);
-  } else {
-    return AIR_EUNSUPPORTED;
-  }
-  AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
-                     reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit, p->KH * p->KW);
-  AIR_CHECK_LAUNCH();
-  return AIR_OK;
+  WgradGeom g = {p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW, p->sh, p->ph, p->pw, p->Ho, p->Wo,
+                 1, (size_t)p->Cin * p->H * p->W, (size_t)p->Cout * p->Ho * p->Wo};
+  return run_wgrad(g, x, dy, dw, in_scale, in_shift, relu, ws, ws_bytes, conv_flops(p), st);
+}
+
+// ------------------------------------------------------------------ conv1d
+// nn.Conv1d (stride 1) of ecapa_tdnn.py (:39,:46,:55,:111,:118,:140,:143) seen as an H = 1
+// image: the same implicit-GEMM kernels, with bias / ReLU / per-utterance bias epilogues
+// (conv -> ReLU -> BN ordering, ecapa_tdnn.py:67-69) and batch strides so the Res2 channel
+// groups and the (x1,x2,x3) concat are views, never copies.
+static bool c1d_ok(const AirConv1d* p) {
+  if (!p || p->B <= 0 || p->Cin <= 0 || p->T <= 0 || p->Cout <= 0) return false;
+  if (p->K == 1) return p->pad == 0;
+  if (p->K == 3) return p->dil >= 2 && p->dil <= 4 && p->pad == p->dil;
+  if (p->K == 5) return p->dil == 1 && p->pad == 2;
+  return false;
+}
+static size_t c1d_xb(const AirConv1d* p) { return p->x_bstride ? p->x_bstride : (size_t)p->Cin * p->T; }
+static size_t c1d_yb(const AirConv1d* p) { return p->y_bstride ? p->y_bstride : (size_t)p->Cout * p->T; }
+
+size_t air_conv1d_ws_bytes(const AirConv1d* p) {
+  if (!c1d_ok(p)) return 0;
+  const size_t cin_p = (size_t)(p->Cin + 63) / 64 * 64, cout_p = (size_t)(p->Cout + 63) / 64 * 64;
+  const size_t packed = cin_p * cout_p * p->K;
+  const size_t wgrad = (size_t)256 * p->Cout * p->Cin * p->K;
+  return (packed > wgrad ? packed : wgrad) * sizeof(float) + 256;
+}
+
+int air_conv1d_fwd(const AirConv1d* p, const float* x, const float* w, const float* bias,
+                   const float* bias_bc, int relu, float* y, void* ws, size_t ws_bytes,
+                   air_stream_t stream) {
+  if (!c1d_ok(p) || !x || !w || !y) return AIR_EINVAL;
+  if (p->Cout % BM != 0) return AIR_EUNSUPPORTED;
+  if (!ws || ws_bytes < air_conv1d_ws_bytes(p)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  float* wp = reinterpret_cast<float*>(ws);
+  const int ck = pick_ck(p->K, p->Cin);
+  TapSel sel;
+  sel.n = p->K;
+  for (int t = 0; t < p->K; ++t) sel.idx[t] = t;
+  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 0, ck, sel, st);
+  if (rc != AIR_OK) return rc;
+  FwdGeom g = plain_geom(p->B, p->Cin, 1, p->T, p->Cout, 1, p->K, 1, 0, p->pad, 1, p->T);
+  g.x_bstride = c1d_xb(p); g.y_bstride = c1d_yb(p);
+  g.bias = bias; g.bias_bc = bias_bc; g.out_relu = relu; g.dil = p->K == 3 ? p->dil : 1;
+  return run_fwd(x, wp, y, nullptr, nullptr, 0, nullptr, g, ck,
+                 2.0 * p->B * p->T * (double)p->Cout * p->Cin * p->K, st);
+}
+
+int air_conv1d_dgrad(const AirConv1d* p, const float* dy, const float* w, float* dx,
+                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!c1d_ok(p) || !dy || !w || !dx) return AIR_EINVAL;
+  if (p->Cout % 8 != 0) return AIR_EUNSUPPORTED;
+  if (!ws || ws_bytes < air_conv1d_ws_bytes(p)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  float* wp = reinterpret_cast<float*>(ws);
+  const int ck = pick_ck(p->K, p->Cout);
+  TapSel sel;
+  sel.n = p->K;
+  for (int t = 0; t < p->K; ++t) sel.idx[t] = p->K - 1 - t;
+  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 1, ck, sel, st);
+  if (rc != AIR_OK) return rc;
+  const int dil = p->K == 3 ? p->dil : 1;
+  FwdGeom g = plain_geom(p->B, p->Cout, 1, p->T, p->Cin, 1, p->K, 1, 0, dil * (p->K - 1) - p->pad,
+                         1, p->T);
+  g.x_bstride = c1d_yb(p); g.y_bstride = c1d_xb(p); g.dil = dil;
+  return run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck,
+                 2.0 * p->B * p->T * (double)p->Cout * p->Cin * p->K, st);
+}
+
+int air_conv1d_wgrad(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
+                     size_t ws_bytes, air_stream_t stream) {
+  if (!c1d_ok(p) || !x || !dy || !dw) return AIR_EINVAL;
+  if (p->Cout % BM != 0) return AIR_EUNSUPPORTED;
+  WgradGeom g = {p->B, p->Cin, 1, p->T, p->Cout, 1, p->K, 1, 0, p->pad, 1, p->T,
+                 p->K == 3 ? p->dil : 1, c1d_xb(p), c1d_yb(p)};
+  return run_wgrad(g, x, dy, dw, nullptr, nullptr, 0, ws, ws_bytes,
+                   2.0 * p->B * p->T * (double)p->Cout * p->Cin * p->K, air_stream(stream));
 }
 
 }  // extern "C"

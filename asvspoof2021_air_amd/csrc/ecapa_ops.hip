@@ -1,0 +1,331 @@
+// Small HBM/latency-bound kernels of the ECAPA-TDNN path (ecapa_tdnn.py) for gfx950:
+// strided copies/adds between channel groups (the Res2 split / concat as views),
+// per-channel sums (bias gradients), per-row statistics over time (SE mean, context
+// mean/std), the SE gate, and the attentive-statistics pooling with its softmax over time.
+// Tensors are (B, C, T) fp32, time contiguous; one wave per (b, c) row where rows matter.
+#include "air_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+  v = air_wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < NT / 64; ++w) r += sh[w];
+  return r;
+}
+
+// out[b][c][s] = a[b][c][s] (+ b2[b][c][s]); each tensor has its own batch stride
+__global__ __launch_bounds__(NT) void add_strided_kernel(float* __restrict__ out, size_t ob,
+                                                         const float* __restrict__ a, size_t ab,
+                                                         const float* __restrict__ b2, size_t bb,
+                                                         int CS) {
+  const int b = blockIdx.y;
+  const float* __restrict__ pa = a + (size_t)b * ab;
+  const float* __restrict__ pb = b2 ? b2 + (size_t)b * bb : nullptr;
+  float* __restrict__ po = out + (size_t)b * ob;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < CS; i += gridDim.x * NT)
+    po[i] = pb ? pa[i] + pb[i] : pa[i];
+}
+
+// out[c] = sum_{b,s} x[b][c][s]   (bias gradients); grid = C
+__global__ __launch_bounds__(NT) void channel_sum_kernel(const float* __restrict__ x, int B, int S,
+                                                         size_t bstride, float* __restrict__ out) {
+  __shared__ double sh[NT / 64];
+  const int c = blockIdx.x;
+  double d = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* __restrict__ p = x + (size_t)b * bstride + (size_t)c * S;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < S; i += NT) s += p[i];
+    d += (double)s;
+  }
+  d = block_sum_d(d, sh);
+  if (threadIdx.x == 0) out[c] = (float)d;
+}
+
+// per (b,c) row over T: mean and std = sqrt(clamp(unbiased var, 1e-4)) (ecapa_tdnn.py:178);
+// one wave per row.  std may be null (SE squeeze only needs the mean, ecapa_tdnn.py:19).
+__global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__ x, size_t rows,
+                                                       int T, float* __restrict__ mean,
+                                                       float* __restrict__ std_, float clamp_min) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* __restrict__ p = x + row * T;
+  float s = 0.0f;
+  for (int t = lane; t < T; t += 64) s += p[t];
+  const float m = air_wave_sum(s) / (float)T;
+  if (lane == 0) mean[row] = m;
+  if (std_ != nullptr) {
+    float q = 0.0f;
+    for (int t = lane; t < T; t += 64) {
+      const float d = p[t] - m;
+      q = fmaf(d, d, q);
+    }
+    q = air_wave_sum(q) / (float)(T - 1);
+    if (lane == 0) std_[row] = sqrtf(fmaxf(q, clamp_min));
+  }
+}
+
+// dx[row][t] (+)= dmean/T + dstd * (x - mean) / ((T-1) std)   [dstd term only where var > clamp]
+__global__ __launch_bounds__(NT) void row_stats_bwd_kernel(
+    const float* __restrict__ x, size_t rows, int T, const float* __restrict__ mean,
+    const float* __restrict__ std_, const float* __restrict__ dmean,
+    const float* __restrict__ dstd, float clamp_min, float* __restrict__ dx, int accumulate) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float m = mean[row];
+  const float k0 = dmean ? dmean[row] / (float)T : 0.0f;
+  float k1 = 0.0f;
+  if (dstd != nullptr) {
+    const float sd = std_[row];
+    if (sd * sd > clamp_min) k1 = dstd[row] / ((float)(T - 1) * sd);
+  }
+  for (int t = lane; t < T; t += 64) {
+    const float v = k0 + k1 * (x[row * T + t] - m);
+    dx[row * T + t] = accumulate ? dx[row * T + t] + v : v;
+  }
+}
+
+// SE gate + residual (ecapa_tdnn.py:27-29, :93): out = x * sigmoid(z[b][c]) + res; wave per row
+__global__ __launch_bounds__(NT) void se_scale_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ z,
+                                                      const float* __restrict__ res, size_t res_b,
+                                                      int C, int T, float* __restrict__ out,
+                                                      size_t out_b, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t b = row / C, c = row - b * C;
+  const float g = 1.0f / (1.0f + expf(-z[row]));
+  const float* __restrict__ px = x + row * T;
+  const float* __restrict__ pr = res + b * res_b + c * T;
+  float* __restrict__ po = out + b * out_b + c * T;
+  for (int t = lane; t < T; t += 64) po[t] = fmaf(px[t], g, pr[t]);
+}
+
+// backward: dx = dout * sigmoid(z); dz = s(1-s) * sum_t dout*x   (dres = dout, same tensor)
+__global__ __launch_bounds__(NT) void se_scale_bwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ z,
+                                                          const float* __restrict__ dout,
+                                                          size_t dout_b, int C, int T,
+                                                          float* __restrict__ dx,
+                                                          float* __restrict__ dz, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t b = row / C, c = row - b * C;
+  const float g = 1.0f / (1.0f + expf(-z[row]));
+  const float* __restrict__ px = x + row * T;
+  const float* __restrict__ pd = dout + b * dout_b + c * T;
+  float acc = 0.0f;
+  for (int t = lane; t < T; t += 64) {
+    const float d = pd[t];
+    acc = fmaf(d, px[t], acc);
+    dx[row * T + t] = d * g;
+  }
+  acc = air_wave_sum(acc);
+  if (lane == 0) dz[row] = acc * g * (1.0f - g);
+}
+
+// Attentive statistics pooling (ecapa_tdnn.py:143-185): per (b,c) row
+//   w = softmax_T(a);  mu = sum x w;  sg = sqrt(clamp(sum x^2 w - mu^2, 1e-4))
+// a is overwritten with w (saved for backward); out = [mu | sg] as (B, 2C)
+__global__ __launch_bounds__(NT) void asp_fwd_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ a, int C, int T,
+                                                     float* __restrict__ out, size_t rows) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t b = row / C, c = row - b * C;
+  float* __restrict__ pa = a + row * T;
+  const float* __restrict__ px = x + row * T;
+  float m = -INFINITY;
+  for (int t = lane; t < T; t += 64) m = fmaxf(m, pa[t]);
+  m = air_wave_max(m);
+  float se = 0.0f;
+  for (int t = lane; t < T; t += 64) se += expf(pa[t] - m);
+  se = air_wave_sum(se);
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int t = lane; t < T; t += 64) {
+    const float w = expf(pa[t] - m) / se;
+    const float xv = px[t];
+    pa[t] = w;
+    s1 = fmaf(xv, w, s1);
+    s2 = fmaf(xv * xv, w, s2);
+  }
+  s1 = air_wave_sum(s1);
+  s2 = air_wave_sum(s2);
+  if (lane == 0) {
+    out[b * 2 * C + c] = s1;
+    out[b * 2 * C + C + c] = sqrtf(fmaxf(s2 - s1 * s1, 1e-4f));
+  }
+}
+
+// backward: given dout (B,2C): dx (accumulated into dx_acc) and da (written over w)
+__global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ w, int C, int T,
+                                                     const float* __restrict__ out,
+                                                     const float* __restrict__ dout,
+                                                     float* __restrict__ dx, int accumulate,
+                                                     size_t rows) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t b = row / C, c = row - b * C;
+  const float mu = out[b * 2 * C + c], sg = out[b * 2 * C + C + c];
+  const float dmu = dout[b * 2 * C + c], dsg = dout[b * 2 * C + C + c];
+  const float dq = (sg * sg > 1e-4f) ? dsg / (2.0f * sg) : 0.0f;  // clamp passes no gradient
+  const float dm = dmu - 2.0f * mu * dq;
+  float* __restrict__ pw = w + row * T;
+  const float* __restrict__ px = x + row * T;
+  float dot = 0.0f;
+  for (int t = lane; t < T; t += 64) {
+    const float xv = px[t];
+    dot = fmaf(pw[t], dm * xv + dq * xv * xv, dot);
+  }
+  dot = air_wave_sum(dot);
+  for (int t = lane; t < T; t += 64) {
+    const float xv = px[t], wv = pw[t];
+    const float dwv = dm * xv + dq * xv * xv;
+    const float g = dm * wv + 2.0f * dq * xv * wv;
+    dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
+    pw[t] = wv * (dwv - dot);  // softmax backward
+  }
+}
+
+// dx *= (y > 0): backward of a stand-alone ReLU (ecapa_tdnn.py:173)
+__global__ void relu_mask_kernel(float* __restrict__ dx, const float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.0f ? dx[i] : 0.0f;
+}
+
+// out[row] = sum_t x[row][t]
+__global__ __launch_bounds__(NT) void row_sum_kernel(const float* __restrict__ x, size_t rows, int T,
+                                                     float* __restrict__ out) {
+  const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.0f;
+  for (int t = lane; t < T; t += 64) s += x[row * T + t];
+  s = air_wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int air_relu_mask(float* dx, const float* y, size_t n, air_stream_t stream) {
+  if (!dx || !y) return AIR_EINVAL;
+  if (n == 0) return AIR_OK;
+  size_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)g), dim3(256), 0, air_stream(stream), dx, y, n);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_row_sum(const float* x, int B, int C, int T, float* out, air_stream_t stream) {
+  if (!x || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, rows, T, out);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
+                    const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream) {
+  if (!out || !a || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
+  const int CS = C * S;
+  dim3 grid(min((CS + NT - 1) / NT, 1024), B);
+  hipLaunchKernelGGL(add_strided_kernel, grid, dim3(NT), 0, air_stream(stream), out, out_bstride,
+                     a, a_bstride, b, b_bstride, CS);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out,
+                    air_stream_t stream) {
+  if (!x || !out || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(NT), 0, air_stream(stream), x, B, S,
+                     bstride ? bstride : (size_t)C * S, out);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_or_null,
+                  float clamp_min, air_stream_t stream) {
+  if (!x || !mean || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, rows, T, mean, std_or_null, clamp_min);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
+                      const float* dmean, const float* dstd, float clamp_min, float* dx,
+                      int accumulate, air_stream_t stream) {
+  if (!x || !mean || !dx || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
+  if (dstd != nullptr && std_ == nullptr) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(row_stats_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, rows, T, mean, std_, dmean, dstd, clamp_min, dx,
+                     accumulate);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
+                     int C, int T, float* out, size_t out_bstride, air_stream_t stream) {
+  if (!x || !z || !res || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, z, res, res_bstride ? res_bstride : (size_t)C * T, C, T,
+                     out, out_bstride ? out_bstride : (size_t)C * T, rows);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_se_scale_bwd(const float* x, const float* z, const float* dout, size_t dout_bstride, int B,
+                     int C, int T, float* dx, float* dz, air_stream_t stream) {
+  if (!x || !z || !dout || !dx || !dz || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(se_scale_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, z, dout, dout_bstride ? dout_bstride : (size_t)C * T, C,
+                     T, dx, dz, rows);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* out,
+                air_stream_t stream) {
+  if (!x || !logits_to_w || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(asp_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, logits_to_w, C, T, out, rows);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
+                const float* dout, float* dx, int accumulate, air_stream_t stream) {
+  if (!x || !w_to_dlogits || !out || !dout || !dx || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  const size_t rows = (size_t)B * C;
+  hipLaunchKernelGGL(asp_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                     air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rows);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+}  // extern "C"

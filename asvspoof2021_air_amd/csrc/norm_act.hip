@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
-    float* __restrict__ dx) {
+    int relu_in, float* __restrict__ dx) {
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float mu = mean[c], is = invstd[c];
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
     const float xh = (xv - mu) * is;
     float r = sc * (g - k1 - xh * k2);
+    if (relu_in && !(xv > 0.0f)) r = 0.0f;  // x = relu(c): no gradient where the ReLU clipped
     if (accum) r += dx[base + i];
     dx[base + i] = r;
   }
@@ -284,7 +285,7 @@ int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, B, C, S,
-                     nsplit, mean, invstd, gamma, beta, relu, partial);
+                     nsplit, mean, invstd, gamma, beta, relu & 1, partial);
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit,
                      C, dgamma, dbeta);
@@ -292,7 +293,7 @@ int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, C, S,
                      (float)(1.0 / ((double)B * (double)S)), mean, invstd, gamma, beta, dgamma,
-                     dbeta, relu, dx_accum, dx);
+                     dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

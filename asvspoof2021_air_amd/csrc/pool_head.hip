@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
 __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, int K,
-                                                        int N, float* __restrict__ y) {
+                                                        int N, int relu, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const int m = blockIdx.x;
   for (int k = threadIdx.x; k < K; k += NT) xs[k] = x[(size_t)m * K + k];
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
     float s = 0.0f;
     for (int k = lane; k < K; k += 64) s = fmaf(xs[k], wr[k], s);
     s = air_wave_sum(s);
-    if (lane == 0) y[(size_t)m * N + n] = s + (bias ? bias[n] : 0.0f);
+    if (lane == 0) {
+      const float v = s + (bias ? bias[n] : 0.0f);
+      y[(size_t)m * N + n] = relu ? fmaxf(v, 0.0f) : v;
+    }
   }
 }
 
@@ -329,14 +332,24 @@ int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w
   return AIR_OK;
 }
 
-int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K, int N, float* y,
-                   air_stream_t stream) {
+static int linear_fwd_impl(const float* x, const float* w, const float* b, int M, int K, int N,
+                           int relu, float* y, air_stream_t stream) {
   if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return AIR_EINVAL;
   if ((size_t)K * sizeof(float) > 64 * 1024) return AIR_EUNSUPPORTED;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(M), dim3(NT), (size_t)K * sizeof(float),
-                     air_stream(stream), x, w, b, K, N, y);
+                     air_stream(stream), x, w, b, K, N, relu, y);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_linear_relu_fwd(const float* x, const float* w, const float* b, int M, int K, int N,
+                        float* y, air_stream_t stream) {
+  return linear_fwd_impl(x, w, b, M, K, N, 1, y, stream);
+}
+
+int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K, int N, float* y,
+                   air_stream_t stream) {
+  return linear_fwd_impl(x, w, b, M, K, N, 0, y, stream);
 }
 
 int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K, int N, float* dx,

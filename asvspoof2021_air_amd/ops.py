@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _hip
-from ._hip import AirConv2d, ci, cf, csz, dptr, stream
+from ._hip import AirConv1d, AirConv2d, ci, cf, csz, dptr, stream
 
 _WS = {}
 
@@ -119,8 +119,10 @@ def bn_apply(x, scale, shift, relu=False, out=None):
 
 
 def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=False,
-           dgamma=None, dbeta=None):
-    """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta)."""
+           dgamma=None, dbeta=None, relu_in=False):
+    """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta).
+    relu_in: x is itself a ReLU output (conv -> ReLU -> BN); dx is then the gradient
+    w.r.t. the pre-ReLU tensor."""
     B, C, S = _bcs(x)
     if dx is None:
         if accumulate:
@@ -134,7 +136,7 @@ def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=Fal
     n = lib.air_bn_ws_bytes(ci(B), ci(C), ci(S))
     ws = workspace(n, x.device)
     _hip.check(lib.air_bn_bwd(dptr(x), dptr(dy), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd),
-                              dptr(gamma), dptr(beta), ci(1 if relu else 0), dptr(dx),
+                              dptr(gamma), dptr(beta), ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
                               ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
                               dptr(ws, torch.uint8), csz(n), stream()), "air_bn_bwd")
     return dx, dgamma, dbeta
@@ -163,12 +165,13 @@ def selfatt_pool_bwd(x, att_w, noise, alpha, out, dout):
     return dx, datt
 
 
-def linear_fwd(x, w, b=None):
+def linear_fwd(x, w, b=None, relu=False):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-    _hip.check(_hip.lib().air_linear_fwd(dptr(x), dptr(w), dptr(b, allow_none=True), ci(M), ci(K),
-                                         ci(N), dptr(y), stream()), "air_linear_fwd")
+    fn = _hip.lib().air_linear_relu_fwd if relu else _hip.lib().air_linear_fwd
+    _hip.check(fn(dptr(x), dptr(w), dptr(b, allow_none=True), ci(M), ci(K), ci(N), dptr(y),
+                  stream()), "air_linear_fwd")
     return y
 
 
@@ -239,3 +242,157 @@ def randn(shape, device, seed, offset, scale=1.0):
     _hip.check(_hip.lib().air_randn(dptr(out), csz(out.numel()), ctypes.c_uint64(seed),
                                     ctypes.c_uint64(offset), cf(scale), stream()), "air_randn")
     return out
+
+
+# ------------------------------------------------------------------ ECAPA (B, C, T) ops
+def vptr(t):
+    """(pointer, batch stride) of a (B, C, T) tensor or channel-slice view whose (C, T)
+    block is dense."""
+    if t.dim() != 3 or not t.is_cuda or t.dtype != torch.float32:
+        raise _hip.AirError("expected a (B, C, T) fp32 GPU tensor")
+    B, C, T = t.shape
+    if t.stride(2) != 1 or (C > 1 and t.stride(1) != T):
+        raise _hip.AirError("channel-slice view must keep (C, T) dense")
+    return ctypes.c_void_p(t.data_ptr()), (t.stride(0) if B > 1 else C * T)
+
+
+def _c1d(x, cout, K, dil, pad, y=None):
+    B, Cin, T = x.shape
+    xp, xb = vptr(x)
+    yb = vptr(y)[1] if y is not None else cout * T
+    d = AirConv1d(B, Cin, T, cout, K, dil, pad, xb, yb)
+    n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
+    if n == 0:
+        raise _hip.AirError("conv1d: unsupported configuration K=%d dil=%d pad=%d" % (K, dil, pad))
+    return d, workspace(n, x.device), n
+
+
+def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None):
+    """y = relu?(conv1d(x, w) + bias + bias_bc[b]); x / out may be channel-slice views."""
+    Cout, Cin, K = w.shape
+    B, _, T = x.shape
+    y = out if out is not None else torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    d, ws, n = _c1d(x, Cout, K, dil, pad, y)
+    _hip.check(_hip.lib().air_conv1d_fwd(ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
+                                         dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
+                                         dptr(ws, torch.uint8), csz(n), stream()), "air_conv1d_fwd")
+    return y
+
+
+def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None):
+    """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out)."""
+    Cout, Cin, K = w.shape
+    B, _, T = dy.shape
+    dx = out if out is not None else torch.empty((B, Cin, T), device=dy.device, dtype=torch.float32)
+    xp, xb = vptr(dx)
+    yp, yb = vptr(dy)
+    d = AirConv1d(B, Cin, T, Cout, K, dil, pad, xb, yb)
+    n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
+    ws = workspace(n, dy.device)
+    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
+    _hip.check(_hip.lib().air_conv1d_dgrad(ctypes.byref(d), yp, dptr(w), xp, acc, dptr(ws, torch.uint8),
+                                           csz(n), stream()), "air_conv1d_dgrad")
+    return dx
+
+
+def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None):
+    Cout, Cin, K = w_shape
+    B, _, T = x.shape
+    dw = out if out is not None else torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
+    xp, xb = vptr(x)
+    yp, yb = vptr(dy)
+    d = AirConv1d(B, Cin, T, Cout, K, dil, pad, xb, yb)
+    n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
+    ws = workspace(n, x.device)
+    _hip.check(_hip.lib().air_conv1d_wgrad(ctypes.byref(d), xp, yp, dptr(dw), dptr(ws, torch.uint8),
+                                           csz(n), stream()), "air_conv1d_wgrad")
+    return dw
+
+
+def add_strided(out, a, b=None):
+    """out = a (+ b) over (B, C, T) tensors / channel-slice views."""
+    B, C, T = out.shape
+    op, ob = vptr(out)
+    ap, ab = vptr(a)
+    bp, bb = vptr(b) if b is not None else (ctypes.c_void_p(0), 0)
+    _hip.check(_hip.lib().air_add_strided(op, csz(ob), ap, csz(ab), bp, csz(bb), ci(B), ci(C), ci(T),
+                                          stream()), "air_add_strided")
+    return out
+
+
+def channel_sum(x, out=None):
+    B, C, T = x.shape
+    xp, xb = vptr(x)
+    if out is None:
+        out = torch.empty(C, device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_channel_sum(xp, ci(B), ci(C), ci(T), csz(xb), dptr(out), stream()),
+               "air_channel_sum")
+    return out
+
+
+def row_stats(x, want_std=True, clamp_min=1e-4, mean_out=None, std_out=None):
+    B, C, T = x.shape
+    mean = mean_out if mean_out is not None else torch.empty((B, C), device=x.device, dtype=torch.float32)
+    std = None
+    if want_std:
+        std = std_out if std_out is not None else torch.empty((B, C), device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_row_stats(dptr(x), ci(B), ci(C), ci(T), dptr(mean), dptr(std, allow_none=True),
+                                        cf(clamp_min), stream()), "air_row_stats")
+    return mean, std
+
+
+def row_stats_bwd(x, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4):
+    B, C, T = x.shape
+    _hip.check(_hip.lib().air_row_stats_bwd(dptr(x), ci(B), ci(C), ci(T), dptr(mean), dptr(std, allow_none=True),
+                                            dptr(dmean, allow_none=True), dptr(dstd, allow_none=True),
+                                            cf(clamp_min), dptr(dx), ci(1 if accumulate else 0), stream()),
+               "air_row_stats_bwd")
+    return dx
+
+
+def row_sum(x):
+    B, C, T = x.shape
+    out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_row_sum(dptr(x), ci(B), ci(C), ci(T), dptr(out), stream()), "air_row_sum")
+    return out
+
+
+def relu_mask_(dx, y):
+    _hip.check(_hip.lib().air_relu_mask(dptr(dx), dptr(y), csz(dx.numel()), stream()), "air_relu_mask")
+    return dx
+
+
+def se_scale_fwd(x, z, res, out):
+    B, C, T = x.shape
+    rp, rb = vptr(res)
+    op, ob = vptr(out)
+    _hip.check(_hip.lib().air_se_scale_fwd(dptr(x), dptr(z), rp, csz(rb), ci(B), ci(C), ci(T), op, csz(ob),
+                                           stream()), "air_se_scale_fwd")
+    return out
+
+
+def se_scale_bwd(x, z, dout):
+    B, C, T = x.shape
+    dp, db = vptr(dout)
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(z)
+    _hip.check(_hip.lib().air_se_scale_bwd(dptr(x), dptr(z), dp, csz(db), ci(B), ci(C), ci(T), dptr(dx),
+                                           dptr(dz), stream()), "air_se_scale_bwd")
+    return dx, dz
+
+
+def asp_fwd(x, logits):
+    """Overwrites ``logits`` with the softmax weights; returns (B, 2C) = [mu | sg]."""
+    B, C, T = x.shape
+    out = torch.empty((B, 2 * C), device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_asp_fwd(dptr(x), dptr(logits), ci(B), ci(C), ci(T), dptr(out), stream()),
+               "air_asp_fwd")
+    return out
+
+
+def asp_bwd(x, w, out, dout, dx, accumulate=False):
+    """Overwrites ``w`` with d(logits); writes / accumulates dx."""
+    B, C, T = x.shape
+    _hip.check(_hip.lib().air_asp_bwd(dptr(x), dptr(w), ci(B), ci(C), ci(T), dptr(out), dptr(dout), dptr(dx),
+                                      ci(1 if accumulate else 0), stream()), "air_asp_bwd")
+    return dx

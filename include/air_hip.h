@@ -103,6 +103,29 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
                      const float* in_scale, const float* in_shift, int relu,
                      void* ws, size_t ws_bytes, air_stream_t stream);
 
+/* --------------------------------------------------------------- conv1d --
+ * nn.Conv1d (stride 1) as used by ecapa_tdnn.py:39,46,55,111,118,140,143, with the
+ * conv -> ReLU -> BN ordering of ecapa_tdnn.py:67-69 supported by bias / ReLU epilogues.
+ * x (B, Cin, T), w (Cout, Cin, K), y (B, Cout, T).  Supported: K=1; K=3 with
+ * dilation 2..4 and pad = dilation; K=5 with pad 2.  x_bstride / y_bstride are batch
+ * strides in floats (0 = contiguous) so channel groups of a wider tensor (the Res2
+ * split, the (x1,x2,x3) concat) are addressed in place.
+ */
+typedef struct AirConv1d {
+  int B, Cin, T, Cout, K, dil, pad;
+  size_t x_bstride, y_bstride;
+} AirConv1d;
+
+size_t air_conv1d_ws_bytes(const AirConv1d* p);
+/* y = relu?(conv1d(x, w) + bias[co] + bias_bc[b][co]); bias, bias_bc may be NULL. */
+int air_conv1d_fwd(const AirConv1d* p, const float* x, const float* w, const float* bias,
+                   const float* bias_bc, int relu, float* y, void* ws, size_t ws_bytes,
+                   air_stream_t stream);
+int air_conv1d_dgrad(const AirConv1d* p, const float* dy, const float* w, float* dx,
+                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+int air_conv1d_wgrad(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
+                     size_t ws_bytes, air_stream_t stream);
+
 /* ------------------------------------------------------- batchnorm/relu --
  * nn.BatchNorm2d/1d (+ F.relu) as used at resnet.py:55-67,132,142 and
  * ecapa_tdnn.py.  x is (B, C, S) with S = H*W (or T).
@@ -124,7 +147,10 @@ int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* y = x*scale[c] + shift[c], optional ReLU. */
 int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
                  int relu, float* y, air_stream_t stream);
-/* Backward of y = relu?(bn(x)) in training mode.  dy: grad wrt y.
+/* Backward of y = relu?(bn(x)) in training mode.  dy: grad wrt y.  relu bit 0: a ReLU
+ * follows the BN (resnet.py:64); bit 1: the BN input is itself a ReLU output
+ * (conv -> ReLU -> BN, ecapa_tdnn.py:67-69), so dx is masked where x == 0 and is the
+ * gradient w.r.t. the pre-ReLU conv output.
  * dx_accum: if non-zero dx += result (gradient joining a residual branch).
  * dgamma/dbeta: (C,) written. */
 int air_bn_bwd(const float* x, const float* dy, int B, int C, int S,
@@ -159,8 +185,44 @@ int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
  */
 int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K, int N, float* y,
                    air_stream_t stream);
+int air_linear_relu_fwd(const float* x, const float* w, const float* b, int M, int K, int N,
+                        float* y, air_stream_t stream); /* y = max(0, x W^T + b) */
 int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K, int N,
                    float* dx, float* dw, float* db, air_stream_t stream);
+
+/* ------------------------------------------------------ ECAPA small ops ---
+ * (B, C, T) fp32, time contiguous; *_bstride = batch stride in floats (0 = contiguous).
+ */
+/* out = a (+ b): copies / joins channel groups that are views of wider tensors
+ * (torch.split / torch.cat / "sp + spx[i]" of ecapa_tdnn.py:71-83). */
+int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
+                    const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream);
+/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradients. */
+int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out,
+                    air_stream_t stream);
+/* mean_T and sqrt(clamp(var_T unbiased, clamp_min)) per (b,c) row: SE squeeze
+ * (ecapa_tdnn.py:19) and the context statistics (:178).  std may be NULL. */
+int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_or_null,
+                  float clamp_min, air_stream_t stream);
+int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
+                      const float* dmean, const float* dstd, float clamp_min, float* dx,
+                      int accumulate, air_stream_t stream);
+/* dx *= (y > 0): backward of the stand-alone ReLU after layer4 (ecapa_tdnn.py:173). */
+int air_relu_mask(float* dx, const float* y, size_t n, air_stream_t stream);
+/* out[b][c] = sum_t x[b][c][t]: gradient of a per-utterance bias. */
+int air_row_sum(const float* x, int B, int C, int T, float* out, air_stream_t stream);
+/* SEModule gate + block residual (ecapa_tdnn.py:27-29,:93): out = x*sigmoid(z[b][c]) + res. */
+int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
+                     int C, int T, float* out, size_t out_bstride, air_stream_t stream);
+int air_se_scale_bwd(const float* x, const float* z, const float* dout, size_t dout_bstride, int B,
+                     int C, int T, float* dx, float* dz, air_stream_t stream);
+/* Attentive statistics pooling (ecapa_tdnn.py:143-185): softmax over T of the attention
+ * logits (overwritten with the weights w), mu = sum x w, sg = sqrt(clamp(sum x^2 w - mu^2,
+ * 1e-4)); out (B, 2C) = [mu | sg].  bwd overwrites w with d(logits). */
+int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* out,
+                air_stream_t stream);
+int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
+                const float* dout, float* dx, int accumulate, air_stream_t stream);
 
 /* ----------------------------------------------------------- OC-Softmax ---
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
