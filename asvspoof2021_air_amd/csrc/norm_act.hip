@@ -39,6 +39,9 @@ __global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __res
   const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
   const int per = (B + nsplit - 1) / nsplit;
   const int b0 = split * per, b1 = min(B, b0 + per);
+  // Shifted sums: accumulate (x - K) with K = the channel's first element, so that
+  // var = E[(x-K)^2] - E[x-K]^2 does not cancel when |mean| >> std (or when N is tiny).
+  const float K = x[(size_t)c * S];
   float s1 = 0.0f, s2 = 0.0f;
   double d1 = 0.0, d2 = 0.0;
   for (int b = b0; b < b1; ++b) {
@@ -46,13 +49,14 @@ __global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __res
     if ((S & 3) == 0 && ((((size_t)p) & 15) == 0)) {
       const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
       for (int i = threadIdx.x; i < S / 4; i += NT) {
-        const float4 v = p4[i];
+        float4 v = p4[i];
+        v.x -= K; v.y -= K; v.z -= K; v.w -= K;
         s1 += (v.x + v.y) + (v.z + v.w);
         s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       }
     } else {
       for (int i = threadIdx.x; i < S; i += NT) {
-        const float v = p[i];
+        const float v = p[i] - K;
         s1 += v;
         s2 += v * v;
       }
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __res
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int nsplit, int C, double N,
+__global__ void bn_finalize_kernel(const float* __restrict__ x, int S,
+                                   const double* __restrict__ partial, int nsplit, int C, double N,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ mean,
@@ -83,9 +88,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int nspli
     s1 += partial[((size_t)c * nsplit + k) * 2];
     s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
   }
-  const double m = s1 / N;
-  double var = s2 / N - m * m;
+  const double ms = s1 / N;  // mean of the shifted data
+  double var = s2 / N - ms * ms;
   if (var < 0.0) var = 0.0;
+  const double m = ms + (double)x[(size_t)c * S];
   const float mf = (float)m;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = mf;
@@ -245,7 +251,7 @@ int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, co
   hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S,
                      nsplit, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, x, S, partial, nsplit, C,
                      (double)B * (double)S, gamma, beta, eps, momentum, running_mean, running_var,
                      mean, invstd, scale, shift);
   AIR_CHECK_LAUNCH();

@@ -1,0 +1,363 @@
+"""Drop-in for the reference's ``ecapa_tdnn.Res2Net2`` (ECAPA-TDNN, ecapa_tdnn.py:97-198)
+with ``Bottle2neck`` (:31-95) and ``SEModule`` (:15-29).
+
+Same constructors, ``forward(x:(B,n_mels,T)) -> (feat:(B,256), out:(B,nOut))``, the
+reference's 248 ``state_dict`` keys and conv -> ReLU -> BN ordering.  Forward and backward run
+in the gfx950 kernels of csrc/conv2d.hip (conv1d entry points), norm_act.hip and
+ecapa_ops.hip; this file only sequences them inside one ``autograd.Function``.
+
+Layout choices that remove the reference's copies:
+  * ``torch.split`` / ``torch.cat`` of the Res2 branch and ``cat(x1,x2,x3)`` are channel-slice
+    views (batch-strided kernel arguments): every block writes straight into its slice;
+  * the (B,4608,T) context tensor (ecapa_tdnn.py:178) is never built: the tiled mean/std
+    part of ``attention.0`` is constant over T, so it is applied as a per-utterance bias
+    W[:,1536:] @ [mean; std] in the conv epilogue (same arithmetic, re-associated).
+fp32 throughout in this round.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _hip, ops
+from .arena import ParamArena
+
+
+class SEModule(nn.Module):
+    """Parameter holder for ecapa_tdnn.py:15-29."""
+
+    def __init__(self, channels, bottleneck=128):
+        super().__init__()
+        self.se = nn.Sequential(
+            nn.AdaptiveAvgPool1d(1),
+            nn.Conv1d(channels, bottleneck, kernel_size=1, padding=0),
+            nn.ReLU(),
+            nn.BatchNorm1d(bottleneck),
+            nn.Conv1d(bottleneck, channels, kernel_size=1, padding=0),
+            nn.Sigmoid(),
+        )
+
+    def forward(self, input):
+        raise NotImplementedError("SEModule runs inside Res2Net2.forward (fused HIP path)")
+
+
+class Bottle2neck(nn.Module):
+    """Parameter holder for ecapa_tdnn.py:31-95."""
+
+    def __init__(self, inplanes, planes, kernel_size=None, dilation=None, scale=4):
+        super().__init__()
+        width = int(math.floor(planes / scale))
+        self.conv1 = nn.Conv1d(inplanes, width * scale, kernel_size=1)
+        self.bn1 = nn.BatchNorm1d(width * scale)
+        self.nums = scale - 1
+        convs, bns = [], []
+        num_pad = math.floor(kernel_size / 2) * dilation
+        for i in range(self.nums):
+            convs.append(nn.Conv1d(width, width, kernel_size=kernel_size, dilation=dilation, padding=num_pad))
+            bns.append(nn.BatchNorm1d(width))
+        self.convs = nn.ModuleList(convs)
+        self.bns = nn.ModuleList(bns)
+        self.conv3 = nn.Conv1d(width * scale, planes, kernel_size=1)
+        self.bn3 = nn.BatchNorm1d(planes)
+        self.relu = nn.ReLU()
+        self.width = width
+        self.dilation = dilation
+        self.se = SEModule(planes)
+
+    def forward(self, x):
+        raise NotImplementedError("Bottle2neck runs inside Res2Net2.forward (fused HIP path)")
+
+
+def _bn(x3, bn, training):
+    """BatchNorm1d on a (B, C, S) tensor: returns (mean, invstd, scale, shift)."""
+    if training:
+        st = ops.bn_stats(x3, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                          bn.eps, bn.momentum)
+        bn.num_batches_tracked += 1
+        return st
+    scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                      bn.running_var, bn.eps)
+    return None, None, scale, shift
+
+
+class _EcapaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.set_materialize_grads(False)
+        feat, out, saved = model._forward_impl(x, save=True)
+        ctx.model, ctx.saved = model, saved
+        return feat, out
+
+    @staticmethod
+    def backward(ctx, dfeat, dout):
+        model, saved = ctx.model, ctx.saved
+        ctx.saved = None
+        return (None, None) + tuple(model._backward_impl(saved, dfeat, dout))
+
+
+class Res2Net2(nn.Module):
+    def __init__(self, block, C, model_scale, nOut, n_mels, encoder_type="ECA", context=True,
+                 summed=False, out_bn=True, **kwargs):
+        self.context = context
+        self.summed = summed
+        self.n_mfcc = n_mels
+        self.encoder_type = encoder_type
+        self.out_bn = out_bn
+        super().__init__()
+        if encoder_type != "ECA" or not context or summed:
+            raise NotImplementedError("hot path: encoder_type='ECA', context=True, summed=False "
+                                      "(main_train.py:167)")
+        self.scale = model_scale
+        self.conv1 = nn.Conv1d(self.n_mfcc, C, kernel_size=5, stride=1, padding=2)
+        self.relu = nn.ReLU()
+        self.bn1 = nn.BatchNorm1d(C)
+        self.layer1 = block(C, C, kernel_size=3, dilation=2, scale=self.scale)
+        self.layer2 = block(C, C, kernel_size=3, dilation=3, scale=self.scale)
+        self.layer3 = block(C, C, kernel_size=3, dilation=4, scale=self.scale)
+        self.layer4 = nn.Conv1d(3 * C, 1536, kernel_size=1)
+        self.instancenorm = nn.InstanceNorm1d(self.n_mfcc)  # constructed, never applied (:120)
+        attn_input = 1536 * 3
+        attn_output = 1536
+        self.attention = nn.Sequential(
+            nn.Conv1d(attn_input, 128, kernel_size=1),
+            nn.ReLU(),
+            nn.BatchNorm1d(128),
+            nn.Conv1d(128, attn_output, kernel_size=1),
+            nn.Softmax(dim=2),
+        )
+        self.bn5 = nn.BatchNorm1d(3072)
+        self.fc6 = nn.Linear(3072, 256)
+        self.fc7 = nn.Linear(256, nOut)
+        self.bn7 = nn.BatchNorm1d(nOut)
+        self.C = C
+        self._arena = None
+
+    # ------------------------------------------------------------------ plumbing
+    def arena(self):
+        dev = self.conv1.weight.device
+        if self._arena is None:
+            self._arena = ParamArena(list(self.named_parameters()),
+                                     tail_names=("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias"))
+        if not self._arena.bound() or self._arena.device != dev:
+            self._arena.bind(dev)
+        return self._arena
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _hip.AirError("Res2Net2 HIP path needs a GPU tensor; there is no CPU fallback")
+        if x.dim() != 3 or x.shape[1] != self.n_mfcc:
+            raise ValueError("Res2Net2 expects (B, %d, T), got %s" % (self.n_mfcc, tuple(x.shape)))
+        x = x.float().contiguous()
+        arena = self.arena()
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _EcapaFn.apply(self, x, *[p for _, p, _, _ in arena.entries])
+        feat, out, _ = self._forward_impl(x, save=False)
+        return feat, out
+
+    # ------------------------------------------------------------------ forward
+    def _block_fwd(self, blk, inp, out, training, save):
+        """Bottle2neck (ecapa_tdnn.py:64-95).  ``inp`` / ``out`` may be channel-slice views."""
+        B, C, T = inp.shape
+        w, d, nums = blk.width, blk.dilation, blk.nums
+        det = lambda p: p.detach()
+        r1 = ops.conv1d_fwd(inp, det(blk.conv1.weight), det(blk.conv1.bias), relu=True)
+        st1 = _bn(r1, blk.bn1, training)
+        o1 = ops.bn_apply(r1, st1[2], st1[3])
+        cat = torch.empty_like(o1)
+        t_list, r_list, st_list = [], [], []
+        sp = None
+        for i in range(nums):
+            grp = o1[:, i * w:(i + 1) * w]
+            if i == 0:
+                t_i = grp
+            else:
+                t_i = ops.add_strided(torch.empty((B, w, T), device=inp.device), sp, grp)
+            r_i = ops.conv1d_fwd(t_i, det(blk.convs[i].weight), det(blk.convs[i].bias), relu=True,
+                                 dil=d, pad=d)
+            st_i = _bn(r_i, blk.bns[i], training)
+            sp = ops.bn_apply(r_i, st_i[2], st_i[3])
+            ops.add_strided(cat[:, i * w:(i + 1) * w], sp)
+            t_list.append(t_i)
+            r_list.append(r_i)
+            st_list.append(st_i)
+        ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
+        r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True)
+        st3 = _bn(r3, blk.bn3, training)
+        o3 = ops.bn_apply(r3, st3[2], st3[3])
+        se = blk.se.se
+        m, _ = ops.row_stats(o3, want_std=False)
+        z1 = ops.linear_fwd(m, det(se[1].weight).view(se[1].out_channels, -1), det(se[1].bias), relu=True)
+        stS = _bn(z1.view(B, -1, 1), se[3], training)
+        z1n = ops.bn_apply(z1.view(B, -1, 1), stS[2], stS[3]).view(B, -1)
+        z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
+        ops.se_scale_fwd(o3, z2, inp, out)
+        if save:
+            return dict(blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat,
+                        r3=r3, st3=st3, o3=o3, m=m, z1=z1, stS=stS, z1n=z1n, z2=z2)
+        return None
+
+    def _forward_impl(self, x, save):
+        training = self.training
+        det = lambda p: p.detach()
+        B, _, T = x.shape
+        C = self.C
+        r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
+        st0 = _bn(r0, self.bn1, training)
+        h = ops.bn_apply(r0, st0[2], st0[3])  # :161
+        cat123 = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
+        blocks = []
+        inp = h
+        for k, blk in enumerate((self.layer1, self.layer2, self.layer3)):
+            out = cat123[:, k * C:(k + 1) * C]
+            blocks.append(self._block_fwd(blk, inp, out, training, save))
+            inp = out
+        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True)  # :172-173
+        mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178)
+        ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
+        a0, a3 = self.attention[0], self.attention[3]
+        w0 = det(a0.weight).view(128, -1)  # (128, 4608)
+        w_x = ops.add_strided(torch.empty((128, 1, 1536), device=x.device),
+                              w0[:, :1536].unsqueeze(1)).view(128, 1536, 1)
+        w_c = ops.add_strided(torch.empty((128, 1, 3072), device=x.device),
+                              w0[:, 1536:].unsqueeze(1)).view(128, 3072)
+        ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std]
+        a1 = ops.conv1d_fwd(x4, w_x, det(a0.bias), bias_bc=ctxb, relu=True)  # attention.0 + ReLU
+        stA = _bn(a1, self.attention[2], training)
+        a1n = ops.bn_apply(a1, stA[2], stA[3])
+        wts = ops.conv1d_fwd(a1n, det(a3.weight), det(a3.bias))  # logits -> softmax weights below
+        pooled = ops.asp_fwd(x4, wts)  # :184-187 (mu | sg)
+        st5 = _bn(pooled.view(B, -1, 1), self.bn5, training)
+        p5 = ops.bn_apply(pooled.view(B, -1, 1), st5[2], st5[3]).view(B, -1)
+        feat = ops.linear_fwd(p5, det(self.fc6.weight), det(self.fc6.bias))  # :191
+        o7 = ops.linear_fwd(feat, det(self.fc7.weight), det(self.fc7.bias))  # :193
+        st7 = None
+        out = o7
+        if self.out_bn:
+            st7 = _bn(o7.view(B, -1, 1), self.bn7, training)
+            out = ops.bn_apply(o7.view(B, -1, 1), st7[2], st7[3]).view(B, -1)
+        S = None
+        if save:
+            if not training:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
+            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
+                     ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
+                     p5=p5, feat=feat, o7=o7, st7=st7)
+        return feat, out, S
+
+    # ----------------------------------------------------------------- backward
+    def _block_bwd(self, S, dout, G, pre):
+        """dout: gradient w.r.t. the block output (dense (B,C,T)).  Returns d(inp) dense."""
+        blk = S["blk"]
+        det = lambda p: p.detach()
+        B, C, T = S["o3"].shape
+        w, d, nums = blk.width, blk.dilation, blk.nums
+        se = blk.se.se
+        gv = lambda n: G[pre + n]
+        do3, dz2 = ops.se_scale_bwd(S["o3"], S["z2"], dout)
+        dz1n, _, _ = ops.linear_bwd(S["z1n"], det(se[4].weight).view(se[4].out_channels, -1), dz2, True,
+                                    dw=gv("se.se.4.weight").view(se[4].out_channels, -1),
+                                    db=gv("se.se.4.bias"))
+        stS = S["stS"]
+        dz1, _, _ = ops.bn_bwd(S["z1"].view(B, -1, 1), dz1n.view(B, -1, 1), stS[0], stS[1],
+                               det(se[3].weight), det(se[3].bias), relu_in=True,
+                               dgamma=gv("se.se.3.weight"), dbeta=gv("se.se.3.bias"))
+        dm, _, _ = ops.linear_bwd(S["m"], det(se[1].weight).view(se[1].out_channels, -1), dz1.view(B, -1), True,
+                                  dw=gv("se.se.1.weight").view(se[1].out_channels, -1),
+                                  db=gv("se.se.1.bias"))
+        ops.row_stats_bwd(S["o3"], S["m"], None, dm, None, do3, accumulate=True)
+        st3 = S["st3"]
+        dc3, _, _ = ops.bn_bwd(S["r3"], do3, st3[0], st3[1], det(blk.bn3.weight), det(blk.bn3.bias),
+                               relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"))
+        ops.channel_sum(dc3, out=gv("conv3.bias"))
+        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"))
+        dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight))
+        do1 = torch.empty_like(dcat)
+        ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
+        din_next = None
+        for i in reversed(range(nums)):
+            dsp = torch.empty((B, w, T), device=dcat.device, dtype=torch.float32)
+            ops.add_strided(dsp, dcat[:, i * w:(i + 1) * w], din_next)
+            st_i = S["st"][i]
+            dc_i, _, _ = ops.bn_bwd(S["r"][i], dsp, st_i[0], st_i[1], det(blk.bns[i].weight),
+                                    det(blk.bns[i].bias), relu_in=True, dx=dsp,
+                                    dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i))
+            ops.channel_sum(dc_i, out=gv("convs.%d.bias" % i))
+            ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
+            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d)
+            ops.add_strided(do1[:, i * w:(i + 1) * w], din)
+            din_next = din if i > 0 else None
+        st1 = S["st1"]
+        dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),
+                               relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"))
+        ops.channel_sum(dc1, out=gv("conv1.bias"))
+        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"))
+        dinp = ops.conv1d_dgrad(dc1, det(blk.conv1.weight))
+        ops.add_strided(dinp, dinp, dout)  # residual branch (ecapa_tdnn.py:93)
+        return dinp
+
+    def _backward_impl(self, S, dfeat, dout):
+        arena = self.arena()
+        G = arena.grad_views()
+        det = lambda p: p.detach()
+        B, _, T = S["x"].shape
+        C = self.C
+        tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")
+        have_tail = dout is not None
+        if dfeat is None:
+            dfeat = torch.zeros_like(S["feat"])
+        dfeat = dfeat.contiguous()
+        if have_tail:  # CE branch through fc7/bn7 (dead under ang_iso, main_train.py:355 -> 376)
+            do7 = dout.contiguous()
+            if self.out_bn:
+                st7 = S["st7"]
+                do7, _, _ = ops.bn_bwd(S["o7"].view(B, -1, 1), do7.view(B, -1, 1), st7[0], st7[1],
+                                       det(self.bn7.weight), det(self.bn7.bias),
+                                       dgamma=G["bn7.weight"], dbeta=G["bn7.bias"])
+                do7 = do7.view(B, -1)
+            dx7, _, _ = ops.linear_bwd(S["feat"], det(self.fc7.weight), do7, True, dw=G["fc7.weight"],
+                                       db=G["fc7.bias"])
+            dfeat = ops.add_(dx7, dfeat)
+        dp5, _, _ = ops.linear_bwd(S["p5"], det(self.fc6.weight), dfeat, True, dw=G["fc6.weight"],
+                                   db=G["fc6.bias"])
+        st5 = S["st5"]
+        dpooled, _, _ = ops.bn_bwd(S["pooled"].view(B, -1, 1), dp5.view(B, -1, 1), st5[0], st5[1],
+                                   det(self.bn5.weight), det(self.bn5.bias),
+                                   dgamma=G["bn5.weight"], dbeta=G["bn5.bias"])
+        x4, wts = S["x4"], S["wts"]
+        dx4 = torch.empty_like(x4)
+        ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False)  # wts -> dlogits
+        a0, a3 = self.attention[0], self.attention[3]
+        ops.channel_sum(wts, out=G["attention.3.bias"])
+        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"])
+        da1n = ops.conv1d_dgrad(wts, det(a3.weight))
+        stA = S["stA"]
+        da1, _, _ = ops.bn_bwd(S["a1"], da1n, stA[0], stA[1], det(self.attention[2].weight),
+                               det(self.attention[2].bias), relu_in=True, dx=da1n,
+                               dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"])
+        ops.channel_sum(da1, out=G["attention.0.bias"])
+        gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
+        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1))
+        ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
+        ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4)
+        dctxb = ops.row_sum(da1)  # (B,128)
+        dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb, True, need_db=False)
+        ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
+        dmean = dctx[:, :1536].contiguous()
+        dstd = dctx[:, 1536:].contiguous()
+        ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True)
+        ops.relu_mask_(dx4, x4)  # ReLU after layer4 (:173)
+        ops.channel_sum(dx4, out=G["layer4.bias"])
+        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"])
+        dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight))
+        dnext = None
+        for k in (2, 1, 0):
+            dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
+            ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
+            dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1))
+        st0 = S["st0"]
+        dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),
+                               relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"])
+        ops.channel_sum(dc0, out=G["conv1.bias"])
+        ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
+        arena.tail_has_grad = have_tail
+        return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]

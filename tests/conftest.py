@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is PyTorch-CPU fp32.  On the 128-thread host of the GPU box its conv
+    # backward returned gradients 16 % off for some layers (fp64 or <= 8 threads agree with
+    # the reference goldens and with the HIP path), so the oracle always runs on <= 8 threads,
+    # the configuration the goldens were generated and pinned with.
+    import torch
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
 
 
 def load_golden(name):

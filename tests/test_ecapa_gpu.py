@@ -1,0 +1,99 @@
+"""GPU parity of the drop-in ECAPA-TDNN (Res2Net2) against the oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as o_ecapa
+from oracle import train as o_train
+from oracle.filler import fill_module_, fill_state, fill_value, synth_feat
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model():
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+    fill_module_(m)
+    return m.cuda()
+
+
+def test_state_dict_surface():
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+    want = o_ecapa.ecapa_shapes()
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(got.items()) == [(k, tuple(v)) for k, v in want.items()]
+    assert sum(p.numel() for p in m.parameters()) == 6337734
+
+
+@pytest.mark.parametrize("tag,B,T", [("small", 2, 96), ("full", 2, 750)])
+def test_forward_vs_golden(golden, tag, B, T):
+    g = golden("ecapa.npz")
+    m = make_model()
+    x = synth_feat((B, 60, T), seed=400 + T)
+    for mode in ("train", "eval"):
+        fill_module_(m)
+        m.train(mode == "train")
+        with torch.no_grad():
+            feat, out = m(x.cuda())
+        # |feat| ~ 3; fp32 summation-order noise through ~40 layers
+        np.testing.assert_allclose(feat.cpu().numpy(), g["feat_%s_%s" % (tag, mode)], atol=2e-4)
+        np.testing.assert_allclose(out.cpu().numpy(), g["out_%s_%s" % (tag, mode)], atol=5e-4)
+
+
+def test_grads_vs_oracle_small(golden):
+    g = golden("ecapa.npz")
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    m = make_model().train()
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    lossm = lossm.cuda()
+    x = synth_feat((2, 60, 96), seed=496)
+    labels = torch.tensor([0, 1])
+    feat, out = m(x.cuda())
+    loss, _ = lossm(feat, labels.cuda())
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["loss_small"], rtol=1e-4)
+    tr = o_train.OracleTrainer("ecapa", fill_state(o_ecapa.ecapa_shapes()), fill_value("center", (1, 256)))
+    lo, no, fo, go, gco, _ = tr.loss_and_grads(x, labels)
+    worst = ("", 0.0)
+    # attention.2.bias and attention.3.bias have analytically ZERO gradients (they shift every
+    # logit of a (b, c) row by the same amount and softmax over T ignores that), so both sides
+    # hold rounding noise there: bound it against the gradient scale of the sibling gamma.
+    noise_floor = 1e-4 * float(go["attention.2.weight"].abs().max())
+    for k, p in m.named_parameters():
+        if go[k] is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        ref = go[k].numpy()
+        diff = np.abs(p.grad.cpu().numpy() - ref).max()
+        err = diff / (np.abs(ref).max() + 1e-30)
+        if k in ("attention.2.bias", "attention.3.bias"):
+            assert diff < noise_floor, (k, diff, noise_floor)
+            continue
+        if err > worst[1]:
+            worst = (k, err)
+        assert err < 2e-3, "%s: rel-to-max grad err %.3g (|ref|max %.3g)" % (k, err, np.abs(ref).max())
+    print("worst rel-to-max grad err", worst)
+
+
+def test_ce_branch_gradients():
+    """With a loss on ``out`` too (base-loss branch, main_train.py:355) fc7/bn7 receive gradients."""
+    m = make_model().train()
+    x = synth_feat((4, 60, 64), seed=3)
+    wo, wf = synth_feat((4, 2), 9), synth_feat((4, 256), 10)  # non-degenerate readout
+    feat, out = m(x.cuda())
+    ((feat * wf.cuda()).sum() * 0.01 + (out * wo.cuda()).sum()).backward()
+    assert m.fc7.weight.grad is not None and m.bn7.weight.grad is not None
+    tr = o_train.OracleTrainer("ecapa", fill_state(o_ecapa.ecapa_shapes()), fill_value("center", (1, 256)))
+    names = tr.trainable()
+    for k in names:
+        tr.params[k] = tr.params[k].detach().requires_grad_(True)
+    fo, oo = tr.forward(x)
+    ((fo * wf).sum() * 0.01 + (oo * wo).sum()).backward()
+    for k in ("fc7.weight", "bn7.bias", "layer2.convs.3.weight", "conv1.weight", "attention.0.weight"):
+        ref = tr.params[k].grad.numpy()
+        got = dict(m.named_parameters())[k].grad.cpu().numpy()
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+        assert err < 2e-3, (k, err)
