@@ -969,6 +969,7 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     if (rc != AIR_OK) return rc;
     FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, 1, 1, 1, 0, 0, p->Ho, p->Wo);
     g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = 0; g.oplane = plane;
+    g.y_bstride = (size_t)p->Cin * plane;
     return run_fwd(dy, wp, dx, nullptr, nullptr, 0, dx, g, ck, conv_flops(p), st);
   }
   for (int a = 0; a < 2; ++a) {
@@ -988,6 +989,7 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
       if (rc != AIR_OK) return rc;
       FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, nh, nw, 1, 0, 0, Hc, Wc);
       g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = a * p->W + b; g.oplane = plane;
+      g.y_bstride = (size_t)p->Cin * plane;
       rc = run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck,
                    conv_flops(p) * sel.n / 9.0, st);
       if (rc != AIR_OK) return rc;
