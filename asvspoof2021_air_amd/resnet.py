@@ -18,6 +18,8 @@ bookkeeping stays out of the autograd engine.  Fusions used:
   * the identity-shortcut gradient join is the BatchNorm-backward epilogue;
   * the 1x1-shortcut gradient join is the dgrad epilogue.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -128,6 +130,10 @@ class ResNet(nn.Module):
         self._noise_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._noise_offset = 0
         self._arena = None
+        # True: BatchNorm-apply + ReLU folded into every conv's operand read (no activated
+        # tensor in HBM).  False: one HBM-bound pass writes the activated tensor and the convs
+        # run their plain (faster) MFMA loop.  Measured on MI355X: see DESIGN.md §4.
+        self.fuse_bn_into_conv = os.environ.get("AIR_FUSE_BN", "0") == "1"
 
     def initialize_params(self):
         """resnet.py:149-157."""
@@ -213,18 +219,27 @@ class ResNet(nn.Module):
         if save:
             S["x"], S["c1"], S["st1"] = x, c1, st1
             S["blocks"] = []
+        fuse = self.fuse_bn_into_conv
         for blk in self.blocks():
             s = blk.stride
             stA = _bn_train_coeffs(cur, blk.bn1, training)
+            if fuse:  # BN-apply + ReLU folded into the conv's operand read (no activated tensor)
+                actA, pA = cur, dict(in_scale=stA[2], in_shift=stA[3], relu=True)
+            else:     # activated tensor written once (HBM-bound pass), convs run their plain loop
+                actA, pA = ops.bn_apply(cur, stA[2], stA[3], relu=True), {}
             if hasattr(blk, "shortcut"):
-                sc = ops.conv2d_fwd(cur, w(blk.shortcut[0]), s, 0, stA[2], stA[3], relu=True)
+                sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, **pA)
             else:
                 sc = cur
-            h = ops.conv2d_fwd(cur, w(blk.conv1), s, 1, stA[2], stA[3], relu=True)
+            h = ops.conv2d_fwd(actA, w(blk.conv1), s, 1, **pA)
             stB = _bn_train_coeffs(h, blk.bn2, training)
-            out = ops.conv2d_fwd(h, w(blk.conv2), 1, 1, stB[2], stB[3], relu=True, residual=sc)
+            if fuse:
+                actB, pB = h, dict(in_scale=stB[2], in_shift=stB[3], relu=True)
+            else:
+                actB, pB = ops.bn_apply(h, stB[2], stB[3], relu=True), {}
+            out = ops.conv2d_fwd(actB, w(blk.conv2), 1, 1, residual=sc, **pB)
             if save:
-                S["blocks"].append((blk, cur, stA, h, stB))
+                S["blocks"].append((blk, cur, stA, h, stB, actA, actB))
             cur = out
         c5 = ops.conv2d_fwd(cur, w(self.conv5), 1, (0, 1))  # resnet.py:182
         st5 = _bn_train_coeffs(c5, self.bn5, training)
@@ -283,22 +298,23 @@ class ResNet(nn.Module):
         l4 = S["l4"]
         ops.conv2d_wgrad(l4, dc5, self.conv5.weight.shape, 1, (0, 1), out=gv("conv5.weight"))
         dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1))
-        for blk, xin, stA, h, stB in reversed(S["blocks"]):
+        fuse = self.fuse_bn_into_conv
+        for blk, xin, stA, h, stB, actA, actB in reversed(S["blocks"]):
             s = blk.stride
             pre = nm(blk.conv1.weight)[:-len("conv1.weight")]
+            pA = dict(in_scale=stA[2], in_shift=stA[3], relu=True) if fuse else {}
+            pB = dict(in_scale=stB[2], in_shift=stB[3], relu=True) if fuse else {}
             # out = conv2(actB(h)) + shortcut
-            ops.conv2d_wgrad(h, dcur, blk.conv2.weight.shape, 1, 1, stB[2], stB[3], relu=True,
-                             out=gv(pre + "conv2.weight"))
+            ops.conv2d_wgrad(actB, dcur, blk.conv2.weight.shape, 1, 1, out=gv(pre + "conv2.weight"), **pB)
             d_actB = ops.conv2d_dgrad(dcur, w(blk.conv2), h.shape, 1, 1)
             dh, _, _ = ops.bn_bwd(h, d_actB, stB[0], stB[1], blk.bn2.weight.detach(),
                                   blk.bn2.bias.detach(), relu=True, dx=d_actB,
                                   dgamma=gv(pre + "bn2.weight"), dbeta=gv(pre + "bn2.bias"))
-            ops.conv2d_wgrad(xin, dh, blk.conv1.weight.shape, s, 1, stA[2], stA[3], relu=True,
-                             out=gv(pre + "conv1.weight"))
+            ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=gv(pre + "conv1.weight"), **pA)
             d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1)
             if hasattr(blk, "shortcut"):
-                ops.conv2d_wgrad(xin, dcur, blk.shortcut[0].weight.shape, s, 0, stA[2], stA[3],
-                                 relu=True, out=gv(pre + "shortcut.0.weight"))
+                ops.conv2d_wgrad(actA, dcur, blk.shortcut[0].weight.shape, s, 0,
+                                 out=gv(pre + "shortcut.0.weight"), **pA)
                 ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
                                  out=d_actA)
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),

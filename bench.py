@@ -129,6 +129,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="resnet", choices=["resnet", "ecapa"],
+                    help="resnet = the headline config (BASELINE configs[1]); ecapa = ECAPA-TDNN-512 "
+                         "fp32 (informational: BASELINE configs[2] asks for bf16, not built yet)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 resnet / 128 ecapa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -143,12 +147,19 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    from asvspoof2021_air_amd.resnet import ResNet
     from asvspoof2021_air_amd.train import Trainer
+    global BATCH
     torch.manual_seed(688)
-    model = ResNet(3, 256, resnet_type="18", nclasses=2)
+    if args.model == "resnet":
+        from asvspoof2021_air_amd.resnet import ResNet
+        model = ResNet(3, 256, resnet_type="18", nclasses=2)
+        BATCH = args.batch or 64
+    else:
+        from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+        model = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+        BATCH = args.batch or 128
     trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
-                      feat_len=FEAT_LEN, device=device)
+                      feat_len=FEAT_LEN, device=device, ecapa=(args.model == "ecapa"))
     if world > 1:  # same initial weights everywhere
         arena = model.arena()
         td.broadcast(arena.flat, src=0)
@@ -193,9 +204,13 @@ def main():
                        "parallelism": "dp%d" % world},
             "final_loss": round(loss_val, 5),
         }
+        if args.model == "ecapa":
+            line["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
+            line["config"]["workload"] = ("informational: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax fp32 train "
+                                          "step, T=401 repeat-padded to 750 (BASELINE configs[2] is the bf16 variant)")
         if not args.no_roofline:
             line["roofline"] = roofline_leg(trainer, batches)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "resnet":
             line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line), flush=True)
     if world > 1:
