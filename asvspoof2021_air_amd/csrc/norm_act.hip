@@ -163,12 +163,30 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
     const float* __restrict__ px = x + ((size_t)b * C + c) * S;
     const float* __restrict__ pg = dy + ((size_t)b * C + c) * S;
     float s1 = 0.0f, s2 = 0.0f;
-    for (int i = threadIdx.x; i < S; i += NT) {
-      const float xv = px[i];
-      float g = pg[i];
-      if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
-      s1 += g;
-      s2 += g * ((xv - mu) * is);
+    if ((S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
+      const float4* __restrict__ px4 = reinterpret_cast<const float4*>(px);
+      const float4* __restrict__ pg4 = reinterpret_cast<const float4*>(pg);
+      for (int i = threadIdx.x; i < S / 4; i += NT) {
+        const float4 xv = px4[i];
+        float4 g = pg4[i];
+        if (relu) {
+          if (!(xv.x * sc + shf > 0.0f)) g.x = 0.0f;
+          if (!(xv.y * sc + shf > 0.0f)) g.y = 0.0f;
+          if (!(xv.z * sc + shf > 0.0f)) g.z = 0.0f;
+          if (!(xv.w * sc + shf > 0.0f)) g.w = 0.0f;
+        }
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) +
+              (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += NT) {
+        const float xv = px[i];
+        float g = pg[i];
+        if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+        s1 += g;
+        s2 += g * ((xv - mu) * is);
+      }
     }
     d1 += (double)s1;
     d2 += (double)s2;
@@ -195,12 +213,13 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
 }
 
 // backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
+// (dy and dx may alias: the in-place gradient joins of resnet.py / ecapa_tdnn.py)
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, int C, int S, float invN,
+    const float* __restrict__ x, const float* dy, int C, int S, float invN,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
-    int relu_in, float* __restrict__ dx) {
+    int relu_in, float* dx) {
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float mu = mean[c], is = invstd[c];
@@ -209,15 +228,29 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   const float k1 = dbeta[c] * invN, k2 = dgamma[c] * invN;
   const size_t base = (size_t)plane * S;
   const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
-  for (int i = i0; i < min(S, i0 + 4); ++i) {
-    const float xv = x[base + i];
-    float g = dy[base + i];
+  if (i0 >= S) return;
+  auto one = [&](float xv, float g, float old) -> float {
     if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
     const float xh = (xv - mu) * is;
     float r = sc * (g - k1 - xh * k2);
     if (relu_in && !(xv > 0.0f)) r = 0.0f;  // x = relu(c): no gradient where the ReLU clipped
-    if (accum) r += dx[base + i];
-    dx[base + i] = r;
+    return accum ? r + old : r;
+  };
+  if (i0 + 3 < S && ((base + i0) & 3) == 0 &&
+      ((((size_t)x) | ((size_t)dy) | ((size_t)dx)) & 15) == 0) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + base + i0);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + base + i0);
+    float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accum) ov = *reinterpret_cast<const float4*>(dx + base + i0);
+    float4 r;
+    r.x = one(xv.x, gv.x, ov.x);
+    r.y = one(xv.y, gv.y, ov.y);
+    r.z = one(xv.z, gv.z, ov.z);
+    r.w = one(xv.w, gv.w, ov.w);
+    *reinterpret_cast<float4*>(dx + base + i0) = r;
+  } else {
+    for (int i = i0; i < min(S, i0 + 4); ++i)
+      dx[base + i] = one(x[base + i], dy[base + i], accum ? dx[base + i] : 0.0f);
   }
 }
 
