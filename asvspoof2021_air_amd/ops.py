@@ -15,8 +15,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """One growing scratch buffer per device (ops run back to back on one stream)."""
-    key = (device.type, device.index)
+    """One growing scratch buffer per (device, stream): ops run back to back on a stream, and
+    the weight-gradient side stream (resnet.py) must not share scratch with the main one."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -134,6 +134,9 @@ class ResNet(nn.Module):
         # tensor in HBM).  False: one HBM-bound pass writes the activated tensor and the convs
         # run their plain (faster) MFMA loop.  Measured on MI355X: see DESIGN.md §4.
         self.fuse_bn_into_conv = os.environ.get("AIR_FUSE_BN", "0") == "1"
+        # weight gradients on a side HIP stream, overlapping the HBM-bound BN-backward passes
+        self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
+        self._side_stream = None
 
     def initialize_params(self):
         """resnet.py:149-157."""
@@ -291,12 +294,45 @@ class ResNet(nn.Module):
         da5, datt = ops.selfatt_pool_bwd(S["a5v"], self.attention.att_weights.detach(), S["noise"],
                                          S["alpha"], S["pooled"], dpooled)
         ops.sum_rows(datt, out=gv("attention.att_weights").view(-1))
+        # Weight gradients feed nothing until the optimiser, so they run on a SIDE stream: the
+        # MFMA-bound wgrad kernels overlap the HBM-bound BatchNorm-backward passes and the tails
+        # of the dgrad chain on the main stream.  Ordering: a wgrad starts after the event that
+        # marks its dy ready; an in-place update of a tensor a wgrad still reads waits for that
+        # wgrad's event; the main stream joins the side stream before the gradients are used.
+        main = torch.cuda.current_stream()
+        use_side = self.overlap_wgrad
+        if use_side and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=main.device)
+        side = self._side_stream if use_side else main
+        keep = []  # tensors the side stream reads: keep them alive until the join
+
+        def on_side(fn, *reads):
+            """Run fn() on the side stream once everything enqueued on main so far is done.
+            Returns an event marking its completion."""
+            if not use_side:
+                fn()
+                return None
+            keep.extend(reads)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            return done
+
+        def wait_for(ev):
+            if ev is not None:
+                main.wait_event(ev)
+
         c5, st5 = S["c5"], S["st5"]
         dc5, _, _ = ops.bn_bwd(c5, da5.view_as(c5), st5[0], st5[1], self.bn5.weight.detach(),
                                self.bn5.bias.detach(), relu=True,
                                dgamma=gv("bn5.weight"), dbeta=gv("bn5.bias"))
         l4 = S["l4"]
-        ops.conv2d_wgrad(l4, dc5, self.conv5.weight.shape, 1, (0, 1), out=gv("conv5.weight"))
+        g5 = gv("conv5.weight")
+        on_side(lambda: ops.conv2d_wgrad(l4, dc5, self.conv5.weight.shape, 1, (0, 1), out=g5), dc5)
         dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1))
         fuse = self.fuse_bn_into_conv
         for blk, xin, stA, h, stB, actA, actB in reversed(S["blocks"]):
@@ -304,17 +340,27 @@ class ResNet(nn.Module):
             pre = nm(blk.conv1.weight)[:-len("conv1.weight")]
             pA = dict(in_scale=stA[2], in_shift=stA[3], relu=True) if fuse else {}
             pB = dict(in_scale=stB[2], in_shift=stB[3], relu=True) if fuse else {}
-            # out = conv2(actB(h)) + shortcut
-            ops.conv2d_wgrad(actB, dcur, blk.conv2.weight.shape, 1, 1, out=gv(pre + "conv2.weight"), **pB)
+            has_sc = hasattr(blk, "shortcut")
+            # out = conv2(actB(h)) + shortcut: both weight gradients read dcur
+            g2 = gv(pre + "conv2.weight")
+            gsc = gv(pre + "shortcut.0.weight") if has_sc else None
+
+            def wg_out(dcur=dcur, actB=actB, actA=actA, blk=blk, s=s, pA=pA, pB=pB, g2=g2, gsc=gsc,
+                       has_sc=has_sc):
+                ops.conv2d_wgrad(actB, dcur, blk.conv2.weight.shape, 1, 1, out=g2, **pB)
+                if has_sc:
+                    ops.conv2d_wgrad(actA, dcur, blk.shortcut[0].weight.shape, s, 0, out=gsc, **pA)
+
+            ev_dcur = on_side(wg_out, dcur)
             d_actB = ops.conv2d_dgrad(dcur, w(blk.conv2), h.shape, 1, 1)
             dh, _, _ = ops.bn_bwd(h, d_actB, stB[0], stB[1], blk.bn2.weight.detach(),
                                   blk.bn2.bias.detach(), relu=True, dx=d_actB,
                                   dgamma=gv(pre + "bn2.weight"), dbeta=gv(pre + "bn2.bias"))
-            ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=gv(pre + "conv1.weight"), **pA)
+            g1 = gv(pre + "conv1.weight")
+            on_side(lambda dh=dh, actA=actA, blk=blk, s=s, pA=pA, g1=g1:
+                    ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=g1, **pA), dh)
             d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1)
-            if hasattr(blk, "shortcut"):
-                ops.conv2d_wgrad(actA, dcur, blk.shortcut[0].weight.shape, s, 0,
-                                 out=gv(pre + "shortcut.0.weight"), **pA)
+            if has_sc:
                 ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
                                  out=d_actA)
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
@@ -322,6 +368,8 @@ class ResNet(nn.Module):
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))
             else:
                 # identity shortcut: d(block input) = bn1-backward(d_actA) + dcur, joined in place
+                # (dcur is still being read by this block's conv2 wgrad on the side stream)
+                wait_for(ev_dcur)
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
                                         blk.bn1.bias.detach(), relu=True, dx=dcur, accumulate=True,
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))
@@ -329,7 +377,12 @@ class ResNet(nn.Module):
         dc1, _, _ = ops.bn_bwd(c1, dcur, st1[0], st1[1], self.bn1.weight.detach(),
                                self.bn1.bias.detach(), relu=True, dx=dcur,
                                dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"))
-        ops.conv2d_wgrad(S["x"], dc1, self.conv1.weight.shape, (3, 1), (1, 1), out=gv("conv1.weight"))
+        gc1 = gv("conv1.weight")
+        ev = on_side(lambda: ops.conv2d_wgrad(S["x"], dc1, self.conv1.weight.shape, (3, 1), (1, 1), out=gc1),
+                     dc1)
+        if use_side:
+            main.wait_stream(side)  # join: every weight gradient is in the arena
+        keep.clear()
         arena.tail_has_grad = "fc_mu.weight" in have
         if accumulating:
             ops.add_(arena.grad, old)
