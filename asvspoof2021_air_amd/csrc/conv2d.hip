@@ -576,19 +576,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dw[e] = sum_k partial[k][e]; with taps > 0 the partials are [tap][co*ci] and dw is [co*ci][tap]
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                       size_t n, int nsplit, int taps) {
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
-       e += (size_t)gridDim.x * blockDim.x) {
+// dw[e] = sum_k partial[k][e]; with taps > 1 the partials are [tap][co*ci] and dw is [co*ci][tap].
+// 4 lanes share one output and stride the split axis, so a 256-way split costs 64 dependent
+// loads per lane instead of 256 (the small layer1 reductions are latency-bound).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              float* __restrict__ dw, size_t n,
+                                                              int nsplit, int taps) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nth = (size_t)gridDim.x * blockDim.x;
+  const int sub = (int)(gid & 3);
+  for (size_t e = gid >> 2; e < ((n + 63) / 64) * 64; e += nth >> 2) {
     float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
-    if (taps > 1) {
-      const size_t plane = n / taps;  // Cout*Cin
-      const size_t t = e / plane, cc = e - t * plane;
-      dw[cc * taps + t] = s;
-    } else {
-      dw[e] = s;
+    if (e < n)
+      for (int k = sub; k < nsplit; k += 4) s += partial[(size_t)k * n + e];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (sub == 0 && e < n) {
+      if (taps > 1) {
+        const size_t plane = n / taps;  // Cout*Cin
+        const size_t t = e / plane, cc = e - t * plane;
+        dw[cc * taps + t] = s;
+      } else {
+        dw[e] = s;
+      }
     }
   }
 }
@@ -852,7 +862,7 @@ int run_wgrad(const WgradGeom& g, const float* x, const float* dy, float* dw, co
       hipLaunchKernelGGL((conv_wgrad_kernel<KH_, KW_, S_, CT_, 0, DIL_>), dim3(nblk), dim3(256), \
                          0, st, a);                                                              \
     AIR_CHECK_LAUNCH();                                                                          \
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,            \
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,        \
                        reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit, g.KH * g.KW);      \
     AIR_CHECK_LAUNCH();                                                                          \
     return AIR_OK;                                                                               \
@@ -1013,7 +1023,7 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
                     p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
     hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
     AIR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, rows, 1);
     AIR_CHECK_LAUNCH();
     return AIR_OK;

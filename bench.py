@@ -50,10 +50,16 @@ def roofline_leg(trainer, batches):
     from asvspoof2021_air_amd import _hip
     lib = _hip.lib()
     lib.air_prof_kernel_name.restype = ctypes.c_char_p
+    # kernels are timed one at a time: the side-stream overlap of the weight-gradient kernels
+    # (resnet.py) is switched off for these two steps, otherwise the event brackets of
+    # co-running kernels would include each other's time
+    overlap = getattr(trainer.model, "overlap_wgrad", False)
+    trainer.model.overlap_wgrad = False
     lib.air_prof_enable(1)
     for pcm, labels in batches[:2]:
         trainer.step(pcm, labels)
     torch.cuda.synchronize()
+    trainer.model.overlap_wgrad = overlap
     rows = []
     for kid in range(lib.air_prof_kernel_count()):
         n, ms, work = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
