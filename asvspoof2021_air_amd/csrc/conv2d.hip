@@ -52,16 +52,17 @@ struct TapSel {
 };
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                    int Cin, int taps_full, int transpose, int ck, TapSel sel) {
+                                    int Cin, int taps_full, int transpose, int ck, int bm,
+                                    TapSel sel) {
   // logical (M = "out" role, Kc = "in" role)
   const int M = transpose ? Cin : Cout;
   const int Kc = transpose ? Cout : Cin;
-  const int Mpad = (M + BM - 1) / BM * BM;  // channel tiles are zero-padded to 64
+  const int Mpad = (M + bm - 1) / bm * bm;  // channel tiles (bm = 64 or 32) are zero-padded
   const size_t total = (size_t)Mpad * ((Kc + ck - 1) / ck * ck) * sel.n;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(e % BM);
-    size_t r = e / BM;
+    const int col = (int)(e % bm);
+    size_t r = e / bm;
     const int cil = (int)(r % ck);
     r /= ck;
     const int tap = (int)(r % sel.n);
@@ -73,7 +74,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     // covers get zero weights there
     const bool last_ragged = chunk == nchunk - 1 && Kc % ck != 0;
     const int k = last_ragged ? Kc - ck + cil : chunk * ck + cil;
-    const int m = cot * BM + col;
+    const int m = cot * bm + col;
     float v = 0.0f;
     if (m < M && !(last_ragged && k < chunk * ck)) {
       const int src = sel.idx[tap];
@@ -136,15 +137,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // CKT = input channels per K chunk (8 for 3x3; more for 1-4 tap kernels so a chunk still
 // holds >= 16 k-steps between barriers)
-template <int KH, int KW, int S, int CKT, int DIL = 1>
+// MT = 32-channel MFMA row tiles per workgroup: 2 (64 output channels), or 1 where that fills
+// the chip's rounds better (small layers) or the layer has <= 32 output channels
+template <int KH, int KW, int S, int CKT, int DIL = 1, int MT = 2>
 struct FwdCfg {
   static constexpr int TAPS = KH * KW;
+  static constexpr int BMT = 32 * MT;                  // output channels per workgroup
   static constexpr int PW = (PXT - 1) * S + (KW - 1) * DIL + 1;  // patch columns (DIL: width dilation)
   static constexpr int CHS = KH * PW;                 // channel pitch (dense: LDS-DMA is lane-linear)
   static constexpr int NE = CKT * CHS;                 // patch elements per wave
   static constexpr int NI = (NE + 63) / 64;           // DMA instructions (elements per lane)
   static constexpr int PATCHP = NI * 64;              // padded so the last DMA stays in the wave's region
-  static constexpr int WSLAB = TAPS * CKT * BM;        // floats per weight slab
+  static constexpr int WSLAB = TAPS * CKT * BMT;       // floats per weight slab
   static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);  // 16-byte DMAs per thread
   static constexpr int BUF = WSLAB + NWAVE * PATCHP;  // floats per LDS buffer
 };
@@ -156,9 +160,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
 // operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
-template <int KH, int KW, int S, int MODE, int CKT, int DIL = 1>
+template <int KH, int KW, int S, int MODE, int CKT, int DIL = 1, int MT = 2>
 __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
-  using C = FwdCfg<KH, KW, S, CKT, DIL>;
+  using C = FwdCfg<KH, KW, S, CKT, DIL, MT>;
   __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
   __shared__ float s_scale[MODE == 1 ? MAXC : 1], s_shift[MODE == 1 ? MAXC : 1];
 
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       const int kh = tap / KW, kw = tap % KW;
       const int cil = 2 * st + half;
       bv = pl[cil * C::CHS + kh * C::PW + kw * DIL + l31 * S];
-      a0 = wl[(tap * CKT + cil) * BM + l31];
-      a1 = wl[(tap * CKT + cil) * BM + 32 + l31];
+      a0 = wl[(tap * CKT + cil) * C::BMT + l31];
+      a1 = MT == 2 ? wl[(tap * CKT + cil) * C::BMT + 32 + l31] : 0.0f;
     };
     // 3-stage software pipeline per k-step: LDS read (n+2) | activate + mask (n+1) | MFMA (n),
     // so neither the LDS round trip nor the VALU chain sits between two MFMAs.  A wave issues
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
         if (n + 1 < NSTEP) rb[(n + 1) % 3] = act(n + 1, rb[(n + 1) % 3]);
         __builtin_amdgcn_sched_barrier(0);  // keep reads / VALU ahead of the MFMAs
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[n % 3], rb[n % 3], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[n % 3], rb[n % 3], acc1, 0, 0, 0);
+        if (MT == 2)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[n % 3], rb[n % 3], acc1, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -319,14 +324,14 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int wo = wo0 + l31;
   if (wo >= a.Wo) return;
   const size_t oplane = a.oplane;
-  const size_t obase = (size_t)b * a.y_bstride + (size_t)cot * BM * oplane +
+  const size_t obase = (size_t)b * a.y_bstride + (size_t)cot * C::BMT * oplane +
                        (size_t)(ho * a.oh_mul) * a.ow_row + (size_t)wo * a.ow_mul + a.o_off;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
     const size_t o0 = obase + (size_t)i * oplane;
     const size_t o1 = o0 + 32 * oplane;
-    const int co = cot * BM + i;
+    const int co = cot * C::BMT + i;
     if (co < a.Cout) {
       float v0 = acc0[r];
       if (a.bias != nullptr) v0 += a.bias[co];
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       if (a.out_relu) v0 = fmaxf(v0, 0.0f);
       a.y[o0] = v0;
     }
-    if (co + 32 < a.Cout) {
+    if (MT == 2 && co + 32 < a.Cout) {
       float v1 = acc1[r];
       if (a.bias != nullptr) v1 += a.bias[co + 32];
       if (a.bias_bc != nullptr) v1 += a.bias_bc[(size_t)b * a.Cout + co + 32];
@@ -689,7 +694,7 @@ int grid_for(size_t n, int per_block = 256, int cap = 256 * 16) {
 bool generic_ok(const AirConv2d* p) {
   const bool k33 = p->KH == 3 && p->KW == 3, k11 = p->KH == 1 && p->KW == 1;
   const bool s_ok = (p->sh == 1 && p->sw == 1) || (p->sh == 2 && p->sw == 2);
-  return (k33 || k11) && s_ok && p->sh == p->sw && p->Cin % 8 == 0 && p->Cout % BM == 0;
+  return (k33 || k11) && s_ok && p->sh == p->sw && p->Cin % 8 == 0 && p->Cout % BM == 0;  // wgrad tiles are 64 wide
 }
 bool direct_ok(const AirConv2d* p) {
   return p->Cout <= 16 && p->Cout * p->Cin * p->KH * p->KW <= DIRECT_MAX_W;
@@ -728,19 +733,38 @@ int pick_ck(int taps, int cin) {
 }
 
 template <int KH, int KW, int S, int CKT, int DIL = 1>
-void launch_fwd(const FwdArgs& a, hipStream_t st) {
+void launch_fwd(const FwdArgs& a, int mt, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
-  if (a.scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 1, CKT, DIL>), dim3(nblk), dim3(NWAVE * 64), 0,
-                       st, a);
-  else
-    hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, 0, CKT, DIL>), dim3(nblk), dim3(NWAVE * 64), 0,
-                       st, a);
+#define AIR_LAUNCH(MODE_, MT_)                                                                   \
+  hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, MODE_, CKT, DIL, MT_>), dim3(nblk),             \
+                     dim3(NWAVE * 64), 0, st, a)
+  if (mt == 2) {
+    if (a.scale != nullptr) AIR_LAUNCH(1, 2); else AIR_LAUNCH(0, 2);
+  } else {
+    if (a.scale != nullptr) AIR_LAUNCH(1, 1); else AIR_LAUNCH(0, 1);
+  }
+#undef AIR_LAUNCH
+}
+
+// 32- or 64-channel workgroup tiles?  Workgroups are equal-sized, so a partially filled last
+// round of the 256 CUs is pure loss (layer4: 1152 workgroups on 512 slots = 2.25 rounds, 25 %
+// idle).  32-channel tiles need less LDS (3 resident workgroups per CU) and double the count.
+int pick_mt(int ntiles, int cout);
+int mt_for(int B, int Ho, int Wo, int cout) { return pick_mt(B * Ho * ((Wo + PXT - 1) / PXT), cout); }
+
+int pick_mt(int ntiles, int cout) {
+  if (cout <= 32) return 1;
+  const int npxg = (ntiles + NWAVE - 1) / NWAVE;
+  const double r2 = npxg * ((cout + 63) / 64) / 512.0, r1 = npxg * ((cout + 31) / 32) / 768.0;
+  const double eff2 = r2 / ceil(r2), eff1 = r1 / ceil(r1);
+  static const int force = getenv("AIR_CONV_MT") ? atoi(getenv("AIR_CONV_MT")) : 0;
+  if (force == 1 || force == 2) return force;
+  return (eff1 > eff2 + 0.08) ? 1 : 2;
 }
 
 // y = conv(act(x), packed w): shared by fwd and every dgrad
 int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
-            int relu, const float* residual, const FwdGeom& g, int ck, double flops,
+            int relu, const float* residual, const FwdGeom& g, int ck, int mt, double flops,
             hipStream_t st) {
   FwdArgs a;
   a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
@@ -749,7 +773,7 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   a.WT = (g.Wo + PXT - 1) / PXT;
   a.ntiles = g.B * g.Ho * a.WT;
   a.npxg = (a.ntiles + NWAVE - 1) / NWAVE;
-  a.ncot = (g.Cout + BM - 1) / BM;
+  a.ncot = (g.Cout + 32 * mt - 1) / (32 * mt);
   a.oh_mul = g.oh_mul; a.ow_row = g.ow_row; a.ow_mul = g.ow_mul; a.o_off = g.o_off;
   a.oplane = g.oplane;
   a.x_bstride = g.x_bstride; a.y_bstride = g.y_bstride;
@@ -761,7 +785,7 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
 #define AIR_FWD_CASE_D(KH_, KW_, S_, CK_, DIL_, KID_)                         \
   if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 + (DIL_ - 1) && ck == CK_) {      \
     AirProfScope ps(KID_, flops, st);                                           \
-    launch_fwd<KH_, KW_, S_, CK_, DIL_>(a, st);                                 \
+    launch_fwd<KH_, KW_, S_, CK_, DIL_>(a, mt, st);                             \
     AIR_CHECK_LAUNCH();                                                         \
     return AIR_OK;                                                              \
   }
@@ -788,11 +812,12 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
 }
 
 int pack(const float* w, float* wp, int Cout, int Cin, int taps_full, int transpose, int ck,
-         const TapSel& sel, hipStream_t st) {
+         int mt, const TapSel& sel, hipStream_t st) {
   const int M = transpose ? Cin : Cout, Kc = transpose ? Cout : Cin;
-  const size_t n = (size_t)((M + BM - 1) / BM * BM) * ((Kc + ck - 1) / ck * ck) * sel.n;
+  const int bm = 32 * mt;
+  const size_t n = (size_t)((M + bm - 1) / bm * bm) * ((Kc + ck - 1) / ck * ck) * sel.n;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, wp, Cout, Cin,
-                     taps_full, transpose, ck, sel);
+                     taps_full, transpose, ck, bm, sel);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -924,12 +949,13 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
   TapSel sel;
   sel.n = taps;
   for (int t = 0; t < taps; ++t) sel.idx[t] = t;
-  int rc = pack(w, wp, p->Cout, p->Cin, taps, 0, ck, sel, st);
+  const int mt = mt_for(p->B, p->Ho, p->Wo, p->Cout);
+  int rc = pack(w, wp, p->Cout, p->Cin, taps, 0, ck, mt, sel, st);
   if (rc != AIR_OK) return rc;
   return run_fwd(x, wp, y, in_scale, in_shift, relu, residual,
                  plain_geom(p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW, p->sh, p->ph, p->pw,
                             p->Ho, p->Wo),
-                 ck, conv_flops(p), st);
+                 ck, mt, conv_flops(p), st);
 }
 
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
@@ -948,12 +974,13 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     TapSel sel;
     sel.n = taps;
     for (int t = 0; t < taps; ++t) sel.idx[t] = taps - 1 - t;
-    int rc = pack(w, wp, p->Cout, p->Cin, taps, 1, ck, sel, st);
+    const int mt = mt_for(p->B, p->H, p->W, p->Cin);
+    int rc = pack(w, wp, p->Cout, p->Cin, taps, 1, ck, mt, sel, st);
     if (rc != AIR_OK) return rc;
     return run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate,
                    plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, p->KH, p->KW, 1,
                               p->KH - 1 - p->ph, p->KW - 1 - p->pw, p->H, p->W),
-                   ck, conv_flops(p), st);
+                   ck, mt, conv_flops(p), st);
   }
   // stride 2: input pixel (2i+a, 2j+b) only sees the taps with kh = (a+1+ph') parity etc.
   // Each of the 4 parity classes is a dense stride-1 conv of dy with 1, 2, 2 or 4 taps that
@@ -975,12 +1002,13 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     TapSel sel;
     sel.n = 1;
     sel.idx[0] = 0;
-    int rc = pack(w, wp, p->Cout, p->Cin, 1, 1, ck, sel, st);
+    const int mt = mt_for(p->B, p->Ho, p->Wo, p->Cin);
+    int rc = pack(w, wp, p->Cout, p->Cin, 1, 1, ck, mt, sel, st);
     if (rc != AIR_OK) return rc;
     FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, 1, 1, 1, 0, 0, p->Ho, p->Wo);
     g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = 0; g.oplane = plane;
     g.y_bstride = (size_t)p->Cin * plane;
-    return run_fwd(dy, wp, dx, nullptr, nullptr, 0, dx, g, ck, conv_flops(p), st);
+    return run_fwd(dy, wp, dx, nullptr, nullptr, 0, dx, g, ck, mt, conv_flops(p), st);
   }
   for (int a = 0; a < 2; ++a) {
     for (int b = 0; b < 2; ++b) {
@@ -995,12 +1023,13 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
       for (int i = 0; i < nh; ++i)
         for (int j = 0; j < nw; ++j) sel.idx[i * nw + j] = khs[i] * 3 + kws[j];
       const int ck = pick_ck(sel.n, p->Cout);
-      int rc = pack(w, wp, p->Cout, p->Cin, 9, 1, ck, sel, st);
+      const int mt = mt_for(p->B, Hc, Wc, p->Cin);
+      int rc = pack(w, wp, p->Cout, p->Cin, 9, 1, ck, mt, sel, st);
       if (rc != AIR_OK) return rc;
       FwdGeom g = plain_geom(p->B, p->Cout, p->Ho, p->Wo, p->Cin, nh, nw, 1, 0, 0, Hc, Wc);
       g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = a * p->W + b; g.oplane = plane;
       g.y_bstride = (size_t)p->Cin * plane;
-      rc = run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck,
+      rc = run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck, mt,
                    conv_flops(p) * sel.n / 9.0, st);
       if (rc != AIR_OK) return rc;
     }
@@ -1070,12 +1099,13 @@ int air_conv1d_fwd(const AirConv1d* p, const float* x, const float* w, const flo
   TapSel sel;
   sel.n = p->K;
   for (int t = 0; t < p->K; ++t) sel.idx[t] = t;
-  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 0, ck, sel, st);
+  const int mt = mt_for(p->B, 1, p->T, p->Cout);
+  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 0, ck, mt, sel, st);
   if (rc != AIR_OK) return rc;
   FwdGeom g = plain_geom(p->B, p->Cin, 1, p->T, p->Cout, 1, p->K, 1, 0, p->pad, 1, p->T);
   g.x_bstride = c1d_xb(p); g.y_bstride = c1d_yb(p);
   g.bias = bias; g.bias_bc = bias_bc; g.out_relu = relu; g.dil = p->K == 3 ? p->dil : 1;
-  return run_fwd(x, wp, y, nullptr, nullptr, 0, nullptr, g, ck,
+  return run_fwd(x, wp, y, nullptr, nullptr, 0, nullptr, g, ck, mt,
                  2.0 * p->B * p->T * (double)p->Cout * p->Cin * p->K, st);
 }
 
@@ -1090,13 +1120,14 @@ int air_conv1d_dgrad(const AirConv1d* p, const float* dy, const float* w, float*
   TapSel sel;
   sel.n = p->K;
   for (int t = 0; t < p->K; ++t) sel.idx[t] = p->K - 1 - t;
-  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 1, ck, sel, st);
+  const int mt = mt_for(p->B, 1, p->T, p->Cin);
+  int rc = pack(w, wp, p->Cout, p->Cin, p->K, 1, ck, mt, sel, st);
   if (rc != AIR_OK) return rc;
   const int dil = p->K == 3 ? p->dil : 1;
   FwdGeom g = plain_geom(p->B, p->Cout, 1, p->T, p->Cin, 1, p->K, 1, 0, dil * (p->K - 1) - p->pad,
                          1, p->T);
   g.x_bstride = c1d_yb(p); g.y_bstride = c1d_xb(p); g.dil = dil;
-  return run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck,
+  return run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck, mt,
                  2.0 * p->B * p->T * (double)p->Cout * p->Cin * p->K, st);
 }
 
