@@ -158,6 +158,30 @@ constexpr int MAXC = 512;  // channels whose BN scale/shift fit the LDS table
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// LDS-DMA (global_load_lds) issued as inline asm.  Through the builtin, hipcc's wait-count
+// pass puts "s_waitcnt vmcnt(0)" in front of EVERY later ds_read (it cannot tell which LDS
+// bytes an in-flight DMA writes), which serialises the next chunk's staging with this chunk's
+// MFMAs.  Hand-issued, the DMA stays in flight across the compute and is drained once, by
+// dma_wait() in front of the buffer-swap barrier.  LDS destination = M0 + lane * size.
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(__UINTPTR_TYPE__)(lptr_t)p;
+}
+// l = LDS BYTE address of lane 0's destination (wave-uniform; lds_addr(array) + offsets)
+__device__ __forceinline__ void dma4(const float* g, unsigned l) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+               :: "v"(g), "s"(l) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16(const float* g, unsigned l) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"(g), "s"(l) : "memory", "m0");
+}
+// the builtin form (compiler-managed waits): measured faster in the wgrad kernel, whose single
+// resident wave per SIMD is bound by instruction issue, not by DMA latency
+__device__ __forceinline__ void dma4_auto(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
 // operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
 template <int KH, int KW, int S, int MODE, int CKT, int DIL = 1, int MT = 2>
@@ -205,23 +229,23 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
     goff[i] = cil * HWi + hi * a.W + wi;
   }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
   auto dma = [&](int chunk, int buf) {
-    float* base = lds + buf * C::BUF;
-    float* pl = base + C::WSLAB + wave * C::PATCHP;
+    const unsigned base = lds0 + 4u * (buf * C::BUF);
+    const unsigned pl = base + 4u * (C::WSLAB + wave * C::PATCHP);
     // the last chunk of a ragged Cin slides back to [Cin-CK, Cin); its already-covered
     // channels carry zero weights (pack_weights_kernel)
     const int cbase = (chunk == nchunk - 1) ? a.last_cbase : chunk * CKT;
     const float* __restrict__ xc = xbc + (size_t)cbase * HW;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(xc + goff[i]), (lptr_t)(pl + 64 * i), 4, 0, 0);
+      dma4(xc + goff[i], pl + 256u * i);
     const float* __restrict__ ws = wslab0 + (size_t)chunk * C::WSLAB;
 #pragma unroll
     for (int i = 0; i < C::NWV; ++i) {
       const int e0 = (wave + NWAVE * i) * 64;  // first float4 of this wave's DMA (wave-uniform)
       if (e0 < C::WSLAB / 4)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ws + 4 * (e0 + lane)), (lptr_t)(base + 4 * e0), 16,
-                                         0, 0);
+        dma16(ws + 4 * (e0 + lane), base + 16u * e0);
     }
   };
 
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
     }
   }
   dma(0, 0);
+  dma_wait();
   __syncthreads();
   float scn[CKT / 2], shn[CKT / 2];
 #pragma unroll
@@ -314,7 +339,8 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       steps(std::false_type{});
     else
       steps(std::true_type{});
-    __syncthreads();  // drains the DMA (vmcnt) and fences the buffer swap
+    dma_wait();
+    __syncthreads();  // fences the buffer swap
   }
 
   // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel.
@@ -454,8 +480,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const float* __restrict__ xt = xb + (hi0 * a.W + wi0);
 #pragma unroll
       for (int i = 0; i < C::NI; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xt + eoff[i]), (lptr_t)(pl + 256 * i + 64 * wave),
-                                         4, 0, 0);
+        dma4_auto(xt + eoff[i], pl + 256 * i + 64 * wave);
     } else {
 #pragma unroll
       for (int i = 0; i < C::NI; ++i) {
@@ -466,8 +491,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int c = rem - r * C::PW;
         const int cc = min(ci0 + cil, a.Cin - 1);
         const int hi = min(max(hi0 + r, 0), a.H - 1), wi = min(max(wi0 + c, 0), a.W - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + cc * HWi + hi * a.W + wi),
-                                         (lptr_t)(pl + 256 * i + 64 * wave), 4, 0, 0);
+        dma4_auto(xb + cc * HWi + hi * a.W + wi, pl + 256 * i + 64 * wave);
       }
     }
     // dy rows (co pairs): lane -> (co = 2j + half, px = l31), column clamped to the row
@@ -477,8 +501,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < C::ND; ++i) {
       const int j = wave + 4 * i;  // row pair
-      __builtin_amdgcn_global_load_lds((gptr_t)(dyb + 2 * j * HoWoi + dyo),
-                                       (lptr_t)(dl + j * C::DPAIR), 4, 0, 0);
+      dma4_auto(dyb + 2 * j * HoWoi + dyo, dl + j * C::DPAIR);
     }
   };
 
