@@ -31,6 +31,8 @@
 
 #include "air_common.h"
 #include "air_prof.h"
+#include "air_lds_dma.h"
+#include "conv_wino.h"
 
 namespace {
 
@@ -126,15 +128,6 @@ struct FwdArgs {
   int last_cbase;               // first channel of the last K chunk (Cin - CK when Cin % CK != 0)
 };
 
-// XCD-aware logical block index: hardware places block b on XCD b % 8; give each
-// XCD one contiguous range of logical tiles so neighbours share L2 (bijective).
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + slot;
-}
-
 // CKT = input channels per K chunk (8 for 3x3; more for 1-4 tap kernels so a chunk still
 // holds >= 16 k-steps between barriers)
 // MT = 32-channel MFMA row tiles per workgroup: 2 (64 output channels), or 1 where that fills
@@ -154,33 +147,6 @@ struct FwdCfg {
 };
 
 constexpr int MAXC = 512;  // channels whose BN scale/shift fit the LDS table
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS-DMA (global_load_lds) issued as inline asm.  Through the builtin, hipcc's wait-count
-// pass puts "s_waitcnt vmcnt(0)" in front of EVERY later ds_read (it cannot tell which LDS
-// bytes an in-flight DMA writes), which serialises the next chunk's staging with this chunk's
-// MFMAs.  Hand-issued, the DMA stays in flight across the compute and is drained once, by
-// dma_wait() in front of the buffer-swap barrier.  LDS destination = M0 + lane * size.
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-  return (unsigned)(__UINTPTR_TYPE__)(lptr_t)p;
-}
-// l = LDS BYTE address of lane 0's destination (wave-uniform; lds_addr(array) + offsets)
-__device__ __forceinline__ void dma4(const float* g, unsigned l) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-               :: "v"(g), "s"(l) : "memory", "m0");
-}
-__device__ __forceinline__ void dma16(const float* g, unsigned l) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-               :: "v"(g), "s"(l) : "memory", "m0");
-}
-// the builtin form (compiler-managed waits): measured faster in the wgrad kernel, whose single
-// resident wave per SIMD is bound by instruction issue, not by DMA latency
-__device__ __forceinline__ void dma4_auto(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 4, 0, 0);
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // MODE 0: plain input.  MODE 1: input = max(0, x*scale[ci]+shift[ci]) applied when the
 // operand is read from LDS (the VALU is idle under the MFMAs), so staging is a pure copy.
@@ -729,6 +695,11 @@ bool shape_ok(const AirConv2d* p) {
          p->Wo == (p->W + 2 * p->pw - p->KW) / p->sw + 1 && p->Ho > 0 && p->Wo > 0;
 }
 
+// 3x3 / stride 1 / pad 1: the Winograd kernels' shape
+bool wino_shape(const AirConv2d* p) {
+  return p->KH == 3 && p->KW == 3 && p->sh == 1 && p->sw == 1 && p->ph == 1 && p->pw == 1;
+}
+
 struct FwdGeom {
   int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
   int oh_mul, ow_row, ow_mul, o_off;  // output addressing (see FwdArgs)
@@ -936,8 +907,13 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
   if (direct_ok(p)) return (size_t)p->B * p->Ho * wsz * sizeof(float) + 256;
   if (!generic_ok(p)) return 0;
-  const size_t fwd = wsz;
-  const size_t dgrad = packed_dgrad_elems(p);
+  size_t fwd = wsz;
+  size_t dgrad = packed_dgrad_elems(p);
+  if (wino_shape(p)) {  // transformed weights are 16/9 the size
+    const size_t wf = air_wino_packed_elems(p->Cout, p->Cin), wd = air_wino_packed_elems(p->Cin, p->Cout);
+    if (wf > fwd) fwd = wf;
+    if (wd > dgrad) dgrad = wd;
+  }
   const size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (wgrad > m) m = wgrad;
@@ -967,6 +943,11 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
   if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
   float* wp = reinterpret_cast<float*>(ws);
+  if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
+                         conv_flops(p), st);
+  }
   const int taps = p->KH * p->KW;
   const int ck = pick_ck(taps, p->Cin);
   TapSel sel;
@@ -991,6 +972,11 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
   float* wp = reinterpret_cast<float*>(ws);
   const int taps = p->KH * p->KW;
   // roles swap: "input" channels = Cout, "output" channels = Cin
+  if (wino_shape(p) && air_wino_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
+    if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
+                         conv_flops(p), st);
+  }
   if (p->sh == 1) {
     // stride 1: dx = conv(dy, flipped taps) with padding K-1-p
     const int ck = pick_ck(taps, p->Cout);

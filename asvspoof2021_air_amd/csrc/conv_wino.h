@@ -1,0 +1,18 @@
+// Internal interface of the Winograd F(2x2,3x3) convolution kernels (conv_wino.hip), used by
+// the C-ABI conv entry points in conv2d.hip for 3x3 / stride 1 / pad 1 layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// true when the Winograd path handles this 3x3 s1 p1 problem (M = output-role channels,
+// Kc = input-role channels of the launch: swapped for a dgrad)
+bool air_wino_ok(int B, int Kc, int H, int W, int M);
+
+// floats of transformed, packed weights for (M, Kc)
+size_t air_wino_packed_elems(int M, int Kc);
+
+// y (B, M, H, W) = conv3x3_s1_p1(x (B, Kc, H, W), w) [+ residual].
+// dgrad == 0: w is (M, Kc, 3, 3).  dgrad == 1: w is (Kc, M, 3, 3) and taps are flipped, i.e. the
+// data gradient of the forward conv whose weight is w.  up: workspace of air_wino_packed_elems.
+int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,
+                  int H, int W, int M, int dgrad, float* up, double flops, hipStream_t st);
