@@ -17,6 +17,8 @@
 // Tile groups are 1 x 32 or 2 x 16 tiles, whichever wastes less of the (H, W) at hand.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "air_common.h"
 #include "air_lds_dma.h"
 #include "air_prof.h"
@@ -84,7 +86,8 @@ struct WinoArgs {
   int THG, TWG;           // tile groups per image
   int ngroups;            // B * THG * TWG
   int ncot;               // Cout / 64 rounded up
-  int dbg;
+  int nitems;             // work items: ceil(ngroups / 2) * ncot
+  long long* trace;       // debug: cycle stamps of workgroup 0 (null in production)
 };
 
 template <int TR>
@@ -109,11 +112,120 @@ __device__ __forceinline__ void dma_wait_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TR>
+// Position of a tile group / of a work item, wave-uniform.  A work item = (64 output
+// channels) x (2 consecutive tile groups); items are numbered cot-fastest.
+struct GroupPos {
+  int b, thg, twg;
+};
+struct ItemPos {
+  int cot;
+  GroupPos g[2];
+};
+__device__ __forceinline__ void group_init(GroupPos& g, int idx, const WinoArgs& a) {
+  g.twg = idx % a.TWG;
+  const int r = idx / a.TWG;
+  g.thg = r % a.THG;
+  g.b = r / a.THG;  // == B for the padding group behind an odd group count
+}
+__device__ __forceinline__ void group_adv2(GroupPos& g, const WinoArgs& a) {
+  g.twg += 2;
+  while (g.twg >= a.TWG) {
+    g.twg -= a.TWG;
+    if (++g.thg == a.THG) {
+      g.thg = 0;
+      ++g.b;
+    }
+  }
+}
+__device__ __forceinline__ void item_init(ItemPos& it, int item, const WinoArgs& a) {
+  it.cot = item % a.ncot;
+  const int pg = item / a.ncot;
+  group_init(it.g[0], 2 * pg, a);
+  group_init(it.g[1], 2 * pg + 1, a);
+}
+__device__ __forceinline__ void item_next(ItemPos& it, const WinoArgs& a) {
+  if (++it.cot == a.ncot) {
+    it.cot = 0;
+    group_adv2(it.g[0], a);
+    group_adv2(it.g[1], a);
+  }
+}
+
+// ---- inline-asm building blocks -------------------------------------------------------
+// A wave's VALU / LDS / DMA instructions do NOT run under its (or a sibling wave's) f32 MFMAs on
+// this part: tools/ubench/mfma_rot.hip measures 64 + 8 + 4 n cycles per MFMA with n VALU
+// instructions in between, at 1, 2 or 4 waves per SIMD alike.  So the kernel is built to issue
+// as few non-MFMA instructions per MFMA as possible:
+//   * staging is buffer_load ... lds: one 32-bit offset VGPR per element, the chunk advance is
+//     the SGPR soffset, the zero padding is the buffer's out-of-range rule (no mask
+//     instructions, no address arithmetic in the loop), 4 DMAs share one M0 write through the
+//     instruction offset (it moves the LDS and the global address alike, so the per-lane offset
+//     is biased by it);
+//   * the 4x4 input transform is 16 v_pk_add_f32 (source-half selects + negate modifiers).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned XBIAS = 4096;         // the x descriptor starts this many bytes before x
+constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any tensor we accept: reads as zero
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32));  // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// One DMA = 3 instructions: M0 = (wave's LDS base for this buffer) + MIMM, wait state, load.
+// IMM = instruction offset (moves the LDS and the global address alike).
+template <int MIMM, int IMM>
+__device__ __forceinline__ void dma4_buf(i32x4 rsrc, unsigned soff, unsigned mbase, unsigned v0) {
+  asm volatile("s_add_i32 m0, %1, %4\n\ts_nop 0\n\t"
+               "buffer_load_dword %3, %0, %2 offen offset:%5 lds"
+               :: "s"(rsrc), "s"(mbase), "s"(soff), "v"(v0), "n"(MIMM), "n"(IMM) : "memory", "m0", "scc");
+}
+template <int MIMM>
+__device__ __forceinline__ void dma16_buf(i32x4 rsrc, unsigned soff, unsigned mbase, unsigned v0) {
+  asm volatile("s_add_i32 m0, %1, %4\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %3, %0, %2 offen lds"
+               :: "s"(rsrc), "s"(mbase), "s"(soff), "v"(v0), "n"(MIMM) : "memory", "m0", "scc");
+}
+// (a.x - b.x, a.y - b.y) / (a.x + b.x, a.y + b.y)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// columns of B^T d B from a transformed row (lo = t0,t1; hi = t2,t3):
+// (t0 - t2, t1 + t2) and (t2 - t1, t1 - t3)
+__device__ __forceinline__ f32x2 pk_col01(f32x2 lo, f32x2 hi) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]"
+               : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_col23(f32x2 lo, f32x2 hi) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]"
+               : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// Persistent workgroups: each of the (at most 256) workgroups walks a contiguous range of work
+// items, and the K-chunk stream runs on ACROSS item boundaries, so the staging of the next
+// item's first chunks overlaps the tail and the epilogue of the current one.
+// TRACE: debug build that stamps cycle counters of workgroup 0 (tools/wino_trace.py); the
+// production instance carries none of it.
+template <int TR, bool TRACE = false>
 __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   using C = WinoCfg<TR>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  static_assert((NBUF - 2) * C::ND <= 63, "vmcnt is a 6-bit counter");
+  static_assert((NBUF - 1) * C::ND <= 63, "vmcnt is a 6-bit counter");
+  static_assert(C::NI <= 12, "patch DMAs are issued as at most 3 groups of 4");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,79 +233,125 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int cw = wave & 1;   // channel half of the workgroup's 64
   const int gw = wave >> 1;  // tile group of the workgroup's 2
-
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int cot = lb % a.ncot;
-  const int pg = lb / a.ncot;
   const int HWi = a.H * a.W;
   const int nchunk = a.Cin / WCK;
 
-  // origins of both tile groups of this workgroup (every thread stages for both)
-  int gb[2], gh0[2], gw0[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int g = min(pg * 2 + k, a.ngroups - 1);
-    const int twg = g % a.TWG;
-    const int r = g / a.TWG;
-    gb[k] = r / a.THG;
-    gh0[k] = 2 * TR * (r % a.THG) - 1;
-    gw0[k] = 2 * C::TC * twg - 1;
+  const int lw = xcd_remap(blockIdx.x, gridDim.x);
+  const int i0 = (int)((long long)lw * a.nitems / (int)gridDim.x);
+  const int i1 = (int)((long long)(lw + 1) * a.nitems / (int)gridDim.x);
+  if (i0 >= i1) return;
+  if (TRACE && a.trace != nullptr && blockIdx.x == 0 && tid == 0) {
+    a.trace[62] = clock64();
+    a.trace[63] = wall_clock64();
   }
-  // chunk-invariant source offsets of this thread's patch elements (clamped into the image;
-  // zero padding is applied when the operand is read)
-  int goff[C::NI];
+  const int S = (i1 - i0) * nchunk;  // chunks in this workgroup's stream
+
+  // ---- staging state: runs NBUF-1 chunks ahead of the compute state
+  const i32x4 xrs = make_rsrc(reinterpret_cast<const char*>(a.x) - XBIAS,
+                              (unsigned)a.B * a.Cin * HWi * 4u + XBIAS);
+  const i32x4 urs = make_rsrc(a.up, (unsigned)a.ncot * WBM * a.Cin * 64u);
+  // item-invariant decomposition of this thread's patch elements: grp<<24 | cil<<16 | r<<8 | c
+  // (kept in LDS behind the ring, not in registers: it is needed once per item, and a value the
+  // register allocator spills to scratch comes back through vmcnt, behind the DMAs in flight)
+  int* epack = reinterpret_cast<int*>(lds + NBUF * C::BUF) + tid;
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
-    const int e = min(i * 256 + tid, C::NE - 1);
+    const int e = i * 256 + tid;
     const int grp = e / (WCK * C::CHS);
     const int rem = e - grp * (WCK * C::CHS);
     const int cil = rem / C::CHS;
     const int rem2 = rem - cil * C::CHS;
     const int r = rem2 / C::PC;
-    const int c = rem2 - r * C::PC;
-    const int hi = min(max((grp ? gh0[1] : gh0[0]) + r, 0), a.H - 1);
-    const int wi = min(max((grp ? gw0[1] : gw0[0]) + c, 0), a.W - 1);
-    goff[i] = ((grp ? gb[1] : gb[0]) * a.Cin + cil) * HWi + hi * a.W + wi;
+    epack[i * 256] = e < C::NE ? (grp << 24) | (cil << 16) | (r << 8) | (rem2 - r * C::PC) : -1;
   }
+  unsigned voff[C::NI];  // byte offsets of the patch elements into the x descriptor; padding and
+                         // unused slots point out of range and arrive as zeros
+  unsigned usoff = 0;    // byte offset of the staging item's weight slabs
+  auto set_voff = [&](int item) {
+    ItemPos D;
+    item_init(D, item, a);
+    const int b0 = D.g[0].b, b1 = D.g[1].b;
+    const int h00 = 2 * TR * D.g[0].thg - 1, h01 = 2 * TR * D.g[1].thg - 1;
+    const int w00 = 2 * C::TC * D.g[0].twg - 1, w01 = 2 * C::TC * D.g[1].twg - 1;
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      const int ep = epack[i * 256];
+      const int grp = (ep >> 24) & 1, cil = (ep >> 16) & 255, r = (ep >> 8) & 255, c = ep & 255;
+      const int bb = grp ? b1 : b0;
+      const int hi = (grp ? h01 : h00) + r, wi = (grp ? w01 : w00) + c;
+      const bool ok = ep >= 0 && bb < a.B && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const unsigned off = (unsigned)(((bb * a.Cin + cil) * HWi + hi * a.W + wi) * 4) + XBIAS;
+      voff[i] = (ok ? off : OOB) - (unsigned)(i & 3) * 1024u;  // minus the instruction offset
+    }
+    usoff = __builtin_amdgcn_readfirstlane((unsigned)D.cot * (unsigned)nchunk * (USLAB * 4u));
+  };
+  set_voff(i0);
+  // Everything a DMA needs besides its per-lane offset is wave-uniform and lives in SGPRs that
+  // move once per chunk: the x / weight-slab soffsets and the wave's two LDS bases in the target
+  // buffer.  Behind the end of the stream the staging state stays on the last chunk (it is staged
+  // again into free buffers), so issue counts - and with them the vmcnt waits - never vary.
+  int dItem = i0, dChunk = 0, dBuf = 0, dLeft = S;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-  const float* __restrict__ uslab0 = a.up + (size_t)cot * nchunk * USLAB;
-  // DMA instruction k (0 .. ND-1) of chunk -> buffer
-  auto dma_one = [&](int chunk, int buf, int k) {
-    const unsigned base = lds0 + 4u * (buf * C::BUF);
-    if (k < C::NI) {
-      const float* __restrict__ xc = a.x + (size_t)chunk * WCK * HWi;
-      dma4(xc + goff[k < C::NI ? k : 0], base + 4u * (USLAB + k * 256 + wave * 64));
+  const unsigned mP0 = lds0 + 4u * USLAB + wave * 256u, mU0 = lds0 + wave * 1024u;
+  unsigned xso = 0, uso = usoff, mP = mP0, mU = mU0;
+  unsigned uvoff[4];
+  auto dma_unit = [&](int u) {
+    if (u < C::NI) {
+      const unsigned vo = voff[u < C::NI ? u : 0];
+#define AIR_PATCH_DMA(G_, K_) \
+  if (u == 4 * G_ + K_) dma4_buf<G_ * 4096, K_ * 1024>(xrs, xso, mP, vo);
+      AIR_PATCH_DMA(0, 0) AIR_PATCH_DMA(0, 1) AIR_PATCH_DMA(0, 2) AIR_PATCH_DMA(0, 3)
+      AIR_PATCH_DMA(1, 0) AIR_PATCH_DMA(1, 1) AIR_PATCH_DMA(1, 2) AIR_PATCH_DMA(1, 3)
+      AIR_PATCH_DMA(2, 0) AIR_PATCH_DMA(2, 1) AIR_PATCH_DMA(2, 2) AIR_PATCH_DMA(2, 3)
+#undef AIR_PATCH_DMA
     } else {
-      const int i = k - C::NI;
-      const float* __restrict__ us = uslab0 + (size_t)chunk * USLAB;
-      dma16(us + 4 * (i * 256 + tid), base + 16u * (i * 256 + wave * 64));
+      const int q = u - C::NI;
+      if (q == 0) dma16_buf<0>(urs, uso, mU, uvoff[0]);
+      if (q == 1) dma16_buf<4096>(urs, uso, mU, uvoff[1]);
+      if (q == 2) dma16_buf<8192>(urs, uso, mU, uvoff[2]);
+      if (q == 3) dma16_buf<12288>(urs, uso, mU, uvoff[3]);
     }
   };
+  auto dma_advance = [&]() {
+    dBuf = dBuf + 1 == NBUF ? 0 : dBuf + 1;
+    if (dLeft > 1) {
+      --dLeft;
+      if (++dChunk == nchunk) {
+        dChunk = 0;
+        ++dItem;
+        set_voff(dItem);
+      }
+    }
+    xso = __builtin_amdgcn_readfirstlane((unsigned)dChunk * (unsigned)(WCK * HWi * 4));
+    uso = __builtin_amdgcn_readfirstlane(usoff + (unsigned)dChunk * (USLAB * 4u));
+    mP = __builtin_amdgcn_readfirstlane(mP0 + (unsigned)dBuf * (C::BUF * 4u));
+    mU = __builtin_amdgcn_readfirstlane(mU0 + (unsigned)dBuf * (C::BUF * 4u));
+  };
 
-  // this lane's tile
-  const int g = pg * 2 + gw;
-  const bool g_ok = g < a.ngroups;
-  const int tr = l31 / C::TC, tc = l31 % C::TC;
-  const int h0 = gh0[gw] + 2 * tr, w0 = gw0[gw] + 2 * tc;  // top-left of the 4x4 input patch
-  bool okm[4][4];
+  // ---- compute state
+  // Per-lane constants are RE-DERIVED from the thread id at the top of every item (behind an
+  // opaque asm so the derivation is not hoisted): kept live across the epilogue they get
+  // spilled to scratch, and their reload would put vmcnt waits - which also drain the DMAs in
+  // flight - into the chunk loop.
+  int pb_lane, ub_lane;  // LDS offsets (floats, within a buffer) of the lane's patch / weights
+  auto lane_consts = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int l31_ = t & 31, half_ = (t >> 5) & 1;
+    const int tr_ = l31_ / C::TC, tc_ = l31_ % C::TC;  // this lane's tile within its group
+    pb_lane = USLAB + (gw * WCK + half_) * C::CHS + (2 * tr_) * C::PC + 2 * tc_;
+    ub_lane = half_ * (16 * WBM) + (cw * 32 + l31_) * 4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      okm[r][c] = h0 + r >= 0 && h0 + r < a.H && w0 + c >= 0 && w0 + c < a.W;
-
-  // per-lane LDS offsets (floats, within a buffer)
-  const int pb_lane = USLAB + (gw * WCK + half) * C::CHS + (2 * tr) * C::PC + 2 * tc;
-  const int ub_lane = half * (16 * WBM) + (cw * 32 + l31) * 4;
+    for (int q = 0; q < 4; ++q) uvoff[q] = t * 16u + q * 4096u;
+  };
+  lane_consts();
 
   f32x16 acc[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = (f32x16){0};
 
-  f32x4 U0[4], U1[4];   // transformed weights of step 0 / 1
-  float v0[16], v1[16];  // transformed input of step 0 / 1
-  f32x2 d[8];            // raw patch rows: d[2r], d[2r+1] = columns 0-1, 2-3 of row r
-  float t[4][4];
+  f32x4 U0[4], U1[4];     // transformed weights of step 0 / 1
+  f32x2 V0[8], V1[8];     // transformed input of step 0 / 1: V[2i] = v[4i], v[4i+1]; V[2i+1] = v[4i+2], v[4i+3]
+  f32x2 d[8];             // raw patch rows: d[2r], d[2r+1] = columns 0-1, 2-3 of row r
+  f32x2 tl[4], th[4];     // row-transformed: columns 0-1 / 2-3
 
   auto ldU = [&](const float* __restrict__ bufp, int s, f32x4(&u)[4]) {
 #pragma unroll
@@ -208,126 +366,194 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
       d[2 * r + 1] = *reinterpret_cast<const f32x2*>(p + r * C::PC + 2);
     }
   };
-  // B^T d B in two passes of 4 pieces each: rows (with the zero-padding mask), then columns
-  auto row_piece = [&](int c) {
-    float x[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float raw = (c & 1) ? d[2 * r + (c >> 1)][1] : d[2 * r + (c >> 1)][0];
-      x[r] = okm[r][c] ? raw : 0.0f;
-    }
-    t[0][c] = x[0] - x[2];
-    t[1][c] = x[1] + x[2];
-    t[2][c] = x[2] - x[1];
-    t[3][c] = x[1] - x[3];
-    // pin the results to this MFMA slot (the optimiser otherwise sinks them to their use)
-    asm volatile("" : "+v"(t[0][c]), "+v"(t[1][c]), "+v"(t[2][c]), "+v"(t[3][c]));
+  // B^T d B as 16 packed adds in 8 pieces (the asm statements pin each piece to its MFMA slot)
+  auto row_piece = [&](int k) {  // transformed row k, both column pairs
+    if (k == 0) { tl[0] = pk_sub(d[0], d[4]); th[0] = pk_sub(d[1], d[5]); }
+    if (k == 1) { tl[1] = pk_add(d[2], d[4]); th[1] = pk_add(d[3], d[5]); }
+    if (k == 2) { tl[2] = pk_sub(d[4], d[2]); th[2] = pk_sub(d[5], d[3]); }
+    if (k == 3) { tl[3] = pk_sub(d[2], d[6]); th[3] = pk_sub(d[3], d[7]); }
   };
-  auto col_piece = [&](int i, float(&v)[16]) {
-    v[4 * i + 0] = t[i][0] - t[i][2];
-    v[4 * i + 1] = t[i][1] + t[i][2];
-    v[4 * i + 2] = t[i][2] - t[i][1];
-    v[4 * i + 3] = t[i][1] - t[i][3];
-    asm volatile("" : "+v"(v[4 * i]), "+v"(v[4 * i + 1]), "+v"(v[4 * i + 2]), "+v"(v[4 * i + 3]));
+  auto col_piece = [&](int i, f32x2(&V)[8]) {
+    V[2 * i] = pk_col01(tl[i], th[i]);
+    V[2 * i + 1] = pk_col23(tl[i], th[i]);
   };
 
-  // prologue: chunk 0 staged and transformed (exposed once), chunk 1 in flight
+  // Y = A^T M A per lane for the item at (eb, ethg, etwg, ecot); D row i = (r&3) + 8*(r>>2) +
+  // 4*half -> channel
+  auto epilogue = [&](int eb, int ethg, int etwg, int ecot) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int l31 = t & 31, half = (t >> 5) & 1;
+    const int tr = l31 / C::TC, tc = l31 % C::TC;
+    const int th_ = TR * ethg + tr, tw_ = C::TC * etwg + tc;
+    // (accumulators are read in uniform control flow; only the stores are predicated.  Read
+    // under a divergent branch, all 256 of them get copied to VGPRs up front and spill.)
+    const bool valid = eb < a.B && th_ < a.TH && tw_ < a.TW;
+    const int ho = 2 * th_, wo = 2 * tw_;
+    const bool w1 = wo + 1 < a.W, h1 = ho + 1 < a.H;
+    // per-lane part of the address once; the row part is wave-uniform (kept out of VGPRs: the
+    // compiler hoists whatever is item-invariant here, and 16 hoisted 64-bit lane offsets spill)
+    const size_t olane = (size_t)(4 * half) * HWi + (size_t)ho * a.W + wo;
+    const int co0 = ecot * WBM + cw * 32;
+    float* __restrict__ yb = a.y + ((size_t)eb * a.Cout + co0) * HWi + olane;
+    const float* __restrict__ rb =
+        a.residual != nullptr ? a.residual + ((size_t)eb * a.Cout + co0) * HWi + olane : nullptr;
+    // Output transform on whole accumulators (16 rows at a time), so every AGPR is read exactly
+    // once: s0 = m[j] + m[4+j] + m[8+j], s1 = m[4+j] - m[8+j] - m[12+j] per column j, then
+    // y[.][0] = s[0] + s[1] + s[2], y[.][1] = s[1] - s[2] - s[3].  (Row-wise extraction makes the
+    // compiler copy whole 16-register tuples per element and spill.)
+    // Two passes (output row 0, then row 1) keep the live set at 3 x 16 registers next to the
+    // prefetched operands of the next item, so nothing spills around the epilogue.
 #pragma unroll
-  for (int cb = 0; cb < NBUF - 1; ++cb) {
-    if (cb < nchunk) {
+    for (int half_row = 0; half_row < 2; ++half_row) {
+      f32x16 ya, yb2;  // y[half_row][0], y[half_row][1] for the 16 D rows
 #pragma unroll
-      for (int k = 0; k < C::ND; ++k) dma_one(cb, cb, k);
+      for (int j = 0; j < 4; ++j) {
+        const f32x16 sj = half_row == 0 ? acc[j] + acc[4 + j] + acc[8 + j]
+                                        : acc[4 + j] - acc[8 + j] - acc[12 + j];
+        if (j == 0) ya = sj;
+        if (j == 1) { ya += sj; yb2 = sj; }
+        if (j == 2) { ya += sj; yb2 -= sj; }
+        if (j == 3) yb2 -= sj;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (valid && (half_row == 0 || h1)) {
+        const size_t hoff = half_row ? (size_t)a.W : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int iu = (r & 3) + 8 * (r >> 2);  // + 4 * half = D row = channel within the 32
+          if (co0 + iu + 4 * half >= a.Cout) continue;
+          const size_t orow = (size_t)__builtin_amdgcn_readfirstlane(iu * HWi) + hoff;
+          float v0 = ya[r], v1 = yb2[r];
+          if (rb != nullptr) {
+            const float* __restrict__ rp = rb + orow;
+            const float r0 = rp[0];
+            const float r1 = w1 ? rp[1] : 0.0f;
+            v0 += r0; v1 += r1;
+          }
+          float* __restrict__ yp = yb + orow;
+          yp[0] = v0;
+          if (w1) yp[1] = v1;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+
+  // prologue: fill the ring, wait for the first chunk, transform its first step
+#pragma nounroll
+  for (int cb = 0; cb < NBUF; ++cb) {
+#pragma unroll
+    for (int u = 0; u < C::ND; ++u) dma_unit(u);
+    dma_advance();
   }
-  if (nchunk >= NBUF - 1)
-    dma_wait_n<(NBUF - 2) * C::ND>();  // chunk 0 has landed; the others may still fly
-  else
-    dma_wait();
+  dma_wait_n<(NBUF - 1) * C::ND>();  // chunk 0 has landed; the others may still fly
   __syncthreads();
   ldU(lds, 0, U0);
   ldD(lds, 0);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) row_piece(c);
+  for (int k = 0; k < 4; ++k) row_piece(k);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) col_piece(i, v0);
+  for (int i = 0; i < 4; ++i) col_piece(i, V0);
 
-  constexpr int DPS = (C::ND + 3) / 4;  // DMA instructions per MFMA slot (slots 0-3)
-  int cur = 0;
-  for (int chunk = 0; chunk < nchunk; ++chunk, cur = (cur + 1 == NBUF ? 0 : cur + 1)) {
+  int ntr = 0;
+  auto stamp = [&]() {
+    if (TRACE && a.trace != nullptr && blockIdx.x == 0 && tid == 0 && ntr < 60) {
+      a.trace[ntr] = clock64();
+      a.trace[64 + ntr] = wall_clock64();
+      ++ntr;
+    }
+  };
+  stamp();
+  int cur = 0, p = 0;
+  // one K chunk = 2 k-steps.  FIRST: the item's first chunk, whose step 0 starts the
+  // accumulators from a zero C operand (no separate zeroing pass over 256 AGPRs).
+  constexpr int NU1 = 8;  // DMAs issued in step 1 (slots 0, 2, .. 14); the rest in the next step 0
+  static_assert(C::ND - NU1 <= 7, "step 0 has 7 even slots from 2 on");
+  long long tS0 = 0, tWait = 0, tBar = 0, tS1 = 0;
+  const bool tracing = TRACE && a.trace != nullptr && blockIdx.x == 0;
+  // PEND: a chunk's staging began behind the previous barrier (false only for the very first
+  // chunk of the stream, whose predecessors the prologue staged whole)
+  auto chunk_body = [&](auto first_tag, auto pend_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool PEND = decltype(pend_tag)::value;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (tracing) c0 = clock64();
     const int nxt = cur + 1 == NBUF ? 0 : cur + 1;
-    const int prv = cur == 0 ? NBUF - 1 : cur - 1;  // buffer of chunk - 1 = of chunk + NBUF - 1
     const float* __restrict__ bcur = lds + cur * C::BUF;
     const float* __restrict__ bnxt = lds + nxt * C::BUF;
-    // ---- step 0 of this chunk; fetch + transform step 1 in the MFMA shadow
+    // ---- step 0 of this chunk; fetch + transform step 1 in between
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j == 0) ldU(bcur, 1, U1);
       if (j == 1) ldD(bcur, 1);
       if (j >= 4 && j < 8) row_piece(j - 4);
-      if (j >= 8 && j < 12) col_piece(j - 8, v1);
+      if (j >= 8 && j < 12) col_piece(j - 8, V1);
+      // second half of the DMAs of the chunk whose staging began behind the last barrier
+      if (PEND && j >= 2 && (j & 1) == 0 && NU1 + (j - 2) / 2 < C::ND) dma_unit(NU1 + (j - 2) / 2);
+      if (PEND && j == 15) dma_advance();
       __builtin_amdgcn_sched_barrier(0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(U0[j >> 2][j & 3], v0[j], acc[j], 0, 0, 0);
+      if (FIRST)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(U0[j >> 2][j & 3], V0[j >> 1][j & 1],
+                                                     (f32x16){0}, 0, 0, 0);
+      else
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(U0[j >> 2][j & 3], V0[j >> 1][j & 1], acc[j],
+                                                     0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- step 1; the next chunk has landed: swap, restage the freed buffer, fetch step 0
-    // chunk + 1 must have landed (DMAs complete in order; chunks up to + NBUF - 2 are in flight)
-    if (!(a.dbg & 1)) {
-    if (chunk + NBUF - 2 < nchunk)
-      dma_wait_n<(NBUF - 3) * C::ND>();
-    else
-      dma_wait();
+    // ---- step 1.  Stream chunk p+1 must have landed (DMAs complete in order; chunks up to
+    // p+NBUF-2 are in flight).  Behind an epilogue its stores share the counter: drain.
+    if (tracing) c1 = clock64();
+    // (vmcnt also counts the epilogue's stores, but loads retire in order: "at most N operations
+    // outstanding" still means at most the N youngest LOADS are, and chunk p+1 has >= N younger)
+    dma_wait_n<(NBUF - 2) * C::ND>();
+    if (tracing) c2 = clock64();
     __syncthreads();
-    }
-    const bool more2 = chunk + NBUF - 1 < nchunk && !(a.dbg & 1);
+    if (tracing) c3 = clock64();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      if (j < 4 && more2) {
-#pragma unroll
-        for (int k = j * DPS; k < (j + 1) * DPS && k < C::ND; ++k) dma_one(chunk + NBUF - 1, prv, k);
-      }
-      // (after the last chunk these read stale LDS: unused, but branch-free)
-      if (j == 4) ldU(bnxt, 0, U0);
-      if (j == 5) ldD(bnxt, 0);
+      // this chunk's buffer is free (every wave read its last operands before the barrier):
+      // restage it with stream chunk p + NBUF, first half of the DMAs here
+      if ((j & 1) == 0) dma_unit(j / 2);
+      // (behind the last chunk of the stream these read stale LDS: unused, but branch-free)
+      if (j == 5) ldU(bnxt, 0, U0);
+      if (j == 7) ldD(bnxt, 0);
       if (j >= 8 && j < 12) row_piece(j - 8);
-      if (j >= 12) col_piece(j - 12, v0);
+      if (j >= 12) col_piece(j - 12, V0);
       __builtin_amdgcn_sched_barrier(0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(U1[j >> 2][j & 3], v1[j], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(U1[j >> 2][j & 3], V1[j >> 1][j & 1], acc[j],
+                                                   0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (tracing) {
+      const long long c4 = clock64();
+      tS0 += c1 - c0; tWait += c2 - c1; tBar += c3 - c2; tS1 += c4 - c3;
+    }
+    ++p;
+    cur = nxt;
+  };
+  for (int item = i0; item < i1; ++item) {
+    if (item != i0) lane_consts();
+    if (item == i0)
+      chunk_body(std::true_type{}, std::false_type{});
+    else
+      chunk_body(std::true_type{}, std::true_type{});
+    for (int chunk = 1; chunk < nchunk; ++chunk) chunk_body(std::false_type{}, std::true_type{});
+    stamp();
+    {
+      ItemPos P;
+      item_init(P, item, a);
+      epilogue(gw ? P.g[1].b : P.g[0].b, gw ? P.g[1].thg : P.g[0].thg,
+               gw ? P.g[1].twg : P.g[0].twg, P.cot);
+    }
+    // Compiler-visible vmcnt(0): whatever it spilled around the epilogue has come back, so it
+    // puts no vmcnt waits (which would also drain the DMAs in flight) into the chunk loop.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    stamp();
   }
-
-  // epilogue: Y = A^T M A per lane; D row i = (r&3) + 8*(r>>2) + 4*half -> channel
-  if (!g_ok || (a.dbg & 2)) return;
-  const int th = (gh0[gw] + 1) / 2 + tr, tw = (gw0[gw] + 1) / 2 + tc;
-  if (th >= a.TH || tw >= a.TW) return;
-  const int ho = 2 * th, wo = 2 * tw;
-  const bool w1 = wo + 1 < a.W, h1 = ho + 1 < a.H;
-  const size_t obase = ((size_t)gb[gw] * a.Cout + cot * WBM + cw * 32) * HWi + (size_t)ho * a.W + wo;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const int co = cot * WBM + cw * 32 + i;
-    if (co >= a.Cout) continue;
-    float s0[4], s1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
-      s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-    }
-    float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3];
-    float y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-    const size_t o = obase + (size_t)i * HWi;
-    if (a.residual != nullptr) {
-      const float r00 = a.residual[o];
-      const float r01 = w1 ? a.residual[o + 1] : 0.0f;
-      const float r10 = h1 ? a.residual[o + a.W] : 0.0f;
-      const float r11 = (w1 && h1) ? a.residual[o + a.W + 1] : 0.0f;
-      y00 += r00; y01 += r01; y10 += r10; y11 += r11;
-    }
-    a.y[o] = y00;
-    if (w1) a.y[o + 1] = y01;
-    if (h1) a.y[o + a.W] = y10;
-    if (w1 && h1) a.y[o + a.W + 1] = y11;
+  if (tracing && lane == 0 && wave < 4) {
+    a.trace[96 + wave * 4 + 0] = tS0; a.trace[96 + wave * 4 + 1] = tWait;
+    a.trace[96 + wave * 4 + 2] = tBar; a.trace[96 + wave * 4 + 3] = tS1;
   }
 }
 
@@ -339,12 +565,17 @@ int grid_for(size_t n) {
 
 }  // namespace
 
+static long long* g_wino_trace = nullptr;
+extern "C" void air_dbg_wino_trace(long long* p) { g_wino_trace = p; }
+
 bool air_wino_ok(int B, int Kc, int H, int W, int M) {
   static const int off = getenv("AIR_NO_WINOGRAD") ? atoi(getenv("AIR_NO_WINOGRAD")) : 0;
   if (off) return false;
   if (M < 32 || Kc < WCK || Kc % WCK != 0) return false;
-  const double ein = (double)B * Kc * H * W, eout = (double)B * M * H * W;
-  return ein < 2147483647.0 && eout < 1e18 && H >= 1 && W >= 2;
+  // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
+  const double ein = (double)B * Kc * H * W;
+  return ein * 4.0 + 8192.0 < 2147483648.0 && (double)air_wino_packed_elems(M, Kc) * 4.0 < 4294967296.0 &&
+         H >= 1 && W >= 2;
 }
 
 size_t air_wino_packed_elems(int M, int Kc) {
@@ -367,24 +598,33 @@ int air_wino_conv(const float* x, const float* w, float* y, const float* residua
   a.TWG = (a.TW + 32 / trows - 1) / (32 / trows);
   a.ngroups = B * a.THG * a.TWG;
   a.ncot = (M + WBM - 1) / WBM;
-  a.dbg = getenv("AIR_WINO_DBG") ? atoi(getenv("AIR_WINO_DBG")) : 0;
-  const int nblk = (a.ngroups + 1) / 2 * a.ncot;
-  AirProfScope ps(AIR_K_CONV_WINO, flops, st);
-  static const bool attr_ok = [] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               NBUF * WinoCfg<1>::BUF * sizeof(float)) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               NBUF * WinoCfg<2>::BUF * sizeof(float)) == hipSuccess;
+  a.trace = g_wino_trace;
+  a.nitems = (a.ngroups + 1) / 2 * a.ncot;
+  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  const size_t lds1 = (NBUF * WinoCfg<1>::BUF + WinoCfg<1>::NI * 256) * sizeof(float);
+  const size_t lds2 = (NBUF * WinoCfg<2>::BUF + WinoCfg<2>::NI * 256) * sizeof(float);
+  static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    const void* ks[4] = {reinterpret_cast<const void*>(wino_conv_kernel<1, false>),
+                         reinterpret_cast<const void*>(wino_conv_kernel<1, true>),
+                         reinterpret_cast<const void*>(wino_conv_kernel<2, false>),
+                         reinterpret_cast<const void*>(wino_conv_kernel<2, true>)};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i)
+      ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(i < 2 ? lds1 : lds2)) == hipSuccess;
+    return ok;
   }();
   if (!attr_ok) return AIR_ELAUNCH;
-  if (trows == 2)
-    hipLaunchKernelGGL(wino_conv_kernel<2>, dim3(nblk), dim3(256),
-                       NBUF * WinoCfg<2>::BUF * sizeof(float), st, a);
-  else
-    hipLaunchKernelGGL(wino_conv_kernel<1>, dim3(nblk), dim3(256),
-                       NBUF * WinoCfg<1>::BUF * sizeof(float), st, a);
+  if (a.trace != nullptr) {
+    if (trows == 2)
+      hipLaunchKernelGGL((wino_conv_kernel<2, true>), dim3(nblk), dim3(256), lds2, st, a);
+    else
+      hipLaunchKernelGGL((wino_conv_kernel<1, true>), dim3(nblk), dim3(256), lds1, st, a);
+  } else if (trows == 2) {
+    hipLaunchKernelGGL((wino_conv_kernel<2, false>), dim3(nblk), dim3(256), lds2, st, a);
+  } else {
+    hipLaunchKernelGGL((wino_conv_kernel<1, false>), dim3(nblk), dim3(256), lds1, st, a);
+  }
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -228,3 +228,44 @@ def test_adam_sgd(ops):
     ops.sgd_step(cg, g[:256].reshape(1, 256).cuda(), 5e-4)
     np.testing.assert_allclose(cg.cpu().numpy(), (c - 5e-4 * g[:256].reshape(1, 256)).numpy(), atol=1e-7)
     ops.sgd_step(cg, g[:256].reshape(1, 256).cuda(), 5e-4, grad_scale=0.5)
+
+
+# Winograd F(2x2,3x3) path (conv_wino.hip): every 3x3 / stride 1 / pad 1 forward without fused
+# prologue and every such dgrad.  Shapes cover both tile-group forms (1x32, 2x16), odd H / W,
+# an odd group count (padding group), W = 2 / H = 1, more work items than workgroups (each
+# persistent workgroup walks several items, with and without an output-channel-tile change
+# between them) and the residual epilogue.
+WINO = [
+    # (B, Cin, H, W, Cout)
+    (2, 64, 18, 75, 64),
+    (1, 512, 3, 94, 512),
+    (3, 32, 5, 47, 64),
+    (3, 8, 2, 64, 64),
+    (1, 8, 1, 2, 64),
+    (2, 8, 7, 3, 128),
+    (40, 16, 18, 150, 64),
+    (60, 32, 9, 75, 128),
+]
+
+
+@pytest.mark.parametrize("cfg", WINO)
+def test_conv2d_winograd(ops, cfg):
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 11)
+    w = synth_feat((Cout, Cin, 3, 3), 12, scale=0.1)
+    res = synth_feat((B, Cout, H, W), 13)
+    xd = x.double().requires_grad_(True)
+    y = F.conv2d(xd, w.double(), None, 1, 1)
+    got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1)
+    # fp32 Winograd: the input transform subtracts neighbours, so it is a few times noisier than
+    # the direct f32 MFMA chain (measured 1e-6 of the output scale); still fp32-grade
+    close(got, y, rtol=1e-5, name="winograd fwd")
+    got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1, residual=res.cuda())
+    close(got, y + res.double(), rtol=1e-5, name="winograd fwd + residual")
+    dy = synth_feat((B, Cout, H, W), 14)
+    y.backward(dy.double())
+    got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1)
+    close(got, xd.grad, rtol=1e-5, name="winograd dgrad")
+    acc = synth_feat((B, Cin, H, W), 15)
+    got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda())
+    close(got, xd.grad + acc.double(), rtol=1e-5, name="winograd dgrad + accumulate")

@@ -112,7 +112,10 @@ def test_grads_vs_oracle_small(golden):
 def test_trajectory_vs_golden(golden):
     """3 optimisation steps (Adam on the arena + SGD on the centre) against the reference's
     losses.  Step 1 is pre-update (tight); later steps sit on Adam's sign-SGD noise floor
-    (see tests/golden/make_golden.py), where the oracle itself differs by 1e-4."""
+    (see tests/golden/make_golden.py): the first Adam updates are lr * sign(g), so rounding-level
+    gradient differences flip whole updates of near-zero-gradient weights.  There the fp32 and
+    fp64 oracles differ by 1e-4, the direct-conv kernels by 1e-4, and the Winograd convs (input
+    transform subtracts neighbours: ~1e-6 of scale per conv instead of ~1e-7) by 2e-3."""
     g = golden("trajectory.npz")
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     from asvspoof2021_air_amd.train import Trainer
@@ -129,7 +132,8 @@ def test_trajectory_vs_golden(golden):
         loss, _ = tr.step_features(xb, labels)
         losses.append(loss.item())
     np.testing.assert_allclose(losses[0], g["losses"][0], rtol=2e-5)
-    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
+    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=1e-4)
+    np.testing.assert_allclose(losses, g["losses"], rtol=5e-3)
     sd = m.state_dict()
     assert np.abs(sd["conv1.weight"].cpu().numpy() - g["conv1_w"]).max() <= 3 * 2 * 5e-4 + 1e-6
     np.testing.assert_allclose(tr.loss.center.detach().cpu().numpy(), g["center"], atol=1e-5)
