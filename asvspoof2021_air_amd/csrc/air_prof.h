@@ -17,6 +17,7 @@ enum AirKernelId {
   AIR_K_CONV_WG_1D,        // conv_wgrad_kernel<1, 3|5, 1>: ECAPA conv1d layers
   AIR_K_LFCC,              // lfcc_kernel
   AIR_K_CONV_WINO,         // wino_conv_kernel: 3x3 s1 forward and dgrad, Winograd F(2x2,3x3)
+  AIR_K_CONV_WINO_WG,      // wino_wgrad_kernel: 3x3 s1 weight gradient, Winograd F(3x3,2x2)
   AIR_K_COUNT
 };
 

@@ -914,7 +914,11 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
     if (wf > fwd) fwd = wf;
     if (wd > dgrad) dgrad = wd;
   }
-  const size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
+  size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
+  if (wino_shape(p) && air_wino_wgrad_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    const size_t ww = (size_t)air_wino_wgrad_nsplit(p->B, p->Cin, p->H, p->W, p->Cout) * wsz;
+    if (ww > wgrad) wgrad = ww;
+  }
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (wgrad > m) m = wgrad;
   return m * sizeof(float) + 256;
@@ -1068,6 +1072,17 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
   }
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
   if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;  // BN-apply + ReLU together, or none
+  if (in_scale == nullptr && wino_shape(p) && air_wino_wgrad_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    const int nsplit = air_wino_wgrad_nsplit(p->B, p->Cin, p->H, p->W, p->Cout);
+    if (!ws || ws_bytes < (size_t)nsplit * wsz * sizeof(float)) return AIR_EWORKSPACE;
+    int rc = air_wino_wgrad_partials(x, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H, p->W,
+                                     p->Cout, conv_flops(p), st);
+    if (rc != AIR_OK) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), dw, wsz, nsplit, 9);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
   WgradGeom g = {p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW, p->sh, p->ph, p->pw, p->Ho, p->Wo,
                  1, (size_t)p->Cin * p->H * p->W, (size_t)p->Cout * p->Ho * p->Wo};
   return run_wgrad(g, x, dy, dw, in_scale, in_shift, relu, ws, ws_bytes, conv_flops(p), st);

@@ -16,3 +16,10 @@ size_t air_wino_packed_elems(int M, int Kc);
 // data gradient of the forward conv whose weight is w.  up: workspace of air_wino_packed_elems.
 int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,
                   int H, int W, int M, int dgrad, float* up, double flops, hipStream_t st);
+
+// Weight gradient of the same convolution (Winograd F(3x3,2x2)).  Writes K-split partial sums
+// partial[nsplit][9][Cout][Cin] (nsplit = air_wino_wgrad_nsplit) for reduce_partials_kernel.
+bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout);
+int air_wino_wgrad_nsplit(int B, int Cin, int H, int W, int Cout);
+int air_wino_wgrad_partials(const float* x, const float* dy, float* partial, int B, int Cin, int H,
+                            int W, int Cout, double flops, hipStream_t st);

@@ -557,6 +557,265 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient of the same 3x3 / stride 1 / pad 1 convolution as Winograd F(3x3,2x2):
+//   dW[co][ci] (3x3) = sum over 2x2 output tiles of  A'^T [ (G' g G'^T) .* (B^T d B) ] A'
+// with g the 2x2 tile of dy[co], d the 4x4 patch of x[ci] around it (the same B^T d B as the
+// forward transform).  16 multiplies per (co, ci, tile) instead of 36: 16 GEMMs
+// M_xn[co][ci] = sum_tiles Gd_xn[co][tile] * V_xn[ci][tile] whose K dimension is the tile index.
+//   * a wave owns 32 co x 32 ci x 16 accumulators; a workgroup 64 x 64; the tile stream is split
+//     over workgroups (K-split) and the partial 3x3 results are reduced by reduce_partials_kernel.
+//   * an MFMA k-step is 2 neighbouring tiles: a lane transforms the patch of ITS input channel
+//     (16 packed adds) and the dy tile of ITS output channel (6 packed adds) for one tile.
+//   * a stage = 16 tiles of one tile row: x rows of 64 channels (one dwordx4 DMA per channel: the
+//     24 idle lanes write zeros that the next channel's DMA, issued by the same wave, overwrites;
+//     a pad takes the last one's) and dy rows of 64 channels (one dword DMA per channel), channel
+//     pitches chosen so that 32 lanes reading 32 channels hit 32 distinct LDS bank pairs.
+//   * zero padding = the buffer descriptor's out-of-range rule per 16-byte lane; a lane chunk that
+//     straddles the right image edge brings the next row's first pixels instead of zeros: the
+//     two cells a valid tile can see (columns W, W+1) are zeroed in LDS by the reading wave.
+constexpr int WG_SEG = 16;                    // tiles per stage
+constexpr int WG_XC = 40;                     // staged x columns per row: image cols 32 seg - 4 ...
+constexpr int WG_XP = 4 * WG_XC + 2;          // floats per channel (odd half: conflict-free b64 / b32x2)
+constexpr int WG_XWAVE = 16 * WG_XP + 96;     // a wave's 16 channels + pad for the last DMA's idle lanes
+constexpr int WG_XF = 4 * WG_XWAVE;
+constexpr int WG_DP = 66;                     // dy floats per channel: 2 rows x 32 columns + 2
+constexpr int WG_DF = 64 * WG_DP;
+constexpr int WG_BUF = WG_XF + WG_DF;         // floats per stage buffer (59.9 KB)
+
+struct WinoWgArgs {
+  const float* x;    // (B, Cin, H, W)
+  const float* dy;   // (B, Cout, H, W)
+  float* partial;    // [nsplit][9][Cout][Cin]
+  int B, Cin, H, W, Cout;
+  int TH, NTS;       // tile rows, tile-row segments per row
+  int nseg;          // B * TH * NTS
+  int ncob, ncib, nsplit;
+};
+
+// (x + y, x - y) of one register pair
+__device__ __forceinline__ f32x2 pk_sumdiff(f32x2 q) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]"
+               : "=v"(r) : "v"(q));
+  return r;
+}
+template <int MIMM>
+__device__ __forceinline__ void dma16_at(i32x4 rsrc, unsigned soff, unsigned mbase, unsigned v0) {
+  asm volatile("s_add_i32 m0, %1, %4\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %3, %0, %2 offen lds"
+               :: "s"(rsrc), "s"(mbase), "s"(soff), "v"(v0), "n"(MIMM) : "memory", "m0", "scc");
+}
+template <int MIMM>
+__device__ __forceinline__ void dma4_at(i32x4 rsrc, unsigned soff, unsigned mbase, unsigned v0) {
+  asm volatile("s_add_i32 m0, %1, %4\n\ts_nop 0\n\t"
+               "buffer_load_dword %3, %0, %2 offen lds"
+               :: "s"(rsrc), "s"(mbase), "s"(soff), "v"(v0), "n"(MIMM) : "memory", "m0", "scc");
+}
+
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = wave & 1;   // co half of the workgroup's 64
+  const int ch = wave >> 1;  // ci half
+  const int HWi = a.H * a.W;
+
+  int lb = blockIdx.x;
+  const int split = lb % a.nsplit;
+  lb /= a.nsplit;
+  const int cib = lb % a.ncib;
+  const int cob = lb / a.ncib;
+  const int per = (a.nseg + a.nsplit - 1) / a.nsplit;
+  const int s0 = split * per, s1 = min(a.nseg, s0 + per);
+
+  const i32x4 xrs = make_rsrc(a.x, (unsigned)a.B * a.Cin * HWi * 4u);
+  const i32x4 drs = make_rsrc(a.dy, (unsigned)a.B * a.Cout * HWi * 4u);
+  const unsigned hw4 = (unsigned)HWi * 4u;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+  // LDS bases (bytes) of this wave's DMA destinations inside a buffer
+  const unsigned mX0 = lds0 + wave * (WG_XWAVE * 4u);
+  const unsigned mD0 = lds0 + WG_XF * 4u + wave * (16 * WG_DP * 4u);
+
+  // stage geometry -> per-lane source offsets (one VGPR each) and the wave's channel bases
+  unsigned vox = OOB, vod = OOB, xs0 = 0, ds0 = 0;
+  int edge_col = -1;  // staged column of image column W if a valid tile of the stage sees it
+  auto set_stage = [&](int s, unsigned& vx, unsigned& vd, unsigned& xs, unsigned& dsf, int& ecol) {
+    const int seg = s % a.NTS;
+    const int r = s / a.NTS;
+    const int th = r % a.TH;
+    const int b = r / a.TH;
+    {
+      const int row = 2 * th - 1 + lane / 10, col0 = 32 * seg - 4 + 4 * (lane % 10);
+      const bool ok = lane < 40 && row >= 0 && row < a.H && col0 >= 0 && col0 < a.W;
+      vx = ok ? (unsigned)((row * a.W + col0) * 4) : OOB;
+    }
+    {
+      const int row = 2 * th + half, col = 32 * seg + l31;
+      vd = (row < a.H && col < a.W) ? (unsigned)((row * a.W + col) * 4) : OOB;
+    }
+    xs = __builtin_amdgcn_readfirstlane((unsigned)((b * a.Cin + cib * 64 + wave * 16) * HWi) * 4u);
+    dsf = __builtin_amdgcn_readfirstlane((unsigned)((b * a.Cout + cob * 64 + wave * 16) * HWi) * 4u);
+    const int wc = a.W - (32 * seg - 4);  // staged column of image column W
+    ecol = (wc >= 4 && wc < WG_XC) ? wc : -1;
+  };
+
+  // DMA unit u (0 .. 31) of the stage being staged into buffer `buf`: 16 x channels, 16 dy channels
+  unsigned n_vox = OOB, n_vod = OOB, n_xs = 0, n_ds = 0, mXn = 0, mDn = 0;
+  int n_edge = -1;
+  auto dma_unit = [&](int u) {
+#define AIR_XU(K_) if (u == K_) dma16_at<K_ * WG_XP * 4>(xrs, n_xs + K_ * hw4, mXn, n_vox);
+#define AIR_DU(K_) if (u == 16 + K_) dma4_at<K_ * WG_DP * 4>(drs, n_ds + K_ * hw4, mDn, n_vod);
+    AIR_XU(0) AIR_XU(1) AIR_XU(2) AIR_XU(3) AIR_XU(4) AIR_XU(5) AIR_XU(6) AIR_XU(7)
+    AIR_XU(8) AIR_XU(9) AIR_XU(10) AIR_XU(11) AIR_XU(12) AIR_XU(13) AIR_XU(14) AIR_XU(15)
+    AIR_DU(0) AIR_DU(1) AIR_DU(2) AIR_DU(3) AIR_DU(4) AIR_DU(5) AIR_DU(6) AIR_DU(7)
+    AIR_DU(8) AIR_DU(9) AIR_DU(10) AIR_DU(11) AIR_DU(12) AIR_DU(13) AIR_DU(14) AIR_DU(15)
+#undef AIR_XU
+#undef AIR_DU
+  };
+
+  // per-lane LDS read offsets (floats within a buffer)
+  const int cil = ch * 32 + l31, col = mt * 32 + l31;
+  const int xb_lane = (cil >> 4) * WG_XWAVE + (cil & 15) * WG_XP + 2 * half + 3;
+  const int db_lane = WG_XF + col * WG_DP + 2 * half;
+
+  f32x16 acc[16];
+  f32x2 d[8], g[2];      // raw: patch rows (cols 0-1, 2-3), dy tile rows
+  f32x2 V[8], Q[4], Sd[4];  // operands: V[2i], V[2i+1]; Gd row i = Q[i].x, Sd[i].x, Sd[i].y, Q[i].y
+  f32x2 tl[4], th2[4];
+
+  auto ld = [&](const float* __restrict__ bufp, int ks) {
+    const float* __restrict__ px = bufp + xb_lane + 4 * ks;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d[2 * r][0] = px[r * WG_XC];
+      d[2 * r][1] = px[r * WG_XC + 1];
+      d[2 * r + 1][0] = px[r * WG_XC + 2];
+      d[2 * r + 1][1] = px[r * WG_XC + 3];
+    }
+    const float* __restrict__ pd = bufp + db_lane + 4 * ks;
+    g[0] = *reinterpret_cast<const f32x2*>(pd);
+    g[1] = *reinterpret_cast<const f32x2*>(pd + 32);
+  };
+  auto transform = [&]() {
+    tl[0] = pk_sub(d[0], d[4]); th2[0] = pk_sub(d[1], d[5]);
+    tl[1] = pk_add(d[2], d[4]); th2[1] = pk_add(d[3], d[5]);
+    tl[2] = pk_sub(d[4], d[2]); th2[2] = pk_sub(d[5], d[3]);
+    tl[3] = pk_sub(d[2], d[6]); th2[3] = pk_sub(d[3], d[7]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      V[2 * i] = pk_col01(tl[i], th2[i]);
+      V[2 * i + 1] = pk_col23(tl[i], th2[i]);
+    }
+    // G' g G'^T without its 1/2 factors (they are applied in the output transform)
+    Q[0] = g[0];
+    Q[1] = pk_add(g[0], g[1]);
+    Q[2] = pk_sub(g[0], g[1]);
+    Q[3] = g[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Sd[i] = pk_sumdiff(Q[i]);
+  };
+  auto opA = [&](int i, int j) -> float {
+    return j == 0 ? Q[i][0] : (j == 1 ? Sd[i][0] : (j == 2 ? Sd[i][1] : Q[i][1]));
+  };
+  // zero the cells (columns W, W+1 of the 4 patch rows of this lane's channel) that a chunk
+  // straddling the right image edge filled with the next row's pixels
+  auto fix_edge = [&](float* bufp, int ecol) {
+    float* px = bufp + (cil >> 4) * WG_XWAVE + (cil & 15) * WG_XP + ecol;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      px[r * WG_XC] = 0.0f;
+      if (ecol + 1 < WG_XC) px[r * WG_XC + 1] = 0.0f;
+    }
+  };
+
+  if (s0 < s1) {
+    // prologue: stage s0 whole, wait, fix, first operands
+    set_stage(s0, n_vox, n_vod, n_xs, n_ds, n_edge);
+    mXn = mX0; mDn = mD0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) dma_unit(u);
+    edge_col = n_edge;
+    dma_wait();
+    __syncthreads();
+  }
+  auto stage_body = [&](auto first_tag, int s, int cur) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    float* bcur = lds + cur * WG_BUF;
+    if (edge_col >= 0) fix_edge(bcur, edge_col);
+    const bool more = s + 1 < s1;
+    if (more) {
+      set_stage(s + 1, n_vox, n_vod, n_xs, n_ds, n_edge);
+      const unsigned nb = (unsigned)(cur ^ 1) * (WG_BUF * 4u);
+      mXn = __builtin_amdgcn_readfirstlane(mX0 + nb);
+      mDn = __builtin_amdgcn_readfirstlane(mD0 + nb);
+    }
+    ld(bcur, 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      transform();
+      if (ks < 7) ld(bcur, ks + 1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        // the next stage's 32 DMAs: one per second MFMA slot of the first four k-steps
+        if (ks < 4 && (j & 1) == 0 && more) dma_unit(ks * 8 + j / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FIRST && ks == 0)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(j >> 2, j & 3), V[j >> 1][j & 1],
+                                                       (f32x16){0}, 0, 0, 0);
+        else
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(j >> 2, j & 3), V[j >> 1][j & 1],
+                                                       acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    edge_col = n_edge;
+    dma_wait();
+    __syncthreads();
+  };
+  if (s0 < s1) {
+    stage_body(std::true_type{}, s0, 0);
+    int cur = 1;
+    for (int s = s0 + 1; s < s1; ++s, cur ^= 1) stage_body(std::false_type{}, s, cur);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = (f32x16){0};
+  }
+
+  // Output transform R = A'^T (s s^T .* M) A', s = (1, 1/2, 1/2, 1), A'^T = [[1,1,1,0],[0,1,-1,0],
+  // [0,1,1,-1]], on whole accumulators; partial[split][tap][co][ci]: lanes = consecutive ci.
+  float* __restrict__ out = a.partial + (size_t)split * 9 * a.Cout * a.Cin;
+  const int ci = cib * 64 + ch * 32 + l31;
+#pragma unroll
+  for (int ra = 0; ra < 3; ++ra) {
+    f32x16 T[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ra == 0) T[j] = acc[j] + 0.5f * (acc[4 + j] + acc[8 + j]);
+      if (ra == 1) T[j] = 0.5f * (acc[4 + j] - acc[8 + j]);
+      if (ra == 2) T[j] = 0.5f * (acc[4 + j] + acc[8 + j]) - acc[12 + j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rb = 0; rb < 3; ++rb) {
+      f32x16 R;
+      if (rb == 0) R = T[0] + 0.5f * (T[1] + T[2]);
+      if (rb == 1) R = 0.5f * (T[1] - T[2]);
+      if (rb == 2) R = 0.5f * (T[1] + T[2]) - T[3];
+      const int tap = ra * 3 + rb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = cob * 64 + mt * 32 + i;
+        out[((size_t)tap * a.Cout + co) * a.Cin + ci] = R[r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 int grid_for(size_t n) {
   size_t g = (n + 255) / 256;
   if (g > 4096) g = 4096;
@@ -580,6 +839,43 @@ bool air_wino_ok(int B, int Kc, int H, int W, int M) {
 
 size_t air_wino_packed_elems(int M, int Kc) {
   return (size_t)((M + WBM - 1) / WBM * WBM) * Kc * 16;
+}
+
+bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout) {
+  static const int off = getenv("AIR_NO_WINOGRAD") ? atoi(getenv("AIR_NO_WINOGRAD")) : 0;
+  if (off & 2) return false;
+  if (Cin % 64 != 0 || Cout % 64 != 0 || W < 2) return false;
+  const double ein = (double)B * Cin * H * W, eout = (double)B * Cout * H * W;
+  return ein * 4.0 < 2147483648.0 && eout * 4.0 < 2147483648.0;
+}
+
+int air_wino_wgrad_nsplit(int B, int Cin, int H, int W, int Cout) {
+  const int nseg = B * ((H + 1) / 2) * (((W + 1) / 2 + WG_SEG - 1) / WG_SEG);
+  int n = 256 / ((Cin / 64) * (Cout / 64));
+  if (n < 1) n = 1;
+  if (n > nseg) n = nseg;
+  return n;
+}
+
+int air_wino_wgrad_partials(const float* x, const float* dy, float* partial, int B, int Cin, int H,
+                            int W, int Cout, double flops, hipStream_t st) {
+  WinoWgArgs a;
+  a.x = x; a.dy = dy; a.partial = partial;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
+  a.TH = (H + 1) / 2;
+  a.NTS = ((W + 1) / 2 + WG_SEG - 1) / WG_SEG;
+  a.nseg = B * a.TH * a.NTS;
+  a.ncob = Cout / 64; a.ncib = Cin / 64;
+  a.nsplit = air_wino_wgrad_nsplit(B, Cin, H, W, Cout);
+  const size_t ldsb = 2 * WG_BUF * sizeof(float);
+  static const bool attr_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess;
+  if (!attr_ok) return AIR_ELAUNCH;
+  AirProfScope ps(AIR_K_CONV_WINO_WG, flops, st);
+  hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.ncob * a.ncib * a.nsplit), dim3(256), ldsb, st, a);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
 }
 
 int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,

@@ -245,6 +245,9 @@ WINO = [
     (2, 8, 7, 3, 128),
     (40, 16, 18, 150, 64),
     (60, 32, 9, 75, 128),
+    (5, 64, 18, 750, 64),     # wgrad: 24 stages per tile row, right edge inside a lane chunk
+    (7, 128, 9, 375, 64),     # odd W: columns W and W+1 are both seen by the last tile
+    (3, 64, 4, 33, 128),
 ]
 
 
@@ -269,3 +272,8 @@ def test_conv2d_winograd(ops, cfg):
     acc = synth_feat((B, Cin, H, W), 15)
     got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda())
     close(got, xd.grad + acc.double(), rtol=1e-5, name="winograd dgrad + accumulate")
+    # weight gradient: Winograd F(3x3,2x2) when both channel counts are multiples of 64
+    wd = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wd, None, 1, 1).backward(dy.double())
+    got = ops.conv2d_wgrad(x.cuda(), dy.cuda(), tuple(w.shape), 1, 1)
+    close(got, wd.grad, rtol=1e-5, name="winograd wgrad")
