@@ -911,6 +911,7 @@ int air_wino_conv(const float* x, const float* w, float* y, const float* residua
     return ok;
   }();
   if (!attr_ok) return AIR_ELAUNCH;
+  AirProfScope ps(AIR_K_CONV_WINO, flops, st);
   if (a.trace != nullptr) {
     if (trows == 2)
       hipLaunchKernelGGL((wino_conv_kernel<2, true>), dim3(nblk), dim3(256), lds2, st, a);

@@ -69,7 +69,7 @@ def roofline_leg(trainer, batches):
             rows.append({"kernel": lib.air_prof_kernel_name(kid).decode(), "launches": n.value,
                          "total_ms": ms.value, "work": work.value})
     lib.air_prof_enable(0)
-    convs = [r for r in rows if r["kernel"].startswith("conv")]
+    convs = [r for r in rows if r["kernel"].startswith(("conv", "wino"))]
     dom = max(convs, key=lambda r: r["total_ms"])
     achieved = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
     all_flops = sum(r["work"] for r in convs)
@@ -77,6 +77,11 @@ def roofline_leg(trainer, batches):
     out = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
            "traffic": None,
+           # "achieved" counts ALGORITHMIC FLOPs (2 * MACs of the direct convolution, SURVEY.md
+           # 8d).  The Winograd kernels issue 36/16 = 2.25x fewer MFMA FLOPs than that (plus
+           # tile padding), so their algorithmic rate may exceed the MFMA peak; the FLOPs they
+           # actually issue to the matrix pipe are reported beside it.
+           "mfma_issued": (round(achieved / 2.25, 2) if dom["kernel"].startswith("wino") else round(achieved, 2)),
            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches_per_step": dom["launches"] // 2,
            "all_conv_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                 "ms_per_step": round(all_ms / 2, 3)}}
