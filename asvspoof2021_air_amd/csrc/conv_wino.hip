@@ -29,6 +29,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr int WCK = 4;                  // input channels per K chunk (= 2 k-steps)
 constexpr int WBM = 64;                 // output channels per workgroup
@@ -121,21 +122,14 @@ struct ItemPos {
   int cot;
   GroupPos g[2];
 };
+// Groups are numbered DOWN the image first (tile row fastest): the two groups of a work item and
+// the items a workgroup walks next are vertical neighbours, which share 2 of their 4 input rows
+// while those are still in L1/L2 (numbered along the row, FETCH_SIZE showed 3x the input bytes).
 __device__ __forceinline__ void group_init(GroupPos& g, int idx, const WinoArgs& a) {
-  g.twg = idx % a.TWG;
-  const int r = idx / a.TWG;
-  g.thg = r % a.THG;
-  g.b = r / a.THG;  // == B for the padding group behind an odd group count
-}
-__device__ __forceinline__ void group_adv2(GroupPos& g, const WinoArgs& a) {
-  g.twg += 2;
-  while (g.twg >= a.TWG) {
-    g.twg -= a.TWG;
-    if (++g.thg == a.THG) {
-      g.thg = 0;
-      ++g.b;
-    }
-  }
+  g.thg = idx % a.THG;
+  const int r = idx / a.THG;
+  g.twg = r % a.TWG;
+  g.b = r / a.TWG;  // == B for the padding group behind an odd group count
 }
 __device__ __forceinline__ void item_init(ItemPos& it, int item, const WinoArgs& a) {
   it.cot = item % a.ncot;
@@ -143,14 +137,6 @@ __device__ __forceinline__ void item_init(ItemPos& it, int item, const WinoArgs&
   group_init(it.g[0], 2 * pg, a);
   group_init(it.g[1], 2 * pg + 1, a);
 }
-__device__ __forceinline__ void item_next(ItemPos& it, const WinoArgs& a) {
-  if (++it.cot == a.ncot) {
-    it.cot = 0;
-    group_adv2(it.g[0], a);
-    group_adv2(it.g[1], a);
-  }
-}
-
 // ---- inline-asm building blocks -------------------------------------------------------
 // A wave's VALU / LDS / DMA instructions do NOT run under its (or a sibling wave's) f32 MFMAs on
 // this part: tools/ubench/mfma_rot.hip measures 64 + 8 + 4 n cycles per MFMA with n VALU
@@ -432,8 +418,15 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
             v0 += r0; v1 += r1;
           }
           float* __restrict__ yp = yb + orow;
-          yp[0] = v0;
-          if (w1) yp[1] = v1;
+          if (w1) {  // both columns in one 8-byte store (4-byte aligned is enough for global memory):
+                     // as two dword stores the halves of each 128-byte line reached HBM separately
+            f32x2a4 v;
+            v[0] = v0;
+            v[1] = v1;
+            *reinterpret_cast<f32x2a4*>(yp) = v;
+          } else {
+            yp[0] = v0;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
