@@ -403,29 +403,40 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
         if (j == 3) yb2 -= sj;
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (valid && (half_row == 0 || h1)) {
+      // Stores.  The common case is branch-free per row: the channel test is wave-uniform
+      // (Cout % 32 == 0), an even W makes every valid lane own both columns, so one exec region
+      // (valid lanes) holds 16 x [8-byte residual load] + [8-byte store].
+      if (co0 + 32 <= a.Cout && valid && (half_row == 0 || h1)) {
         const size_t hoff = half_row ? (size_t)a.W : 0;
+        if ((a.W & 1) == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int iu = (r & 3) + 8 * (r >> 2);  // + 4 * half = D row = channel within the 32
-          if (co0 + iu + 4 * half >= a.Cout) continue;
-          const size_t orow = (size_t)__builtin_amdgcn_readfirstlane(iu * HWi) + hoff;
-          float v0 = ya[r], v1 = yb2[r];
-          if (rb != nullptr) {
-            const float* __restrict__ rp = rb + orow;
-            const float r0 = rp[0];
-            const float r1 = w1 ? rp[1] : 0.0f;
-            v0 += r0; v1 += r1;
-          }
-          float* __restrict__ yp = yb + orow;
-          if (w1) {  // both columns in one 8-byte store (4-byte aligned is enough for global memory):
-                     // as two dword stores the halves of each 128-byte line reached HBM separately
+          for (int r = 0; r < 16; ++r) {
+            const size_t orow =
+                (size_t)__builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * HWi) + hoff;
             f32x2a4 v;
-            v[0] = v0;
-            v[1] = v1;
-            *reinterpret_cast<f32x2a4*>(yp) = v;
-          } else {
+            v[0] = ya[r];
+            v[1] = yb2[r];
+            if (rb != nullptr) {
+              const f32x2a4 rv = *reinterpret_cast<const f32x2a4*>(rb + orow);
+              v[0] += rv[0];
+              v[1] += rv[1];
+            }
+            *reinterpret_cast<f32x2a4*>(yb + orow) = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const size_t orow =
+                (size_t)__builtin_amdgcn_readfirstlane(((r & 3) + 8 * (r >> 2)) * HWi) + hoff;
+            float v0 = ya[r], v1 = yb2[r];
+            if (rb != nullptr) {
+              const float* __restrict__ rp = rb + orow;
+              v0 += rp[0];
+              if (w1) v1 += rp[1];
+            }
+            float* __restrict__ yp = yb + orow;
             yp[0] = v0;
+            if (w1) yp[1] = v1;
           }
         }
       }
@@ -823,7 +834,7 @@ extern "C" void air_dbg_wino_trace(long long* p) { g_wino_trace = p; }
 bool air_wino_ok(int B, int Kc, int H, int W, int M) {
   static const int off = getenv("AIR_NO_WINOGRAD") ? atoi(getenv("AIR_NO_WINOGRAD")) : 0;
   if (off) return false;
-  if (M < 32 || Kc < WCK || Kc % WCK != 0) return false;
+  if (M < 32 || M % 32 != 0 || Kc < WCK || Kc % WCK != 0) return false;
   // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
   const double ein = (double)B * Kc * H * W;
   return ein * 4.0 + 8192.0 < 2147483648.0 && (double)air_wino_packed_elems(M, Kc) * 4.0 < 4294967296.0 &&
