@@ -268,19 +268,38 @@ def _c1d(x, cout, K, dil, pad, y=None):
     return d, workspace(n, x.device), n
 
 
-def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None):
-    """y = relu?(conv1d(x, w) + bias + bias_bc[b]); x / out may be channel-slice views."""
+def _c1d_bf16(d, device, which):
+    """Workspace for the bf16 pointwise kernels, or None when the layer is not theirs
+    (K > 1 or channel counts off the 128/32 grid): the caller then runs the fp32 kernels."""
+    lib = _hip.lib()
+    if d.K != 1 or not lib.air_conv1d_bf16_supported(ctypes.byref(d), ci(which)):
+        return None, 0
+    n = lib.air_conv1d_bf16_ws_bytes(ctypes.byref(d))
+    return workspace(n, device), n
+
+
+def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None, bf16=False):
+    """y = relu?(conv1d(x, w) + bias + bias_bc[b]); x / out may be channel-slice views.
+    bf16: pointwise layers run on the bf16 matrix cores (operands rounded, fp32 accumulate)."""
     Cout, Cin, K = w.shape
     B, _, T = x.shape
     y = out if out is not None else torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
     d, ws, n = _c1d(x, Cout, K, dil, pad, y)
+    if bf16:
+        wsb, nb = _c1d_bf16(d, x.device, 0)
+        if wsb is not None:
+            _hip.check(_hip.lib().air_conv1d_fwd_bf16(
+                ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
+                dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
+                dptr(wsb, torch.uint8), csz(nb), stream()), "air_conv1d_fwd_bf16")
+            return y
     _hip.check(_hip.lib().air_conv1d_fwd(ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
                                          dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
                                          dptr(ws, torch.uint8), csz(n), stream()), "air_conv1d_fwd")
     return y
 
 
-def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None):
+def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False):
     """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out)."""
     Cout, Cin, K = w.shape
     B, _, T = dy.shape
@@ -288,21 +307,35 @@ def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None):
     xp, xb = vptr(dx)
     yp, yb = vptr(dy)
     d = AirConv1d(B, Cin, T, Cout, K, dil, pad, xb, yb)
+    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
+    if bf16:
+        wsb, nb = _c1d_bf16(d, dy.device, 1)
+        if wsb is not None:
+            _hip.check(_hip.lib().air_conv1d_dgrad_bf16(ctypes.byref(d), yp, dptr(w), xp, acc,
+                                                        dptr(wsb, torch.uint8), csz(nb), stream()),
+                       "air_conv1d_dgrad_bf16")
+            return dx
     n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
     ws = workspace(n, dy.device)
-    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
     _hip.check(_hip.lib().air_conv1d_dgrad(ctypes.byref(d), yp, dptr(w), xp, acc, dptr(ws, torch.uint8),
                                            csz(n), stream()), "air_conv1d_dgrad")
     return dx
 
 
-def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None):
+def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None, bf16=False):
     Cout, Cin, K = w_shape
     B, _, T = x.shape
     dw = out if out is not None else torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
     xp, xb = vptr(x)
     yp, yb = vptr(dy)
     d = AirConv1d(B, Cin, T, Cout, K, dil, pad, xb, yb)
+    if bf16:
+        wsb, nb = _c1d_bf16(d, x.device, 2)
+        if wsb is not None:
+            _hip.check(_hip.lib().air_conv1d_wgrad_bf16(ctypes.byref(d), xp, yp, dptr(dw),
+                                                        dptr(wsb, torch.uint8), csz(nb), stream()),
+                       "air_conv1d_wgrad_bf16")
+            return dw
     n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
     ws = workspace(n, x.device)
     _hip.check(_hip.lib().air_conv1d_wgrad(ctypes.byref(d), xp, yp, dptr(dw), dptr(ws, torch.uint8),

@@ -126,6 +126,23 @@ int air_conv1d_dgrad(const AirConv1d* p, const float* dy, const float* w, float*
 int air_conv1d_wgrad(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
                      size_t ws_bytes, air_stream_t stream);
 
+/* bf16-compute variants of the pointwise (K = 1) layers (BASELINE.json configs[2], "ECAPA-TDNN-512
+ * bf16 train"): ecapa_tdnn.py:39,55,118,140,143.  Same tensors (fp32 in HBM), same epilogues;
+ * both operands are rounded to bf16 (nearest even) as they are staged, products accumulate in
+ * fp32 on v_mfma_f32_32x32x16_bf16 - the arithmetic of torch.autocast(bfloat16) for nn.Conv1d.
+ * air_conv1d_bf16_supported(p, pass): pass 0 forward (Cout % 128 == 0, Cin % 32 == 0),
+ * 1 dgrad (Cin % 128 == 0, Cout % 32 == 0), 2 wgrad (Cout % 128 == 0, Cin % 128 == 0); 1 = yes.
+ * Other layers (K = 3 dilated, K = 5) stay on the fp32 entry points above. */
+int air_conv1d_bf16_supported(const AirConv1d* p, int pass);
+size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p);
+int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias,
+                        const float* bias_bc, int relu, float* y, void* ws, size_t ws_bytes,
+                        air_stream_t stream);
+int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx,
+                          const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
+                          size_t ws_bytes, air_stream_t stream);
+
 /* ------------------------------------------------------- batchnorm/relu --
  * nn.BatchNorm2d/1d (+ F.relu) as used at resnet.py:55-67,132,142 and
  * ecapa_tdnn.py.  x is (B, C, S) with S = H*W (or T).
