@@ -12,7 +12,11 @@ Layout choices that remove the reference's copies:
   * the (B,4608,T) context tensor (ecapa_tdnn.py:178) is never built: the tiled mean/std
     part of ``attention.0`` is constant over T, so it is applied as a per-utterance bias
     W[:,1536:] @ [mean; std] in the conv epilogue (same arithmetic, re-associated).
-fp32 throughout in this round.
+``compute_dtype``: "fp32" (the reference's arithmetic) or "bf16" (BASELINE.json configs[2]):
+the pointwise layers that hold 97 % of the FLOPs (Bottle2neck conv1/conv3, layer4, attention.0's
+layer4 part, attention.3) run forward, dgrad and wgrad on the bf16 matrix cores with fp32
+accumulation (csrc/conv1d_bf16.hip); tensors in HBM, BatchNorm, pooling and the dilated K=3
+convs stay fp32.  Set it with ``model.set_compute_dtype("bf16")``.
 """
 import math
 
@@ -131,6 +135,13 @@ class Res2Net2(nn.Module):
         self.bn7 = nn.BatchNorm1d(nOut)
         self.C = C
         self._arena = None
+        self.compute_dtype = "fp32"
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+        self.compute_dtype = dtype
+        return self
 
     # ------------------------------------------------------------------ plumbing
     def arena(self):
@@ -160,7 +171,8 @@ class Res2Net2(nn.Module):
         B, C, T = inp.shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         det = lambda p: p.detach()
-        r1 = ops.conv1d_fwd(inp, det(blk.conv1.weight), det(blk.conv1.bias), relu=True)
+        bf = self.compute_dtype == "bf16"
+        r1 = ops.conv1d_fwd(inp, det(blk.conv1.weight), det(blk.conv1.bias), relu=True, bf16=bf)
         st1 = _bn(r1, blk.bn1, training)
         o1 = ops.bn_apply(r1, st1[2], st1[3])
         cat = torch.empty_like(o1)
@@ -181,7 +193,7 @@ class Res2Net2(nn.Module):
             r_list.append(r_i)
             st_list.append(st_i)
         ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
-        r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True)
+        r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True, bf16=bf)
         st3 = _bn(r3, blk.bn3, training)
         o3 = ops.bn_apply(r3, st3[2], st3[3])
         se = blk.se.se
@@ -199,6 +211,7 @@ class Res2Net2(nn.Module):
     def _forward_impl(self, x, save):
         training = self.training
         det = lambda p: p.detach()
+        bf = self.compute_dtype == "bf16"
         B, _, T = x.shape
         C = self.C
         r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
@@ -211,7 +224,7 @@ class Res2Net2(nn.Module):
             out = cat123[:, k * C:(k + 1) * C]
             blocks.append(self._block_fwd(blk, inp, out, training, save))
             inp = out
-        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True)  # :172-173
+        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf)  # :172-173
         mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178)
         ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
         a0, a3 = self.attention[0], self.attention[3]
@@ -221,10 +234,10 @@ class Res2Net2(nn.Module):
         w_c = ops.add_strided(torch.empty((128, 1, 3072), device=x.device),
                               w0[:, 1536:].unsqueeze(1)).view(128, 3072)
         ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std]
-        a1 = ops.conv1d_fwd(x4, w_x, det(a0.bias), bias_bc=ctxb, relu=True)  # attention.0 + ReLU
+        a1 = ops.conv1d_fwd(x4, w_x, det(a0.bias), bias_bc=ctxb, relu=True, bf16=bf)  # attention.0 + ReLU
         stA = _bn(a1, self.attention[2], training)
         a1n = ops.bn_apply(a1, stA[2], stA[3])
-        wts = ops.conv1d_fwd(a1n, det(a3.weight), det(a3.bias))  # logits -> softmax weights below
+        wts = ops.conv1d_fwd(a1n, det(a3.weight), det(a3.bias), bf16=bf)  # logits -> softmax weights below
         pooled = ops.asp_fwd(x4, wts)  # :184-187 (mu | sg)
         st5 = _bn(pooled.view(B, -1, 1), self.bn5, training)
         p5 = ops.bn_apply(pooled.view(B, -1, 1), st5[2], st5[3]).view(B, -1)
@@ -249,6 +262,7 @@ class Res2Net2(nn.Module):
         """dout: gradient w.r.t. the block output (dense (B,C,T)).  Returns d(inp) dense."""
         blk = S["blk"]
         det = lambda p: p.detach()
+        bf = self.compute_dtype == "bf16"
         B, C, T = S["o3"].shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         se = blk.se.se
@@ -269,8 +283,8 @@ class Res2Net2(nn.Module):
         dc3, _, _ = ops.bn_bwd(S["r3"], do3, st3[0], st3[1], det(blk.bn3.weight), det(blk.bn3.bias),
                                relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"))
         ops.channel_sum(dc3, out=gv("conv3.bias"))
-        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"))
-        dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight))
+        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf)
+        dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight), bf16=bf)
         do1 = torch.empty_like(dcat)
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
         din_next = None
@@ -290,8 +304,8 @@ class Res2Net2(nn.Module):
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),
                                relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"))
         ops.channel_sum(dc1, out=gv("conv1.bias"))
-        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"))
-        dinp = ops.conv1d_dgrad(dc1, det(blk.conv1.weight))
+        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf)
+        dinp = ops.conv1d_dgrad(dc1, det(blk.conv1.weight), bf16=bf)
         ops.add_strided(dinp, dinp, dout)  # residual branch (ecapa_tdnn.py:93)
         return dinp
 
@@ -299,6 +313,7 @@ class Res2Net2(nn.Module):
         arena = self.arena()
         G = arena.grad_views()
         det = lambda p: p.detach()
+        bf = self.compute_dtype == "bf16"
         B, _, T = S["x"].shape
         C = self.C
         tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")
@@ -328,17 +343,17 @@ class Res2Net2(nn.Module):
         ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False)  # wts -> dlogits
         a0, a3 = self.attention[0], self.attention[3]
         ops.channel_sum(wts, out=G["attention.3.bias"])
-        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"])
-        da1n = ops.conv1d_dgrad(wts, det(a3.weight))
+        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf)
+        da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
         stA = S["stA"]
         da1, _, _ = ops.bn_bwd(S["a1"], da1n, stA[0], stA[1], det(self.attention[2].weight),
                                det(self.attention[2].bias), relu_in=True, dx=da1n,
                                dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"])
         ops.channel_sum(da1, out=G["attention.0.bias"])
         gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
-        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1))
+        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf)
         ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
-        ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4)
+        ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4, bf16=bf)
         dctxb = ops.row_sum(da1)  # (B,128)
         dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb, True, need_db=False)
         ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
@@ -347,8 +362,8 @@ class Res2Net2(nn.Module):
         ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True)
         ops.relu_mask_(dx4, x4)  # ReLU after layer4 (:173)
         ops.channel_sum(dx4, out=G["layer4.bias"])
-        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"])
-        dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight))
+        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf)
+        dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None
         for k in (2, 1, 0):
             dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)

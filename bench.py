@@ -32,6 +32,7 @@ BATCH = 64          # per-GPU batch (the reference's --batch_size, main_train.py
 LENGTH = 64000      # 4 s @ 16 kHz
 FEAT_LEN = 750      # reference default --feat_len (main_train.py:43), padding='repeat'
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0
 
 
@@ -69,13 +70,15 @@ def roofline_leg(trainer, batches):
             rows.append({"kernel": lib.air_prof_kernel_name(kid).decode(), "launches": n.value,
                          "total_ms": ms.value, "work": work.value})
     lib.air_prof_enable(0)
-    convs = [r for r in rows if r["kernel"].startswith(("conv", "wino"))]
+    convs = [r for r in rows if r["kernel"].startswith(("conv", "wino", "c1b"))]
     dom = max(convs, key=lambda r: r["total_ms"])
     achieved = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
     all_flops = sum(r["work"] for r in convs)
     all_ms = sum(r["total_ms"] for r in convs)
+    # the bf16 pointwise kernels (ECAPA, --dtype bf16) are priced against the bf16 MFMA peak
+    peak = PEAK_BF16_MFMA_TFLOPS if dom["kernel"].startswith("c1b") else PEAK_F32_MFMA_TFLOPS
     out = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
-           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+           "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            "traffic": None,
            # "achieved" counts ALGORITHMIC FLOPs (2 * MACs of the direct convolution, SURVEY.md
            # 8d).  The Winograd kernels issue 36/16 = 2.25x fewer MFMA FLOPs than that (plus
@@ -142,7 +145,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="resnet", choices=["resnet", "ecapa"],
                     help="resnet = the headline config (BASELINE configs[1]); ecapa = ECAPA-TDNN-512 "
-                         "fp32 (informational: BASELINE configs[2] asks for bf16, not built yet)")
+                         "(BASELINE configs[2], see --dtype)")
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16"],
+                    help="ecapa only: bf16 = BASELINE configs[2] (pointwise convs on the bf16 matrix cores, "
+                         "fp32 accumulate; default for --model ecapa), fp32 = the reference's arithmetic")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 resnet / 128 ecapa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -168,6 +174,7 @@ def main():
     else:
         from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
         model = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+        model.set_compute_dtype(args.dtype or "bf16")
         BATCH = args.batch or 128
     trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
                       feat_len=FEAT_LEN, device=device, ecapa=(args.model == "ecapa"))
@@ -217,8 +224,13 @@ def main():
         }
         if args.model == "ecapa":
             line["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
-            line["config"]["workload"] = ("informational: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax fp32 train "
-                                          "step, T=401 repeat-padded to 750 (BASELINE configs[2] is the bf16 variant)")
+            dt = model.compute_dtype
+            line["dtype"] = "bf16" if dt == "bf16" else "f32"
+            line["config"]["workload"] = (
+                "BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, T=401 repeat-padded to "
+                "750, " + ("bf16 compute (pointwise convs = 97 % of FLOPs on v_mfma_f32_32x32x16_bf16, fp32 "
+                           "accumulate; tensors, BatchNorm and K=3 convs fp32)" if dt == "bf16" else
+                           "fp32 compute (the reference's arithmetic; configs[2] itself is the bf16 variant)"))
         if not args.no_roofline:
             line["roofline"] = roofline_leg(trainer, batches)
         if world == 1 and not args.no_cpu_baseline and args.model == "resnet":

@@ -10,6 +10,14 @@ Follows ecapa_tdnn.py:
 
 Ordering is conv -> ReLU -> BN throughout.  Parameter names
 are the reference's ``state_dict`` keys.
+
+``bf16=True`` restates BASELINE.json configs[2] ("ECAPA-TDNN-512 bf16 train"; the reference
+itself is fp32 only): the pointwise layers that hold the FLOPs - Bottle2neck conv1/conv3
+(:39,:55), layer4 (:118), attention.0's layer4 part and attention.3 (:140,:143) - compute like
+torch.autocast(bfloat16): both operands of the forward, dgrad and wgrad contractions are rounded
+to bf16 (nearest even), products accumulate in fp32; everything else (dilated K=3 convs, conv1,
+SE, BatchNorm, pooling, biases) stays fp32.  The bf16 oracle is pinned against the reference
+through the fp32 goldens at bf16 tolerance (tests/test_oracle_golden.py).
 """
 from collections import OrderedDict
 
@@ -77,8 +85,28 @@ def _bn(x, p, prefix, training, updates):
     return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
 
 
-def _conv(x, p, prefix, dilation=1, padding=0):
-    return F.conv1d(x, p[prefix + ".weight"], p[prefix + ".bias"], 1, padding, dilation)
+class _Bf16Pointwise(torch.autograd.Function):
+    """K = 1 Conv1d with bf16-rounded operands in all three contractions, fp32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        rnd = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        xb, wb = rnd(x), rnd(w)
+        ctx.save_for_backward(xb, wb)
+        return F.conv1d(xb, wb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16).to(dy.dtype)
+        return F.conv_transpose1d(dyb, wb), torch.einsum("bot,bit->oi", dyb, xb).unsqueeze(2)
+
+
+def _conv(x, p, prefix, dilation=1, padding=0, bf16=False):
+    w = p[prefix + ".weight"]
+    if bf16 and w.shape[2] == 1:
+        return _Bf16Pointwise.apply(x, w) + p[prefix + ".bias"][None, :, None]
+    return F.conv1d(x, w, p[prefix + ".bias"], 1, padding, dilation)
 
 
 def se_module(x, p, prefix, training, updates):
@@ -90,9 +118,9 @@ def se_module(x, p, prefix, training, updates):
     return x * s
 
 
-def bottle2neck(x, p, prefix, dilation, scale, training, updates):
+def bottle2neck(x, p, prefix, dilation, scale, training, updates, bf16=False):
     """ecapa_tdnn.py:64-95."""
-    out = _bn(F.relu(_conv(x, p, prefix + ".conv1")), p, prefix + ".bn1", training, updates)
+    out = _bn(F.relu(_conv(x, p, prefix + ".conv1", bf16=bf16)), p, prefix + ".bn1", training, updates)
     width = out.shape[1] // scale
     spx = torch.split(out, width, 1)
     outs = []
@@ -104,12 +132,13 @@ def bottle2neck(x, p, prefix, dilation, scale, training, updates):
         outs.append(sp)
     outs.append(spx[scale - 1])
     out = torch.cat(outs, 1)
-    out = _bn(F.relu(_conv(out, p, prefix + ".conv3")), p, prefix + ".bn3", training, updates)
+    out = _bn(F.relu(_conv(out, p, prefix + ".conv3", bf16=bf16)), p, prefix + ".bn3", training, updates)
     out = se_module(out, p, prefix + ".se", training, updates)
     return out + x
 
 
-def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context=True, out_bn=True):
+def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context=True, out_bn=True,
+                  bf16=False):
     """Res2Net2.forward (ecapa_tdnn.py:152-198), encoder_type 'ECA', summed=False.
     x: (B, n_mels, T).  Returns (feat (B,256), out (B,nOut))."""
     def tap(name, t):
@@ -118,10 +147,10 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
         return t
 
     x = _bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates)  # :159-161
-    x1 = tap("x1", bottle2neck(x, p, "layer1", 2, scale, training, updates))
-    x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates))
-    x3 = tap("x3", bottle2neck(x2, p, "layer3", 4, scale, training, updates))
-    x = F.relu(_conv(torch.cat((x1, x2, x3), 1), p, "layer4"))  # :172-173
+    x1 = tap("x1", bottle2neck(x, p, "layer1", 2, scale, training, updates, bf16))
+    x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates, bf16))
+    x3 = tap("x3", bottle2neck(x2, p, "layer3", 4, scale, training, updates, bf16))
+    x = F.relu(_conv(torch.cat((x1, x2, x3), 1), p, "layer4", bf16=bf16))  # :172-173
     tap("layer4", x)
     t = x.shape[-1]
     if context:  # :177-178
@@ -129,8 +158,16 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
                         torch.sqrt(x.var(2, keepdim=True).clamp(min=1e-4)).repeat(1, 1, t)), 1)
     else:
         gx = x
-    a = _bn(F.relu(_conv(gx, p, "attention.0")), p, "attention.2", training, updates)
-    w = torch.softmax(_conv(a, p, "attention.3"), dim=2)  # :139-145
+    if bf16 and context:
+        # the time-constant mean/std rows of gx enter attention.0 as a per-utterance fp32 term;
+        # only the layer4 part is a (B, 1536, T) contraction and runs in bf16
+        w0, c = p["attention.0.weight"], x.shape[1]
+        a0 = (_Bf16Pointwise.apply(x, w0[:, :c]) + F.conv1d(gx[:, c:, :1], w0[:, c:])
+              + p["attention.0.bias"][None, :, None])
+    else:
+        a0 = _conv(gx, p, "attention.0", bf16=bf16)
+    a = _bn(F.relu(a0), p, "attention.2", training, updates)
+    w = torch.softmax(_conv(a, p, "attention.3", bf16=bf16), dim=2)  # :139-145
     tap("w", w)
     mu = torch.sum(x * w, dim=2)  # :184
     sg = torch.sqrt((torch.sum((x ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4))  # :185

@@ -38,9 +38,10 @@ class OracleTrainer:
     """Functional train loop over a parameter dict (CPU)."""
 
     def __init__(self, model, params, center, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
-                 weight_loss=1.0):
+                 weight_loss=1.0, bf16=False):
         assert model in ("resnet", "ecapa")
         self.model = model
+        self.bf16 = bf16  # ECAPA only: BASELINE configs[2] arithmetic (oracle/ecapa.py)
         self.params = {k: v.clone() for k, v in params.items()}
         self.center = center.clone()
         self.lr = lr
@@ -57,7 +58,8 @@ class OracleTrainer:
     def forward(self, x, training=True, noise=None, updates=None, taps=None):
         if self.model == "resnet":
             return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps)
-        return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps)
+        return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps,
+                                          bf16=self.bf16)
 
     def loss_and_grads(self, x, labels, noise=None):
         names = self.trainable()
