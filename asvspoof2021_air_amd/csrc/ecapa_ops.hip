@@ -33,20 +33,37 @@ __global__ __launch_bounds__(NT) void add_strided_kernel(float* __restrict__ out
     po[i] = pb ? pa[i] + pb[i] : pa[i];
 }
 
-// out[c] = sum_{b,s} x[b][c][s]   (bias gradients); grid = C
+// out[c] = sum_{b,s} x[b][c][s]   (bias gradients).  grid (C, nsplit): a channel's utterances are
+// split over nsplit workgroups so narrow layers (the 64-channel Res2 groups) still fill the chip;
+// the fp64 partials are folded in a fixed order by channel_sum_final_kernel (deterministic).
 __global__ __launch_bounds__(NT) void channel_sum_kernel(const float* __restrict__ x, int B, int S,
-                                                         size_t bstride, float* __restrict__ out) {
+                                                         size_t bstride, int b_per_split,
+                                                         float* __restrict__ out,
+                                                         double* __restrict__ partial) {
   __shared__ double sh[NT / 64];
   const int c = blockIdx.x;
+  const int b_lo = blockIdx.y * b_per_split, b_hi = min(B, b_lo + b_per_split);
   double d = 0.0;
-  for (int b = 0; b < B; ++b) {
+  for (int b = b_lo; b < b_hi; ++b) {
     const float* __restrict__ p = x + (size_t)b * bstride + (size_t)c * S;
     float s = 0.0f;
     for (int i = threadIdx.x; i < S; i += NT) s += p[i];
     d += (double)s;
   }
   d = block_sum_d(d, sh);
-  if (threadIdx.x == 0) out[c] = (float)d;
+  if (threadIdx.x == 0) {
+    if (gridDim.y == 1) out[c] = (float)d;
+    else partial[(size_t)c * gridDim.y + blockIdx.y] = d;
+  }
+}
+
+__global__ __launch_bounds__(NT) void channel_sum_final_kernel(const double* __restrict__ partial, int C,
+                                                               int nsplit, float* __restrict__ out) {
+  const int c = blockIdx.x * NT + threadIdx.x;
+  if (c >= C) return;
+  double d = 0.0;
+  for (int k = 0; k < nsplit; ++k) d += partial[(size_t)c * nsplit + k];
+  out[c] = (float)d;
 }
 
 // per (b,c) row over T: mean and std = sqrt(clamp(unbiased var, 1e-4)) (ecapa_tdnn.py:178);
@@ -254,12 +271,35 @@ int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bst
   return AIR_OK;
 }
 
-int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out,
-                    air_stream_t stream) {
+static int channel_sum_split(int B, int C, int* b_per_split) {
+  int want = 2048 / C;
+  if (want < 1) want = 1;
+  if (want > B) want = B;
+  *b_per_split = (B + want - 1) / want;
+  return (B + *b_per_split - 1) / *b_per_split;
+}
+
+size_t air_channel_sum_ws_bytes(int B, int C) {
+  if (B <= 0 || C <= 0) return 0;
+  int per;
+  return (size_t)channel_sum_split(B, C, &per) * C * sizeof(double) + 256;
+}
+
+int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out, void* ws,
+                    size_t ws_bytes, air_stream_t stream) {
   if (!x || !out || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(NT), 0, air_stream(stream), x, B, S,
-                     bstride ? bstride : (size_t)C * S, out);
+  int per;
+  const int nsplit = channel_sum_split(B, C, &per);
+  if (nsplit > 1 && (!ws || ws_bytes < air_channel_sum_ws_bytes(B, C))) return AIR_EWORKSPACE;
+  double* partial = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(NT), 0, air_stream(stream), x, B, S,
+                     bstride ? bstride : (size_t)C * S, per, out, partial);
   AIR_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, air_stream(stream),
+                       partial, C, nsplit, out);
+    AIR_CHECK_LAUNCH();
+  }
   return AIR_OK;
 }
 

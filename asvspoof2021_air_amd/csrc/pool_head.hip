@@ -170,26 +170,41 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   }
 }
 
-// y[m][n] = sum_k x[m][k] w[n][k] + b[n]; one workgroup per row m, one wave per
-// output n at a time with lanes striding k (coalesced weight rows).
+// y[m][n] = sum_k x[m][k] w[n][k] + b[n].  grid (ceil(N/4), ceil(M/8)): one wave per output n
+// for 8 rows m at once, lanes striding k (coalesced weight rows, each read once per 8 rows instead
+// of once per row: the SE / fc6 layers of ECAPA at batch 128 were re-streaming W 128 times).
+// Per (m, n) the summation order is the same as a lane-strided dot + butterfly.
+constexpr int LIN_MB = 8;
 __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int K,
+                                                        const float* __restrict__ bias, int M, int K,
                                                         int N, int relu, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-  const int m = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += NT) xs[k] = x[(size_t)m * K + k];
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = wave; n < N; n += NT / 64) {
-    const float* __restrict__ wr = w + (size_t)n * K;
-    float s = 0.0f;
-    for (int k = lane; k < K; k += 64) s = fmaf(xs[k], wr[k], s);
-    s = air_wave_sum(s);
-    if (lane == 0) {
-      const float v = s + (bias ? bias[n] : 0.0f);
-      y[(size_t)m * N + n] = relu ? fmaxf(v, 0.0f) : v;
+  const int n = blockIdx.x * (NT / 64) + wave;
+  const int m0 = blockIdx.y * LIN_MB;
+  if (n >= N) return;
+  const float* __restrict__ wr = w + (size_t)n * K;
+  float s[LIN_MB];
+#pragma unroll
+  for (int i = 0; i < LIN_MB; ++i) s[i] = 0.0f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = wr[k];
+#pragma unroll
+    for (int i = 0; i < LIN_MB; ++i) {
+      const int m = min(m0 + i, M - 1);
+      s[i] = fmaf(x[(size_t)m * K + k], wv, s[i]);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < LIN_MB; ++i) s[i] = air_wave_sum(s[i]);
+  if (lane == 0) {
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < LIN_MB; ++i)
+      if (m0 + i < M) {
+        const float v = s[i] + bv;
+        y[(size_t)(m0 + i) * N + n] = relu ? fmaxf(v, 0.0f) : v;
+      }
   }
 }
 
@@ -335,9 +350,8 @@ int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w
 static int linear_fwd_impl(const float* x, const float* w, const float* b, int M, int K, int N,
                            int relu, float* y, air_stream_t stream) {
   if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return AIR_EINVAL;
-  if ((size_t)K * sizeof(float) > 64 * 1024) return AIR_EUNSUPPORTED;
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(M), dim3(NT), (size_t)K * sizeof(float),
-                     air_stream(stream), x, w, b, K, N, relu, y);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((N + NT / 64 - 1) / (NT / 64), (M + LIN_MB - 1) / LIN_MB), dim3(NT), 0,
+                     air_stream(stream), x, w, b, M, K, N, relu, y);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

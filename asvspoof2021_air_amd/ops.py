@@ -359,8 +359,10 @@ def channel_sum(x, out=None):
     xp, xb = vptr(x)
     if out is None:
         out = torch.empty(C, device=x.device, dtype=torch.float32)
-    _hip.check(_hip.lib().air_channel_sum(xp, ci(B), ci(C), ci(T), csz(xb), dptr(out), stream()),
-               "air_channel_sum")
+    n = _hip.lib().air_channel_sum_ws_bytes(ci(B), ci(C))
+    ws = workspace(n, x.device)
+    _hip.check(_hip.lib().air_channel_sum(xp, ci(B), ci(C), ci(T), csz(xb), dptr(out), dptr(ws, torch.uint8),
+                                          csz(n), stream()), "air_channel_sum")
     return out
 
 

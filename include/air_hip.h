@@ -214,9 +214,10 @@ int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K
  * (torch.split / torch.cat / "sp + spx[i]" of ecapa_tdnn.py:71-83). */
 int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
                     const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream);
-/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradients. */
-int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out,
-                    air_stream_t stream);
+/* out[c] = sum_{b,s} x[b][c][s]: conv bias gradients (fp64 partials, fixed order). */
+size_t air_channel_sum_ws_bytes(int B, int C);
+int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out, void* ws,
+                    size_t ws_bytes, air_stream_t stream);
 /* mean_T and sqrt(clamp(var_T unbiased, clamp_min)) per (b,c) row: SE squeeze
  * (ecapa_tdnn.py:19) and the context statistics (:178).  std may be NULL. */
 int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_or_null,
