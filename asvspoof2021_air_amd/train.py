@@ -27,7 +27,7 @@ def adjust_learning_rate(lr0, optimizer, epoch_num, lr_decay=0.5, interval=30):
 class Trainer:
     def __init__(self, model, enc_dim=256, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, r_real=0.9,
                  r_fake=0.2, alpha=20.0, weight_loss=1.0, feat_len=750, device="cuda", ecapa=False,
-                 loss_module=None):
+                 loss_module=None, augment=None):
         self.device = torch.device(device)
         self.model = model.to(self.device)
         self.loss = (loss_module if loss_module is not None else
@@ -41,6 +41,9 @@ class Trainer:
         self.feat_len = feat_len
         self.ecapa = ecapa
         self.world = air_dist.world_size()
+        # optional augment.ChannelAugment: on-the-fly IR convolution of the TRAINING batches ahead
+        # of the LFCC kernel (BASELINE configs[4]; replaces channel_simulation/*.py's offline pass)
+        self.augment = augment
 
     def set_epoch(self, epoch_num, lr_decay=0.5, interval=30):
         adjust_learning_rate(self.lr0, self.feat_optimizer, epoch_num, lr_decay, interval)
@@ -68,6 +71,8 @@ class Trainer:
         return loss.detach(), neg_scores
 
     def step(self, pcm, labels, start=None):
+        if self.augment is not None:
+            pcm = self.augment(pcm)
         return self.step_features(self.features(pcm, start), labels)
 
     @torch.no_grad()

@@ -150,6 +150,9 @@ def main():
                     help="ecapa only: bf16 = BASELINE configs[2] (pointwise convs on the bf16 matrix cores, "
                          "fp32 accumulate; default for --model ecapa), fp32 = the reference's arithmetic")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 resnet / 128 ecapa)")
+    ap.add_argument("--augment", action="store_true",
+                    help="on-the-fly IR-convolution channel augmentation of every utterance in the HIP front-end "
+                         "(BASELINE configs[4]; 30 synthetic 1024-tap IRs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -178,6 +181,9 @@ def main():
         BATCH = args.batch or 128
     trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
                       feat_len=FEAT_LEN, device=device, ecapa=(args.model == "ecapa"))
+    if args.augment:
+        from asvspoof2021_air_amd.augment import ChannelAugment
+        trainer.augment = ChannelAugment(p=1.0, seed=688 + rank, device=device)
     if world > 1:  # same initial weights everywhere
         arena = model.arena()
         td.broadcast(arena.flat, src=0)
@@ -231,6 +237,8 @@ def main():
                 "750, " + ("bf16 compute (pointwise convs = 97 % of FLOPs on v_mfma_f32_32x32x16_bf16, fp32 "
                            "accumulate; tensors, BatchNorm and K=3 convs fp32)" if dt == "bf16" else
                            "fp32 compute (the reference's arithmetic; configs[2] itself is the bf16 variant)"))
+        if args.augment:
+            line["config"]["workload"] += "; + on-the-fly IR convolution (1024 taps) of every utterance ahead of LFCC"
         if not args.no_roofline:
             line["roofline"] = roofline_leg(trainer, batches)
         if world == 1 and not args.no_cpu_baseline and args.model == "resnet":

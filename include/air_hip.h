@@ -103,6 +103,18 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
                      const float* in_scale, const float* in_shift, int relu,
                      void* ws, size_t ws_bytes, air_stream_t stream);
 
+/* ------------------------------------------------- channel augmentation --
+ * On-the-fly IR convolution ahead of the LFCC kernel (BASELINE.json configs[4]).  Replaces the
+ * OFFLINE augmentation of channel_simulation/simulated_device.py:16-61 and
+ * simulated_device_channel.py:6-56, which shell out to the un-vendored idiap/acoustic-simulator
+ * tool (PARITY UNPINNED: spec = oracle/channel.py, checked against scipy.signal.fftconvolve).
+ * y[b] = (x[b] * irs[ir_idx[b]])[:L]; ir_idx[b] < 0 copies the utterance unchanged; ir_idx NULL
+ * uses IR 0 for all.  normalize != 0 rescales each augmented utterance to its input peak
+ * (max|y| = max|x|).  irs is (n_ir, H) fp32, rows zero-padded to H taps.  x and y must not alias. */
+size_t air_ir_convolve_ws_bytes(int B);
+int air_ir_convolve(const float* x, int B, int L, const float* irs, int n_ir, int H, const int* ir_idx,
+                    int normalize, float* y, void* ws, size_t ws_bytes, air_stream_t stream);
+
 /* --------------------------------------------------------------- conv1d --
  * nn.Conv1d (stride 1) as used by ecapa_tdnn.py:39,46,55,111,118,140,143, with the
  * conv -> ReLU -> BN ordering of ecapa_tdnn.py:67-69 supported by bias / ReLU epilogues.
