@@ -103,6 +103,26 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
                      const float* in_scale, const float* in_shift, int relu,
                      void* ws, size_t ws_bytes, air_stream_t stream);
 
+/* ------------------------------------------- adversarial channel head ----
+ * model.ChannelClassifier (model.py:976-1023: GRL -> Linear -> Dropout(0.3) -> ReLU -> Linear ->
+ * ReLU) and nn.CrossEntropyLoss (main_train.py:251) of the --ADV_AUG branch
+ * (main_train.py:377-403, :420-453).  The two Linear layers use air_linear_fwd / air_linear_bwd. */
+/* keep[i] = (u_i >= p) / (1 - p), u from Philox4x32-10(seed, offset + i/4): nn.Dropout's scaled mask. */
+int air_dropout_mask(float* keep, size_t n, float p, uint64_t seed, uint64_t offset, air_stream_t stream);
+/* y = relu(x * keep); keep NULL = eval mode. */
+int air_mask_relu_fwd(const float* x, const float* keep, size_t n, float* y, air_stream_t stream);
+/* dx = alpha * dy * keep * (y > 0). */
+int air_mask_relu_bwd(const float* dy, const float* y, const float* keep, size_t n, float alpha, float* dx,
+                      air_stream_t stream);
+/* x *= alpha (gradient reversal: alpha = -lambda, model.py:990-995). */
+int air_scale(float* x, size_t n, float alpha, air_stream_t stream);
+/* probs = softmax(logits (B,C)); loss = mean_b -log probs[b][labels[b]]; *correct = #(argmax == label). */
+int air_softmax_ce_fwd(const float* logits, const long long* labels, int B, int C, float* probs, float* loss,
+                       int* correct_or_null, air_stream_t stream);
+/* dlogits = g * (probs - onehot(labels)) / B, g = *gscale_or_null (device scalar) or 1. */
+int air_softmax_ce_bwd(const float* probs, const long long* labels, int B, int C, const float* gscale_or_null,
+                       float* dlogits, air_stream_t stream);
+
 /* ------------------------------------------------- channel augmentation --
  * On-the-fly IR convolution ahead of the LFCC kernel (BASELINE.json configs[4]).  Replaces the
  * OFFLINE augmentation of channel_simulation/simulated_device.py:16-61 and
