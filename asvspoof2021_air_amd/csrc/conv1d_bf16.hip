@@ -77,102 +77,106 @@ struct C1bFwd {
   int B, M, K, T, relu, tiles_m, tiles_t, total, per_xcd;
 };
 
-struct Frags {
-  bf16x8 a[2], b[2];
-};
-
+// One K = 32 stage of a wave's (32 TM) x (32 TN) quadrant from the staged LDS tiles.
+template <int TM, int TN>
 __device__ __forceinline__ void mma_stage(const unsigned short* __restrict__ sa, const unsigned short* __restrict__ sb,
-                                          int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+                                          int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
   const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < BK / 16; ++kk) {
-    Frags f;
+    bf16x8 a[TM], b[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      f.a[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 32 + r) * LDK + kk * 16 + kg * 8);
+    for (int i = 0; i < TM; ++i)
+      a[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 32 * TM + i * 32 + r) * LDK + kk * 16 + kg * 8);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      f.b[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + j * 32 + r) * LDK + kk * 16 + kg * 8);
+    for (int j = 0; j < TN; ++j)
+      b[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * 32 * TN + j * 32 + r) * LDK + kk * 16 + kg * 8);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 }
 
 // Y_b[m][t] = sum_k A[m][k] X_b[k][t]  (+ bias[m] + bias_bc[b][m] + acc_b[m][t], optional ReLU)
-__global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDK];
+// Workgroup tile (64 TM) x 128: TM = 4 for the wide layers (every X tile is then re-read by half
+// as many workgroups), TM = 2 otherwise.
+template <int TM>
+__global__ __launch_bounds__(256, 2) void c1b_fwd_kernel(const C1bFwd p) {
+  constexpr int TBM = 64 * TM;
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][TBM * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDK];
   const int work = xcd_chunked(blockIdx.x, p.per_xcd);
   if (work >= p.total) return;
   const int mt = work % p.tiles_m;
   const int rest = work / p.tiles_m;
   const int tt = rest % p.tiles_t, b = rest / p.tiles_t;
-  const int m0 = mt * BM, t0 = tt * BN;
+  const int m0 = mt * TBM, t0 = tt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // staging roles.  A: 128 rows x 4 16-byte chunks; B: 128 t x 4 groups of 8 channels.
-  const int a_row = tid >> 2, a_ch = tid & 3;  // + 64 rows for the second slot
+  // staging roles.  A: TBM rows x 4 16-byte chunks (TM slots of 64 rows); B: 128 t x 4 groups of 8 channels.
+  const int a_row = tid >> 2, a_ch = tid & 3;
   const int b_t = tid & 127, b_kg = tid >> 7;  // + 2 groups for the second slot
   const bool t_ok = t0 + b_t < p.T;
   const unsigned short* __restrict__ ga = p.a + (size_t)(m0 + a_row) * p.K + a_ch * 8;
   const float* __restrict__ gx = p.x + (size_t)b * p.x_bs + (size_t)(b_kg * 8) * p.T + t0 + b_t;
 
-  uint4 ra0, ra1;
+  uint4 ra[TM];
   float rb[2][8];
-  auto fetch = [&](int k0) {
-    ra0 = *reinterpret_cast<const uint4*>(ga + k0);
-    ra1 = *reinterpret_cast<const uint4*>(ga + (size_t)64 * p.K + k0);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rb[s][j] = t_ok ? gx[(size_t)(k0 + s * 16 + j) * p.T] : 0.0f;
-  };
-  auto stash = [&](int buf) {
-    *reinterpret_cast<uint4*>(&sA[buf][a_row * LDK + a_ch * 8]) = ra0;
-    *reinterpret_cast<uint4*>(&sA[buf][(a_row + 64) * LDK + a_ch * 8]) = ra1;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 v;
-      v.x = pack2(rb[s][0], rb[s][1]);
-      v.y = pack2(rb[s][2], rb[s][3]);
-      v.z = pack2(rb[s][4], rb[s][5]);
-      v.w = pack2(rb[s][6], rb[s][7]);
-      *reinterpret_cast<uint4*>(&sB[buf][b_t * LDK + (b_kg + s * 2) * 8]) = v;
-    }
-  };
+#define C1B_FETCH(k0)                                                                                   \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < TM; ++s_)                                                   \
+        ra[s_] = *reinterpret_cast<const uint4*>(ga + (size_t)s_ * 64 * p.K + (k0));                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                \
+            rb[s_][j_] = t_ok ? gx[(size_t)((k0) + s_ * 16 + j_) * p.T] : 0.0f;                        \
+  } while (0)
+#define C1B_STASH(buf)                                                                                  \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int s_ = 0; s_ < TM; ++s_)                                                   \
+        *reinterpret_cast<uint4*>(&sA[buf][(a_row + s_ * 64) * LDK + a_ch * 8]) = ra[s_];               \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                  \
+      uint4 v_;                                                                                         \
+      v_.x = pack2(rb[s_][0], rb[s_][1]);                                                               \
+      v_.y = pack2(rb[s_][2], rb[s_][3]);                                                               \
+      v_.z = pack2(rb[s_][4], rb[s_][5]);                                                               \
+      v_.w = pack2(rb[s_][6], rb[s_][7]);                                                               \
+      *reinterpret_cast<uint4*>(&sB[buf][b_t * LDK + (b_kg + s_ * 2) * 8]) = v_;                        \
+    }                                                                                                   \
+  } while (0)
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int nk = p.K / BK;
-  fetch(0);
-  stash(0);
+  C1B_FETCH(0);
+  C1B_STASH(0);
   __syncthreads();
   for (int s = 0; s < nk; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nk) fetch((s + 1) * BK);
-    mma_stage(sA[cur], sB[cur], wm, wn, lane, acc);
-    if (s + 1 < nk) stash(cur ^ 1);
+    if (s + 1 < nk) C1B_FETCH((s + 1) * BK);
+    mma_stage<TM, 2>(sA[cur], sB[cur], wm, wn, lane, acc);
+    if (s + 1 < nk) C1B_STASH(cur ^ 1);
     __syncthreads();
   }
+#undef C1B_FETCH
+#undef C1B_STASH
 
   const int col = lane & 31, half = lane >> 5;
   float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
   const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       float add = 0.0f;
       if (p.bias) add += p.bias[m];
       if (p.bias_bc) add += p.bias_bc[(size_t)b * p.M + m];
@@ -209,52 +213,60 @@ __device__ __forceinline__ void load4(const float* __restrict__ row, int t, int 
   }
 }
 
-// dW[m][n] = sum_{b in split} sum_t dY_b[m][t] X_b[n][t]
+// dW[m][n] = sum_{b in split} sum_t dY_b[m][t] X_b[n][t].  Workgroup tile (64 TM) x (64 TN):
+// 256 x 256 where the layer allows it - every staged fp32 byte then feeds twice the MFMA work of a
+// 128 x 128 tile, which is what bounds this kernel (L2 -> LDS traffic, not HBM and not the MFMA).
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDK];
+  constexpr int TBM = 64 * TM, TBN = 64 * TN;
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][TBM * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][TBN * LDK];
   const int work = xcd_chunked(blockIdx.x, p.per_xcd);
   if (work >= p.total) return;
   const int tiles = p.tiles_m * p.tiles_n;
   const int tile = work % tiles, split = work / tiles;
   const int mt = tile % p.tiles_m, nt = tile / p.tiles_m;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int m0 = mt * TBM, n0 = nt * TBN;
   const int b_lo = split * p.b_per_split;
   const int b_hi = min(p.B, b_lo + p.b_per_split);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const bool vec = p.vec_ok != 0;
 
-  // staging: 128 rows x 8 float4 chunks per operand = 4 slots per thread (rows +32 per slot)
+  // staging: rows x 8 float4 chunks per operand, 32 rows per slot
   const int s_row = tid >> 3, s_c4 = tid & 7;
-  float ra[4][4], rb[4][4];
+  float ra[2 * TM][4], rb[2 * TN][4];
   auto fetch = [&](int b, int t0) {
     const float* __restrict__ gy = p.dy + (size_t)b * p.dy_bs + (size_t)(m0 + s_row) * p.T;
     const float* __restrict__ gx = p.x + (size_t)b * p.x_bs + (size_t)(n0 + s_row) * p.T;
     const int t = t0 + s_c4 * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) load4(gy + (size_t)s * 32 * p.T, t, p.T, vec, ra[s]);
+    for (int s = 0; s < 2 * TM; ++s) load4(gy + (size_t)s * 32 * p.T, t, p.T, vec, ra[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) load4(gx + (size_t)s * 32 * p.T, t, p.T, vec, rb[s]);
+    for (int s = 0; s < 2 * TN; ++s) load4(gx + (size_t)s * 32 * p.T, t, p.T, vec, rb[s]);
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 2 * TM; ++s) {
       uint2 v;
       v.x = pack2(ra[s][0], ra[s][1]);
       v.y = pack2(ra[s][2], ra[s][3]);
       *reinterpret_cast<uint2*>(&sA[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
+    }
+#pragma unroll
+    for (int s = 0; s < 2 * TN; ++s) {
+      uint2 v;
       v.x = pack2(rb[s][0], rb[s][1]);
       v.y = pack2(rb[s][2], rb[s][3]);
       *reinterpret_cast<uint2*>(&sB[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
     if (s + 1 < nsteps) { fetch(nb, nt0); advance(); }
-    mma_stage(sA[cur], sB[cur], wm, wn, lane, acc);
+    mma_stage<TM, TN>(sA[cur], sB[cur], wm, wn, lane, acc);
     if (s + 1 < nsteps) stash(cur ^ 1);
     __syncthreads();
   }
@@ -282,12 +294,12 @@ __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
   const int col = lane & 31, half = lane >> 5;
   float* __restrict__ out = p.out + (p.nsplit > 1 ? (size_t)split * p.M * p.N : 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) out[(size_t)m * p.N + n0 + wn * 64 + j * 32 + col] = acc[i][j][r];
+      for (int j = 0; j < TN; ++j) out[(size_t)m * p.N + n0 + wn * 32 * TN + j * 32 + col] = acc[i][j][r];
     }
 }
 
@@ -310,8 +322,12 @@ bool shape_ok(const AirConv1d* p) {
 size_t xbs(const AirConv1d* p) { return p->x_bstride ? p->x_bstride : (size_t)p->Cin * p->T; }
 size_t ybs(const AirConv1d* p) { return p->y_bstride ? p->y_bstride : (size_t)p->Cout * p->T; }
 
+// weight-gradient tile: 256 where the channel count divides, else 128
+int wg_tm(const AirConv1d* p) { return p->Cout % 256 == 0 ? 4 : 2; }
+int wg_tn(const AirConv1d* p) { return p->Cin % 256 == 0 ? 4 : 2; }
+
 int wgrad_nsplit(const AirConv1d* p, int* b_per_split) {
-  const int tiles = (p->Cout / BM) * (p->Cin / BN);
+  const int tiles = (p->Cout / (64 * wg_tm(p))) * (p->Cin / (64 * wg_tn(p)));
   int want = 512 / tiles;
   if (want < 1) want = 1;
   if (want > p->B) want = p->B;
@@ -331,12 +347,17 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.x = x; p.a = a; p.y = y; p.bias = bias; p.bias_bc = bias_bc; p.acc = acc;
   p.x_bs = x_bs; p.y_bs = y_bs;
   p.B = B; p.M = M; p.K = K; p.T = T; p.relu = relu;
-  p.tiles_m = M / BM;
+  // 256-row tiles once the layer is wide enough to still fill the chip with them
+  const int tm = (M % 256 == 0 && M >= 1024) ? 4 : 2;
+  p.tiles_m = M / (64 * tm);
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
   AirProfScope prof(AIR_K_C1B_FWD, flops, st);
-  hipLaunchKernelGGL(c1b_fwd_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  if (tm == 4)
+    hipLaunchKernelGGL(c1b_fwd_kernel<4>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(c1b_fwd_kernel<2>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -395,7 +416,8 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
   a.dy = dy; a.x = x;
   a.dy_bs = ybs(p); a.x_bs = xbs(p);
   a.B = p->B; a.M = p->Cout; a.N = p->Cin; a.T = p->T;
-  a.tiles_m = a.M / BM; a.tiles_n = a.N / BN;
+  const int tm = wg_tm(p), tn = wg_tn(p);
+  a.tiles_m = a.M / (64 * tm); a.tiles_n = a.N / (64 * tn);
   a.nsplit = wgrad_nsplit(p, &a.b_per_split);
   a.out = a.nsplit > 1 ? reinterpret_cast<float*>(ws) : dw;
   a.total = a.tiles_m * a.tiles_n * a.nsplit;
@@ -405,7 +427,11 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
              (reinterpret_cast<size_t>(dy) & 7) == 0;
   {
     AirProfScope prof(AIR_K_C1B_WGRAD, 2.0 * p->B * p->T * (double)p->Cout * p->Cin, st);
-    hipLaunchKernelGGL(c1b_wgrad_kernel, dim3(a.per_xcd * NXCD), dim3(256), 0, st, a);
+    const dim3 grid(a.per_xcd * NXCD), blk(256);
+    if (tm == 4 && tn == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<4, 4>), grid, blk, 0, st, a);
+    else if (tm == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<4, 2>), grid, blk, 0, st, a);
+    else if (tn == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<2, 4>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((c1b_wgrad_kernel<2, 2>), grid, blk, 0, st, a);
     AIR_CHECK_LAUNCH();
   }
   if (a.nsplit > 1) {

@@ -88,6 +88,17 @@ def roofline_leg(trainer, batches):
            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches_per_step": dom["launches"] // 2,
            "all_conv_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                 "ms_per_step": round(all_ms / 2, 3)}}
+    # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command: profiles/r01_k_pmc_traffic.md)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        model_key = "ecapa" if dom["kernel"].startswith("c1b") else "resnet"
+        if BATCH == (128 if model_key == "ecapa" else 64) and FEAT_LEN == 750:  # the measured configuration only
+            out["traffic"] = round(pmc[model_key][dom["kernel"]]["traffic_bytes_per_launch"])
+            out["traffic_source"] = "profiles/r01_k_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)"
+    except (OSError, KeyError, ValueError):
+        pass
     lf = [r for r in rows if r["kernel"] == "lfcc_kernel"]
     if lf:
         gbs = lf[0]["work"] / (lf[0]["total_ms"] * 1e-3) / 1e9
@@ -150,6 +161,9 @@ def main():
                     help="ecapa only: bf16 = BASELINE configs[2] (pointwise convs on the bf16 matrix cores, "
                          "fp32 accumulate; default for --model ecapa), fp32 = the reference's arithmetic")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 resnet / 128 ecapa)")
+    ap.add_argument("--feat-len", type=int, default=750,
+                    help="model frames per utterance: 750 = the reference default (--feat_len, padding='repeat': "
+                         "401 LFCC frames tiled to 750); 401 = the native frame count of 4 s audio")
     ap.add_argument("--augment", action="store_true",
                     help="on-the-fly IR-convolution channel augmentation of every utterance in the HIP front-end "
                          "(BASELINE configs[4]; 30 synthetic 1024-tap IRs)")
@@ -168,7 +182,8 @@ def main():
     device = torch.device("cuda", local)
 
     from asvspoof2021_air_amd.train import Trainer
-    global BATCH
+    global BATCH, FEAT_LEN
+    FEAT_LEN = args.feat_len
     torch.manual_seed(688)
     if args.model == "resnet":
         from asvspoof2021_air_amd.resnet import ResNet
@@ -223,7 +238,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: fused HIP LFCC(320,160,512,20 filters) + ResNet-18 + "
                                    "OC-Softmax(ang_iso) fp32 train step (fwd+bwd+Adam+SGD), 4 s @ 16 kHz PCM in HBM, "
-                                   "T=401 frames repeat-padded to feat_len=750",
+                                   "T=401 frames repeat-padded to feat_len=%d" % FEAT_LEN,
                        "global_batch": world * BATCH, "per_gpu_batch": BATCH, "feat_len": FEAT_LEN,
                        "parallelism": "dp%d" % world},
             "final_loss": round(loss_val, 5),
@@ -234,7 +249,7 @@ def main():
             line["dtype"] = "bf16" if dt == "bf16" else "f32"
             line["config"]["workload"] = (
                 "BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, T=401 repeat-padded to "
-                "750, " + ("bf16 compute (pointwise convs = 97 % of FLOPs on v_mfma_f32_32x32x16_bf16, fp32 "
+                "%d, " % FEAT_LEN + ("bf16 compute (pointwise convs = 97 % of FLOPs on v_mfma_f32_32x32x16_bf16, fp32 "
                            "accumulate; tensors, BatchNorm and K=3 convs fp32)" if dt == "bf16" else
                            "fp32 compute (the reference's arithmetic; configs[2] itself is the bf16 variant)"))
         if args.augment:
