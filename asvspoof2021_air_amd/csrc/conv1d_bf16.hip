@@ -77,106 +77,102 @@ struct C1bFwd {
   int B, M, K, T, relu, tiles_m, tiles_t, total, per_xcd;
 };
 
-// One K = 32 stage of a wave's (32 TM) x (32 TN) quadrant from the staged LDS tiles.
-template <int TM, int TN>
+struct Frags {
+  bf16x8 a[2], b[2];
+};
+
 __device__ __forceinline__ void mma_stage(const unsigned short* __restrict__ sa, const unsigned short* __restrict__ sb,
-                                          int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
+                                          int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
   const int r = lane & 31, kg = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < BK / 16; ++kk) {
-    bf16x8 a[TM], b[TN];
+    Frags f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      a[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 32 * TM + i * 32 + r) * LDK + kk * 16 + kg * 8);
+    for (int i = 0; i < 2; ++i)
+      f.a[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 32 + r) * LDK + kk * 16 + kg * 8);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      b[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * 32 * TN + j * 32 + r) * LDK + kk * 16 + kg * 8);
+    for (int j = 0; j < 2; ++j)
+      f.b[j] = *reinterpret_cast<const bf16x8*>(sb + (wn * 64 + j * 32 + r) * LDK + kk * 16 + kg * 8);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
   }
 }
 
 // Y_b[m][t] = sum_k A[m][k] X_b[k][t]  (+ bias[m] + bias_bc[b][m] + acc_b[m][t], optional ReLU)
-// Workgroup tile (64 TM) x 128: TM = 4 for the wide layers (every X tile is then re-read by half
-// as many workgroups), TM = 2 otherwise.
-template <int TM>
-__global__ __launch_bounds__(256, 2) void c1b_fwd_kernel(const C1bFwd p) {
-  constexpr int TBM = 64 * TM;
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][TBM * LDK];
+__global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDK];
   const int work = xcd_chunked(blockIdx.x, p.per_xcd);
   if (work >= p.total) return;
   const int mt = work % p.tiles_m;
   const int rest = work / p.tiles_m;
   const int tt = rest % p.tiles_t, b = rest / p.tiles_t;
-  const int m0 = mt * TBM, t0 = tt * BN;
+  const int m0 = mt * BM, t0 = tt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // staging roles.  A: TBM rows x 4 16-byte chunks (TM slots of 64 rows); B: 128 t x 4 groups of 8 channels.
-  const int a_row = tid >> 2, a_ch = tid & 3;
+  // staging roles.  A: 128 rows x 4 16-byte chunks; B: 128 t x 4 groups of 8 channels.
+  const int a_row = tid >> 2, a_ch = tid & 3;  // + 64 rows for the second slot
   const int b_t = tid & 127, b_kg = tid >> 7;  // + 2 groups for the second slot
   const bool t_ok = t0 + b_t < p.T;
   const unsigned short* __restrict__ ga = p.a + (size_t)(m0 + a_row) * p.K + a_ch * 8;
   const float* __restrict__ gx = p.x + (size_t)b * p.x_bs + (size_t)(b_kg * 8) * p.T + t0 + b_t;
 
-  uint4 ra[TM];
+  uint4 ra0, ra1;
   float rb[2][8];
-#define C1B_FETCH(k0)                                                                                   \
-  do {                                                                                                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < TM; ++s_)                                                   \
-        ra[s_] = *reinterpret_cast<const uint4*>(ga + (size_t)s_ * 64 * p.K + (k0));                    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                    \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                \
-            rb[s_][j_] = t_ok ? gx[(size_t)((k0) + s_ * 16 + j_) * p.T] : 0.0f;                        \
-  } while (0)
-#define C1B_STASH(buf)                                                                                  \
-  do {                                                                                                  \
-    _Pragma("unroll") for (int s_ = 0; s_ < TM; ++s_)                                                   \
-        *reinterpret_cast<uint4*>(&sA[buf][(a_row + s_ * 64) * LDK + a_ch * 8]) = ra[s_];               \
-    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                  \
-      uint4 v_;                                                                                         \
-      v_.x = pack2(rb[s_][0], rb[s_][1]);                                                               \
-      v_.y = pack2(rb[s_][2], rb[s_][3]);                                                               \
-      v_.z = pack2(rb[s_][4], rb[s_][5]);                                                               \
-      v_.w = pack2(rb[s_][6], rb[s_][7]);                                                               \
-      *reinterpret_cast<uint4*>(&sB[buf][b_t * LDK + (b_kg + s_ * 2) * 8]) = v_;                        \
-    }                                                                                                   \
-  } while (0)
-
-  f32x16 acc[TM][2];
+  auto fetch = [&](int k0) {
+    ra0 = *reinterpret_cast<const uint4*>(ga + k0);
+    ra1 = *reinterpret_cast<const uint4*>(ga + (size_t)64 * p.K + k0);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rb[s][j] = t_ok ? gx[(size_t)(k0 + s * 16 + j) * p.T] : 0.0f;
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<uint4*>(&sA[buf][a_row * LDK + a_ch * 8]) = ra0;
+    *reinterpret_cast<uint4*>(&sA[buf][(a_row + 64) * LDK + a_ch * 8]) = ra1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 v;
+      v.x = pack2(rb[s][0], rb[s][1]);
+      v.y = pack2(rb[s][2], rb[s][3]);
+      v.z = pack2(rb[s][4], rb[s][5]);
+      v.w = pack2(rb[s][6], rb[s][7]);
+      *reinterpret_cast<uint4*>(&sB[buf][b_t * LDK + (b_kg + s * 2) * 8]) = v;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int nk = p.K / BK;
-  C1B_FETCH(0);
-  C1B_STASH(0);
+  fetch(0);
+  stash(0);
   __syncthreads();
   for (int s = 0; s < nk; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nk) C1B_FETCH((s + 1) * BK);
-    mma_stage<TM, 2>(sA[cur], sB[cur], wm, wn, lane, acc);
-    if (s + 1 < nk) C1B_STASH(cur ^ 1);
+    if (s + 1 < nk) fetch((s + 1) * BK);
+    mma_stage(sA[cur], sB[cur], wm, wn, lane, acc);
+    if (s + 1 < nk) stash(cur ^ 1);
     __syncthreads();
   }
-#undef C1B_FETCH
-#undef C1B_STASH
 
   const int col = lane & 31, half = lane >> 5;
   float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
   const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       float add = 0.0f;
       if (p.bias) add += p.bias[m];
       if (p.bias_bc) add += p.bias_bc[(size_t)b * p.M + m];
@@ -213,60 +209,52 @@ __device__ __forceinline__ void load4(const float* __restrict__ row, int t, int 
   }
 }
 
-// dW[m][n] = sum_{b in split} sum_t dY_b[m][t] X_b[n][t].  Workgroup tile (64 TM) x (64 TN):
-// 256 x 256 where the layer allows it - every staged fp32 byte then feeds twice the MFMA work of a
-// 128 x 128 tile, which is what bounds this kernel (L2 -> LDS traffic, not HBM and not the MFMA).
-template <int TM, int TN>
+// dW[m][n] = sum_{b in split} sum_t dY_b[m][t] X_b[n][t]
 __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
-  constexpr int TBM = 64 * TM, TBN = 64 * TN;
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][TBM * LDK];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][TBN * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDK];
   const int work = xcd_chunked(blockIdx.x, p.per_xcd);
   if (work >= p.total) return;
   const int tiles = p.tiles_m * p.tiles_n;
   const int tile = work % tiles, split = work / tiles;
   const int mt = tile % p.tiles_m, nt = tile / p.tiles_m;
-  const int m0 = mt * TBM, n0 = nt * TBN;
+  const int m0 = mt * BM, n0 = nt * BN;
   const int b_lo = split * p.b_per_split;
   const int b_hi = min(p.B, b_lo + p.b_per_split);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const bool vec = p.vec_ok != 0;
 
-  // staging: rows x 8 float4 chunks per operand, 32 rows per slot
+  // staging: 128 rows x 8 float4 chunks per operand = 4 slots per thread (rows +32 per slot)
   const int s_row = tid >> 3, s_c4 = tid & 7;
-  float ra[2 * TM][4], rb[2 * TN][4];
+  float ra[4][4], rb[4][4];
   auto fetch = [&](int b, int t0) {
     const float* __restrict__ gy = p.dy + (size_t)b * p.dy_bs + (size_t)(m0 + s_row) * p.T;
     const float* __restrict__ gx = p.x + (size_t)b * p.x_bs + (size_t)(n0 + s_row) * p.T;
     const int t = t0 + s_c4 * 4;
 #pragma unroll
-    for (int s = 0; s < 2 * TM; ++s) load4(gy + (size_t)s * 32 * p.T, t, p.T, vec, ra[s]);
+    for (int s = 0; s < 4; ++s) load4(gy + (size_t)s * 32 * p.T, t, p.T, vec, ra[s]);
 #pragma unroll
-    for (int s = 0; s < 2 * TN; ++s) load4(gx + (size_t)s * 32 * p.T, t, p.T, vec, rb[s]);
+    for (int s = 0; s < 4; ++s) load4(gx + (size_t)s * 32 * p.T, t, p.T, vec, rb[s]);
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 2 * TM; ++s) {
+    for (int s = 0; s < 4; ++s) {
       uint2 v;
       v.x = pack2(ra[s][0], ra[s][1]);
       v.y = pack2(ra[s][2], ra[s][3]);
       *reinterpret_cast<uint2*>(&sA[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
-    }
-#pragma unroll
-    for (int s = 0; s < 2 * TN; ++s) {
-      uint2 v;
       v.x = pack2(rb[s][0], rb[s][1]);
       v.y = pack2(rb[s][2], rb[s][3]);
       *reinterpret_cast<uint2*>(&sB[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -286,7 +274,7 @@ __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
     if (s + 1 < nsteps) { fetch(nb, nt0); advance(); }
-    mma_stage<TM, TN>(sA[cur], sB[cur], wm, wn, lane, acc);
+    mma_stage(sA[cur], sB[cur], wm, wn, lane, acc);
     if (s + 1 < nsteps) stash(cur ^ 1);
     __syncthreads();
   }
@@ -294,12 +282,12 @@ __global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
   const int col = lane & 31, half = lane >> 5;
   float* __restrict__ out = p.out + (p.nsplit > 1 ? (size_t)split * p.M * p.N : 0);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) out[(size_t)m * p.N + n0 + wn * 32 * TN + j * 32 + col] = acc[i][j][r];
+      for (int j = 0; j < 2; ++j) out[(size_t)m * p.N + n0 + wn * 64 + j * 32 + col] = acc[i][j][r];
     }
 }
 
@@ -316,18 +304,192 @@ __global__ __launch_bounds__(256) void c1b_reduce_kernel(const float* __restrict
   }
 }
 
+
+// ===================================================================================
+// Path 2: bf16-resident operands + LDS-DMA GEMM (the wide layers and every weight gradient).
+//
+// The fused kernels above stage fp32 and convert in flight; that costs VALU + ds_write work per
+// stage and L2 -> LDS traffic at 4 bytes per operand element, which bounds them once K and M are
+// large (layer4: 1536 x 1536, measured 330-440 TF) and for every weight gradient (both operands
+// re-staged by each tile column/row: 130 TF).  Here one HBM-bound pass per operand writes a bf16
+// copy in the layout the MFMA wants - K contiguous, K padded with zeros to a multiple of 64, rows
+// padded to the tile - and ONE GEMM kernel, C[m][n] = sum_k A[m][k] B[n][k], serves all three
+// passes with `global_load_lds_dwordx4`: 16-byte chunks go global -> LDS directly, no staging
+// registers, no conversion, no ds_write.
+//   forward  A = W   [Cout][Cin]        B = X^T_b  [Tp][Cin]    (c1b_cvt_t_kernel)
+//   dgrad    A = W^T [Cin][Cout]        B = dY^T_b [Tp][Cout]
+//   wgrad    A = dY  [Cout][(b, Tp)]    B = X      [Cin][(b, Tp)]   (c1b_cvt_s_kernel), split-K over b
+// LDS tile rows are 128 bytes (64 bf16) with the 16-byte chunk index XOR-ed by (row >> 1) & 7 - the
+// swizzle is applied to the SOURCE address of the DMA (its LDS destination is lane-linear) and again
+// by the reader, so the 16 lanes of a ds_read_b128 cycle cover all 64 banks.
+
+constexpr int GK = 64;         // K per stage
+constexpr int TP_ALIGN = 128;  // padded frame count: multiple of the N tile and of GK
+
+typedef float f32x2a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// X (B, C, T) fp32 (batch stride xbs) -> Xs bf16 [B][C][Tp], zeros for t >= T.  One thread = 8 frames.
+__global__ __launch_bounds__(256) void c1b_cvt_s_kernel(const float* __restrict__ x, size_t xbs, int C, int T, int Tp,
+                                                        size_t total_chunks, int vec_ok,
+                                                        unsigned short* __restrict__ out) {
+  const int cpr = Tp / 8;  // chunks per row
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total_chunks; e += (size_t)gridDim.x * 256) {
+    const size_t row = e / cpr;  // b * C + c
+    const int t = (int)(e - row * cpr) * 8;
+    const size_t b = row / C, c = row - b * C;
+    const float* __restrict__ src = x + b * xbs + c * (size_t)T;
+    float v[8];
+    if (vec_ok && t + 7 < T) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2a8 w = *reinterpret_cast<const f32x2a8*>(src + t + 2 * q);
+        v[2 * q] = w[0];
+        v[2 * q + 1] = w[1];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = t + q < T ? src[t + q] : 0.0f;
+    }
+    uint4 o;
+    o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+    reinterpret_cast<uint4*>(out)[e] = o;
+  }
+}
+
+// X (B, C, T) fp32 -> Xt bf16 [B][Tp][C] (channels contiguous), zeros for t >= T.  A thread reads 16
+// channel rows at ITS frame (coalesced along t) and writes 32 contiguous bytes of the transposed row.
+// grid (Tp / 64, C / 64, B), 256 threads = 64 frames x 4 channel groups of 16.
+__global__ __launch_bounds__(256) void c1b_cvt_t_kernel(const float* __restrict__ x, size_t xbs, int C, int T, int Tp,
+                                                        unsigned short* __restrict__ out) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int c0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+  const size_t b = blockIdx.z;
+  const float* __restrict__ src = x + b * xbs + (size_t)c0 * T + t;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = t < T ? src[(size_t)i * T] : 0.0f;
+  uint4 o0, o1;
+  o0.x = pack2(v[0], v[1]); o0.y = pack2(v[2], v[3]); o0.z = pack2(v[4], v[5]); o0.w = pack2(v[6], v[7]);
+  o1.x = pack2(v[8], v[9]); o1.y = pack2(v[10], v[11]); o1.z = pack2(v[12], v[13]); o1.w = pack2(v[14], v[15]);
+  uint4* dst = reinterpret_cast<uint4*>(out + (b * Tp + t) * (size_t)C + c0);
+  dst[0] = o0;
+  dst[1] = o1;
+}
+
+struct NtGemm {
+  const unsigned short* a;  // A[m][seg][k]: a + m * a_rs + seg * a_ss + k   (+ batch * a_bs)
+  const unsigned short* b;  // B[n][seg][k]
+  float* out;               // out[batch][m][n]: out + batch * o_bs + m * o_rs + n
+  const float* bias;        // [M]
+  const float* bias_bc;     // [batch][M]
+  const float* acc;         // addressed like out
+  size_t a_rs, a_ss, a_bs, b_rs, b_ss, b_bs, o_rs, o_bs;
+  int M, n_valid, kseg, nseg_per_batch, nseg_total, relu, tiles_m, tiles_n, total, per_xcd;
+};
+
+typedef const __attribute__((address_space(1))) void* c1b_gptr;
+typedef __attribute__((address_space(3))) void* c1b_lptr;
+
+__global__ __launch_bounds__(256) void c1b_gemm_kernel(const NtGemm p) {
+  __shared__ __attribute__((aligned(1024))) unsigned short sA[BM * GK];
+  __shared__ __attribute__((aligned(1024))) unsigned short sB[BN * GK];
+  const int work = xcd_chunked(blockIdx.x, p.per_xcd);
+  if (work >= p.total) return;
+  const int mt = work % p.tiles_m;
+  const int rest = work / p.tiles_m;
+  const int nt = rest % p.tiles_n, batch = rest / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int seg_lo = batch * p.nseg_per_batch;
+  const int nseg = min(p.nseg_per_batch, p.nseg_total - seg_lo);
+
+  // DMA roles: wave w issues 4 + 4 instructions per stage; instruction i covers tile rows
+  // (4 w + i) * 8 .. + 7, lane l -> row + (l >> 3), LDS chunk position l & 7
+  const int rsub = lane >> 3, pos = lane & 7;
+  const unsigned short* ga[4];
+  const unsigned short* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + rsub;
+    const int chunk = pos ^ ((row >> 1) & 7);
+    ga[i] = p.a + (size_t)batch * p.a_bs + (size_t)(m0 + row) * p.a_rs + chunk * 8;
+    gb[i] = p.b + (size_t)batch * p.b_bs + (size_t)(n0 + row) * p.b_rs + chunk * 8;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int r = lane & 31, kg = lane >> 5;
+  const int sw = (r >> 1) & 7;  // tile row = 64 wm + 32 i + r: only r enters (row >> 1) & 7
+  for (int seg = 0; seg < nseg; ++seg) {
+    const size_t aoff = (size_t)seg * p.a_ss, boff = (size_t)seg * p.b_ss;
+    for (int k0 = 0; k0 < p.kseg; k0 += GK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((c1b_gptr)(ga[i] + aoff + k0), (c1b_lptr)(sA + (wave * 4 + i) * 8 * GK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((c1b_gptr)(gb[i] + boff + k0), (c1b_lptr)(sB + (wave * 4 + i) * 8 * GK), 16, 0, 0);
+      }
+      __syncthreads();  // drains the DMAs (vmcnt(0)) and publishes the tile
+#pragma unroll
+      for (int kk = 0; kk < GK / 16; ++kk) {
+        const int cpos = ((kk * 2 + kg) ^ sw) * 8;
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 64 + i * 32 + r) * GK + cpos);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();  // everyone is done reading before the next stage overwrites the tile
+    }
+  }
+
+  const int col = lane & 31, half = lane >> 5;
+  float* __restrict__ ob = p.out + (size_t)batch * p.o_bs;
+  const float* __restrict__ ab = p.acc ? p.acc + (size_t)batch * p.o_bs : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      float add = 0.0f;
+      if (p.bias) add += p.bias[m];
+      if (p.bias_bc) add += p.bias_bc[(size_t)batch * p.M + m];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + col;
+        if (n < p.n_valid) {
+          float v = acc[i][j][q] + add;
+          if (ab) v += ab[(size_t)m * p.o_rs + n];
+          if (p.relu) v = fmaxf(v, 0.0f);
+          ob[(size_t)m * p.o_rs + n] = v;
+        }
+      }
+    }
+  }
+}
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
 bool shape_ok(const AirConv1d* p) {
   return p && p->B > 0 && p->T > 0 && p->Cin > 0 && p->Cout > 0 && p->K == 1 && p->pad == 0;
 }
 size_t xbs(const AirConv1d* p) { return p->x_bstride ? p->x_bstride : (size_t)p->Cin * p->T; }
 size_t ybs(const AirConv1d* p) { return p->y_bstride ? p->y_bstride : (size_t)p->Cout * p->T; }
 
-// weight-gradient tile: 256 where the channel count divides, else 128
-int wg_tm(const AirConv1d* p) { return p->Cout % 256 == 0 ? 4 : 2; }
-int wg_tn(const AirConv1d* p) { return p->Cin % 256 == 0 ? 4 : 2; }
-
 int wgrad_nsplit(const AirConv1d* p, int* b_per_split) {
-  const int tiles = (p->Cout / (64 * wg_tm(p))) * (p->Cin / (64 * wg_tn(p)));
+  const int tiles = (p->Cout / BM) * (p->Cin / BN);
   int want = 512 / tiles;
   if (want < 1) want = 1;
   if (want > p->B) want = p->B;
@@ -347,19 +509,55 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.x = x; p.a = a; p.y = y; p.bias = bias; p.bias_bc = bias_bc; p.acc = acc;
   p.x_bs = x_bs; p.y_bs = y_bs;
   p.B = B; p.M = M; p.K = K; p.T = T; p.relu = relu;
-  // 256-row tiles once the layer is wide enough to still fill the chip with them
-  const int tm = (M % 256 == 0 && M >= 1024) ? 4 : 2;
-  p.tiles_m = M / (64 * tm);
+  p.tiles_m = M / BM;
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
   AirProfScope prof(AIR_K_C1B_FWD, flops, st);
-  if (tm == 4)
-    hipLaunchKernelGGL(c1b_fwd_kernel<4>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL(c1b_fwd_kernel<2>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(c1b_fwd_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+
+int launch_gemm(NtGemm& g, int nbatch, int n_padded, int kid, double flops, hipStream_t st) {
+  g.tiles_m = g.M / BM;
+  g.tiles_n = n_padded / BN;
+  g.total = g.tiles_m * g.tiles_n * nbatch;
+  g.per_xcd = (g.total + NXCD - 1) / NXCD;
+  AirProfScope prof(kid, flops, st);
+  hipLaunchKernelGGL(c1b_gemm_kernel, dim3(g.per_xcd * NXCD), dim3(256), 0, st, g);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+// the wide layers take the bf16-resident path for forward/dgrad as well (measured: layer4 faster,
+// the 512-channel layers not: their fused kernel is already HBM-bound on the fp32 tensors)
+bool wide(int M, int K) { return (size_t)M * K >= (size_t)1024 * 1024 && K % GK == 0; }
+
+size_t gemm_fwd_ws(int B, int M, int K, int T) {
+  return align256((size_t)M * K * 2) + align256((size_t)B * round_up(T, TP_ALIGN) * K * 2);
+}
+
+// forward / dgrad through the GEMM: y_b[m][t] = sum_k A[m][k] x_b[k][t]
+int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, float* y, size_t y_bs, const float* bias,
+                 const float* bias_bc, const float* acc, int relu, int B, int M, int K, int T, void* ws, double flops,
+                 hipStream_t st) {
+  unsigned short* a = reinterpret_cast<unsigned short*>(ws);
+  unsigned short* xt = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + align256((size_t)M * K * 2));
+  const int Tp = round_up(T, TP_ALIGN);
+  const size_t n2 = (size_t)M * K / 2;
+  hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, transpose);
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(c1b_cvt_t_kernel, dim3(Tp / 64, K / 64, B), dim3(256), 0, st, x, x_bs, K, T, Tp, xt);
+  AIR_CHECK_LAUNCH();
+  NtGemm g;
+  g.a = a; g.b = xt; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = acc;
+  g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
+  g.b_rs = K; g.b_ss = 0; g.b_bs = (size_t)Tp * K;
+  g.o_rs = T; g.o_bs = y_bs;
+  g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
+  return launch_gemm(g, B, Tp, AIR_K_C1B_FWD, flops, st);
 }
 
 }  // namespace
@@ -379,9 +577,15 @@ int air_conv1d_bf16_supported(const AirConv1d* p, int pass) {
 size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
   if (!shape_ok(p)) return 0;
   size_t n = (size_t)p->Cout * p->Cin * sizeof(unsigned short);  // packed bf16 weights
+  if (wide(p->Cout, p->Cin) || wide(p->Cin, p->Cout)) {
+    const size_t g = gemm_fwd_ws(p->B, p->Cout, p->Cin, p->T);  // symmetric in (Cout, Cin)
+    if (g > n) n = g;
+  }
   if (air_conv1d_bf16_supported(p, 2)) {
     int per;
-    const size_t part = (size_t)wgrad_nsplit(p, &per) * p->Cout * p->Cin * sizeof(float);
+    const int Tp = round_up(p->T, TP_ALIGN);
+    const size_t part = align256((size_t)wgrad_nsplit(p, &per) * p->Cout * p->Cin * sizeof(float)) +
+                        align256((size_t)p->B * Tp * p->Cout * 2) + align256((size_t)p->B * Tp * p->Cin * 2);
     if (part > n) n = part;
   }
   return n + 256;
@@ -392,6 +596,9 @@ int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, cons
   if (!shape_ok(p) || !x || !w || !y) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 0)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
+  if (wide(p->Cout, p->Cin) && p->Cin % 64 == 0)
+    return run_fwd_gemm(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
+                        2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
   return run_fwd(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
                  2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
 }
@@ -402,6 +609,9 @@ int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, f
   if (!air_conv1d_bf16_supported(p, 1)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
   // A = W^T: w is (Cout, Cin) = [k][m]
+  if (wide(p->Cin, p->Cout) && p->Cout % 64 == 0)
+    return run_fwd_gemm(dy, ybs(p), w, 1, dx, xbs(p), nullptr, nullptr, accumulate, 0, p->B, p->Cin, p->Cout, p->T, ws,
+                        2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
   return run_fwd(dy, ybs(p), w, 1, dx, xbs(p), nullptr, nullptr, accumulate, 0, p->B, p->Cin, p->Cout, p->T, ws,
                  2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
 }
@@ -412,32 +622,35 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
   if (!air_conv1d_bf16_supported(p, 2)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
-  C1bWgrad a;
-  a.dy = dy; a.x = x;
-  a.dy_bs = ybs(p); a.x_bs = xbs(p);
-  a.B = p->B; a.M = p->Cout; a.N = p->Cin; a.T = p->T;
-  const int tm = wg_tm(p), tn = wg_tn(p);
-  a.tiles_m = a.M / (64 * tm); a.tiles_n = a.N / (64 * tn);
-  a.nsplit = wgrad_nsplit(p, &a.b_per_split);
-  a.out = a.nsplit > 1 ? reinterpret_cast<float*>(ws) : dw;
-  a.total = a.tiles_m * a.tiles_n * a.nsplit;
-  a.per_xcd = (a.total + NXCD - 1) / NXCD;
-  // 16-byte loads need every row start 8-byte aligned
-  a.vec_ok = p->T % 2 == 0 && a.dy_bs % 2 == 0 && a.x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0 &&
-             (reinterpret_cast<size_t>(dy) & 7) == 0;
-  {
-    AirProfScope prof(AIR_K_C1B_WGRAD, 2.0 * p->B * p->T * (double)p->Cout * p->Cin, st);
-    const dim3 grid(a.per_xcd * NXCD), blk(256);
-    if (tm == 4 && tn == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<4, 4>), grid, blk, 0, st, a);
-    else if (tm == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<4, 2>), grid, blk, 0, st, a);
-    else if (tn == 4) hipLaunchKernelGGL((c1b_wgrad_kernel<2, 4>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((c1b_wgrad_kernel<2, 2>), grid, blk, 0, st, a);
-    AIR_CHECK_LAUNCH();
-  }
-  if (a.nsplit > 1) {
-    const size_t n = (size_t)a.M * a.N;
-    hipLaunchKernelGGL(c1b_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(ws), dw, n, a.nsplit);
+  // bf16 copies of both operands ([row][(b, Tp)], zero-padded frames), then the split-K GEMM
+  const int B = p->B, M = p->Cout, N = p->Cin, T = p->T, Tp = round_up(T, TP_ALIGN);
+  int per;
+  const int nsplit = wgrad_nsplit(p, &per);
+  char* base = reinterpret_cast<char*>(ws);
+  float* partial = reinterpret_cast<float*>(base);
+  unsigned short* dys = reinterpret_cast<unsigned short*>(base + align256((size_t)nsplit * M * N * sizeof(float)));
+  unsigned short* xs = dys + align256((size_t)B * Tp * M * 2) / 2;
+  const int vec_y = T % 2 == 0 && ybs(p) % 2 == 0 && (reinterpret_cast<size_t>(dy) & 7) == 0;
+  const int vec_x = T % 2 == 0 && xbs(p) % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0;
+  const size_t chy = (size_t)B * M * Tp / 8, chx = (size_t)B * N * Tp / 8;
+  hipLaunchKernelGGL(c1b_cvt_s_kernel, dim3((unsigned)((chy + 255) / 256)), dim3(256), 0, st, dy, ybs(p), M, T, Tp, chy,
+                     vec_y, dys);
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(c1b_cvt_s_kernel, dim3((unsigned)((chx + 255) / 256)), dim3(256), 0, st, x, xbs(p), N, T, Tp, chx,
+                     vec_x, xs);
+  AIR_CHECK_LAUNCH();
+  NtGemm g;
+  g.a = dys; g.b = xs; g.out = nsplit > 1 ? partial : dw; g.bias = nullptr; g.bias_bc = nullptr; g.acc = nullptr;
+  g.a_rs = Tp; g.a_ss = (size_t)M * Tp; g.a_bs = (size_t)per * g.a_ss;
+  g.b_rs = Tp; g.b_ss = (size_t)N * Tp; g.b_bs = (size_t)per * g.b_ss;
+  g.o_rs = N; g.o_bs = (size_t)M * N;
+  g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
+  int rc = launch_gemm(g, nsplit, N, AIR_K_C1B_WGRAD, 2.0 * B * T * (double)M * N, st);
+  if (rc != AIR_OK) return rc;
+  if (nsplit > 1) {
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(c1b_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partial, dw, n,
+                       nsplit);
     AIR_CHECK_LAUNCH();
   }
   return AIR_OK;
