@@ -13,14 +13,16 @@
 // for these layers.  oracle/ecapa.py restates exactly this (operands .bfloat16().float(), fp32
 // conv), so parity differs by summation order only.
 //
-// Tiling (both kernels): 256 threads = 4 waves own a 128 x 128 output tile, each wave a
-// 64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers); K advances 32 per stage
-// through a double-buffered LDS pair.  An MFMA lane needs 8 CONSECUTIVE k of one row/column:
-//   * forward/dgrad: k = input channel, but memory is contiguous along t.  The staging thread
-//     reads 8 channel rows at ITS t (each load 256 B coalesced per wave), packs the 8 values and
-//     writes one 16-byte [t][k0..k0+7] LDS row segment: the transpose happens in registers.
-//   * wgrad: k = t, contiguous in memory for both operands: 16-byte loads, pack, 8-byte LDS writes.
-// LDS rows are padded to 80 bytes: the 16 lanes ds_read_b128 serves per cycle hit 64 distinct banks.
+// Two paths (chosen per layer, see `wide()`):
+//  1. FUSED forward/dgrad for the 512-channel layers (HBM-bound on the fp32 tensors, so one pass
+//     that converts in flight wins): 256 threads = 4 waves own a 128 x 128 output tile, each wave a
+//     64 x 64 quadrant = 2 x 2 MFMA tiles (64 accumulator registers); K advances 32 per stage
+//     through a double-buffered LDS pair.  An MFMA lane needs 8 CONSECUTIVE k (= input channels) of
+//     one column, but memory is contiguous along t: the staging thread reads 8 channel rows at ITS t
+//     (each load 256 B coalesced per wave), packs the 8 values and writes one 16-byte
+//     [t][k0..k0+7] LDS row segment - the transpose happens in registers.  LDS rows are padded to
+//     80 bytes: the 16 lanes ds_read_b128 serves per cycle hit 64 distinct banks.
+//  2. bf16-RESIDENT operands + LDS-DMA GEMM for the wide layers and every weight gradient (below).
 // Workgroups are numbered so the tiles sharing an X_b time tile (all Cout tiles) run
 // back-to-back on ONE XCD and re-read it from that XCD's L2.
 #include "air_common.h"
@@ -188,107 +190,6 @@ __global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
       }
     }
   }
-}
-
-struct C1bWgrad {
-  const float* dy;  // (B, M, T)
-  const float* x;   // (B, N, T)
-  float* out;       // nsplit > 1: partial[split][M][N]; else dW[M][N]
-  size_t dy_bs, x_bs;
-  int B, M, N, T, tiles_m, tiles_n, nsplit, b_per_split, total, per_xcd, vec_ok;
-};
-
-// 4 consecutive t of one row, zero beyond T.  vec: the row start is 8-byte aligned.
-__device__ __forceinline__ void load4(const float* __restrict__ row, int t, int T, bool vec, float (&v)[4]) {
-  if (vec && t + 3 < T) {
-    const f32x4a8 q = *reinterpret_cast<const f32x4a8*>(row + t);
-    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = t + e < T ? row[t + e] : 0.0f;
-  }
-}
-
-// dW[m][n] = sum_{b in split} sum_t dY_b[m][t] X_b[n][t]
-__global__ __launch_bounds__(256) void c1b_wgrad_kernel(const C1bWgrad p) {
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDK];
-  const int work = xcd_chunked(blockIdx.x, p.per_xcd);
-  if (work >= p.total) return;
-  const int tiles = p.tiles_m * p.tiles_n;
-  const int tile = work % tiles, split = work / tiles;
-  const int mt = tile % p.tiles_m, nt = tile / p.tiles_m;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int b_lo = split * p.b_per_split;
-  const int b_hi = min(p.B, b_lo + p.b_per_split);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool vec = p.vec_ok != 0;
-
-  // staging: 128 rows x 8 float4 chunks per operand = 4 slots per thread (rows +32 per slot)
-  const int s_row = tid >> 3, s_c4 = tid & 7;
-  float ra[4][4], rb[4][4];
-  auto fetch = [&](int b, int t0) {
-    const float* __restrict__ gy = p.dy + (size_t)b * p.dy_bs + (size_t)(m0 + s_row) * p.T;
-    const float* __restrict__ gx = p.x + (size_t)b * p.x_bs + (size_t)(n0 + s_row) * p.T;
-    const int t = t0 + s_c4 * 4;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) load4(gy + (size_t)s * 32 * p.T, t, p.T, vec, ra[s]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) load4(gx + (size_t)s * 32 * p.T, t, p.T, vec, rb[s]);
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint2 v;
-      v.x = pack2(ra[s][0], ra[s][1]);
-      v.y = pack2(ra[s][2], ra[s][3]);
-      *reinterpret_cast<uint2*>(&sA[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
-      v.x = pack2(rb[s][0], rb[s][1]);
-      v.y = pack2(rb[s][2], rb[s][3]);
-      *reinterpret_cast<uint2*>(&sB[buf][(s_row + s * 32) * LDK + s_c4 * 4]) = v;
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const int steps_per_b = (p.T + BK - 1) / BK;
-  const int nsteps = (b_hi - b_lo) * steps_per_b;
-  int nb = b_lo, nt0 = 0;  // coordinates of the NEXT stage to fetch
-  auto advance = [&]() {
-    nt0 += BK;
-    if (nt0 >= p.T) { nt0 = 0; ++nb; }
-  };
-  if (nsteps > 0) {
-    fetch(nb, nt0);
-    advance();
-    stash(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) { fetch(nb, nt0); advance(); }
-    mma_stage(sA[cur], sB[cur], wm, wn, lane, acc);
-    if (s + 1 < nsteps) stash(cur ^ 1);
-    __syncthreads();
-  }
-
-  const int col = lane & 31, half = lane >> 5;
-  float* __restrict__ out = p.out + (p.nsplit > 1 ? (size_t)split * p.M * p.N : 0);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) out[(size_t)m * p.N + n0 + wn * 64 + j * 32 + col] = acc[i][j][r];
-    }
 }
 
 // dw[e] = sum_s partial[s][e], fixed order (deterministic)
