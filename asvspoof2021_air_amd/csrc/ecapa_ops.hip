@@ -33,6 +33,29 @@ __global__ __launch_bounds__(NT) void add_strided_kernel(float* __restrict__ out
     po[i] = pb ? pa[i] + pb[i] : pa[i];
 }
 
+// Res2 chain step (ecapa_tdnn.py:78-83): v = x * scale[c] + shift[c] (BatchNorm apply of branch i);
+// y1 = v goes straight into its channel slice of the concat tensor, y2 = v + add is the input of
+// branch i + 1 ("sp + spx[i + 1]").  One pass instead of bn_apply + two strided copies.
+__global__ __launch_bounds__(NT) void res2_bn_apply_kernel(const float* __restrict__ x, int C, int S,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           float* __restrict__ y1, size_t y1_bs,
+                                                           const float* __restrict__ add, size_t add_bs,
+                                                           float* __restrict__ y2) {
+  const int plane = blockIdx.x;  // b * C + c
+  const int b = plane / C, c = plane - b * C;
+  const float sc = scale[c], sh = shift[c];
+  const float* __restrict__ p = x + (size_t)plane * S;
+  float* __restrict__ q1 = y1 + (size_t)b * y1_bs + (size_t)c * S;
+  const float* __restrict__ pa = add ? add + (size_t)b * add_bs + (size_t)c * S : nullptr;
+  float* __restrict__ q2 = y2 ? y2 + (size_t)plane * S : nullptr;
+  for (int i = blockIdx.y * NT + threadIdx.x; i < S; i += gridDim.y * NT) {
+    const float v = p[i] * sc + sh;
+    q1[i] = v;
+    if (q2) q2[i] = v + pa[i];
+  }
+}
+
 // out[c] = sum_{b,s} x[b][c][s]   (bias gradients).  grid (C, nsplit): a channel's utterances are
 // split over nsplit workgroups so narrow layers (the 64-channel Res2 groups) still fill the chip;
 // the fp64 partials are folded in a fixed order by channel_sum_final_kernel (deterministic).
@@ -267,6 +290,17 @@ int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bst
   dim3 grid(min((CS + NT - 1) / NT, 1024), B);
   hipLaunchKernelGGL(add_strided_kernel, grid, dim3(NT), 0, air_stream(stream), out, out_bstride,
                      a, a_bstride, b, b_bstride, CS);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_res2_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
+                      size_t y1_bstride, const float* add, size_t add_bstride, float* y2, air_stream_t stream) {
+  if (!x || !scale || !shift || !y1 || B <= 0 || C <= 0 || S <= 0 || ((add == nullptr) != (y2 == nullptr)))
+    return AIR_EINVAL;
+  hipLaunchKernelGGL(res2_bn_apply_kernel, dim3(B * C, (S + NT * 2 - 1) / (NT * 2)), dim3(NT), 0, air_stream(stream),
+                     x, C, S, scale, shift, y1, y1_bstride ? y1_bstride : (size_t)C * S, add,
+                     add_bstride ? add_bstride : (size_t)C * S, y2);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

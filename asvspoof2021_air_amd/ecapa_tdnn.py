@@ -177,21 +177,23 @@ class Res2Net2(nn.Module):
         o1 = ops.bn_apply(r1, st1[2], st1[3])
         cat = torch.empty_like(o1)
         t_list, r_list, st_list = [], [], []
-        sp = None
+        t_i = o1[:, :w]
         for i in range(nums):
-            grp = o1[:, i * w:(i + 1) * w]
-            if i == 0:
-                t_i = grp
-            else:
-                t_i = ops.add_strided(torch.empty((B, w, T), device=inp.device), sp, grp)
             r_i = ops.conv1d_fwd(t_i, det(blk.convs[i].weight), det(blk.convs[i].bias), relu=True,
                                  dil=d, pad=d)
             st_i = _bn(r_i, blk.bns[i], training)
-            sp = ops.bn_apply(r_i, st_i[2], st_i[3])
-            ops.add_strided(cat[:, i * w:(i + 1) * w], sp)
+            # BN-apply, store into the concat slice and form the next branch's input in one pass
+            if i + 1 < nums:
+                t_next = torch.empty((B, w, T), device=inp.device, dtype=torch.float32)
+                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w],
+                                  o1[:, (i + 1) * w:(i + 2) * w], t_next)
+            else:
+                t_next = None
+                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
             t_list.append(t_i)
             r_list.append(r_i)
             st_list.append(st_i)
+            t_i = t_next
         ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
         r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True, bf16=bf)
         st3 = _bn(r3, blk.bn3, training)
@@ -297,8 +299,8 @@ class Res2Net2(nn.Module):
                                     dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i))
             ops.channel_sum(dc_i, out=gv("convs.%d.bias" % i))
             ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
-            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d)
-            ops.add_strided(do1[:, i * w:(i + 1) * w], din)
+            # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
+            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w])
             din_next = din if i > 0 else None
         st1 = S["st1"]
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),

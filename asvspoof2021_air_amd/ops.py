@@ -354,6 +354,16 @@ def add_strided(out, a, b=None):
     return out
 
 
+def res2_bn_apply(x, scale, shift, y1, add=None, y2=None):
+    """y1 (channel-slice view) = x*scale + shift; y2 (dense) = that + add (channel-slice view)."""
+    B, C, T = x.shape
+    y1p, y1b = vptr(y1)
+    ap, ab = vptr(add) if add is not None else (ctypes.c_void_p(0), 0)
+    _hip.check(_hip.lib().air_res2_bn_apply(dptr(x), ci(B), ci(C), ci(T), dptr(scale), dptr(shift), y1p, csz(y1b),
+                                            ap, csz(ab), dptr(y2, allow_none=True), stream()), "air_res2_bn_apply")
+    return y2
+
+
 def channel_sum(x, out=None):
     B, C, T = x.shape
     xp, xb = vptr(x)

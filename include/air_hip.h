@@ -246,6 +246,11 @@ int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K
  * (torch.split / torch.cat / "sp + spx[i]" of ecapa_tdnn.py:71-83). */
 int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
                     const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream);
+/* Res2 chain step (ecapa_tdnn.py:78-83): v = x*scale[c] + shift[c]; y1 = v (a channel slice of the
+ * concat tensor, batch stride y1_bstride); optional y2 = v + add (dense; add is a channel slice with
+ * batch stride add_bstride): the next branch's input "sp + spx[i+1]".  add and y2 both NULL or both set. */
+int air_res2_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
+                      size_t y1_bstride, const float* add, size_t add_bstride, float* y2, air_stream_t stream);
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradients (fp64 partials, fixed order). */
 size_t air_channel_sum_ws_bytes(int B, int C);
 int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out, void* ws,
