@@ -1,0 +1,133 @@
+"""GPU: the hot path at BASELINE.json's FULL sizes (configs[1]: ResNet-18 fp32, batch 64, 4 s @ 16 kHz,
+feat_len 750; configs[2]: ECAPA-TDNN-512, T = 750) - one whole train step against the CPU oracle, plus
+size-independent properties (determinism, gradient linearity in the loss weight, batch independence in
+eval mode).  The oracle needs ~10-30 s of CPU per case at these sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ecapa as o_ecapa
+from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
+from oracle.filler import fill_module_, fill_state, fill_value, synth_feat, synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def _resnet_trainer(feat_len=750):
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    m = ResNet(3, 256, resnet_type="18", nclasses=2)
+    fill_module_(m)
+    m.set_attention_noise(None)
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    return Trainer(m, loss_module=lossm, feat_len=feat_len)
+
+
+def test_resnet_full_size_step_vs_oracle():
+    """BASELINE configs[1] exactly: 64 x 64000 PCM -> LFCC (401 frames) -> repeat-pad 750 -> ResNet-18 ->
+    OC-Softmax -> backward -> Adam + SGD, against the oracle on the same inputs."""
+    B, L, FL = 64, 64000, 750
+    tr = _resnet_trainer(FL)
+    pcm = synth_pcm(B, L, seed=688)
+    g = torch.Generator().manual_seed(1)
+    labels = (torch.rand(B, generator=g) < 0.9).long()
+    labels[0], labels[1] = 0, 1
+    loss, neg = tr.step(pcm.cuda(), labels.cuda())
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in tr.model.named_parameters() if p.grad is not None}
+    feat = torch.from_numpy(o_lfcc.lfcc_forward(pcm.numpy().copy()))
+    assert feat.shape == (B, 401, 60)
+    xin = torch.stack([o_pad.repeat_pad(feat[b:b + 1], FL) for b in range(B)])
+    xo = o_pad.to_model_input(xin).contiguous()
+    otr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
+    lo, no, _, go, _ = otr.step(xo, labels, None)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
+    np.testing.assert_allclose(neg.cpu().numpy(), no.numpy(), atol=2e-4)
+    # Gradients.  At this size (55 M activations per layer) some pre-activations sit within fp32 rounding
+    # of a ReLU threshold, and a flipped unit moves whole gradient elements: the fp32 CPU oracle ITSELF is
+    # up to 5e-2 of max away from its fp64 evaluation on single elements (layer4.1.conv1.weight), and so is
+    # the HIP path.  So: relative L2 per tensor against the fp64 oracle, bounded by what the fp32 oracle
+    # shows against the same fp64 truth (x3) plus 1e-3.
+    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
+    o64 = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
+    _, _, _, g64, _, _ = o64.loss_and_grads(xo.double(), labels, None)
+    worst = ("", 0.0, 0.0)
+    for k, gh in grads.items():
+        ref = g64[k].numpy().ravel()
+        nrm = np.linalg.norm(ref) + 1e-30
+        e_hip = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / nrm
+        e_cpu = np.linalg.norm(go[k].numpy().ravel().astype(np.float64) - ref) / nrm
+        assert e_hip <= 3.0 * e_cpu + 1e-3, (k, e_hip, e_cpu)
+        if e_hip > worst[1]:
+            worst = (k, e_hip, e_cpu)
+    print("worst relative L2 gradient error vs fp64: %s hip %.2e (fp32 CPU oracle: %.2e)" % worst)
+    # the updated weights (Adam, lr 5e-4: every element moves by ~lr in step 1) agree to a fraction of a step
+    w = tr.model.state_dict()["layer4.1.conv2.weight"].cpu().numpy()
+    assert np.abs(w - otr.params["layer4.1.conv2.weight"].numpy()).max() <= 2 * 5e-4 + 1e-6
+
+
+def test_resnet_full_size_properties():
+    B, FL = 64, 750
+    x = synth_feat((B, 1, 60, FL), seed=3).cuda()
+    labels = (torch.arange(B) % 5 != 0).long().cuda()
+    # (a) determinism: two identical steps from identical state give bit-identical gradients
+    gs = []
+    for _ in range(2):
+        tr = _resnet_trainer(FL)
+        tr.model.train()
+        feats, _ = tr.model(x)
+        loss, _ = tr.loss(feats, labels)
+        loss.backward()
+        gs.append(tr.model.arena().grad.clone())
+    assert torch.equal(gs[0], gs[1])
+    # (b) linearity: backward of 2 * loss doubles every gradient (to rounding)
+    tr = _resnet_trainer(FL)
+    tr.model.train()
+    feats, _ = tr.model(x)
+    loss, _ = tr.loss(feats, labels)
+    (2.0 * loss).backward()
+    g2 = tr.model.arena().grad
+    scale = float(gs[0].abs().max())
+    assert float((g2 - 2.0 * gs[0]).abs().max()) <= 2e-5 * scale
+    # (c) eval mode: utterances are independent - scoring 64 at once equals scoring them 8 at a time
+    tr.model.eval()
+    with torch.no_grad():
+        f_all, _ = tr.model(x)
+        f_parts = torch.cat([tr.model(x[i:i + 8])[0] for i in range(0, B, 8)])
+    assert float((f_all - f_parts).abs().max()) <= 2e-5 * float(f_all.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 5e-3), ("bf16", 0.35)])
+def test_ecapa_full_length_step_vs_oracle(dtype, tol):
+    """ECAPA-TDNN-512 at the reference frame count T = 750 (B = 16 keeps the CPU oracle to seconds):
+    loss and every gradient as relative L2 per tensor; bf16 against the bf16 oracle inside the band
+    the oracle itself shows between fp32 and fp64 evaluation (tests/test_ecapa_gpu.py)."""
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    B, T = 16, 750
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+    fill_module_(m)
+    m = m.cuda().train().set_compute_dtype(dtype)
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    lossm = lossm.cuda()
+    x = synth_feat((B, 60, T), seed=750)
+    labels = (torch.arange(B) % 3 != 0).long()
+    feat, _ = m(x.cuda())
+    loss, _ = lossm(feat, labels.cuda())
+    loss.backward()
+    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_ecapa.ecapa_shapes()).items()}
+    tr = o_train.OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), bf16=(dtype == "bf16"))
+    lo, _, _, go, _, _ = tr.loss_and_grads(x.double(), labels)
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4 if dtype == "fp32" else 2e-3)
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        if go[k] is None or k in ("attention.2.bias", "attention.3.bias"):
+            continue
+        ref, got = go[k].numpy().ravel(), p.grad.cpu().double().numpy().ravel()
+        err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= tol, (k, err)
+    print(dtype, "worst relative L2 gradient error", worst)
