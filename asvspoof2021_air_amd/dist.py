@@ -25,15 +25,16 @@ def rank():
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
 
 
-def init_from_env(backend=None):
-    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns local rank."""
+def init_from_env(backend=None, device_index=None):
+    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns local rank.
+    ``device_index``: GPU of this rank (default LOCAL_RANK)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if ws > 1 and not td.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local if device_index is None else device_index)
         td.init_process_group(backend=backend)
     return local
 

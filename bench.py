@@ -176,9 +176,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs one process per GPU: python -m torch.distributed.run "
                          "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
-    local = air_dist.init_from_env("nccl" if world > 1 else None)
-    rank = air_dist.rank()
+    # AIR_DIST_BACKEND=gloo lets the multi-process path run on a box with fewer GPUs than ranks
+    # (tests/test_dist_gpu.py: two ranks share cuda:0); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("AIR_DIST_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    local = int(os.environ.get("LOCAL_RANK", "0")) % ndev
     torch.cuda.set_device(local)
+    air_dist.init_from_env(backend if world > 1 else None, device_index=local)
+    rank = air_dist.rank()
     device = torch.device("cuda", local)
 
     from asvspoof2021_air_amd.train import Trainer

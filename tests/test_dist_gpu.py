@@ -1,0 +1,111 @@
+"""GPU: the data-parallel train step with TWO ranks (one process each, both on cuda:0, gloo transport -
+RCCL refuses two ranks on one device, and the GPU box has one).  Everything but the transport is the
+code the driver's multi-GPU bench runs: Trainer.step -> backward -> bucketed all-reduce of the gradient
+arena + loss centre -> optimiser with grad_scale 1/world."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle.filler import fill_module_, synth_feat
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make():
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    m = ResNet(3, 256, resnet_type="18", nclasses=2)
+    fill_module_(m)
+    m.set_attention_noise(None)
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    return Trainer(m, loss_module=lossm, feat_len=96)
+
+
+def _shard(rank):
+    x = synth_feat((4, 1, 60, 96), seed=50 + rank)
+    labels = torch.tensor([0, 1, 1, 0]) if rank == 0 else torch.tensor([1, 1, 0, 1])
+    return x, labels
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from asvspoof2021_air_amd import dist as air_dist
+    torch.cuda.set_device(0)
+    air_dist.init_from_env("gloo")
+    tr = _make()
+    assert tr.world == world
+    x, labels = _shard(rank)
+    loss, _ = tr.step_features(x.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_averaged_gradients():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (l0, w0, c0), (l1, w1, c1) = out[0], out[1]
+    assert np.array_equal(w0, w1) and np.array_equal(c0, c1)  # ranks stay in lock-step, bit for bit
+    # single process: per-shard gradients, averaged by hand, one optimiser step
+    grads, cgrads, losses = [], [], []
+    for r in range(world):
+        tr = _make()
+        x, labels = _shard(r)
+        tr.model.train()
+        feats, _ = tr.model(x.cuda())
+        loss, _ = tr.loss(feats, labels.cuda())
+        loss.backward()
+        grads.append(tr.model.arena().grad.clone())
+        cgrads.append(tr.loss.center.grad.clone())
+        losses.append(loss.item())
+    np.testing.assert_allclose([l0, l1], losses, rtol=1e-6)
+    tr = _make()
+    arena = tr.model.arena()
+    for p in tr.model.parameters():
+        p.grad = None
+    arena.grad.copy_(grads[0] + grads[1])
+    arena.tail_has_grad = False
+    tr.loss.center.grad = cgrads[0] + cgrads[1]
+    tr.feat_optimizer.step(grad_scale=0.5)
+    tr.loss_optimizer.step(grad_scale=0.5)
+    n = arena.head_total
+    np.testing.assert_array_equal(arena.flat[:n].cpu().numpy(), w0[:n])
+    np.testing.assert_array_equal(tr.loss.center.detach().cpu().numpy(), c0)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank)."""
+    env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-roofline", "--batch", "8"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only
