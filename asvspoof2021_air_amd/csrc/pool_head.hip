@@ -208,39 +208,66 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
   }
 }
 
-// dx[m][k] = sum_n dy[m][n] w[n][k]; grid (M), threads over k
+// dx[m][k] = sum_n dy[m][n] w[n][k].  grid (ceil(K/256), ceil(M/8)): a thread owns one k for 8 rows
+// m, so every weight row is streamed once per 8 rows (coalesced along k); the 8 dy rows sit in LDS
+// and are read as broadcasts.  Per (m, k) the sum runs over n in ascending order.
+constexpr int LIN_RB = 8;
 __global__ __launch_bounds__(NT) void linear_dx_kernel(const float* __restrict__ dy,
-                                                       const float* __restrict__ w, int K, int N,
+                                                       const float* __restrict__ w, int M, int K, int N,
                                                        float* __restrict__ dx) {
-  extern __shared__ __attribute__((aligned(16))) float ds[];
-  const int m = blockIdx.x;
-  for (int n = threadIdx.x; n < N; n += NT) ds[n] = dy[(size_t)m * N + n];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += NT) {
-    float s = 0.0f;
-    for (int n = 0; n < N; ++n) s = fmaf(ds[n], w[(size_t)n * K + k], s);
-    dx[(size_t)m * K + k] = s;
+  extern __shared__ __attribute__((aligned(16))) float ds[];  // [LIN_RB][N]
+  const int m0 = blockIdx.y * LIN_RB;
+  for (int i = threadIdx.x; i < LIN_RB * N; i += NT) {
+    const int r = i / N, n = i - r * N;
+    ds[i] = m0 + r < M ? dy[(size_t)(m0 + r) * N + n] : 0.0f;
   }
+  __syncthreads();
+  const int k = blockIdx.x * NT + threadIdx.x;
+  if (k >= K) return;
+  float s[LIN_RB];
+#pragma unroll
+  for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
+  for (int n = 0; n < N; ++n) {
+    const float wv = w[(size_t)n * K + k];
+#pragma unroll
+    for (int r = 0; r < LIN_RB; ++r) s[r] = fmaf(ds[r * N + n], wv, s[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_RB; ++r)
+    if (m0 + r < M) dx[(size_t)(m0 + r) * K + k] = s[r];
 }
 
-// dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n]; grid (N), threads over k
+// dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n].  grid (ceil(K/256), ceil(N/8)): a thread
+// owns one k for 8 outputs n, so x is streamed once per 8 outputs; sums run over m ascending.
 __global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ dy, int M, int K,
                                                        int N, float* __restrict__ dw,
                                                        float* __restrict__ db) {
-  extern __shared__ __attribute__((aligned(16))) float ds[];
-  const int n = blockIdx.x;
-  for (int m = threadIdx.x; m < M; m += NT) ds[m] = dy[(size_t)m * N + n];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += NT) {
-    float s = 0.0f;
-    for (int m = 0; m < M; ++m) s = fmaf(ds[m], x[(size_t)m * K + k], s);
-    dw[(size_t)n * K + k] = s;
+  extern __shared__ __attribute__((aligned(16))) float ds[];  // [M][LIN_RB]
+  const int n0 = blockIdx.y * LIN_RB;
+  for (int i = threadIdx.x; i < M * LIN_RB; i += NT) {
+    const int m = i / LIN_RB, r = i - m * LIN_RB;
+    ds[i] = n0 + r < N ? dy[(size_t)m * N + n0 + r] : 0.0f;
   }
-  if (db != nullptr && threadIdx.x == 0) {
-    float s = 0.0f;
-    for (int m = 0; m < M; ++m) s += ds[m];
-    db[n] = s;
+  __syncthreads();
+  const int k = blockIdx.x * NT + threadIdx.x;
+  if (k < K) {
+    float s[LIN_RB];
+#pragma unroll
+    for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
+    for (int m = 0; m < M; ++m) {
+      const float xv = x[(size_t)m * K + k];
+#pragma unroll
+      for (int r = 0; r < LIN_RB; ++r) s[r] = fmaf(ds[m * LIN_RB + r], xv, s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < LIN_RB; ++r)
+      if (n0 + r < N) dw[(size_t)(n0 + r) * K + k] = s[r];
+  }
+  if (db != nullptr && blockIdx.x == 0 && threadIdx.x < LIN_RB && n0 + threadIdx.x < N) {
+    float t = 0.0f;
+    for (int m = 0; m < M; ++m) t += ds[m * LIN_RB + threadIdx.x];
+    db[n0 + threadIdx.x] = t;
   }
 }
 
@@ -369,16 +396,16 @@ int air_linear_fwd(const float* x, const float* w, const float* b, int M, int K,
 int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K, int N, float* dx,
                    float* dw, float* db, air_stream_t stream) {
   if (!x || !w || !dy || M <= 0 || K <= 0 || N <= 0) return AIR_EINVAL;
-  if ((size_t)N * sizeof(float) > 64 * 1024 || (size_t)M * sizeof(float) > 64 * 1024)
+  if ((size_t)N * LIN_RB * sizeof(float) > 64 * 1024 || (size_t)M * LIN_RB * sizeof(float) > 64 * 1024)
     return AIR_EUNSUPPORTED;
   if (dx != nullptr) {
-    hipLaunchKernelGGL(linear_dx_kernel, dim3(M), dim3(NT), (size_t)N * sizeof(float),
-                       air_stream(stream), dy, w, K, N, dx);
+    hipLaunchKernelGGL(linear_dx_kernel, dim3((K + NT - 1) / NT, (M + LIN_RB - 1) / LIN_RB), dim3(NT),
+                       (size_t)N * LIN_RB * sizeof(float), air_stream(stream), dy, w, M, K, N, dx);
     AIR_CHECK_LAUNCH();
   }
   if (dw != nullptr) {
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(N), dim3(NT), (size_t)M * sizeof(float),
-                       air_stream(stream), x, dy, M, K, N, dw, db);
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((K + NT - 1) / NT, (N + LIN_RB - 1) / LIN_RB), dim3(NT),
+                       (size_t)M * LIN_RB * sizeof(float), air_stream(stream), x, dy, M, K, N, dw, db);
     AIR_CHECK_LAUNCH();
   }
   return AIR_OK;
