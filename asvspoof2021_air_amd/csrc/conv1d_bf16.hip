@@ -458,7 +458,7 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   g.b_rs = K; g.b_ss = 0; g.b_bs = (size_t)Tp * K;
   g.o_rs = T; g.o_bs = y_bs;
   g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
-  return launch_gemm(g, B, Tp, AIR_K_C1B_FWD, flops, st);
+  return launch_gemm(g, B, Tp, AIR_K_C1B_GEMM, flops, st);
 }
 
 }  // namespace
@@ -546,7 +546,7 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
   g.b_rs = Tp; g.b_ss = (size_t)N * Tp; g.b_bs = (size_t)per * g.b_ss;
   g.o_rs = N; g.o_bs = (size_t)M * N;
   g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
-  int rc = launch_gemm(g, nsplit, N, AIR_K_C1B_WGRAD, 2.0 * B * T * (double)M * N, st);
+  int rc = launch_gemm(g, nsplit, N, AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
   if (rc != AIR_OK) return rc;
   if (nsplit > 1) {
     const size_t n = (size_t)M * N;
