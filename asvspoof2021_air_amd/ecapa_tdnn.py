@@ -137,6 +137,12 @@ class Res2Net2(nn.Module):
         self._arena = None
         self.compute_dtype = "fp32"
 
+    def __getstate__(self):
+        """Whole-module pickles (main_train.py:675-704): the flat arenas are rebuilt on first use."""
+        st = dict(self.__dict__)
+        st["_arena"] = None
+        return st
+
     def set_compute_dtype(self, dtype):
         if dtype not in ("fp32", "bf16"):
             raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % (dtype,))

@@ -138,6 +138,17 @@ class ResNet(nn.Module):
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self._side_stream = None
 
+    def __getstate__(self):
+        """Whole-module pickles (main_train.py:675-704 -> generate_score.py:46-48): the flat arenas, the
+        side stream and an installed noise tensor are runtime state and are rebuilt on first use."""
+        st = dict(self.__dict__)
+        st["_arena"] = None
+        st["_side_stream"] = None
+        st["_noise_tensor"] = None
+        if st.get("noise_mode") == "tensor":
+            st["noise_mode"] = "device"
+        return st
+
     def initialize_params(self):
         """resnet.py:149-157."""
         for layer in self.modules():

@@ -197,3 +197,17 @@ def test_bf16_training_tracks_fp32():
     print(curves)
     assert curves["bf16"][2] < curves["bf16"][0]
     np.testing.assert_allclose(curves["bf16"], curves["fp32"], rtol=5e-2)
+
+
+def test_whole_module_pickle_roundtrip(tmp_path):
+    m = make_model().train().set_compute_dtype("bf16")
+    x = synth_feat((4, 60, 64), seed=5).cuda()
+    feat, _ = m(x)
+    feat.sum().backward()
+    torch.save(m, tmp_path / "ecapa.pt")
+    m2 = torch.load(tmp_path / "ecapa.pt", weights_only=False)
+    assert m2.compute_dtype == "bf16"
+    m.eval()
+    m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x)[0], m2(x)[0])

@@ -162,3 +162,37 @@ def test_full_path_pcm_to_loss():
     lo, no, _, _, _ = otr.step(o_pad.to_model_input(xin).contiguous(), labels, None)
     np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
     np.testing.assert_allclose(neg.cpu().numpy(), no.numpy(), atol=1e-4)
+
+
+def test_whole_module_pickle_roundtrip(tmp_path):
+    """main_train.py:675-704 saves whole modules with torch.save and generate_score.py:46-48 loads them:
+    after a training step (arenas bound, side stream created) the module still pickles, and the loaded copy
+    scores identically."""
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.train import Trainer
+    m = make_model()
+    m.set_attention_noise(None)
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    tr = Trainer(m, loss_module=lossm, feat_len=96)
+    x = synth_feat((4, 1, 60, 96), seed=8).cuda()
+    tr.step_features(x, torch.tensor([0, 1, 1, 0]).cuda())
+    torch.save(tr.model, tmp_path / "anti-spoofing_cqcc_model.pt")
+    torch.save(tr.loss, tmp_path / "anti-spoofing_loss_model.pt")
+    m2 = torch.load(tmp_path / "anti-spoofing_cqcc_model.pt", weights_only=False)
+    l2 = torch.load(tmp_path / "anti-spoofing_loss_model.pt", weights_only=False)
+    assert list(m2.state_dict().keys()) == list(tr.model.state_dict().keys())
+    for k, v in tr.model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    tr.model.eval()
+    m2.eval()
+    m2.set_attention_noise(None)
+    with torch.no_grad():
+        f1, _ = tr.model(x)
+        f2, _ = m2(x)
+        s1 = tr.loss(f1, torch.zeros(4, dtype=torch.long).cuda())[1]
+        s2 = l2(f2, torch.zeros(4, dtype=torch.long).cuda())[1]
+    assert torch.equal(f1, f2) and torch.equal(s1, s2)
+    # and the loaded module trains (arena rebuilt on first use)
+    tr2 = Trainer(m2, loss_module=l2, feat_len=96)
+    tr2.step_features(x, torch.tensor([0, 1, 1, 0]).cuda())
