@@ -59,14 +59,69 @@ def allreduce_flat(flat, n_elems, bucket_bytes=BUCKET_BYTES):
     return works
 
 
+class GradBucketer:
+    """All-reduce of the gradient arena launched from INSIDE the backward pass (BASELINE configs[3]:
+    "gradient all-reduce overlapped with backward").
+
+    The backward pass produces gradients from the end of the arena towards its start (last layers
+    first).  The model reports ``ready(lo, events)`` after it has enqueued everything that writes
+    arena.grad[lo:]; once a bucket's worth of finished tail has accumulated, its SUM all-reduce is
+    issued from a dedicated launch stream that waits on those events only - the main stream (dgrad
+    chain) and the side stream (weight gradients) keep running underneath the transfer.  What is left
+    at the end of backward (the first layers, < one bucket) is reduced by ``allreduce_grads``."""
+
+    def __init__(self, bucket_bytes=None):
+        self.bucket_bytes = bucket_bytes
+        self.comm = None
+        self.total_launched = 0  # buckets sent from inside backward since construction
+        self.reset(None, 0)
+
+    def reset(self, grad, hi):
+        self.grad, self.hi, self.lo = grad, hi, hi
+        self.events, self.works, self.launched = [], [], 0
+
+    def ready(self, lo, events):
+        if self.grad is None or lo >= self.lo:
+            return
+        self.lo = lo
+        self.events = [e for e in events if e is not None]
+        if (self.hi - self.lo) * 4 >= (self.bucket_bytes or BUCKET_BYTES):
+            self.flush()
+
+    def flush(self):
+        if self.grad is None or self.lo >= self.hi:
+            return
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=self.grad.device)
+        for ev in self.events:
+            self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            self.works.append(td.all_reduce(self.grad[self.lo:self.hi], op=td.ReduceOp.SUM, async_op=True))
+        self.launched += 1
+        self.total_launched += 1
+        self.hi = self.lo
+        self.events = []
+
+
 def allreduce_grads(model, loss_module=None):
     """Sum gradients over ranks: the model's gradient arena (skipping the tail that has
-    no gradient under ang_iso) and the loss centre."""
+    no gradient under ang_iso) and the loss centre.  Regions a GradBucketer already sent during
+    backward are only waited for."""
     if world_size() == 1:
         return
     arena = model.arena()
-    n = arena.total if arena.tail_has_grad else arena.head_total
-    works = allreduce_flat(arena.grad, n)
+    bucketer = getattr(model, "_bucketer", None)
+    works = []
+    if bucketer is not None and bucketer.grad is arena.grad and bucketer.launched:
+        works = allreduce_flat(arena.grad, bucketer.hi) + bucketer.works
+        if arena.tail_has_grad:
+            works.append(td.all_reduce(arena.grad[arena.head_total:arena.total], op=td.ReduceOp.SUM, async_op=True))
+        bucketer.reset(None, 0)
+    else:
+        if bucketer is not None:
+            bucketer.reset(None, 0)
+        n = arena.total if arena.tail_has_grad else arena.head_total
+        works = allreduce_flat(arena.grad, n)
     if loss_module is not None:
         for p in loss_module.parameters():
             if p.grad is not None:

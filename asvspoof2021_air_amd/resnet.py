@@ -137,6 +137,13 @@ class ResNet(nn.Module):
         # weight gradients on a side HIP stream, overlapping the HBM-bound BN-backward passes
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self._side_stream = None
+        self._bucketer = None  # dist.GradBucketer when the all-reduce is overlapped with backward
+
+    def enable_ddp_overlap(self, bucket_bytes=None):
+        """Launch the gradient all-reduce from inside backward (one process per GPU, world size > 1)."""
+        from .dist import GradBucketer
+        self._bucketer = GradBucketer(bucket_bytes)
+        return self
 
     def __getstate__(self):
         """Whole-module pickles (main_train.py:675-704 -> generate_score.py:46-48): the flat arenas, the
@@ -144,6 +151,7 @@ class ResNet(nn.Module):
         st = dict(self.__dict__)
         st["_arena"] = None
         st["_side_stream"] = None
+        st["_bucketer"] = None
         st["_noise_tensor"] = None
         if st.get("noise_mode") == "tensor":
             st["noise_mode"] = "device"
@@ -337,6 +345,24 @@ class ResNet(nn.Module):
             if ev is not None:
                 main.wait_event(ev)
 
+        offsets = {n: o for n, _, o, _ in arena.entries}
+        bucketer = getattr(self, "_bucketer", None)
+        if accumulating:
+            bucketer = None
+        if bucketer is not None:
+            bucketer.reset(arena.grad, arena.head_total)
+
+        def grads_final_from(first_param):
+            """Everything that writes arena.grad[offset(first_param):] has been enqueued."""
+            if bucketer is None:
+                return
+            evs = [torch.cuda.Event()]
+            evs[0].record(main)
+            if use_side:
+                evs.append(torch.cuda.Event())
+                evs[1].record(side)
+            bucketer.ready(offsets[first_param], evs)
+
         c5, st5 = S["c5"], S["st5"]
         dc5, _, _ = ops.bn_bwd(c5, da5.view_as(c5), st5[0], st5[1], self.bn5.weight.detach(),
                                self.bn5.bias.detach(), relu=True,
@@ -344,6 +370,7 @@ class ResNet(nn.Module):
         l4 = S["l4"]
         g5 = gv("conv5.weight")
         on_side(lambda: ops.conv2d_wgrad(l4, dc5, self.conv5.weight.shape, 1, (0, 1), out=g5), dc5)
+        grads_final_from("conv5.weight")
         dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1))
         fuse = self.fuse_bn_into_conv
         for blk, xin, stA, h, stB, actA, actB in reversed(S["blocks"]):
@@ -384,6 +411,7 @@ class ResNet(nn.Module):
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
                                         blk.bn1.bias.detach(), relu=True, dx=dcur, accumulate=True,
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))
+            grads_final_from(pre + "bn1.weight")  # the block's first parameter in arena order
         c1, st1 = S["c1"], S["st1"]
         dc1, _, _ = ops.bn_bwd(c1, dcur, st1[0], st1[1], self.bn1.weight.detach(),
                                self.bn1.bias.detach(), relu=True, dx=dcur,

@@ -8,6 +8,8 @@
 zero_grad x2, loss.backward(), feat_optimizer.step(), ang_iso_optimizer.step()
 (main_train.py:404-409), LR = lr0 * decay^(epoch // interval) (main_train.py:144-147).
 """
+import os
+
 import torch
 
 from . import dist as air_dist
@@ -41,6 +43,9 @@ class Trainer:
         self.feat_len = feat_len
         self.ecapa = ecapa
         self.world = air_dist.world_size()
+        # data parallel: start the gradient all-reduce inside backward where the model supports it
+        if self.world > 1 and hasattr(self.model, "enable_ddp_overlap") and os.environ.get("AIR_DDP_OVERLAP", "1") == "1":
+            self.model.enable_ddp_overlap()
         # optional augment.ChannelAugment: on-the-fly IR convolution of the TRAINING batches ahead
         # of the LFCC kernel (BASELINE configs[4]; replaces channel_simulation/*.py's offline pass)
         self.augment = augment

@@ -1,7 +1,8 @@
 """GPU: the data-parallel train step with TWO ranks (one process each, both on cuda:0, gloo transport -
 RCCL refuses two ranks on one device, and the GPU box has one).  Everything but the transport is the
 code the driver's multi-GPU bench runs: Trainer.step -> backward -> bucketed all-reduce of the gradient
-arena + loss centre -> optimiser with grad_scale 1/world."""
+arena + loss centre -> optimiser with grad_scale 1/world, with the all-reduce buckets launched from
+inside the backward pass (dist.GradBucketer)."""
 import json
 import os
 import socket
@@ -56,7 +57,8 @@ def _worker(rank, world, port, out):
     x, labels = _shard(rank)
     loss, _ = tr.step_features(x.cuda(), labels.cuda())
     torch.cuda.synchronize()
-    out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy())
+    out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy(),
+                 tr.model._bucketer.total_launched if tr.model._bucketer is not None else -1)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -66,8 +68,10 @@ def test_two_rank_step_equals_averaged_gradients():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    (l0, w0, c0), (l1, w1, c1) = out[0], out[1]
+    (l0, w0, c0, nb0), (l1, w1, c1, nb1) = out[0], out[1]
     assert np.array_equal(w0, w1) and np.array_equal(c0, c1)  # ranks stay in lock-step, bit for bit
+    # the all-reduce was overlapped with backward: layer4's buckets left before the backward pass ended
+    assert nb0 == nb1 and nb0 >= 2, (nb0, nb1)
     # single process: per-shard gradients, averaged by hand, one optimiser step
     grads, cgrads, losses = [], [], []
     for r in range(world):
