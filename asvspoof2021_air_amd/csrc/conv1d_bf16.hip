@@ -380,6 +380,176 @@ __global__ __launch_bounds__(256) void c1b_gemm_kernel(const NtGemm p) {
   }
 }
 
+
+// ===================================================================================
+// Path 3: the dilated K = 3 convs of the Res2 branches (ecapa_tdnn.py:46: width -> width channels,
+// dilation 2 / 3 / 4, padding = dilation), forward and dgrad.  7 of them run back to back per block
+// on (B, 64, T) tensors: small, so what matters is one short launch each.  Same in-register
+// transpose staging as the fused pointwise kernel, but the [t][ci] LDS tile carries a halo of
+// `dil` frames each side and the three taps read it at row offsets 0, dil, 2 dil - the shifted
+// operands cost no extra staging.  Zero padding = frames outside [0, T) staged as zeros.
+// Workgroup tile: 64 output channels x 128 frames; wave w owns frames 32 w .. 32 w + 31.
+constexpr int TAP_MAXD = 4;
+constexpr int TAP_ROWS = BN + 2 * TAP_MAXD;  // 136 staged frames
+
+struct C1bTap {
+  const float* x;
+  const unsigned short* a;  // bf16 [3][64 * tiles_m][K]
+  float* y;
+  const float* bias;
+  const float* acc;
+  size_t x_bs, y_bs;
+  int B, M, K, T, dil, relu, tiles_m, tiles_t, total, per_xcd;
+};
+
+// fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
+// transpose = 1: m = ci, k = co, taps flipped (dgrad: dx[t] = sum_k w[..][2 - k'] dy[t + (k' - 1) d]).
+__global__ __launch_bounds__(256) void c1b_pack3_kernel(const float* __restrict__ w, unsigned short* __restrict__ a,
+                                                        int Cout, int Cin, int transpose) {
+  const int M = transpose ? Cin : Cout, K = transpose ? Cout : Cin;
+  const size_t n = (size_t)3 * M * K;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int k = (int)(e % K);
+    const int m = (int)((e / K) % M);
+    const int tap = (int)(e / ((size_t)K * M));
+    const float v = transpose ? w[((size_t)k * Cin + m) * 3 + (2 - tap)] : w[((size_t)m * Cin + k) * 3 + tap];
+    f32x2 pr = {v, 0.0f};
+    bf16x2 r = __builtin_convertvector(pr, bf16x2);
+    a[e] = (unsigned short)(__builtin_bit_cast(unsigned, r) & 0xFFFFu);
+  }
+}
+
+__global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][3 * 64 * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][TAP_ROWS * LDK];
+  const int work = xcd_chunked(blockIdx.x, p.per_xcd);
+  if (work >= p.total) return;
+  const int mt = work % p.tiles_m;
+  const int rest = work / p.tiles_m;
+  const int tt = rest % p.tiles_t, b = rest / p.tiles_t;
+  const int m0 = mt * 64, t0 = tt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = p.dil;
+  const int nrows = BN + 2 * d;  // staged frames: t0 - d .. t0 + 127 + d
+
+  // A: 3 taps x 64 rows x 4 chunks = 768 chunks, 3 per thread
+  // B: nrows frames x 4 channel groups of 8: slot s = tid + 256 i -> frame s % TAP_ROWS, group s / TAP_ROWS
+  const float* __restrict__ xb = p.x + (size_t)b * p.x_bs;
+  // per-thread staging roles (3 slots each), fixed for the whole K loop
+  const unsigned short* ga[3];
+  int la[3], lb_[3];
+  const float* gb[3];
+  bool okb[3], stb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = tid + 256 * i;  // A chunk: tap = c / 256, row = (c % 256) / 4, ch = c % 4
+    ga[i] = p.a + ((size_t)(c >> 8) * p.M + m0 + ((c & 255) >> 2)) * p.K + (c & 3) * 8;
+    la[i] = ((c >> 8) * 64 + ((c & 255) >> 2)) * LDK + (c & 3) * 8;
+    const int fr = c % TAP_ROWS, kg = c / TAP_ROWS;  // B slot: frame, channel group of 8
+    const int t = t0 - d + fr;
+    stb[i] = kg < 4;
+    okb[i] = kg < 4 && fr < nrows && t >= 0 && t < p.T;
+    gb[i] = xb + (size_t)(kg * 8) * p.T + (okb[i] ? t : 0);
+    lb_[i] = fr * LDK + kg * 8;
+  }
+  uint4 ra0, ra1, ra2;
+  float rb[3][8];
+#define TAP_FETCH(k0)                                                                        \
+  do {                                                                                       \
+    ra0 = *reinterpret_cast<const uint4*>(ga[0] + (k0));                                     \
+    ra1 = *reinterpret_cast<const uint4*>(ga[1] + (k0));                                     \
+    ra2 = *reinterpret_cast<const uint4*>(ga[2] + (k0));                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                     \
+            rb[i_][j_] = okb[i_] ? gb[i_][(size_t)((k0) + j_) * p.T] : 0.0f;                 \
+  } while (0)
+#define TAP_STASH(buf)                                                                       \
+  do {                                                                                       \
+    *reinterpret_cast<uint4*>(&sA[buf][la[0]]) = ra0;                                        \
+    *reinterpret_cast<uint4*>(&sA[buf][la[1]]) = ra1;                                        \
+    *reinterpret_cast<uint4*>(&sA[buf][la[2]]) = ra2;                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) if (stb[i_]) {                          \
+      uint4 v_;                                                                              \
+      v_.x = pack2(rb[i_][0], rb[i_][1]);                                                    \
+      v_.y = pack2(rb[i_][2], rb[i_][3]);                                                    \
+      v_.z = pack2(rb[i_][4], rb[i_][5]);                                                    \
+      v_.w = pack2(rb[i_][6], rb[i_][7]);                                                    \
+      *reinterpret_cast<uint4*>(&sB[buf][lb_[i_]]) = v_;                                     \
+    }                                                                                        \
+  } while (0)
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  const int r31 = lane & 31, kgl = lane >> 5;
+  const int nk = p.K / BK;
+  TAP_FETCH(0);
+  TAP_STASH(0);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nk) TAP_FETCH((s + 1) * BK);
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&sB[cur][(wave * 32 + r31 + tap * d) * LDK + kk * 16 + kgl * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&sA[cur][(tap * 64 + i * 32 + r31) * LDK + kk * 16 + kgl * 8]);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (s + 1 < nk) TAP_STASH(cur ^ 1);
+    __syncthreads();
+  }
+#undef TAP_FETCH
+#undef TAP_STASH
+
+  const int t = t0 + wave * 32 + r31;
+  if (t >= p.T) return;
+  float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
+  const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kgl;
+      float v = acc[i][q] + (p.bias ? p.bias[m] : 0.0f);
+      if (ab) v += ab[(size_t)m * p.T + t];
+      if (p.relu) v = fmaxf(v, 0.0f);
+      yb[(size_t)m * p.T + t] = v;
+    }
+}
+
+bool tap_ok(const AirConv1d* p) {
+  return p && p->B > 0 && p->T > 0 && p->K == 3 && p->dil >= 1 && p->dil <= TAP_MAXD && p->pad == p->dil;
+}
+
+int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y, size_t y_bs, const float* bias,
+            const float* acc, int relu, int B, int Cout, int Cin, int T, int dil, void* ws, hipStream_t st) {
+  const int M = transpose ? Cin : Cout, K = transpose ? Cout : Cin;
+  unsigned short* a = reinterpret_cast<unsigned short*>(ws);
+  const size_t n = (size_t)3 * M * K;
+  hipLaunchKernelGGL(c1b_pack3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, a, Cout, Cin, transpose);
+  AIR_CHECK_LAUNCH();
+  C1bTap p;
+  p.x = x; p.a = a; p.y = y; p.bias = bias; p.acc = acc; p.x_bs = x_bs; p.y_bs = y_bs;
+  p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu;
+  p.tiles_m = M / 64;
+  p.tiles_t = (T + BN - 1) / BN;
+  p.total = B * p.tiles_t * p.tiles_m;
+  p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  AirProfScope prof(AIR_K_C1B_FWD, 2.0 * B * T * (double)Cout * Cin * 3, st);
+  hipLaunchKernelGGL(c1b_tap_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -466,6 +636,11 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
 extern "C" {
 
 int air_conv1d_bf16_supported(const AirConv1d* p, int pass) {
+  if (tap_ok(p)) {  // dilated K = 3: forward (M = Cout, K = Cin) and dgrad (M = Cin, K = Cout) only
+    if (pass == 0) return p->Cout % 64 == 0 && p->Cin % BK == 0;
+    if (pass == 1) return p->Cin % 64 == 0 && p->Cout % BK == 0;
+    return 0;
+  }
   if (!shape_ok(p)) return 0;
   switch (pass) {
     case 0: return p->Cout % BM == 0 && p->Cin % BK == 0;  // forward: M = Cout, K = Cin
@@ -476,6 +651,7 @@ int air_conv1d_bf16_supported(const AirConv1d* p, int pass) {
 }
 
 size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
+  if (tap_ok(p)) return (size_t)3 * p->Cout * p->Cin * sizeof(unsigned short) + 256;
   if (!shape_ok(p)) return 0;
   size_t n = (size_t)p->Cout * p->Cin * sizeof(unsigned short);  // packed bf16 weights
   if (wide(p->Cout, p->Cin) || wide(p->Cin, p->Cout)) {
@@ -494,9 +670,14 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
 
 int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
                         int relu, float* y, void* ws, size_t ws_bytes, air_stream_t stream) {
-  if (!shape_ok(p) || !x || !w || !y) return AIR_EINVAL;
+  if ((!shape_ok(p) && !tap_ok(p)) || !x || !w || !y) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 0)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
+  if (p->K == 3) {
+    if (bias_bc) return AIR_EUNSUPPORTED;
+    return run_tap(x, xbs(p), w, 0, y, ybs(p), bias, nullptr, relu, p->B, p->Cout, p->Cin, p->T, p->dil, ws,
+                   air_stream(stream));
+  }
   if (wide(p->Cout, p->Cin) && p->Cin % 64 == 0)
     return run_fwd_gemm(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
                         2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
@@ -506,9 +687,12 @@ int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, cons
 
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
                           void* ws, size_t ws_bytes, air_stream_t stream) {
-  if (!shape_ok(p) || !dy || !w || !dx) return AIR_EINVAL;
+  if ((!shape_ok(p) && !tap_ok(p)) || !dy || !w || !dx) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 1)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
+  if (p->K == 3)
+    return run_tap(dy, ybs(p), w, 1, dx, xbs(p), nullptr, accumulate, 0, p->B, p->Cout, p->Cin, p->T, p->dil, ws,
+                   air_stream(stream));
   // A = W^T: w is (Cout, Cin) = [k][m]
   if (wide(p->Cin, p->Cout) && p->Cout % 64 == 0)
     return run_fwd_gemm(dy, ybs(p), w, 1, dx, xbs(p), nullptr, nullptr, accumulate, 0, p->B, p->Cin, p->Cout, p->T, ws,

@@ -15,8 +15,8 @@ Layout choices that remove the reference's copies:
 ``compute_dtype``: "fp32" (the reference's arithmetic) or "bf16" (BASELINE.json configs[2]):
 the pointwise layers that hold 97 % of the FLOPs (Bottle2neck conv1/conv3, layer4, attention.0's
 layer4 part, attention.3) run forward, dgrad and wgrad on the bf16 matrix cores with fp32
-accumulation (csrc/conv1d_bf16.hip); tensors in HBM, BatchNorm, pooling and the dilated K=3
-convs stay fp32.  Set it with ``model.set_compute_dtype("bf16")``.
+accumulation (csrc/conv1d_bf16.hip), and so do the forward / input-gradient passes of the dilated
+K=3 Res2 convs; tensors in HBM, BatchNorm, pooling and the K=3 weight gradients stay fp32.  Set it with ``model.set_compute_dtype("bf16")``.
 """
 import math
 
@@ -186,7 +186,7 @@ class Res2Net2(nn.Module):
         t_i = o1[:, :w]
         for i in range(nums):
             r_i = ops.conv1d_fwd(t_i, det(blk.convs[i].weight), det(blk.convs[i].bias), relu=True,
-                                 dil=d, pad=d)
+                                 dil=d, pad=d, bf16=bf)
             st_i = _bn(r_i, blk.bns[i], training)
             # BN-apply, store into the concat slice and form the next branch's input in one pass
             if i + 1 < nums:
@@ -306,7 +306,7 @@ class Res2Net2(nn.Module):
             ops.channel_sum(dc_i, out=gv("convs.%d.bias" % i))
             ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
             # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
-            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w])
+            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf)
             din_next = din if i > 0 else None
         st1 = S["st1"]
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),

@@ -269,10 +269,10 @@ def _c1d(x, cout, K, dil, pad, y=None):
 
 
 def _c1d_bf16(d, device, which):
-    """Workspace for the bf16 pointwise kernels, or None when the layer is not theirs
-    (K > 1 or channel counts off the 128/32 grid): the caller then runs the fp32 kernels."""
+    """Workspace for the bf16 kernels (pointwise layers; dilated K = 3 forward / dgrad), or None when the
+    layer is not theirs (K = 5, ragged channel counts, K = 3 wgrad): the caller then runs the fp32 kernels."""
     lib = _hip.lib()
-    if d.K != 1 or not lib.air_conv1d_bf16_supported(ctypes.byref(d), ci(which)):
+    if not lib.air_conv1d_bf16_supported(ctypes.byref(d), ci(which)):
         return None, 0
     n = lib.air_conv1d_bf16_ws_bytes(ctypes.byref(d))
     return workspace(n, device), n

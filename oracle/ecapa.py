@@ -15,8 +15,9 @@ are the reference's ``state_dict`` keys.
 itself is fp32 only): the pointwise layers that hold the FLOPs - Bottle2neck conv1/conv3
 (:39,:55), layer4 (:118), attention.0's layer4 part and attention.3 (:140,:143) - compute like
 torch.autocast(bfloat16): both operands of the forward, dgrad and wgrad contractions are rounded
-to bf16 (nearest even), products accumulate in fp32; everything else (dilated K=3 convs, conv1,
-SE, BatchNorm, pooling, biases) stays fp32.  The bf16 oracle is pinned against the reference
+to bf16 (nearest even), products accumulate in fp32; the dilated K=3 convs of the Res2 branches (:46)
+do the same in their forward and input-gradient contractions (their weight gradient stays fp32);
+everything else (conv1, SE, BatchNorm, pooling, biases) stays fp32.  The bf16 oracle is pinned against the reference
 through the fp32 goldens at bf16 tolerance (tests/test_oracle_golden.py).
 """
 from collections import OrderedDict
@@ -102,10 +103,34 @@ class _Bf16Pointwise(torch.autograd.Function):
         return F.conv_transpose1d(dyb, wb), torch.einsum("bot,bit->oi", dyb, xb).unsqueeze(2)
 
 
+class _Bf16Dilated(torch.autograd.Function):
+    """K = 3 dilated Conv1d (ecapa_tdnn.py:46) in bf16 compute: forward and input gradient contract
+    bf16-rounded operands with fp32 accumulation; the weight gradient (0.6 % of the step's FLOPs)
+    stays an fp32 contraction of the unrounded tensors, as in the HIP path."""
+
+    @staticmethod
+    def forward(ctx, x, w, dilation):
+        rnd = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.dilation = dilation
+        return F.conv1d(rnd(x), rnd(w), None, 1, dilation, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = ctx.dilation
+        rnd = lambda t: t.to(torch.bfloat16).to(t.dtype)
+        dx = F.conv_transpose1d(rnd(dy), rnd(w), None, 1, d, 0, 1, d)
+        dw = torch.nn.grad.conv1d_weight(x, w.shape, dy, 1, d, d)
+        return dx, dw, None
+
+
 def _conv(x, p, prefix, dilation=1, padding=0, bf16=False):
     w = p[prefix + ".weight"]
     if bf16 and w.shape[2] == 1:
         return _Bf16Pointwise.apply(x, w) + p[prefix + ".bias"][None, :, None]
+    if bf16 and w.shape[2] == 3 and padding == dilation and w.shape[0] % 64 == 0 and w.shape[1] % 32 == 0:
+        return _Bf16Dilated.apply(x, w, dilation) + p[prefix + ".bias"][None, :, None]
     return F.conv1d(x, w, p[prefix + ".bias"], 1, padding, dilation)
 
 
@@ -127,7 +152,7 @@ def bottle2neck(x, p, prefix, dilation, scale, training, updates, bf16=False):
     sp = None
     for i in range(scale - 1):
         sp = spx[i] if i == 0 else sp + spx[i]
-        sp = _conv(sp, p, prefix + ".convs.%d" % i, dilation, dilation)  # k=3: pad = dilation (:46)
+        sp = _conv(sp, p, prefix + ".convs.%d" % i, dilation, dilation, bf16=bf16)  # k=3: pad = dilation (:46)
         sp = _bn(F.relu(sp), p, prefix + ".bns.%d" % i, training, updates)
         outs.append(sp)
     outs.append(spx[scale - 1])

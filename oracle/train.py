@@ -95,3 +95,29 @@ class OracleTrainer:
                 if k.endswith("num_batches_tracked") and k.rsplit(".", 1)[0] + ".running_mean" in updates:
                     self.params[k] = self.params[k] + 1
         return loss, neg_scores, feat, grads, gcenter
+
+
+def bf16_gradient_band(x, labels, got):
+    """Test helper for ECAPA in bf16 compute (oracle/ecapa.py, ``bf16=True``).  bf16 rounding is
+    discontinuous, so two correct evaluations of the same graph that differ in fp32 summation order
+    disagree on gradients far more than in fp32.  Returns (band, errs): ``band`` = the oracle's own
+    fp32-vs-fp64 relative-L2 gradient spread on this input (max / median over tensors) and the fp64 loss;
+    ``errs[name]`` = (relative L2, cosine) of ``got[name]`` (flat float64 arrays) against the fp64 evaluation."""
+    from .filler import fill_state, fill_value
+    shapes = ecapa_oracle.ecapa_shapes()
+    p32 = fill_state(shapes)
+    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in p32.items()}
+    t64 = OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), bf16=True)
+    l64, _, _, g64, _, _ = t64.loss_and_grads(x.double(), labels)
+    t32 = OracleTrainer("ecapa", p32, fill_value("center", (1, 256)), bf16=True)
+    _, _, _, g32, _, _ = t32.loss_and_grads(x, labels)
+    own, errs = [], {}
+    for k, ref in g64.items():
+        if ref is None or k in ("attention.2.bias", "attention.3.bias"):  # analytically zero gradients
+            continue
+        r = ref.numpy().ravel()
+        nr = np.linalg.norm(r) + 1e-30
+        own.append(np.linalg.norm(g32[k].double().numpy().ravel() - r) / nr)
+        g = got[k]
+        errs[k] = (np.linalg.norm(g - r) / nr, float(g @ r) / (np.linalg.norm(g) * nr + 1e-30))
+    return {"max": float(max(own)), "median": float(np.median(own)), "loss64": l64.item()}, errs

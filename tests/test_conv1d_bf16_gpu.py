@@ -92,12 +92,40 @@ def test_conv1d_bf16_channel_slice_views(ops):
     assert float(dx[:, :128].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,C,T,dil", [(2, 64, 100, 2), (3, 64, 750, 3), (2, 64, 33, 4), (2, 128, 129, 4), (1, 64, 3, 2)])
+def test_conv1d_bf16_dilated_k3(ops, B, C, T, dil):
+    """The Res2 branch convs (ecapa_tdnn.py:46): forward (+bias, ReLU) and dgrad (+accumulate) in bf16 compute
+    against fp64 contractions of the bf16-rounded operands; zero padding, halo across time tiles, T < halo."""
+    x = synth_feat((B, C, T), 1)
+    w = synth_feat((C, C, 3), 2, scale=0.05)
+    b = synth_feat((C,), 3, scale=0.2)
+    dy = synth_feat((B, C, T), 5)
+    acc = synth_feat((B, C, T), 6)
+    want = F.relu(F.conv1d(bf(x), bf(w), None, 1, dil, dil) + b.double()[None, :, None])
+    got = ops.conv1d_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True, dil=dil, pad=dil, bf16=True)
+    assert relerr(got, want) <= 2e-5
+    want = F.conv_transpose1d(bf(dy), bf(w), None, 1, dil, 0, 1, dil)
+    got = ops.conv1d_dgrad(dy.cuda(), w.cuda(), dil, dil, bf16=True)
+    assert relerr(got, want) <= 2e-5
+    got = ops.conv1d_dgrad(dy.cuda(), w.cuda(), dil, dil, accumulate=acc.cuda(), bf16=True)
+    assert relerr(got, want + acc.double()) <= 2e-5
+    # strided views in and out (the Res2 groups are channel slices of wider tensors)
+    big = synth_feat((B, 3 * C, T), 7).cuda()
+    outbig = torch.zeros((B, 2 * C, T), device="cuda")
+    ops.conv1d_fwd(big[:, C:2 * C], w.cuda(), dil=dil, pad=dil, out=outbig[:, C:], bf16=True)
+    assert relerr(outbig[:, C:], F.conv1d(bf(big[:, C:2 * C].cpu()), bf(w), None, 1, dil, dil)) <= 2e-5
+    assert float(outbig[:, :C].abs().max()) == 0.0
+    # the weight gradient of these layers stays on the fp32 kernels
+    wg = ops.conv1d_wgrad(x.cuda(), dy.cuda(), (C, C, 3), dil, dil, bf16=True)
+    assert relerr(wg, torch.nn.grad.conv1d_weight(x.double(), (C, C, 3), dy.double(), 1, dil, dil)) <= 2e-5
+
+
 def test_conv1d_bf16_falls_through_to_fp32_for_other_layers(ops):
-    """K = 3 / K = 5 / ragged-channel layers are not the bf16 kernels': bf16=True runs the fp32 path."""
-    x = synth_feat((2, 64, 100), 1)
-    w = synth_feat((64, 64, 3), 2, scale=0.05)
-    got = ops.conv1d_fwd(x.cuda(), w.cuda(), dil=2, pad=2, bf16=True)
-    assert relerr(got, F.conv1d(x.double(), w.double(), None, 1, 2, 2)) <= 2e-5
+    """K = 5 / ragged-channel layers are not the bf16 kernels': bf16=True runs the fp32 path."""
+    x = synth_feat((2, 60, 100), 1)
+    w = synth_feat((512, 60, 5), 2, scale=0.05)
+    got = ops.conv1d_fwd(x.cuda(), w.cuda(), pad=2, bf16=True)
+    assert relerr(got, F.conv1d(x.double(), w.double(), None, 1, 2, 1)) <= 2e-5
 
 
 def test_conv1d_bf16_wgrad_is_deterministic(ops):
