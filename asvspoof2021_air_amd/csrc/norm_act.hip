@@ -145,11 +145,17 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   }
 }
 
-// backward stage 1: partial[(c*nsplit+split)*2] = sum g, [+1] = sum g*xhat, g = dy*[y>0]
+// backward stage 1: partial[(c*nsplit+split)*NACC + {0,1}] = sum g, sum g*xhat, g = (dy + rowbias)*[y>0].
+// With want_bias (conv -> ReLU -> BN layers, ecapa_tdnn.py:67-69) three more sums over the positions
+// where the BN input is positive: sum g, count, sum xhat - from them the finalize kernel gets the
+// gradient of the conv BIAS, sum_{b,s} dx, in closed form, so no pass over dx is needed for it:
+//   dx = [x > 0] * gamma*invstd * (g - dbeta/N - xhat * dgamma/N).
+constexpr int NACC = 6;
 __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, int B, int C, int S, int nsplit,
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ rowbias,
+    float rb_scale, int B, int C, int S, int nsplit,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int want_bias,
     double* __restrict__ partial) {
   __shared__ double sh[NT / 64];
   const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
@@ -158,17 +164,19 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
   const float mu = mean[c], is = invstd[c];
   const float sc = gamma[c] * is;
   const float shf = beta[c] - mu * sc;
-  double d1 = 0.0, d2 = 0.0;
+  double d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
   for (int b = b0; b < b1; ++b) {
     const float* __restrict__ px = x + ((size_t)b * C + c) * S;
     const float* __restrict__ pg = dy + ((size_t)b * C + c) * S;
-    float s1 = 0.0f, s2 = 0.0f;
-    if ((S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
+    const float rb = rowbias ? rowbias[(size_t)b * C + c] * rb_scale : 0.0f;
+    float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
+    if (!want_bias && (S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
       const float4* __restrict__ px4 = reinterpret_cast<const float4*>(px);
       const float4* __restrict__ pg4 = reinterpret_cast<const float4*>(pg);
       for (int i = threadIdx.x; i < S / 4; i += NT) {
         const float4 xv = px4[i];
         float4 g = pg4[i];
+        g.x += rb; g.y += rb; g.z += rb; g.w += rb;
         if (relu) {
           if (!(xv.x * sc + shf > 0.0f)) g.x = 0.0f;
           if (!(xv.y * sc + shf > 0.0f)) g.y = 0.0f;
@@ -182,40 +190,62 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
     } else {
       for (int i = threadIdx.x; i < S; i += NT) {
         const float xv = px[i];
-        float g = pg[i];
+        float g = pg[i] + rb;
         if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+        const float xh = (xv - mu) * is;
         s1 += g;
-        s2 += g * ((xv - mu) * is);
+        s2 += g * xh;
+        if (want_bias && xv > 0.0f) {
+          s3 += g;
+          s4 += 1.0f;
+          s5 += xh;
+        }
       }
     }
     d1 += (double)s1;
     d2 += (double)s2;
+    d3 += (double)s3;
+    d4 += (double)s4;
+    d5 += (double)s5;
   }
   d1 = block_sum_d(d1, sh);
   d2 = block_sum_d(d2, sh);
+  if (want_bias) {
+    d3 = block_sum_d(d3, sh);
+    d4 = block_sum_d(d4, sh);
+    d5 = block_sum_d(d5, sh);
+  }
   if (threadIdx.x == 0) {
-    partial[(size_t)blockIdx.x * 2] = d1;
-    partial[(size_t)blockIdx.x * 2 + 1] = d2;
+    double* o = partial + (size_t)blockIdx.x * NACC;
+    o[0] = d1; o[1] = d2; o[2] = d3; o[3] = d4; o[4] = d5;
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nsplit, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nsplit, int C, double invN,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ dbias) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
   for (int k = 0; k < nsplit; ++k) {
-    s1 += partial[((size_t)c * nsplit + k) * 2];
-    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
+    const double* o = partial + ((size_t)c * nsplit + k) * NACC;
+    s1 += o[0]; s2 += o[1]; s3 += o[2]; s4 += o[3]; s5 += o[4];
   }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
+  if (dbias) {
+    // the apply kernel uses the fp32 dbeta / dgamma just written: mirror its constants
+    const double k1 = (double)(float)s1 * invN, k2 = (double)(float)s2 * invN;
+    dbias[c] = (float)((double)gamma[c] * (double)invstd[c] * (s3 - k1 * s4 - k2 * s5));
+  }
 }
 
 // backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
 // (dy and dx may alias: the in-place gradient joins of resnet.py / ecapa_tdnn.py)
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
-    const float* __restrict__ x, const float* dy, int C, int S, float invN,
+    const float* __restrict__ x, const float* dy, const float* __restrict__ rowbias, float rb_scale, int C,
+    int S, float invN,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
@@ -226,10 +256,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   const float sc = gamma[c] * is;
   const float shf = beta[c] - mu * sc;
   const float k1 = dbeta[c] * invN, k2 = dgamma[c] * invN;
+  const float rb = rowbias ? rowbias[plane] * rb_scale : 0.0f;
   const size_t base = (size_t)plane * S;
   const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
   if (i0 >= S) return;
   auto one = [&](float xv, float g, float old) -> float {
+    g += rb;
     if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
     const float xh = (xv - mu) * is;
     float r = sc * (g - k1 - xh * k2);
@@ -266,7 +298,7 @@ extern "C" {
 
 size_t air_bn_ws_bytes(int B, int C, int S) {
   if (B <= 0 || C <= 0 || S <= 0) return 0;
-  return (size_t)C * splits_for(B, C) * 2 * sizeof(double);
+  return (size_t)C * splits_for(B, C) * NACC * sizeof(double);
 }
 
 int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, const float* gamma,
@@ -312,29 +344,38 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
   return AIR_OK;
 }
 
-int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float* mean,
-               const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
-               int dx_accum, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-               air_stream_t stream) {
+int air_bn_bwd_ex(const float* x, const float* dy, const float* dy_rowbias, float rowbias_scale, int B, int C,
+                  int S, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                  float* dx, int dx_accum, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                  air_stream_t stream) {
   if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 ||
       C <= 0 || S <= 0)
     return AIR_EINVAL;
+  if (dbias && !(relu & 2)) return AIR_EINVAL;  // the bias gradient is defined for conv -> ReLU -> BN layers
   if (!ws || ws_bytes < air_bn_ws_bytes(B, C, S)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, B, C, S,
-                     nsplit, mean, invstd, gamma, beta, relu & 1, partial);
+  const double invN = 1.0 / ((double)B * (double)S);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dy_rowbias, rowbias_scale, B,
+                     C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit,
-                     C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C, (double)(float)invN,
+                     gamma, invstd, dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, C, S,
-                     (float)(1.0 / ((double)B * (double)S)), mean, invstd, gamma, beta, dgamma,
-                     dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, dy_rowbias, rowbias_scale, C, S, (float)invN,
+                     mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float* mean,
+               const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
+               int dx_accum, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+               air_stream_t stream) {
+  return air_bn_bwd_ex(x, dy, nullptr, 0.0f, B, C, S, mean, invstd, gamma, beta, relu, dx, dx_accum, dgamma, dbeta,
+                       nullptr, ws, ws_bytes, stream);
 }
 
 int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream) {

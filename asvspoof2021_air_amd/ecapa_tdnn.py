@@ -286,11 +286,12 @@ class Res2Net2(nn.Module):
         dm, _, _ = ops.linear_bwd(S["m"], det(se[1].weight).view(se[1].out_channels, -1), dz1.view(B, -1), True,
                                   dw=gv("se.se.1.weight").view(se[1].out_channels, -1),
                                   db=gv("se.se.1.bias"))
-        ops.row_stats_bwd(S["o3"], S["m"], None, dm, None, do3, accumulate=True)
+        # the SE squeeze's gradient (d mean_T / d o3 = 1/T, ecapa_tdnn.py:19) enters bn3's backward as a
+        # per-(b, c) constant on the incoming gradient; the conv bias gradient comes out of the same pass
         st3 = S["st3"]
         dc3, _, _ = ops.bn_bwd(S["r3"], do3, st3[0], st3[1], det(blk.bn3.weight), det(blk.bn3.bias),
-                               relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"))
-        ops.channel_sum(dc3, out=gv("conv3.bias"))
+                               relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"),
+                               rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"))
         ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf)
         dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight), bf16=bf)
         do1 = torch.empty_like(dcat)
@@ -302,16 +303,16 @@ class Res2Net2(nn.Module):
             st_i = S["st"][i]
             dc_i, _, _ = ops.bn_bwd(S["r"][i], dsp, st_i[0], st_i[1], det(blk.bns[i].weight),
                                     det(blk.bns[i].bias), relu_in=True, dx=dsp,
-                                    dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i))
-            ops.channel_sum(dc_i, out=gv("convs.%d.bias" % i))
+                                    dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i),
+                                    dbias=gv("convs.%d.bias" % i))
             ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
             # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
             din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf)
             din_next = din if i > 0 else None
         st1 = S["st1"]
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),
-                               relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"))
-        ops.channel_sum(dc1, out=gv("conv1.bias"))
+                               relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"),
+                               dbias=gv("conv1.bias"))
         ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf)
         dinp = ops.conv1d_dgrad(dc1, det(blk.conv1.weight), bf16=bf)
         ops.add_strided(dinp, dinp, dout)  # residual branch (ecapa_tdnn.py:93)
@@ -356,8 +357,8 @@ class Res2Net2(nn.Module):
         stA = S["stA"]
         da1, _, _ = ops.bn_bwd(S["a1"], da1n, stA[0], stA[1], det(self.attention[2].weight),
                                det(self.attention[2].bias), relu_in=True, dx=da1n,
-                               dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"])
-        ops.channel_sum(da1, out=G["attention.0.bias"])
+                               dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"],
+                               dbias=G["attention.0.bias"])
         gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
         dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf)
         ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
@@ -379,8 +380,8 @@ class Res2Net2(nn.Module):
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1))
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),
-                               relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"])
-        ops.channel_sum(dc0, out=G["conv1.bias"])
+                               relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"],
+                               dbias=G["conv1.bias"])
         ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
         arena.tail_has_grad = have_tail
         return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]

@@ -120,10 +120,11 @@ def bn_apply(x, scale, shift, relu=False, out=None):
 
 
 def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=False,
-           dgamma=None, dbeta=None, relu_in=False):
+           dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None):
     """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta).
     relu_in: x is itself a ReLU output (conv -> ReLU -> BN); dx is then the gradient
-    w.r.t. the pre-ReLU tensor."""
+    w.r.t. the pre-ReLU tensor.  rowbias (B, C): the incoming gradient is dy + rowbias_scale *
+    rowbias[b, c] (broadcast over time).  dbias (C,): receives sum_{b,t} dx, the conv-bias gradient."""
     B, C, S = _bcs(x)
     if dx is None:
         if accumulate:
@@ -136,10 +137,12 @@ def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=Fal
     lib = _hip.lib()
     n = lib.air_bn_ws_bytes(ci(B), ci(C), ci(S))
     ws = workspace(n, x.device)
-    _hip.check(lib.air_bn_bwd(dptr(x), dptr(dy), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd),
-                              dptr(gamma), dptr(beta), ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
-                              ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
-                              dptr(ws, torch.uint8), csz(n), stream()), "air_bn_bwd")
+    _hip.check(lib.air_bn_bwd_ex(dptr(x), dptr(dy), dptr(rowbias, allow_none=True), cf(rowbias_scale), ci(B),
+                                 ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma), dptr(beta),
+                                 ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
+                                 ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
+                                 dptr(dbias, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()),
+               "air_bn_bwd_ex")
     return dx, dgamma, dbeta
 
 

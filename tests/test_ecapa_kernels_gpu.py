@@ -149,3 +149,33 @@ def test_bn_after_relu_backward(ops):
     close(d2, dy.double() * (r > 0), name="relu mask")
     lin = ops.linear_fwd(synth_feat((3, 40), 5).cuda(), synth_feat((7, 40), 6).cuda(), synth_feat((7,), 7).cuda(), relu=True)
     close(lin, F.relu(F.linear(synth_feat((3, 40), 5), synth_feat((7, 40), 6), synth_feat((7,), 7))), name="linear relu")
+
+
+@pytest.mark.parametrize("B,C,T", [(4, 64, 50), (6, 512, 75), (3, 128, 750)])
+def test_bn_backward_fused_bias_and_rowbias(ops, B, C, T):
+    """air_bn_bwd_ex: (a) the conv-bias gradient sum_{b,t} d(pre-ReLU) comes out of the statistics pass in
+    closed form; (b) a per-(b, c) constant added to the incoming gradient (the SE squeeze's 1/T term,
+    ecapa_tdnn.py:19) is applied inside both passes.  Reference: fp64 autograd of
+    y = BN(relu(conv_out + bias)), loss = <y, dy> + <mean_T(y), dm>."""
+    c = synth_feat((B, C, T), 1).double().requires_grad_(True)
+    bias = (0.3 * synth_feat((C,), 9)).double().requires_grad_(True)
+    gamma = (1 + 0.2 * synth_feat((C,), 2)).double()
+    beta = (0.1 * synth_feat((C,), 3)).double()
+    r = F.relu(c + bias[None, :, None])
+    y = F.batch_norm(r, None, None, gamma, beta, True, 0.1, 1e-5)
+    dy = synth_feat((B, C, T), 4)
+    dm = synth_feat((B, C), 5)
+    ((y * dy.double()).sum() + (y.mean(2) * dm.double()).sum()).backward()
+    rg = r.detach().float().cuda()
+    mean, invstd, _, _ = ops.bn_stats(rg, gamma.float().cuda(), beta.float().cuda())
+    dbias = torch.empty(C, device="cuda")
+    dc, dg, db = ops.bn_bwd(rg, dy.cuda(), mean, invstd, gamma.float().cuda(), beta.float().cuda(), relu=False,
+                            relu_in=True, rowbias=dm.cuda(), rowbias_scale=1.0 / T, dbias=dbias)
+    close(dc, c.grad, rtol=1e-4, name="d pre-relu with row bias")
+    close(dbias, bias.grad, rtol=1e-4, name="conv bias gradient (closed form)")
+    close(dbias, dc.sum(dim=(0, 2)).double(), rtol=1e-4, name="== channel sum of dx")
+    # in place (dx aliases dy), as the model calls it
+    d2 = dy.cuda().clone()
+    ops.bn_bwd(rg, d2, mean, invstd, gamma.float().cuda(), beta.float().cuda(), relu=False, relu_in=True, dx=d2,
+               rowbias=dm.cuda(), rowbias_scale=1.0 / T, dbias=dbias)
+    close(d2, c.grad, rtol=1e-4, name="in place")
