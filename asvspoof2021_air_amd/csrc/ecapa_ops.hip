@@ -117,7 +117,8 @@ __global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(NT) void row_stats_bwd_kernel(
     const float* __restrict__ x, size_t rows, int T, const float* __restrict__ mean,
     const float* __restrict__ std_, const float* __restrict__ dmean,
-    const float* __restrict__ dstd, float clamp_min, float* __restrict__ dx, int accumulate) {
+    const float* __restrict__ dstd, float clamp_min, float* __restrict__ dx, int accumulate, int relu_mask,
+    float* __restrict__ rowsum) {
   const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -128,9 +129,20 @@ __global__ __launch_bounds__(NT) void row_stats_bwd_kernel(
     const float sd = std_[row];
     if (sd * sd > clamp_min) k1 = dstd[row] / ((float)(T - 1) * sd);
   }
+  // relu_mask: x is a ReLU output (ecapa_tdnn.py:173) and dx the gradient w.r.t. its pre-activation;
+  // rowsum[row] = sum_t of the result (its sum over b is the conv bias gradient)
+  float s = 0.0f;
   for (int t = lane; t < T; t += 64) {
-    const float v = k0 + k1 * (x[row * T + t] - m);
-    dx[row * T + t] = accumulate ? dx[row * T + t] + v : v;
+    const float xv = x[row * T + t];
+    float v = k0 + k1 * (xv - m);
+    if (accumulate) v += dx[row * T + t];
+    if (relu_mask && !(xv > 0.0f)) v = 0.0f;
+    dx[row * T + t] = v;
+    s += v;
+  }
+  if (rowsum != nullptr) {
+    s = air_wave_sum(s);
+    if (lane == 0) rowsum[row] = s;
   }
 }
 
@@ -349,13 +361,13 @@ int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_o
 
 int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
                       const float* dmean, const float* dstd, float clamp_min, float* dx,
-                      int accumulate, air_stream_t stream) {
+                      int accumulate, int relu_mask, float* rowsum, air_stream_t stream) {
   if (!x || !mean || !dx || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
   if (dstd != nullptr && std_ == nullptr) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(row_stats_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
                      air_stream(stream), x, rows, T, mean, std_, dmean, dstd, clamp_min, dx,
-                     accumulate);
+                     accumulate, relu_mask, rowsum);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -368,9 +368,11 @@ class Res2Net2(nn.Module):
         ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
         dmean = dctx[:, :1536].contiguous()
         dstd = dctx[:, 1536:].contiguous()
-        ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True)
-        ops.relu_mask_(dx4, x4)  # ReLU after layer4 (:173)
-        ops.channel_sum(dx4, out=G["layer4.bias"])
+        # context-statistics gradient, the ReLU after layer4 (:173) and the per-row sums for the bias
+        # gradient in ONE pass over the (B, 1536, T) tensor
+        rows = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
+        ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows)
+        ops.sum_rows(rows, out=G["layer4.bias"])
         ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf)
         dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None

@@ -390,11 +390,14 @@ def row_stats(x, want_std=True, clamp_min=1e-4, mean_out=None, std_out=None):
     return mean, std
 
 
-def row_stats_bwd(x, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4):
+def row_stats_bwd(x, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4, relu_mask=False, rowsum=None):
+    """dx (+)= gradient of the per-row mean / std statistics; relu_mask zeroes the result where x == 0;
+    rowsum (B, C) receives the time sums of the result rows."""
     B, C, T = x.shape
     _hip.check(_hip.lib().air_row_stats_bwd(dptr(x), ci(B), ci(C), ci(T), dptr(mean), dptr(std, allow_none=True),
                                             dptr(dmean, allow_none=True), dptr(dstd, allow_none=True),
-                                            cf(clamp_min), dptr(dx), ci(1 if accumulate else 0), stream()),
+                                            cf(clamp_min), dptr(dx), ci(1 if accumulate else 0),
+                                            ci(1 if relu_mask else 0), dptr(rowsum, allow_none=True), stream()),
                "air_row_stats_bwd")
     return dx
 

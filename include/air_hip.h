@@ -268,9 +268,12 @@ int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* 
  * (ecapa_tdnn.py:19) and the context statistics (:178).  std may be NULL. */
 int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_or_null,
                   float clamp_min, air_stream_t stream);
+/* dx (+)= dmean/T + dstd * (x - mean) / ((T-1) std).  relu_mask != 0: x is a ReLU output and the result
+ * is zeroed where x == 0 (the stand-alone ReLU after layer4, ecapa_tdnn.py:173, folded in);
+ * rowsum (B*C) or NULL: sum over time of each result row (summed over b it is the conv bias gradient). */
 int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
                       const float* dmean, const float* dstd, float clamp_min, float* dx,
-                      int accumulate, air_stream_t stream);
+                      int accumulate, int relu_mask, float* rowsum_or_null, air_stream_t stream);
 /* dx *= (y > 0): backward of the stand-alone ReLU after layer4 (ecapa_tdnn.py:173). */
 int air_relu_mask(float* dx, const float* y, size_t n, air_stream_t stream);
 /* out[b][c] = sum_t x[b][c][t]: gradient of a per-utterance bias. */

@@ -88,6 +88,19 @@ def test_row_stats_and_bwd(ops):
     ops.row_stats_bwd(xg, m, s, dm.float().cuda(), ds.float().cuda(), dx, accumulate=True)
     close(dx, x.grad, rtol=1e-4, name="row stats bwd")
     close(ops.row_sum(xg), x.sum(2), name="row sum")
+    # fused form used after layer4 (ecapa_tdnn.py:173-178): x = relu(c); gradient w.r.t. c, plus per-row sums
+    c = synth_feat((B, C, T), 4).double().requires_grad_(True)
+    r = torch.relu(c)
+    up = synth_feat((B, C, T), 5)
+    ((r.mean(2) * dm + torch.sqrt(r.var(2).clamp(min=1e-4)) * ds).sum() + (r * up.double()).sum()).backward()
+    rg = r.detach().float().cuda()
+    m2, s2 = ops.row_stats(rg)
+    dxf = up.cuda().clone()
+    rows = torch.empty(B, C, device="cuda")
+    ops.row_stats_bwd(rg, m2, s2, dm.float().cuda(), ds.float().cuda(), dxf, accumulate=True, relu_mask=True, rowsum=rows)
+    close(dxf, c.grad, rtol=1e-4, name="row stats bwd + relu mask")
+    close(rows, c.grad.sum(2), rtol=1e-4, name="row sums")
+    close(ops.sum_rows(rows), c.grad.sum(dim=(0, 2)), rtol=1e-4, name="bias gradient")
 
 
 def test_se_scale(ops):
