@@ -189,7 +189,11 @@ __global__ __launch_bounds__(NT) void se_scale_bwd_kernel(const float* __restric
 
 // Attentive statistics pooling (ecapa_tdnn.py:143-185): per (b,c) row
 //   w = softmax_T(a);  mu = sum x w;  sg = sqrt(clamp(sum x^2 w - mu^2, 1e-4))
-// a is overwritten with w (saved for backward); out = [mu | sg] as (B, 2C)
+// a is overwritten with w (saved for backward); out = [mu | sg] as (B, 2C).
+// One wave per row.  Rows of up to 64 * ASP_R frames (the reference's 750 fits) are held in
+// registers: each tensor is read from memory once and every exp is evaluated once.
+constexpr int ASP_R = 16;
+template <bool CACHED>
 __global__ __launch_bounds__(NT) void asp_fwd_kernel(const float* __restrict__ x,
                                                      float* __restrict__ a, int C, int T,
                                                      float* __restrict__ out, size_t rows) {
@@ -199,19 +203,50 @@ __global__ __launch_bounds__(NT) void asp_fwd_kernel(const float* __restrict__ x
   const size_t b = row / C, c = row - b * C;
   float* __restrict__ pa = a + row * T;
   const float* __restrict__ px = x + row * T;
-  float m = -INFINITY;
-  for (int t = lane; t < T; t += 64) m = fmaxf(m, pa[t]);
-  m = air_wave_max(m);
-  float se = 0.0f;
-  for (int t = lane; t < T; t += 64) se += expf(pa[t] - m);
-  se = air_wave_sum(se);
   float s1 = 0.0f, s2 = 0.0f;
-  for (int t = lane; t < T; t += 64) {
-    const float w = expf(pa[t] - m) / se;
-    const float xv = px[t];
-    pa[t] = w;
-    s1 = fmaf(xv, w, s1);
-    s2 = fmaf(xv * xv, w, s2);
+  if (CACHED) {
+    float e[ASP_R], xv[ASP_R];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ASP_R; ++k) {
+      const int t = lane + 64 * k;
+      e[k] = t < T ? pa[t] : -INFINITY;
+      xv[k] = t < T ? px[t] : 0.0f;
+      m = fmaxf(m, e[k]);
+    }
+    m = air_wave_max(m);
+    float se = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ASP_R; ++k)
+      if (lane + 64 * k < T) {
+        e[k] = expf(e[k] - m);
+        se += e[k];
+      }
+    se = air_wave_sum(se);
+#pragma unroll
+    for (int k = 0; k < ASP_R; ++k) {
+      const int t = lane + 64 * k;
+      if (t < T) {
+        const float w = e[k] / se;
+        pa[t] = w;
+        s1 = fmaf(xv[k], w, s1);
+        s2 = fmaf(xv[k] * xv[k], w, s2);
+      }
+    }
+  } else {
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += 64) m = fmaxf(m, pa[t]);
+    m = air_wave_max(m);
+    float se = 0.0f;
+    for (int t = lane; t < T; t += 64) se += expf(pa[t] - m);
+    se = air_wave_sum(se);
+    for (int t = lane; t < T; t += 64) {
+      const float w = expf(pa[t] - m) / se;
+      const float xv = px[t];
+      pa[t] = w;
+      s1 = fmaf(xv, w, s1);
+      s2 = fmaf(xv * xv, w, s2);
+    }
   }
   s1 = air_wave_sum(s1);
   s2 = air_wave_sum(s2);
@@ -221,13 +256,15 @@ __global__ __launch_bounds__(NT) void asp_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// backward: given dout (B,2C): dx (accumulated into dx_acc) and da (written over w)
+// backward: given dout (B,2C): dx (accumulated into dx_acc) and da (written over w);
+// rowsum[row] (optional) = sum_t da: summed over b it is the gradient of attention.3's bias
+template <bool CACHED>
 __global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x,
                                                      float* __restrict__ w, int C, int T,
                                                      const float* __restrict__ out,
                                                      const float* __restrict__ dout,
                                                      float* __restrict__ dx, int accumulate,
-                                                     size_t rows) {
+                                                     float* __restrict__ rowsum, size_t rows) {
   const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -238,18 +275,48 @@ __global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x
   const float dm = dmu - 2.0f * mu * dq;
   float* __restrict__ pw = w + row * T;
   const float* __restrict__ px = x + row * T;
-  float dot = 0.0f;
-  for (int t = lane; t < T; t += 64) {
-    const float xv = px[t];
-    dot = fmaf(pw[t], dm * xv + dq * xv * xv, dot);
+  float dot = 0.0f, rs = 0.0f;
+  if (CACHED) {
+    float wv[ASP_R], xv[ASP_R];
+#pragma unroll
+    for (int k = 0; k < ASP_R; ++k) {
+      const int t = lane + 64 * k;
+      wv[k] = t < T ? pw[t] : 0.0f;
+      xv[k] = t < T ? px[t] : 0.0f;
+      if (t < T) dot = fmaf(wv[k], dm * xv[k] + dq * xv[k] * xv[k], dot);
+    }
+    dot = air_wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < ASP_R; ++k) {
+      const int t = lane + 64 * k;
+      if (t < T) {
+        const float dwv = dm * xv[k] + dq * xv[k] * xv[k];
+        const float g = dm * wv[k] + 2.0f * dq * xv[k] * wv[k];
+        dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
+        const float da = wv[k] * (dwv - dot);  // softmax backward
+        pw[t] = da;
+        rs += da;
+      }
+    }
+  } else {
+    for (int t = lane; t < T; t += 64) {
+      const float xv = px[t];
+      dot = fmaf(pw[t], dm * xv + dq * xv * xv, dot);
+    }
+    dot = air_wave_sum(dot);
+    for (int t = lane; t < T; t += 64) {
+      const float xv = px[t], wv = pw[t];
+      const float dwv = dm * xv + dq * xv * xv;
+      const float g = dm * wv + 2.0f * dq * xv * wv;
+      dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
+      const float da = wv * (dwv - dot);  // softmax backward
+      pw[t] = da;
+      rs += da;
+    }
   }
-  dot = air_wave_sum(dot);
-  for (int t = lane; t < T; t += 64) {
-    const float xv = px[t], wv = pw[t];
-    const float dwv = dm * xv + dq * xv * xv;
-    const float g = dm * wv + 2.0f * dq * xv * wv;
-    dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
-    pw[t] = wv * (dwv - dot);  // softmax backward
+  if (rowsum != nullptr) {
+    rs = air_wave_sum(rs);
+    if (lane == 0) rowsum[row] = rs;
   }
 }
 
@@ -398,18 +465,26 @@ int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* 
                 air_stream_t stream) {
   if (!x || !logits_to_w || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
-  hipLaunchKernelGGL(asp_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
-                     air_stream(stream), x, logits_to_w, C, T, out, rows);
+  if (T <= 64 * ASP_R)
+    hipLaunchKernelGGL(asp_fwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                       air_stream(stream), x, logits_to_w, C, T, out, rows);
+  else
+    hipLaunchKernelGGL(asp_fwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                       air_stream(stream), x, logits_to_w, C, T, out, rows);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
 
 int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
-                const float* dout, float* dx, int accumulate, air_stream_t stream) {
+                const float* dout, float* dx, int accumulate, float* rowsum, air_stream_t stream) {
   if (!x || !w_to_dlogits || !out || !dout || !dx || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
-  hipLaunchKernelGGL(asp_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
-                     air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rows);
+  if (T <= 64 * ASP_R)
+    hipLaunchKernelGGL(asp_bwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows);
+  else
+    hipLaunchKernelGGL(asp_bwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
+                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -349,9 +349,10 @@ class Res2Net2(nn.Module):
                                    dgamma=G["bn5.weight"], dbeta=G["bn5.bias"])
         x4, wts = S["x4"], S["wts"]
         dx4 = torch.empty_like(x4)
-        ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False)  # wts -> dlogits
+        rows3 = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
+        ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False, rowsum=rows3)  # wts -> dlogits
         a0, a3 = self.attention[0], self.attention[3]
-        ops.channel_sum(wts, out=G["attention.3.bias"])
+        ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
         ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf)
         da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
         stA = S["stA"]

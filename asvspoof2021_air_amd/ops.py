@@ -442,9 +442,10 @@ def asp_fwd(x, logits):
     return out
 
 
-def asp_bwd(x, w, out, dout, dx, accumulate=False):
-    """Overwrites ``w`` with d(logits); writes / accumulates dx."""
+def asp_bwd(x, w, out, dout, dx, accumulate=False, rowsum=None):
+    """Overwrites ``w`` with d(logits); writes / accumulates dx; rowsum (B, C) receives sum_t d(logits)."""
     B, C, T = x.shape
     _hip.check(_hip.lib().air_asp_bwd(dptr(x), dptr(w), ci(B), ci(C), ci(T), dptr(out), dptr(dout), dptr(dx),
-                                      ci(1 if accumulate else 0), stream()), "air_asp_bwd")
+                                      ci(1 if accumulate else 0), dptr(rowsum, allow_none=True), stream()),
+               "air_asp_bwd")
     return dx

@@ -288,8 +288,9 @@ int air_se_scale_bwd(const float* x, const float* z, const float* dout, size_t d
  * 1e-4)); out (B, 2C) = [mu | sg].  bwd overwrites w with d(logits). */
 int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* out,
                 air_stream_t stream);
+/* rowsum_or_null (B*C): sum over time of each d(logits) row (summed over b: attention.3's bias gradient). */
 int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
-                const float* dout, float* dx, int accumulate, air_stream_t stream);
+                const float* dout, float* dx, int accumulate, float* rowsum_or_null, air_stream_t stream);
 
 /* ----------------------------------------------------------- OC-Softmax ---
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
