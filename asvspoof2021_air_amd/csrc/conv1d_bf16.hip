@@ -544,7 +544,7 @@ int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
-  AirProfScope prof(AIR_K_C1B_FWD, 2.0 * B * T * (double)Cout * Cin * 3, st);
+  AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
   hipLaunchKernelGGL(c1b_tap_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
