@@ -99,6 +99,13 @@ def roofline_leg(trainer, batches):
             out["traffic_source"] = "profiles/r01_m_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)"
     except (OSError, KeyError, ValueError):
         pass
+    if dom["kernel"] == "c1b_fwd_kernel":
+        # ECAPA: the fused 512-channel pointwise kernel is HBM-bound on the fp32 tensors (127 FLOP per
+        # algorithmic byte < 312 FLOP/B machine balance): price it on bytes as well.  4*(Cin+Cout) bytes
+        # per 2*Cin*Cout FLOP = FLOPs / 128 at Cin = Cout = 512 (12 of its 16 launches per step).
+        gbs = dom["work"] / 128.0 / (dom["total_ms"] * 1e-3) / 1e9
+        out["hbm_view"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(gbs / PEAK_HBM_GBS, 4)}
     lf = [r for r in rows if r["kernel"] == "lfcc_kernel"]
     if lf:
         gbs = lf[0]["work"] / (lf[0]["total_ms"] * 1e-3) / 1e9
