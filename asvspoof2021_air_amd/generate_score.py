@@ -45,16 +45,54 @@ def batch_scores(model, lfcc, loss_model=None, add_loss=None):
     raise NotImplementedError("scoring with add_loss=%r is off the hot path (amsoftmax / p2sgrad heads)" % (add_loss,))
 
 
+class GraphedScorer:
+    """The eval-mode score of ONE fixed-shape batch captured in a hipGraph and replayed.
+
+    generate_score.py scores with ``DataLoader(batch_size=1)`` (:73): ~150 kernel launches of a few
+    microseconds each per utterance, i.e. launch-bound.  When the caller keeps that batch size, capture the
+    whole forward (model + loss score) once for the feature shape and replay it per utterance: one graph
+    launch instead of ~150 kernel launches.  The attention noise of resnet.py:38 is drawn ONCE at capture and
+    replayed (it is 1e-5-scale by construction); use ``model.set_attention_noise(None)`` for none."""
+
+    def __init__(self, model, example, loss_model=None, add_loss=None):
+        if not example.is_cuda:
+            raise ValueError("GraphedScorer needs a GPU example batch")
+        self.model, self.loss_model, self.add_loss = model.eval(), loss_model, add_loss
+        self.static_in = example.detach().clone().contiguous()
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up off the capture: arenas, workspaces, lazy module loads
+                for _ in range(2):
+                    batch_scores(self.model, self.static_in, loss_model, add_loss)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = batch_scores(self.model, self.static_in, loss_model, add_loss)
+
+    @torch.no_grad()
+    def __call__(self, lfcc):
+        """lfcc: model-layout features of the captured shape.  Returns the (B,) ``score`` tensor (a static
+        buffer: consume or clone it before the next call)."""
+        if tuple(lfcc.shape) != tuple(self.static_in.shape):
+            raise ValueError("GraphedScorer was captured for %s, got %s" % (tuple(self.static_in.shape), tuple(lfcc.shape)))
+        self.static_in.copy_(lfcc, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
 @torch.no_grad()
 def test_on_dataset(model, loader, score_file, loss_model=None, add_loss=None, task="19eval", ecapa=False,
-                    device="cuda", keep_dataset_labels=False):
+                    device="cuda", keep_dataset_labels=False, use_graph=False):
     """generate_score.py:75-119 over any iterable of dataset batches
     ``(lfcc:(B,1,feat_len,60), audio_fn, tag, labels[, channel])`` ('19' tasks) or
-    ``(lfcc, audio_fn)`` (2021 LA/DF eval).  Returns the number of lines written."""
+    ``(lfcc, audio_fn)`` (2021 LA/DF eval).  Returns the number of lines written.
+    use_graph: replay a captured hipGraph per batch shape (GraphedScorer) - for the reference's batch size 1."""
     model.eval()
     os.makedirs(os.path.dirname(os.path.abspath(score_file)), exist_ok=True)
     is19 = "19" in task
     n = 0
+    graphs = {}
     with open(score_file, "w") as fh:
         for data in loader:
             if is19:
@@ -65,7 +103,14 @@ def test_on_dataset(model, loader, score_file, loss_model=None, add_loss=None, t
             lfcc = lfcc.to(device).transpose(2, 3)
             if ecapa:
                 lfcc = lfcc.squeeze(1)
-            score = batch_scores(model, lfcc.contiguous(), loss_model, add_loss)
+            lfcc = lfcc.contiguous()
+            if use_graph:
+                key = tuple(lfcc.shape)
+                if key not in graphs:
+                    graphs[key] = GraphedScorer(model, lfcc, loss_model, add_loss)
+                score = graphs[key](lfcc)
+            else:
+                score = batch_scores(model, lfcc, loss_model, add_loss)
             vals = (-score).float().cpu().tolist()
             for j, v in enumerate(vals):
                 if is19:
