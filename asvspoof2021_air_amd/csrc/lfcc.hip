@@ -148,6 +148,7 @@ __device__ __constant__ const float W32S[16] = {
 
 struct LfccArgs {
   const float* pcm;
+  const short* pcm16;  // non-null: 16-bit PCM as stored in the corpus' wav/flac files; x = s / 32768 (exact)
   float* out;
   const LfccPlan* plan;
   const int* start;  // padded mode: per-utterance crop start (may be null)
@@ -176,13 +177,16 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
   const int maxw = plan->maxw;
   const int L = a.L, T = a.T;
   const float* __restrict__ row = a.pcm + (size_t)b * L;
+  const short* __restrict__ row16 = a.pcm16 ? a.pcm16 + (size_t)b * L : nullptr;
+  // sample m of this utterance as the float the reference's loader hands to LFCC.forward
+  auto sample = [&](long m) -> float { return row16 ? (float)row16[m] * (1.0f / 32768.0f) : row[m]; };
 
   // ---- stage tables and pre-emphasised PCM ---------------------------------
   for (int e = tid; e < MAXW * MAXF; e += NTHREADS) s_fbwT[e] = plan->fbwT[e];
   for (int e = tid; e < MAXF * MAXF; e += NTHREADS) s_dctT[e] = plan->dctT[e];
   const long s0 = (long)FS * (t0 - HALO) - FL / 2;  // first staged sample (may be < 0)
   const bool emph = (a.flags & FLAG_EMPH) != 0;
-  const bool vec_ok = ((((size_t)row) & 15) == 0);
+  const bool vec_ok = row16 == nullptr && ((((size_t)row) & 15) == 0);
   for (int e4 = tid; e4 < NSAMP / 4; e4 += NTHREADS) {
     const long n = s0 + 4 * (long)e4;
     float v[4];
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
         const long m = n + k;
         float x = 0.0f;
         if (m >= 0 && m < L) {
-          x = row[m];
-          if (emph && m > 0) x = __fsub_rn(x, __fmul_rn(0.97f, row[m - 1]));
+          x = sample(m);
+          if (emph && m > 0) x = __fsub_rn(x, __fmul_rn(0.97f, sample(m - 1)));
         }
         v[k] = x;
       }
@@ -418,12 +422,13 @@ __global__ __launch_bounds__(256) void pad_transpose_kernel(const float* feat, i
   }
 }
 
-int lfcc_launch(const float* pcm, int B, int L, float* out, int feat_len, const int* start,
+int lfcc_launch(const float* pcm, const short* pcm16, int B, int L, float* out, int feat_len, const int* start,
                 const void* plan_dev, int flags, hipStream_t stream) {
-  if (!pcm || !out || !plan_dev || B <= 0 || L <= 0) return AIR_EINVAL;
+  if ((!pcm && !pcm16) || !out || !plan_dev || B <= 0 || L <= 0) return AIR_EINVAL;
   const int T = 1 + L / FS;
   LfccArgs a;
   a.pcm = pcm;
+  a.pcm16 = pcm16;
   a.out = out;
   a.plan = reinterpret_cast<const LfccPlan*>(plan_dev);
   a.start = start;
@@ -436,7 +441,7 @@ int lfcc_launch(const float* pcm, int B, int L, float* out, int feat_len, const 
     // algorithmic bytes: fp32 PCM in + fp32 features out
     const int nf = (flags & FLAG_DELTA) ? 3 : 1;
     const double out_frames = (flags & FLAG_PADDED) ? (double)feat_len : (double)T;
-    AirProfScope ps(AIR_K_LFCC, 4.0 * B * ((double)L + out_frames * nf * 20.0), stream);
+    AirProfScope ps(AIR_K_LFCC, B * ((pcm16 ? 2.0 : 4.0) * L + 4.0 * out_frames * nf * 20.0), stream);
     hipLaunchKernelGGL(lfcc_kernel, dim3((unsigned)(B * a.tiles)), dim3(NTHREADS), 0, stream, a);
   }
   AIR_CHECK_LAUNCH();
@@ -501,7 +506,7 @@ int air_lfcc_plan_build(const float* fb_host, int nbin, int nfilt, const float* 
 
 int air_lfcc_fwd(const float* pcm, int B, int L, float* out, const void* plan_dev, int flags,
                  air_stream_t stream) {
-  return lfcc_launch(pcm, B, L, out, 0, nullptr, plan_dev,
+  return lfcc_launch(pcm, nullptr, B, L, out, 0, nullptr, plan_dev,
                      flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA), air_stream(stream));
 }
 
@@ -509,8 +514,17 @@ int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len
                         const int* start_dev, const void* plan_dev, int flags,
                         air_stream_t stream) {
   if (feat_len <= 0) return AIR_EINVAL;
-  return lfcc_launch(pcm, B, L, out, feat_len, start_dev, plan_dev,
+  return lfcc_launch(pcm, nullptr, B, L, out, feat_len, start_dev, plan_dev,
                      (flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA)) | FLAG_PADDED,
+                     air_stream(stream));
+}
+
+int air_lfcc_fwd_padded_i16(const int16_t* pcm16, int B, int L, float* out, int feat_len,
+                            const int* start_dev, const void* plan_dev, int flags, air_stream_t stream) {
+  // feat_len <= 0: the (B, T, D) layout of air_lfcc_fwd
+  return lfcc_launch(nullptr, reinterpret_cast<const short*>(pcm16), B, L, out, feat_len > 0 ? feat_len : 0,
+                     start_dev, plan_dev,
+                     (flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA)) | (feat_len > 0 ? FLAG_PADDED : 0),
                      air_stream(stream));
 }
 

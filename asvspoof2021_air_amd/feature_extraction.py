@@ -125,6 +125,8 @@ class LFCC(nn.Module):
     def forward(self, x):
         self._check(x)
         B, L = x.shape
+        if x.dtype == torch.int16:  # raw 16-bit PCM: nothing to mutate (the reference never sees integers)
+            return self._forward_i16(x, 0, None)
         T = 1 + L // self.fs
         src = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
         out = torch.empty((B, T, self.out_dim), device=x.device, dtype=torch.float32)
@@ -144,6 +146,8 @@ class LFCC(nn.Module):
         mutate ``x``.  ``start``: optional int32 (B,) crop offsets for T > feat_len."""
         self._check(x)
         B, L = x.shape
+        if x.dtype == torch.int16:
+            return self._forward_i16(x, feat_len, start)
         src = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
         out = torch.empty((B, self.out_dim, feat_len), device=x.device, dtype=torch.float32)
         lib = _hip.lib()
@@ -152,6 +156,22 @@ class LFCC(nn.Module):
                                            _hip.dptr(self.plan(x.device), torch.uint8),
                                            _hip.ci(self._flags()), _hip.stream()),
                    "air_lfcc_fwd_padded")
+        return out
+
+    def _forward_i16(self, x, feat_len, start):
+        """16-bit PCM straight from the wav/flac samples (x = s / 32768 inside the kernel: the floats
+        soundfile / librosa hand the reference), in either layout (feat_len 0 = (B, T, D))."""
+        B, L = x.shape
+        x = x.contiguous()
+        T = 1 + L // self.fs
+        shape = (B, self.out_dim, feat_len) if feat_len > 0 else (B, T, self.out_dim)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+        lib = _hip.lib()
+        _hip.check(lib.air_lfcc_fwd_padded_i16(_hip.dptr(x, torch.int16), _hip.ci(B), _hip.ci(L), _hip.dptr(out),
+                                               _hip.ci(feat_len), _hip.dptr(start, torch.int32, True),
+                                               _hip.dptr(self.plan(x.device), torch.uint8),
+                                               _hip.ci(self._flags()), _hip.stream()),
+                   "air_lfcc_fwd_padded_i16")
         return out
 
     def _preemph_inplace(self, x):

@@ -59,6 +59,12 @@ int air_lfcc_fwd(const float* pcm, int B, int L, float* out, const void* plan_de
  * T >= feat_len (chop; start_dev may be NULL = 0).  */
 int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len,
                         const int* start_dev, const void* plan_dev, int flags, air_stream_t stream);
+/* Same from 16-bit PCM as stored in the corpus' wav/flac files: the kernel converts s -> s / 32768 (exact, what
+ * soundfile/librosa hand the reference, preprocess.py:239-241), so the features are bit-identical to the fp32
+ * entry points on the converted samples while the kernel reads half the bytes (128 KB instead of 256 KB per
+ * 4 s utterance) and the caller uploads half as much.  feat_len <= 0 selects the (B, T, D) layout. */
+int air_lfcc_fwd_padded_i16(const int16_t* pcm16, int B, int L, float* out, int feat_len,
+                            const int* start_dev, const void* plan_dev, int flags, air_stream_t stream);
 /* The reference mutates its input (feature_extraction.py:106).  This applies
  * the same in-place x[n] -= coef*x[n-1] (n>=1).  ws: >= air_preemph_ws_bytes. */
 size_t air_preemph_ws_bytes(int B, int L);

@@ -132,3 +132,20 @@ def test_lfcc_rejects_cpu_and_energy(lfcc):
         lfcc(torch.zeros(1, 1600))
     with pytest.raises(NotImplementedError):
         LFCC(320, 160, 512, 16000, 20, with_energy=True).cuda()(torch.zeros(1, 1600).cuda())
+
+
+def test_lfcc_int16_pcm_is_bit_identical_to_float_path(lfcc):
+    """16-bit PCM entry point: features equal, bit for bit, those of the fp32 path on s / 32768 (the floats
+    soundfile hands the reference), in both layouts; half the input bytes."""
+    g = torch.Generator().manual_seed(11)
+    s16 = torch.randint(-32768, 32768, (5, 64000), generator=g, dtype=torch.int32).to(torch.int16)
+    s16[0, :7] = torch.tensor([-32768, 32767, 0, 1, -1, 12345, -12345], dtype=torch.int16)
+    xf = (s16.float() / 32768.0)
+    a = lfcc(s16.cuda())
+    b = lfcc(xf.cuda().clone())
+    assert a.shape == (5, 401, 60) and torch.equal(a, b)
+    ap = lfcc.forward_padded(s16.cuda(), 750)
+    bp = lfcc.forward_padded(xf.cuda(), 750)
+    assert ap.shape == (5, 60, 750) and torch.equal(ap, bp)
+    short = s16[:2, :4001].contiguous()  # odd length, tail tile
+    assert torch.equal(lfcc(short.cuda()), lfcc((short.float() / 32768.0).cuda()))
