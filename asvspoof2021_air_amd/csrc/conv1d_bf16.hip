@@ -655,7 +655,8 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
   if (!shape_ok(p)) return 0;
   size_t n = (size_t)p->Cout * p->Cin * sizeof(unsigned short);  // packed bf16 weights
   if (wide(p->Cout, p->Cin) || wide(p->Cin, p->Cout)) {
-    const size_t g = gemm_fwd_ws(p->B, p->Cout, p->Cin, p->T);  // symmetric in (Cout, Cin)
+    // forward transposes X (B x Tp x Cin), dgrad transposes dY (B x Tp x Cout): size for the larger one
+    const size_t g = gemm_fwd_ws(p->B, p->Cout, p->Cin > p->Cout ? p->Cin : p->Cout, p->T);
     if (g > n) n = g;
   }
   if (air_conv1d_bf16_supported(p, 2)) {

@@ -39,6 +39,8 @@ CASES = [  # (B, Cin, T, Cout)
     (2, 512, 750, 512),    # reference feat_len: 6 time tiles, last one 110 wide; 24 wgrad stages per utterance
     (5, 128, 401, 128),    # odd T (native 4 s frame count): scalar-load path of the wgrad kernel
     (1, 128, 1, 128),      # single frame
+    (2, 512, 40, 2048),    # asymmetric wide layers: forward and dgrad both on the GEMM path, transposed
+    (2, 2048, 40, 512),    # operand copies of different widths (workspace sized for the larger)
 ]
 
 
