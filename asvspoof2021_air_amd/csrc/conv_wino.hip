@@ -855,7 +855,8 @@ bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout) {
 
 int air_wino_wgrad_nsplit(int B, int Cin, int H, int W, int Cout) {
   const int nseg = B * ((H + 1) / 2) * (((W + 1) / 2 + WG_SEG - 1) / WG_SEG);
-  int n = 256 / ((Cin / 64) * (Cout / 64));
+  static const int total = getenv("AIR_WINO_WGRAD_WGS") ? atoi(getenv("AIR_WINO_WGRAD_WGS")) : 256;
+  int n = total / ((Cin / 64) * (Cout / 64));
   if (n < 1) n = 1;
   if (n > nseg) n = nseg;
   return n;

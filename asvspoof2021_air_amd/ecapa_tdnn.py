@@ -136,11 +136,21 @@ class Res2Net2(nn.Module):
         self.C = C
         self._arena = None
         self.compute_dtype = "fp32"
+        self._bucketer = None  # dist.GradBucketer when the all-reduce is overlapped with backward
+
+    def enable_ddp_overlap(self, bucket_bytes=8 << 20):
+        """Launch the gradient all-reduce from inside backward (one process per GPU, world size > 1):
+        layer4 + attention + bn5 + fc6 (15.7 of the 25 MB) leave as soon as layer4's weight gradient is
+        enqueued, underneath the three Bottle2neck blocks' backward."""
+        from .dist import GradBucketer
+        self._bucketer = GradBucketer(bucket_bytes)
+        return self
 
     def __getstate__(self):
         """Whole-module pickles (main_train.py:675-704): the flat arenas are rebuilt on first use."""
         st = dict(self.__dict__)
         st["_arena"] = None
+        st["_bucketer"] = None
         return st
 
     def set_compute_dtype(self, dtype):
@@ -375,12 +385,26 @@ class Res2Net2(nn.Module):
         ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows)
         ops.sum_rows(rows, out=G["layer4.bias"])
         ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf)
+        # data parallel: everything from layer4.weight to the end of the gradient arena is final
+        bucketer = getattr(self, "_bucketer", None)
+        offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
+
+        def grads_final_from(first_param):
+            if bucketer is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                bucketer.ready(offsets[first_param], [ev])
+
+        if bucketer is not None:
+            bucketer.reset(arena.grad, arena.head_total)
+        grads_final_from("layer4.weight")
         dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None
         for k in (2, 1, 0):
             dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
             ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1))
+            grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),
                                relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"],

@@ -28,33 +28,39 @@ def _free_port():
     return port
 
 
-def _make():
+def _make(kind="resnet"):
     from asvspoof2021_air_amd.loss import AngularIsoLoss
-    from asvspoof2021_air_amd.resnet import ResNet
     from asvspoof2021_air_amd.train import Trainer
-    m = ResNet(3, 256, resnet_type="18", nclasses=2)
-    fill_module_(m)
-    m.set_attention_noise(None)
+    if kind == "resnet":
+        from asvspoof2021_air_amd.resnet import ResNet
+        m = ResNet(3, 256, resnet_type="18", nclasses=2)
+        fill_module_(m)
+        m.set_attention_noise(None)
+    else:
+        from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+        m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+        fill_module_(m)
+        m.set_compute_dtype("bf16")
     lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
     fill_module_(lossm)
-    return Trainer(m, loss_module=lossm, feat_len=96)
+    return Trainer(m, loss_module=lossm, feat_len=96, ecapa=(kind == "ecapa"))
 
 
-def _shard(rank):
-    x = synth_feat((4, 1, 60, 96), seed=50 + rank)
+def _shard(rank, kind="resnet"):
+    x = synth_feat((4, 1, 60, 96) if kind == "resnet" else (4, 60, 96), seed=50 + rank)
     labels = torch.tensor([0, 1, 1, 0]) if rank == 0 else torch.tensor([1, 1, 0, 1])
     return x, labels
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, kind="resnet"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from asvspoof2021_air_amd import dist as air_dist
     torch.cuda.set_device(0)
     air_dist.init_from_env("gloo")
-    tr = _make()
+    tr = _make(kind)
     assert tr.world == world
-    x, labels = _shard(rank)
+    x, labels = _shard(rank, kind)
     loss, _ = tr.step_features(x.cuda(), labels.cuda())
     torch.cuda.synchronize()
     out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy(),
@@ -63,20 +69,21 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_equals_averaged_gradients():
+@pytest.mark.parametrize("kind", ["resnet", "ecapa"])
+def test_two_rank_step_equals_averaged_gradients(kind):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, kind), nprocs=world, join=True)
     (l0, w0, c0, nb0), (l1, w1, c1, nb1) = out[0], out[1]
     assert np.array_equal(w0, w1) and np.array_equal(c0, c1)  # ranks stay in lock-step, bit for bit
     # the all-reduce was overlapped with backward: layer4's buckets left before the backward pass ended
-    assert nb0 == nb1 and nb0 >= 2, (nb0, nb1)
+    assert nb0 == nb1 and nb0 >= (2 if kind == "resnet" else 1), (nb0, nb1)
     # single process: per-shard gradients, averaged by hand, one optimiser step
     grads, cgrads, losses = [], [], []
     for r in range(world):
-        tr = _make()
-        x, labels = _shard(r)
+        tr = _make(kind)
+        x, labels = _shard(r, kind)
         tr.model.train()
         feats, _ = tr.model(x.cuda())
         loss, _ = tr.loss(feats, labels.cuda())
@@ -85,7 +92,7 @@ def test_two_rank_step_equals_averaged_gradients():
         cgrads.append(tr.loss.center.grad.clone())
         losses.append(loss.item())
     np.testing.assert_allclose([l0, l1], losses, rtol=1e-6)
-    tr = _make()
+    tr = _make(kind)
     arena = tr.model.arena()
     for p in tr.model.parameters():
         p.grad = None
