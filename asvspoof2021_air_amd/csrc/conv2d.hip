@@ -797,6 +797,7 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   AIR_FWD_CASE(2, 2, 1, 8, AIR_K_CONV_FWD_CLS)
   // ECAPA-TDNN conv1d layers seen as H = 1 images (ecapa_tdnn.py:46,111)
   AIR_FWD_CASE(1, 5, 1, 8, AIR_K_CONV_FWD_1D)
+  AIR_FWD_CASE_D(1, 3, 1, 16, 1, AIR_K_CONV_FWD_CLS)  // one kernel row of a full-height conv's dgrad (conv5)
   AIR_FWD_CASE_D(1, 3, 1, 16, 2, AIR_K_CONV_FWD_1D)
   AIR_FWD_CASE_D(1, 3, 1, 16, 3, AIR_K_CONV_FWD_1D)
   AIR_FWD_CASE_D(1, 3, 1, 16, 4, AIR_K_CONV_FWD_1D)
@@ -980,6 +981,28 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
     return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
                          conv_flops(p), st);
+  }
+  if (p->sh == 1 && p->Ho == 1 && p->ph == 0 && p->KH == p->H && p->KH > 1 && p->KW == 3 && p->Cout % 16 == 0) {
+    // The kernel spans the whole image height (resnet.py:140 conv5: (num_nodes, 3) taps, no vertical padding,
+    // one output row): input row h only ever meets kernel row h.  As ONE KH x 3 convolution over the
+    // zero-padded single dy row, (KH-1)/KH of the MFMAs would multiply padding; instead every kernel row is
+    // its own dense 1 x 3 convolution of dy that writes row h of dx.
+    const size_t plane = (size_t)p->H * p->W;
+    const int ck = pick_ck(3, p->Cout);
+    const int mt = mt_for(p->B, 1, p->W, p->Cin);
+    for (int h = 0; h < p->KH; ++h) {
+      TapSel sel;
+      sel.n = 3;
+      for (int j = 0; j < 3; ++j) sel.idx[j] = h * 3 + (2 - j);  // flipped along w
+      int rc = pack(w, wp, p->Cout, p->Cin, taps, 1, ck, mt, sel, st);
+      if (rc != AIR_OK) return rc;
+      FwdGeom g = plain_geom(p->B, p->Cout, 1, p->Wo, p->Cin, 1, 3, 1, 0, 2 - p->pw, 1, p->W);
+      g.oh_mul = 1; g.ow_row = p->W; g.ow_mul = 1; g.o_off = h * p->W; g.oplane = plane;
+      g.y_bstride = (size_t)p->Cin * plane;
+      rc = run_fwd(dy, wp, dx, nullptr, nullptr, 0, accumulate, g, ck, mt, conv_flops(p) / p->KH, st);
+      if (rc != AIR_OK) return rc;
+    }
+    return AIR_OK;
   }
   if (p->sh == 1) {
     // stride 1: dx = conv(dy, flipped taps) with padding K-1-p

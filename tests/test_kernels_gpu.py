@@ -45,6 +45,7 @@ CONVS = [
     (2, 64, 18, 75, 128, (1, 1), 2, (0, 0)),    # layer2.0.shortcut
     (2, 256, 5, 47, 512, (1, 1), 2, (0, 0)),    # layer4.0.shortcut-like
     (2, 512, 3, 94, 256, (3, 3), 1, (0, 1)),    # conv5
+    (3, 512, 3, 47, 256, (3, 3), 1, (0, 1)),    # conv5 geometry, odd width (dgrad = three 1x3 row convs)
 ]
 
 
