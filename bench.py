@@ -89,14 +89,14 @@ def roofline_leg(trainer, batches):
            "all_conv_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                 "ms_per_step": round(all_ms / 2, 3)}}
     # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command: profiles/r01_m_pmc_traffic.md)
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command: profiles/r01_n_pmc_traffic.md)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_m_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         model_key = "ecapa" if dom["kernel"].startswith("c1b") else "resnet"
         if BATCH == (128 if model_key == "ecapa" else 64) and FEAT_LEN == 750:  # the measured configuration only
             out["traffic"] = round(pmc[model_key][dom["kernel"]]["traffic_bytes_per_launch"])
-            out["traffic_source"] = "profiles/r01_m_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)"
+            out["traffic_source"] = "profiles/r01_n_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)"
     except (OSError, KeyError, ValueError):
         pass
     if dom["kernel"] == "c1b_fwd_kernel":
