@@ -152,8 +152,8 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
 //   dx = [x > 0] * gamma*invstd * (g - dbeta/N - xhat * dgamma/N).
 constexpr int NACC = 6;
 __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ rowbias,
-    float rb_scale, int B, int C, int S, int nsplit,
+    const float* __restrict__ x, const float* __restrict__ dy, size_t dy_bs, const float* __restrict__ dy2,
+    size_t dy2_bs, const float* __restrict__ rowbias, float rb_scale, int B, int C, int S, int nsplit,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int want_bias,
     double* __restrict__ partial) {
@@ -167,10 +167,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
   double d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
   for (int b = b0; b < b1; ++b) {
     const float* __restrict__ px = x + ((size_t)b * C + c) * S;
-    const float* __restrict__ pg = dy + ((size_t)b * C + c) * S;
+    const float* __restrict__ pg = dy + (size_t)b * dy_bs + (size_t)c * S;
+    const float* __restrict__ pg2 = dy2 ? dy2 + (size_t)b * dy2_bs + (size_t)c * S : nullptr;
     const float rb = rowbias ? rowbias[(size_t)b * C + c] * rb_scale : 0.0f;
     float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
-    if (!want_bias && (S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
+    if (!want_bias && pg2 == nullptr && (S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
       const float4* __restrict__ px4 = reinterpret_cast<const float4*>(px);
       const float4* __restrict__ pg4 = reinterpret_cast<const float4*>(pg);
       for (int i = threadIdx.x; i < S / 4; i += NT) {
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
       for (int i = threadIdx.x; i < S; i += NT) {
         const float xv = px[i];
         float g = pg[i] + rb;
+        if (pg2) g += pg2[i];
         if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
         const float xh = (xv - mu) * is;
         s1 += g;
@@ -244,8 +246,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
 // backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
 // (dy and dx may alias: the in-place gradient joins of resnet.py / ecapa_tdnn.py)
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
-    const float* __restrict__ x, const float* dy, const float* __restrict__ rowbias, float rb_scale, int C,
-    int S, float invN,
+    const float* __restrict__ x, const float* dy, size_t dy_bs, const float* dy2, size_t dy2_bs,
+    const float* __restrict__ rowbias, float rb_scale, int C, int S, float invN,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
@@ -258,6 +260,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   const float k1 = dbeta[c] * invN, k2 = dgamma[c] * invN;
   const float rb = rowbias ? rowbias[plane] * rb_scale : 0.0f;
   const size_t base = (size_t)plane * S;
+  const int bb = plane / C;
+  const float* pdy = dy + (size_t)bb * dy_bs + (size_t)c * S;               // may alias dx (in-place joins)
+  const float* pdy2 = dy2 ? dy2 + (size_t)bb * dy2_bs + (size_t)c * S : nullptr;
   const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
   if (i0 >= S) return;
   auto one = [&](float xv, float g, float old) -> float {
@@ -268,10 +273,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     if (relu_in && !(xv > 0.0f)) r = 0.0f;  // x = relu(c): no gradient where the ReLU clipped
     return accum ? r + old : r;
   };
-  if (i0 + 3 < S && ((base + i0) & 3) == 0 &&
-      ((((size_t)x) | ((size_t)dy) | ((size_t)dx)) & 15) == 0) {
+  if (pdy2 == nullptr && i0 + 3 < S && ((base + i0) & 3) == 0 &&
+      ((((size_t)x) | ((size_t)(pdy + i0)) | ((size_t)dx)) & 15) == 0) {
     const float4 xv = *reinterpret_cast<const float4*>(x + base + i0);
-    const float4 gv = *reinterpret_cast<const float4*>(dy + base + i0);
+    const float4 gv = *reinterpret_cast<const float4*>(pdy + i0);
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
     if (accum) ov = *reinterpret_cast<const float4*>(dx + base + i0);
     float4 r;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     *reinterpret_cast<float4*>(dx + base + i0) = r;
   } else {
     for (int i = i0; i < min(S, i0 + 4); ++i)
-      dx[base + i] = one(x[base + i], dy[base + i], accum ? dx[base + i] : 0.0f);
+      dx[base + i] = one(x[base + i], pdy[i] + (pdy2 ? pdy2[i] : 0.0f), accum ? dx[base + i] : 0.0f);
   }
 }
 
@@ -344,10 +349,10 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
   return AIR_OK;
 }
 
-int air_bn_bwd_ex(const float* x, const float* dy, const float* dy_rowbias, float rowbias_scale, int B, int C,
-                  int S, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
-                  float* dx, int dx_accum, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                  air_stream_t stream) {
+int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                  const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                  const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 ||
       C <= 0 || S <= 0)
     return AIR_EINVAL;
@@ -357,14 +362,17 @@ int air_bn_bwd_ex(const float* x, const float* dy, const float* dy_rowbias, floa
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
   const double invN = 1.0 / ((double)B * (double)S);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dy_rowbias, rowbias_scale, B,
-                     C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
+  const size_t dense = (size_t)C * S;
+  const size_t dbs = dy_bstride ? dy_bstride : dense, d2bs = dy2_bstride ? dy2_bstride : dense;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
+                     rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C, (double)(float)invN,
                      gamma, invstd, dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, dy_rowbias, rowbias_scale, C, S, (float)invN,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale, C, S,
+                     (float)invN,
                      mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
@@ -374,8 +382,8 @@ int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float
                const float* invstd, const float* gamma, const float* beta, int relu, float* dx,
                int dx_accum, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                air_stream_t stream) {
-  return air_bn_bwd_ex(x, dy, nullptr, 0.0f, B, C, S, mean, invstd, gamma, beta, relu, dx, dx_accum, dgamma, dbeta,
-                       nullptr, ws, ws_bytes, stream);
+  return air_bn_bwd_ex(x, dy, 0, nullptr, 0, nullptr, 0.0f, B, C, S, mean, invstd, gamma, beta, relu, dx, dx_accum,
+                       dgamma, dbeta, nullptr, ws, ws_bytes, stream);
 }
 
 int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream) {

@@ -308,13 +308,14 @@ class Res2Net2(nn.Module):
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
         din_next = None
         for i in reversed(range(nums)):
-            dsp = torch.empty((B, w, T), device=dcat.device, dtype=torch.float32)
-            ops.add_strided(dsp, dcat[:, i * w:(i + 1) * w], din_next)
+            # d(sp_i) = d(cat slice i) + d(input of branch i + 1): both are channel-slice views and the sum is
+            # formed inside the BatchNorm backward passes
             st_i = S["st"][i]
-            dc_i, _, _ = ops.bn_bwd(S["r"][i], dsp, st_i[0], st_i[1], det(blk.bns[i].weight),
-                                    det(blk.bns[i].bias), relu_in=True, dx=dsp,
-                                    dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i),
-                                    dbias=gv("convs.%d.bias" % i))
+            dc_i = torch.empty((B, w, T), device=dcat.device, dtype=torch.float32)
+            ops.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], st_i[0], st_i[1], det(blk.bns[i].weight),
+                       det(blk.bns[i].bias), relu_in=True, dx=dc_i, dy2=din_next,
+                       dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i),
+                       dbias=gv("convs.%d.bias" % i))
             ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
             # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
             din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf)

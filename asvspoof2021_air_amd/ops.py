@@ -120,12 +120,18 @@ def bn_apply(x, scale, shift, relu=False, out=None):
 
 
 def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=False,
-           dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None):
+           dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None, dy2=None):
     """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta).
     relu_in: x is itself a ReLU output (conv -> ReLU -> BN); dx is then the gradient
     w.r.t. the pre-ReLU tensor.  rowbias (B, C): the incoming gradient is dy + rowbias_scale *
-    rowbias[b, c] (broadcast over time).  dbias (C,): receives sum_{b,t} dx, the conv-bias gradient."""
+    rowbias[b, c] (broadcast over time).  dbias (C,): receives sum_{b,t} dx, the conv-bias gradient.
+    dy (and the optional second gradient dy2, added on the fly) may be channel-slice views."""
     B, C, S = _bcs(x)
+    if dy.dim() == 3 and (dy2 is not None or not dy.is_contiguous()):
+        dyp, dyb = vptr(dy)
+        dy2p, dy2b = vptr(dy2) if dy2 is not None else (ctypes.c_void_p(0), 0)
+    else:
+        dyp, dyb, dy2p, dy2b = dptr(dy), 0, ctypes.c_void_p(0), 0
     if dx is None:
         if accumulate:
             raise _hip.AirError("bn_bwd: accumulate needs an existing dx")
@@ -137,8 +143,9 @@ def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=Fal
     lib = _hip.lib()
     n = lib.air_bn_ws_bytes(ci(B), ci(C), ci(S))
     ws = workspace(n, x.device)
-    _hip.check(lib.air_bn_bwd_ex(dptr(x), dptr(dy), dptr(rowbias, allow_none=True), cf(rowbias_scale), ci(B),
-                                 ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma), dptr(beta),
+    _hip.check(lib.air_bn_bwd_ex(dptr(x), dyp, csz(dyb), dy2p, csz(dy2b), dptr(rowbias, allow_none=True),
+                                 cf(rowbias_scale), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma),
+                                 dptr(beta),
                                  ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
                                  ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
                                  dptr(dbias, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()),

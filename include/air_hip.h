@@ -212,15 +212,18 @@ int air_bn_bwd(const float* x, const float* dy, int B, int C, int S,
                const float* mean, const float* invstd, const float* gamma, const float* beta,
                int relu, float* dx, int dx_accum, float* dgamma, float* dbeta,
                void* ws, size_t ws_bytes, air_stream_t stream);
-/* Same with two fusions for the conv -> ReLU -> BN layers of ecapa_tdnn.py:
+/* Same with three fusions for the conv -> ReLU -> BN layers of ecapa_tdnn.py:
+ *  - dy may be a channel-slice view (dy_bstride = batch stride in floats, 0 = dense) and a second gradient dy2
+ *    (same shape, own batch stride, may be NULL) is added to it on the fly: the Res2 chain's
+ *    "d(sp_i) = d(cat slice) + d(next branch input)" join (ecapa_tdnn.py:78-83) without a pass that forms the sum;
  *  - dy_rowbias (B*C) or NULL: the incoming gradient is dy + rowbias_scale * dy_rowbias[b][c] - the SE
  *    squeeze's mean-over-time gradient (ecapa_tdnn.py:19: d mean / d x = 1/T) without a pass that adds it;
  *  - dbias (C) or NULL (needs relu bit 1): gradient of the conv bias, sum_{b,s} dx, obtained in closed
  *    form from three extra sums of the statistics pass - no pass over dx. */
-int air_bn_bwd_ex(const float* x, const float* dy, const float* dy_rowbias, float rowbias_scale, int B, int C,
-                  int S, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
-                  float* dx, int dx_accum, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                  air_stream_t stream);
+int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                  const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                  const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, air_stream_t stream);
 
 /* ------------------------------------------------------------- pooling ---
  * SelfAttention.forward (resnet.py:23-46) on x (B, C, T) (the squeezed conv5

@@ -192,3 +192,13 @@ def test_bn_backward_fused_bias_and_rowbias(ops, B, C, T):
     ops.bn_bwd(rg, d2, mean, invstd, gamma.float().cuda(), beta.float().cuda(), relu=False, relu_in=True, dx=d2,
                rowbias=dm.cuda(), rowbias_scale=1.0 / T, dbias=dbias)
     close(d2, c.grad, rtol=1e-4, name="in place")
+    # the incoming gradient as the sum of two channel-slice views (the Res2 chain's join)
+    big1 = synth_feat((B, 3 * C, T), 11).cuda()
+    big2 = synth_feat((B, 2 * C, T), 12).cuda()
+    part = dy.cuda() - big2[:, C:]
+    big1[:, C:2 * C] = part
+    dx3 = torch.empty(B, C, T, device="cuda")
+    ops.bn_bwd(rg, big1[:, C:2 * C], mean, invstd, gamma.float().cuda(), beta.float().cuda(), relu=False, relu_in=True,
+               dx=dx3, dy2=big2[:, C:], rowbias=dm.cuda(), rowbias_scale=1.0 / T, dbias=dbias)
+    close(dx3, c.grad, rtol=1e-4, name="two strided gradients joined")
+    close(dbias, bias.grad, rtol=1e-4, name="bias gradient, joined gradients")
