@@ -241,6 +241,10 @@ def main():
         dt = float(t.item())
     loss_val = float(last.item())
 
+    # The instrumented roofline steps are ordinary train steps: with world > 1 they contain the gradient
+    # all-reduce, so EVERY rank runs them (rank 0 alone would wait for its peers forever); only rank 0 reports.
+    roofline = None if args.no_roofline else roofline_leg(trainer, batches)
+
     if rank == 0:
         line = {
             "metric": "utterances/sec (LFCC+ResNet-OCSoftmax train step, 4 s@16 kHz)",
@@ -266,8 +270,8 @@ def main():
                            "fp32 compute (the reference's arithmetic; configs[2] itself is the bf16 variant)"))
         if args.augment:
             line["config"]["workload"] += "; + on-the-fly IR convolution (1024 taps) of every utterance ahead of LFCC"
-        if not args.no_roofline:
-            line["roofline"] = roofline_leg(trainer, batches)
+        if roofline is not None:
+            line["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline and args.model == "resnet":
             line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line), flush=True)

@@ -111,7 +111,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-roofline", "--batch", "8"]
+           "--warmup", "1", "--batch", "8"]  # default flags otherwise: the roofline leg runs on every rank
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -120,3 +120,4 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+    assert d["roofline"]["kernel"].startswith(("wino", "conv")) and d["roofline"]["achieved"] > 0
