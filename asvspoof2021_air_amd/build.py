@@ -18,8 +18,14 @@ LIB = os.path.join(LIBDIR, "libair_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-          "-I" + CSRC, "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+          "-I" + CSRC, "-Wall", "-Wno-unused-function", "-Wno-inline-asm", "-ffp-contract=off"]
 # -ffp-contract=off: the oracle is plain fp32; kernels that want FMAs say fmaf().
+
+
+# per-file extra flags (A/B knobs for single kernels)
+# conv_wino4.hip: the SLP vectoriser packs the Winograd transforms into v_pk_* plus register shuffles,
+# which is slower beside the f32 MFMAs than the scalar form (MI355X_MICROARCH.md, packed f32 VALU)
+EXTRA = {"conv_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -45,7 +51,7 @@ def build(verbose=True, force=False):
         o = os.path.join(OBJ, src[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + CFLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + CFLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

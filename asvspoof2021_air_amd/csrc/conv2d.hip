@@ -931,6 +931,9 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
     const size_t wf = air_wino_packed_elems(p->Cout, p->Cin), wd = air_wino_packed_elems(p->Cin, p->Cout);
     if (wf > fwd) fwd = wf;
     if (wd > dgrad) dgrad = wd;
+    const size_t wf4 = air_wino4_packed_elems(p->Cout, p->Cin), wd4 = air_wino4_packed_elems(p->Cin, p->Cout);
+    if (wf4 > fwd) fwd = wf4;  // F(4x4,3x3): 36/9 the size
+    if (wd4 > dgrad) dgrad = wd4;
   }
   size_t wgrad = (size_t)wgrad_nsplit(p) * wsz;
   if (wino_shape(p) && air_wino_wgrad_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
@@ -970,6 +973,11 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
   if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
   float* wp = reinterpret_cast<float*>(ws);
+  if (in_scale == nullptr && wino_shape(p) && air_wino4_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    if (ws_bytes < air_wino4_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    return air_wino4_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
+                          conv_flops(p), st);
+  }
   if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
     if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
     return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
@@ -999,6 +1007,11 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
   float* wp = reinterpret_cast<float*>(ws);
   const int taps = p->KH * p->KW;
   // roles swap: "input" channels = Cout, "output" channels = Cin
+  if (wino_shape(p) && air_wino4_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
+    if (ws_bytes < air_wino4_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
+                          conv_flops(p), st);
+  }
   if (wino_shape(p) && air_wino_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
     if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
     return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,

@@ -23,3 +23,10 @@ bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout);
 int air_wino_wgrad_nsplit(int B, int Cin, int H, int W, int Cout);
 int air_wino_wgrad_partials(const float* x, const float* dy, float* partial, int B, int Cin, int H,
                             int W, int Cout, double flops, hipStream_t st);
+
+// Winograd F(4x4,3x3) forward / data-gradient kernel (conv_wino4.hip): same contract as air_wino_conv with
+// its own packing (36 transformed weights per (co, ci)); preferred over F(2x2,3x3) where it applies.
+bool air_wino4_ok(int B, int Kc, int H, int W, int M);
+size_t air_wino4_packed_elems(int M, int Kc);
+int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
+                   int W, int M, int dgrad, float* up, double flops, hipStream_t st);

@@ -1,0 +1,668 @@
+// 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4,3x3) on the f32 MFMA of gfx950.
+//
+// Replaces the 3x3 nn.Conv2d of PreActBlock (resnet.py:56-61) in forward and data-gradient direction.
+// Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A with 6x6 transformed tiles: 36 multiplies per 4x4 output
+// tile instead of 144 (F(2x2,3x3) in conv_wino.hip: 16 per 2x2 = 64 per 4x4), i.e. 36 independent GEMMs
+//   M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile]
+// run as v_mfma_f32_16x16x4_f32 (16 co x 16 tiles x 4 ci, 32 cycles):
+//   * a wave owns 32 output channels (2 MFMA row blocks) x 16 tiles: 72 accumulators x 4 registers = 288,
+//     of which 64 are pinned to the AGPR half of the register file and 8 to VGPRs through inline-asm
+//     constraints (left to the compiler, 288 accumulators get shuffled between the two halves);
+//   * the f32 MFMA shares the issue port with the VALU on this part (tools/ubench/mfma16_rot.hip: 32 cycles
+//     per MFMA + 4 per VALU instruction, +10 for every MFMA -> VALU -> MFMA switch), so nothing is gained
+//     by interleaving: a k-step is [72 MFMAs with the 18 ds_read_b128 of their A operands running three
+//     groups ahead] then [the 6x6 input transform of the next step as one batch of 144 VALU operations]:
+//     3250 cycles per k-step in isolation (tools/ubench/wino4_loop.hip) against 2304 for the bare MFMAs;
+//   * a lane transforms the patch of ITS tile and ITS input channel (the B operand layout of the MFMA:
+//     lane = 16 ci + tile), read from LDS-staged image rows; transformed weights come pre-packed from a
+//     small transform kernel; nothing transformed ever touches HBM; the output transform is per lane.
+//   * staging is hand-issued LDS-DMA (buffer_load_dwordx4 ... lds): 16-byte chunks aligned to image columns
+//     that are multiples of 4, so a chunk is inside or outside the row as a whole (outside = the buffer's
+//     out-of-range rule = zero padding); only the chunk that straddles the right edge when W % 4 != 0
+//     brings the next row's first pixels, and the reading wave zeroes those cells in LDS.
+//   * weights (U) and patches run through separate 3-deep LDS rings: the patch of step s+1 is read during
+//     step s (transform) and U(s) during step s (MFMA operands), so at step s the DMAs of U(s+2) and
+//     patch(s+3) are issued and everything lands two steps (about 3 us) before it is read.
+// A workgroup = 4 waves = 4 tile groups sharing one 32-channel weight slab; persistent workgroups walk
+// contiguous work items (32 channels x 4 groups) and the k-step stream runs on across item boundaries.
+// Tile groups are 1 x 16 or 2 x 8 tiles of the image rows STACKED over the batch (tile row = b * TH + th),
+// so short images (layer4: 3 x 94) fill the 16-tile MFMA width with tiles of two images.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "air_common.h"
+#include "air_lds_dma.h"
+#include "air_prof.h"
+#include "conv_wino.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4_CO = 32;                       // output channels per workgroup
+constexpr int W4_CK = 4;                        // input channels per k-step (MFMA K)
+constexpr int W4_NP = 36;                       // Winograd positions
+constexpr int W4_USLAB = W4_CK * W4_CO * W4_NP;  // floats of transformed weights per k-step: [ci][co][36]
+constexpr int W4_ULDS = 5120;                   // LDS pitch of a slab: 5 x 16-byte DMAs per thread
+constexpr int W4_NU = 5;
+constexpr int W4_NI = 8;                        // patch DMAs per thread: 4 groups x 4 planes x 128 chunks
+constexpr int W4_ND = W4_NU + W4_NI;
+constexpr int W4_PLF = 512;                     // floats per (group, ci) plane (multiple of 64: bank-aligned)
+constexpr int W4_GRPF = W4_CK * W4_PLF;         // floats per tile group
+constexpr int W4_PATCHF = 4 * W4_GRPF;          // floats per patch buffer
+constexpr int W4_NBUF = 3;
+constexpr unsigned W4_OOB = 0x80000000u;        // byte offset beyond any tensor we accept: reads as zero
+
+template <int TRG>
+struct W4Cfg {
+  static constexpr int TCG = 16 / TRG;          // tile columns of a group
+  static constexpr int RC = TCG + 2;            // 16-byte chunks per staged row: columns 4 TCG twg - 4 ...
+  static constexpr int ROWF = 4 * RC;           // floats per staged row
+  static constexpr int BANDC = 6 * RC;          // chunks per band (6 input rows of one tile row)
+  static constexpr int BANDF = 4 * BANDC;
+  static_assert(TRG * BANDC <= 128, "a plane holds 128 chunks");
+};
+
+// U = G g G^T in double, rounded once.  Packed [cot][chunk][ci 4][co 32][36].
+__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int Kc,
+                                     int dgrad) {
+  const int nchunk = Kc / W4_CK;
+  const size_t total = (size_t)M * Kc;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % W4_CO);
+    size_t r = e / W4_CO;
+    const int k = (int)(r % Kc);
+    const int cot = (int)(r / Kc);
+    const int m = cot * W4_CO + col;
+    double g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      g[t] = dgrad ? w[((size_t)k * M + m) * 9 + (8 - t)] : w[((size_t)m * Kc + k) * 9 + t];
+    double tmp[6][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+      tmp[0][c] = g0 / 4.0;
+      tmp[1][c] = -(g0 + g1 + g2) / 6.0;
+      tmp[2][c] = -(g0 - g1 + g2) / 6.0;
+      tmp[3][c] = g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
+      tmp[4][c] = g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
+      tmp[5][c] = g2;
+    }
+    float* o = up + ((((size_t)cot * nchunk + k / W4_CK) * W4_CK + k % W4_CK) * W4_CO + col) * W4_NP;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double g0 = tmp[i][0], g1 = tmp[i][1], g2 = tmp[i][2];
+      o[6 * i + 0] = (float)(g0 / 4.0);
+      o[6 * i + 1] = (float)(-(g0 + g1 + g2) / 6.0);
+      o[6 * i + 2] = (float)(-(g0 - g1 + g2) / 6.0);
+      o[6 * i + 3] = (float)(g0 / 24.0 + g1 / 12.0 + g2 / 6.0);
+      o[6 * i + 4] = (float)(g0 / 24.0 - g1 / 12.0 + g2 / 6.0);
+      o[6 * i + 5] = (float)g2;
+    }
+  }
+}
+
+struct W4Args {
+  const float* x;         // (B, Cin, H, W)
+  const float* up;        // packed transformed weights
+  float* y;               // (B, Cout, H, W)
+  const float* residual;  // same shape as y (may be null)
+  int B, Cin, H, W, Cout;
+  int TH, TW;             // 4x4 output tiles per image
+  int SR;                 // stacked tile rows: B * TH
+  int GRR, TWG;           // group rows (of TRG stacked tile rows), group columns
+  int ngroups;            // GRR * TWG
+  int ncot;               // Cout / 32
+  int nitems;             // work items: ceil(ngroups / 4) * ncot, numbered cot-fastest
+  int dbg;                // debug ablations (AIR_WINO4_DBG): 1 no restaging, 2 no wait/barrier, 4 no transform
+  int stagger;            // rotate each workgroup's k-step stream (see the kernel)
+  long long* trace;       // debug: cycle totals of workgroup 0 (null in production)
+};
+
+__device__ __forceinline__ i32x4 w4_rsrc(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32));  // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+// One DMA = 3 instructions: M0 = (wave's LDS base in the target buffer) + MIMM, wait state, load.
+template <int MIMM>
+__device__ __forceinline__ void w4_dma16(i32x4 rsrc, unsigned soff, unsigned mbase, unsigned v0) {
+  asm volatile("s_add_i32 m0, %1, %4\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %3, %0, %2 offen lds"
+               :: "s"(rsrc), "s"(mbase), "s"(soff), "v"(v0), "n"(MIMM) : "memory", "m0", "scc");
+}
+template <int N>
+__device__ __forceinline__ void w4_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// accumulate / start (C = 0) forms, accumulator pinned to the AGPR ("a") or VGPR ("v") half
+#define W4_MFMA_A(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define W4_MFMA_V(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define W4_MFMA_A0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
+// (early clobber: a fresh VGPR destination must not share registers with the A / B operands)
+#define W4_MFMA_V0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
+
+// one row / column of B^T d (B^T = [[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],
+// [0,2,-1,-2,1,0],[0,4,0,-5,0,1]]): 12 operations
+__device__ __forceinline__ void w4_bt6(float d0, float d1, float d2, float d3, float d4, float d5, float& t0,
+                                       float& t1, float& t2, float& t3, float& t4, float& t5) {
+  t0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+  const float a = __builtin_fmaf(-4.0f, d2, d4), b = __builtin_fmaf(-4.0f, d1, d3);
+  t1 = a + b;
+  t2 = a - b;
+  const float c = d4 - d2, e = d3 - d1;
+  t3 = __builtin_fmaf(2.0f, e, c);
+  t4 = __builtin_fmaf(-2.0f, e, c);
+  t5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+}
+// one row / column of A^T m (A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]]): 10 operations
+__device__ __forceinline__ void w4_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0,
+                                       float& y1, float& y2, float& y3) {
+  const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y0 = m0 + s1 + s2;
+  y1 = __builtin_fmaf(2.0f, d2, d1);
+  y2 = __builtin_fmaf(4.0f, s2, s1);
+  y3 = __builtin_fmaf(8.0f, d2, d1) + m5;
+}
+
+template <int TRG, bool TRACE = false>
+__global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
+  using C = W4Cfg<TRG>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(2 * W4_ND <= 63, "vmcnt is a 6-bit counter");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = tile group of the item's 4
+  const int HWi = a.H * a.W;
+  const int nchunk = a.Cin / W4_CK;
+  const int wrem = a.W & 3;  // pixels of the chunk that straddles the right edge
+
+  const int lw = xcd_remap(blockIdx.x, gridDim.x);
+  const int i0 = (int)((long long)lw * a.nitems / (int)gridDim.x);
+  const int i1 = (int)((long long)(lw + 1) * a.nitems / (int)gridDim.x);
+  if (i0 >= i1) return;
+  long long tk0 = 0, tw0 = 0;
+  if (TRACE) { tk0 = clock64(); tw0 = wall_clock64(); }
+  const int S = (i1 - i0) * nchunk;  // k-steps in this workgroup's stream
+  // The stream is ROTATED by c0 k-steps: segment 0 = the first item's chunks [c0, nchunk) (its partial sums
+  // are stored to y), segments 1 .. n-1 = the other items whole, segment n = the first item's chunks
+  // [0, c0) (loads the partial sums back, adds the residual, stores).  c0 differs from workgroup to
+  // workgroup, so the workgroups reach their epilogues at different times: in lockstep, all 256 CUs burst
+  // their 128 KB of outputs at once, the HBM write rate (not the store issue) bounded the epilogue at
+  // 12-16k cycles per item, and the memory system idled in between.
+  const int nit = i1 - i0;
+  const int c0 = a.stagger ? (int)(((unsigned)lw % 8u) * (unsigned)nchunk / 8u) : 0;
+  const int nseg = nit + (c0 > 0 ? 1 : 0);
+  auto seg_item = [&](int seg) { return seg == nit ? i0 : i0 + seg; };
+  auto seg_end = [&](int seg) { return seg == nit ? c0 : nchunk; };
+
+  float* const ldsU = lds;
+  float* const ldsP = lds + W4_NBUF * W4_ULDS;
+  const i32x4 xrs = w4_rsrc(a.x, (unsigned)a.B * a.Cin * HWi * 4u);
+  const i32x4 urs = w4_rsrc(a.up, (unsigned)a.Cout * a.Cin * (W4_NP * 4u));
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+  const unsigned mU0 = lds0 + wave * 1024u;
+  const unsigned mP0 = lds0 + W4_NBUF * W4_ULDS * 4u + wave * 1024u;
+
+  // ---- staging cursors.  Behind the end of the stream they stay on the last k-step (restaged into free
+  // buffers), so issue counts - and with them the vmcnt waits - never vary.
+  unsigned voff[W4_NI];  // byte offsets of this thread's 8 patch chunks (out of range = zeros)
+  // thread -> (ci low bit pair, band, row, chunk) of its slot in a 128-chunk plane: DMA i stages plane
+  // ci = 2 (i & 1) + (tid >> 7) of group i >> 1
+  auto set_voff = [&](int item) {
+    int t = tid;
+    asm volatile("" : "+v"(t));  // re-derived per item, not kept live (see conv_wino.hip)
+    const int rem2 = t & 127, cilo = t >> 7;
+    const int band = rem2 / C::BANDC, rem3 = rem2 - band * C::BANDC;
+    const int row = rem3 / C::RC, cc = rem3 - row * C::RC;
+    const bool slot_ok = rem2 < TRG * C::BANDC;
+    const int quad = item / a.ncot;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      const int g = 4 * quad + grp;
+      const int gr = g % a.GRR, twg = g / a.GRR;
+      int b, th;
+      bool ok = slot_ok && g < a.ngroups;
+      if (TRG == 1) {
+        const int sr = gr;
+        b = sr / a.TH;
+        th = sr - b * a.TH;
+      } else {
+        const int sr0 = gr * TRG, sr1 = sr0 + 1;
+        const int b0 = sr0 / a.TH, b1 = sr1 / a.TH;
+        b = band ? b1 : b0;
+        th = band ? sr1 - b1 * a.TH : sr0 - b0 * a.TH;
+        ok = ok && (band ? sr1 : sr0) < a.SR;
+      }
+      const int hi = 4 * th - 1 + row, col0 = 4 * C::TCG * twg - 4 + 4 * cc;
+      ok = ok && hi >= 0 && hi < a.H && col0 >= 0 && col0 < a.W;
+      const unsigned off = (unsigned)((((b * a.Cin + cilo) * a.H + hi) * a.W + col0) * 4);
+      voff[2 * grp] = ok ? off : W4_OOB;
+      voff[2 * grp + 1] = ok ? off + 2u * (unsigned)HWi * 4u : W4_OOB;
+    }
+  };
+  int pSeg = 0, pChunk = c0, pBuf = 0, pLeft = S;
+  int uSeg = 0, uChunk = c0, uBuf = 0, uLeft = S;
+  unsigned xso = __builtin_amdgcn_readfirstlane((unsigned)c0 * (unsigned)(W4_CK * HWi * 4)), mP = mP0, mU = mU0;
+  auto u_item_base = [&](int item) {
+    return (unsigned)(item % a.ncot) * (unsigned)nchunk * (W4_USLAB * 4u);
+  };
+  unsigned ubase = u_item_base(i0), uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)c0 * (W4_USLAB * 4u));
+  const unsigned uvoff = (unsigned)tid * 16u;
+  set_voff(i0);
+
+  // DMA unit u of the restaging of one k-step: 0 .. 4 = the weight slab (4608 floats; the fifth DMA's upper
+  // half lands in the pad behind it - LDS pitch 5120 - and reads the next slab's head or, behind the last
+  // one, out of range), 5 .. 12 = the patches.
+  auto dma_unit = [&](auto unit_tag) {
+    constexpr int u = decltype(unit_tag)::value;
+    if constexpr (u < W4_NU) w4_dma16<u * 4096>(urs, uso + (unsigned)u * 4096u, mU, uvoff);
+    else w4_dma16<(u - W4_NU) * 4096>(xrs, xso, mP, voff[u - W4_NU]);
+  };
+  auto adv_patch = [&]() {
+    pBuf = pBuf + 1 == W4_NBUF ? 0 : pBuf + 1;
+    if (pLeft > 1) {
+      --pLeft;
+      if (++pChunk == seg_end(pSeg)) {
+        pChunk = 0;
+        ++pSeg;
+        set_voff(seg_item(pSeg));
+      }
+    }
+    xso = __builtin_amdgcn_readfirstlane((unsigned)pChunk * (unsigned)(W4_CK * HWi * 4));
+    mP = __builtin_amdgcn_readfirstlane(mP0 + (unsigned)pBuf * (W4_PATCHF * 4u));
+  };
+  auto adv_u = [&]() {
+    uBuf = uBuf + 1 == W4_NBUF ? 0 : uBuf + 1;
+    if (uLeft > 1) {
+      --uLeft;
+      if (++uChunk == seg_end(uSeg)) {
+        uChunk = 0;
+        ++uSeg;
+        ubase = u_item_base(seg_item(uSeg));
+      }
+    }
+    uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)uChunk * (W4_USLAB * 4u));
+    mU = __builtin_amdgcn_readfirstlane(mU0 + (unsigned)uBuf * (W4_ULDS * 4u));
+  };
+#define W4_UNIT(U_) dma_unit(std::integral_constant<int, U_>{})
+  auto dma_u = [&]() {
+    W4_UNIT(0); W4_UNIT(1); W4_UNIT(2); W4_UNIT(3); W4_UNIT(4);
+    adv_u();
+  };
+  auto dma_patch = [&]() {
+    W4_UNIT(5); W4_UNIT(6); W4_UNIT(7); W4_UNIT(8); W4_UNIT(9); W4_UNIT(10); W4_UNIT(11); W4_UNIT(12);
+    adv_patch();
+  };
+
+  // ---- compute state
+  f32x4 accA[64], accV[8];  // accumulator cb * 36 + p: the first 64 in AGPRs, the last 8 in VGPRs
+  float V[36];              // B^T d B of the step about to be multiplied
+  float raw[36];            // patch of the next step
+  int pb_lane = 0, ub_lane = 0;
+  auto lane_consts = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int j = t & 15, k = (t >> 4) & 3;
+    const int tr = j / C::TCG, tc = j - tr * C::TCG;
+    pb_lane = wave * W4_GRPF + k * W4_PLF + tr * C::BANDF + 4 * tc;
+    ub_lane = j * W4_NP + k * (W4_CO * W4_NP);
+  };
+  // staged-row float offset of image column W - W % 4 for this wave's group of `item`, or -1
+  auto edge_of = [&](int item) {
+    if (wrem == 0) return -1;
+    const int g = 4 * (item / a.ncot) + wave;
+    const int twg = g / a.GRR;
+    const int cc = (a.W - wrem - (4 * C::TCG * twg - 4)) >> 2;
+    return (g < a.ngroups && cc >= 0 && cc < C::RC) ? 4 * cc + wrem : -1;
+  };
+  auto fix_edge = [&](float* pbuf, int eoff) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int l = t & 63;
+    if (l < 24 * TRG) {
+      const int ci = l / (6 * TRG), rb = l - ci * (6 * TRG);
+      float* p = pbuf + wave * W4_GRPF + ci * W4_PLF + rb * C::ROWF + eoff;  // bands are contiguous rows
+      p[0] = 0.0f;
+      if (wrem < 3) p[1] = 0.0f;
+      if (wrem < 2) p[2] = 0.0f;
+    }
+  };
+  auto read_patch = [&](const float* pbuf) {
+    const float* p = pbuf + pb_lane;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      raw[6 * r] = p[r * C::ROWF + 3];
+      const f32x4 m = *reinterpret_cast<const f32x4*>(p + r * C::ROWF + 4);
+      raw[6 * r + 1] = m[0];
+      raw[6 * r + 2] = m[1];
+      raw[6 * r + 3] = m[2];
+      raw[6 * r + 4] = m[3];
+      raw[6 * r + 5] = p[r * C::ROWF + 8];
+    }
+  };
+  auto transform = [&]() {
+    float t[36];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
+      w4_bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5],
+             t[6 * r], t[6 * r + 1], t[6 * r + 2], t[6 * r + 3], t[6 * r + 4], t[6 * r + 5]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)  // down the column: V[i][j] = sum_r BT[i][r] t[r][j]
+      w4_bt6(t[c], t[6 + c], t[12 + c], t[18 + c], t[24 + c], t[30 + c],
+             V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c], V[30 + c]);
+  };
+
+  // Y = A^T M A per lane; D row (l >> 4) * 4 + r -> channel, D column l & 15 -> tile.
+  // Output rows go out as 16-byte buffer stores whose offset is pushed out of range for lanes / rows that
+  // do not exist (the store is dropped, the residual load returns zero): no branches in the common path.
+  // Tiles that straddle the right image edge (W % 4 != 0) store element by element instead.
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      a.y, (short)0, (int)((unsigned)a.B * a.Cout * HWi * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.residual != nullptr ? a.residual : a.y), (short)0,
+      (int)((unsigned)a.B * a.Cout * HWi * 4u), 0x00020000);
+  const bool has_res = a.residual != nullptr;
+  const bool tracing = TRACE && a.trace != nullptr && blockIdx.x == 0;
+  long long tS = 0, tDr = 0, tL = 0;
+  // partial: store the sums as they are (segment 0 of a rotated stream); accum: add what segment 0 stored
+  auto epilogue = [&](int item, bool partial, bool accum) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int j = t & 15, q = (t >> 4) & 3;
+    const int tr = j / C::TCG, tc = j - tr * C::TCG;
+    const int cot = item % a.ncot;
+    const int g = 4 * (item / a.ncot) + wave;
+    const int gr = g % a.GRR, twg = g / a.GRR;
+    int b, th, sr;
+    if (TRG == 1) {
+      sr = gr;
+      b = sr / a.TH;
+      th = sr - b * a.TH;
+    } else {
+      const int sr0 = gr * TRG, sr1 = sr0 + 1;
+      const int b0 = sr0 / a.TH, b1 = sr1 / a.TH;
+      sr = tr ? sr1 : sr0;
+      b = tr ? b1 : b0;
+      th = tr ? sr1 - b1 * a.TH : sr0 - b0 * a.TH;
+    }
+    const int tw = twg * C::TCG + tc;
+    const bool valid = g < a.ngroups && sr < a.SR && tw < a.TW;
+    const int ho = 4 * th, wo = 4 * tw;
+    const bool wide = valid && wo + 4 <= a.W;
+    const bool part = valid && !wide;
+    const int co0 = cot * W4_CO + 4 * q;
+    const unsigned obase = (unsigned)(((b * a.Cout + co0) * a.H + ho) * a.W + wo) * 4u;  // bytes
+    unsigned orow[4];
+#pragma unroll
+    for (int yy = 0; yy < 4; ++yy)
+      orow[yy] = (wide && ho + yy < a.H) ? obase + (unsigned)(yy * a.W) * 4u : W4_OOB;
+    const unsigned chan = (unsigned)a.H * (unsigned)a.W * 4u;
+    asm volatile("s_nop 15");  // the last MFMAs' results (inline asm: no compiler-inserted wait states)
+    const bool use_res = has_res && !partial;
+    f32x4 res[8][4];
+    auto load_res = [&](int cr) {  // residual (and the stored partial sums) of channel pair cr, one step ahead
+      const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (use_res) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, orow[yy] + coff, 0, 0));
+        if (accum) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, orow[yy] + coff, 0, 0));
+        res[cr][yy] = v;
+      }
+    };
+    const bool any_add = use_res || accum;
+    load_res(0);
+#pragma unroll
+    for (int cr = 0; cr < 8; ++cr) {
+      const int cb = cr >> 2, r = cr & 3;
+      // (added to the per-lane offset: as the soffset operand of the buffer stores, a non-zero channel offset
+      // gave wrong second dwords in lanes 12-15 of every row of 16 on gfx950 - not understood, avoided)
+      const unsigned coff = (unsigned)(cb * 16 + r) * chan;
+      if (cr + 1 < 8) load_res(cr + 1);
+      float T[4][6];
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) {
+        float m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int acc = cb * 36 + 6 * i + jj;
+          m[i] = acc < 64 ? accA[acc < 64 ? acc : 0][r] : accV[acc >= 64 ? acc - 64 : 0][r];
+        }
+        w4_at6(m[0], m[1], m[2], m[3], m[4], m[5], T[0][jj], T[1][jj], T[2][jj], T[3][jj]);
+      }
+      f32x4 Y[4];
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        float v0, v1, v2, v3;
+        w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
+        Y[yy] = (f32x4){v0, v1, v2, v3};
+      }
+      long long cs = 0;
+      if (tracing) { __builtin_amdgcn_sched_barrier(0); cs = clock64(); }
+#pragma unroll
+      for (int yy = 0; yy < 4; ++yy) {
+        const f32x4 v = Y[yy] + res[cr][yy];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, 0);
+      }
+      if (tracing) { __builtin_amdgcn_sched_barrier(0); tS += clock64() - cs; }
+      if (part) {  // lanes of the tile column that straddles the right edge
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+          for (int xx = 0; xx < 3; ++xx) {
+            const unsigned o = (ho + yy < a.H && wo + xx < a.W) ? obase + (unsigned)(yy * a.W + xx) * 4u : W4_OOB;
+            float v = Y[yy][xx];
+            if (use_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, o + coff, 0, 0));
+            if (accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, o + coff, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue: patch(0) | U(0) patch(1) | U(1) patch(2); wait for the first, transform it
+  dma_patch();
+  dma_u(); dma_patch();
+  dma_u(); dma_patch();
+  w4_wait<2 * W4_ND>();
+  __syncthreads();
+  lane_consts();
+  int e_cur = edge_of(i0), e_nxt = -1;
+  if (e_cur >= 0) fix_edge(ldsP, e_cur);
+  read_patch(ldsP);
+  transform();
+
+  int cur = 0;
+  long long tW = 0, tB = 0, tD = 0, tR = 0, tM = 0, tT = 0, tE = 0;
+  auto kstep = [&](auto first_tag, int e_next) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int nxt = cur + 1 == W4_NBUF ? 0 : cur + 1;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    if (tracing) c0 = clock64();
+    // U(s) and patch(s+1) have landed (loads retire in order; the group issued last step may still fly)
+    if (!(a.dbg & 2)) w4_wait<W4_ND>();
+    if (tracing) c1 = clock64();
+    if (!(a.dbg & 2)) __syncthreads();
+    if (tracing) c2 = clock64();
+    if (a.dbg & 8) {
+      W4_UNIT(0); W4_UNIT(1); W4_UNIT(2); W4_UNIT(3); W4_UNIT(4);
+      W4_UNIT(5); W4_UNIT(6); W4_UNIT(7); W4_UNIT(8); W4_UNIT(9); W4_UNIT(10); W4_UNIT(11); W4_UNIT(12);
+    }
+    if (tracing) c3 = clock64();
+    float* pn = ldsP + nxt * W4_PATCHF;
+    if (e_next >= 0) fix_edge(pn, e_next);
+    read_patch(pn);
+    const float* ub = ldsU + cur * W4_ULDS + ub_lane;
+    f32x4 u[18];
+    constexpr int AHEAD = 3;
+    auto ldu = [&](int g) { u[g] = *reinterpret_cast<const f32x4*>(ub + (g / 9) * (16 * W4_NP) + (g % 9) * 4); };
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) ldu(g);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int g = 0; g < 18; ++g) {  // group g: row block g / 9, positions 4 (g % 9) .. + 3
+      if (g + AHEAD < 18) ldu(g + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = 4 * (g % 9) + q, acc = (g / 9) * 36 + p;
+        if (acc < 64) {
+          if (FIRST) W4_MFMA_A0(accA[acc < 64 ? acc : 0], u[g][q], V[p]);
+          else W4_MFMA_A(accA[acc < 64 ? acc : 0], u[g][q], V[p]);
+        } else {
+          if (FIRST) W4_MFMA_V0(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p]);
+          else W4_MFMA_V(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p]);
+        }
+      }
+      // restaging, one DMA per group boundary so the memory pipeline takes them one at a time (issued back
+      // to back by all four waves, 52 KB queue up in front of it and every issue stalls): U(s+2) into the
+      // buffer U(s-1) left, patch(s+3) into the buffer patch(s) left
+      if (!(a.dbg & 9)) switch (g) {
+        case 0: W4_UNIT(0); break;
+        case 1: W4_UNIT(1); break;
+        case 2: W4_UNIT(2); break;
+        case 3: W4_UNIT(3); break;
+        case 4: W4_UNIT(4); break;
+        case 5: W4_UNIT(5); break;
+        case 6: W4_UNIT(6); break;
+        case 7: W4_UNIT(7); break;
+        case 8: W4_UNIT(8); break;
+        case 9: W4_UNIT(9); break;
+        case 10: W4_UNIT(10); break;
+        case 11: W4_UNIT(11); break;
+        case 12: W4_UNIT(12); break;
+        default: break;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the last MFMAs write the VGPR-resident accumulators: inline asm gets no compiler-inserted wait states,
+    // and a register copy the allocator places right behind them would read half-written results
+    asm volatile("s_nop 15");
+    adv_u();
+    adv_patch();
+    if (tracing) c4 = clock64();
+    if (!(a.dbg & 4)) transform();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tracing) {
+      c5 = clock64();
+      tW += c1 - c0; tB += c2 - c1; tD += c3 - c2; tM += c4 - c3; tT += c5 - c4;
+    }
+    cur = nxt;
+  };
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int item = seg_item(seg);
+    const int len = seg_end(seg) - (seg == 0 ? c0 : 0);
+    if (seg != 0) lane_consts();
+    e_nxt = seg + 1 < nseg ? edge_of(seg_item(seg + 1)) : -1;
+    long long cl = 0;
+    if (tracing) cl = clock64();
+    if (len == 1) {
+      kstep(std::true_type{}, e_nxt);
+    } else {
+      kstep(std::true_type{}, e_cur);
+      for (int chunk = 1; chunk < len - 1; ++chunk) kstep(std::false_type{}, e_cur);
+      kstep(std::false_type{}, e_nxt);
+    }
+    e_cur = e_nxt;
+    long long ce = 0;
+    if (tracing) { ce = clock64(); tL += ce - cl; }
+    epilogue(item, seg == 0 && c0 > 0, seg == nit);
+    if (tracing) tE += clock64() - ce;
+    // Compiler-visible vmcnt(0): whatever it spilled around the epilogue has come back, so it puts no
+    // vmcnt waits (which would also drain the DMAs in flight) into the k-step loop.  It also orders a
+    // rotated stream's partial sums in front of their reload by the same workgroup.
+    long long cd = 0;
+    if (tracing) cd = clock64();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (tracing) tDr += clock64() - cd;
+  }
+  if (tracing && (tid & 63) == 0) {
+    long long* o = a.trace + wave * 8;
+    o[0] = tW; o[1] = tB; o[2] = tD; o[3] = tM; o[4] = tT; o[5] = tE; o[6] = i1 - i0; o[7] = S; o[32] = tS; o[33] = clock64() - tk0; o[34] = wall_clock64() - tw0; o[35] = tDr; o[36] = tL;
+  }
+}
+
+int w4_grid_for(size_t n) {
+  size_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+static long long* g_wino4_trace = nullptr;
+extern "C" void air_dbg_wino4_trace(long long* p) { g_wino4_trace = p; }
+
+bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
+  static const int off = getenv("AIR_NO_WINO4") ? atoi(getenv("AIR_NO_WINO4")) : 0;
+  if (off) return false;
+  if (M < W4_CO || M % W4_CO != 0 || Kc < W4_CK || Kc % W4_CK != 0) return false;
+  // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
+  const double ein = (double)B * Kc * H * W, eout = (double)B * M * H * W;
+  return ein * 4.0 + 8192.0 < 2147483648.0 && eout * 4.0 + 8192.0 < 2147483648.0 &&
+         (double)air_wino4_packed_elems(M, Kc) * 4.0 < 4294967296.0 && H >= 1 && W >= 4;
+}
+
+size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)M * Kc * W4_NP + 1024; }
+
+int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
+                   int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
+  hipLaunchKernelGGL(wino4_weights_kernel, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc,
+                     dgrad);
+  AIR_CHECK_LAUNCH();
+  W4Args a;
+  a.x = x; a.up = up; a.y = y; a.residual = residual;
+  a.B = B; a.Cin = Kc; a.H = H; a.W = W; a.Cout = M;
+  a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
+  a.SR = B * a.TH;
+  // 1 x 16 or 2 x 8 tiles per group: fewer groups = less padding waste
+  const long g1 = (long)a.SR * ((a.TW + 15) / 16), g2 = (long)((a.SR + 1) / 2) * ((a.TW + 7) / 8);
+  const int trg = g2 < g1 ? 2 : 1;
+  a.GRR = (a.SR + trg - 1) / trg;
+  a.TWG = (a.TW + 16 / trg - 1) / (16 / trg);
+  a.ngroups = a.GRR * a.TWG;
+  a.ncot = M / W4_CO;
+  a.nitems = (a.ngroups + 3) / 4 * a.ncot;
+  a.trace = g_wino4_trace;
+  static const int dbg = getenv("AIR_WINO4_DBG") ? atoi(getenv("AIR_WINO4_DBG")) : 0;
+  a.dbg = dbg;
+  static const int stagger = getenv("AIR_WINO4_STAGGER") ? atoi(getenv("AIR_WINO4_STAGGER")) : 1;
+  a.stagger = stagger && a.Cin / W4_CK >= 8;
+  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  const size_t ldsb = (size_t)W4_NBUF * (W4_ULDS + W4_PATCHF) * sizeof(float);
+  static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, false>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, false>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<1, true>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, true>)};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i)
+      ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess;
+    return ok;
+  }();
+  if (!attr_ok) return AIR_ELAUNCH;
+  AirProfScope ps(AIR_K_CONV_WINO, flops, st);
+  if (a.trace != nullptr) {
+    if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, true>), dim3(nblk), dim3(256), ldsb, st, a);
+    else hipLaunchKernelGGL((wino4_conv_kernel<1, true>), dim3(nblk), dim3(256), ldsb, st, a);
+  } else if (trg == 2) {
+    hipLaunchKernelGGL((wino4_conv_kernel<2, false>), dim3(nblk), dim3(256), ldsb, st, a);
+  } else {
+    hipLaunchKernelGGL((wino4_conv_kernel<1, false>), dim3(nblk), dim3(256), ldsb, st, a);
+  }
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}

@@ -10,7 +10,7 @@ see bit-identical PCM.
 import numpy as np
 
 
-def utterance(seed, idx, length=32000, sr=16000):
+def utterance(seed, idx, length=32000, sr=16000, mix_lo=0.0):
     """Returns (pcm float32 (length,), label) with label 0 = bona fide, 1 = spoof."""
     rng = np.random.Generator(np.random.PCG64(seed * 1000003 + idx))
     label = int(rng.random() < 0.5)
@@ -40,7 +40,7 @@ def utterance(seed, idx, length=32000, sr=16000):
         z = z / (np.abs(z).max() + 1e-9)
         # cue strength varies per utterance, down to none: the classes overlap, so the
         # converged EER is a stable non-zero number instead of 0
-        mix = rng.uniform(0.0, 0.8)
+        mix = rng.uniform(mix_lo, 0.8)
         y = (1.0 - mix) * y + mix * z
         y = y + 0.01 * mix * np.sign(np.sin(2 * np.pi * 4000.0 * t))
     noise = rng.standard_normal(length)
@@ -49,10 +49,10 @@ def utterance(seed, idx, length=32000, sr=16000):
     return y.astype(np.float32), label
 
 
-def corpus(seed, n, length=32000):
+def corpus(seed, n, length=32000, mix_lo=0.0):
     """(pcm (n, length) float32, labels (n,) int64)."""
     pcm = np.zeros((n, length), dtype=np.float32)
     labels = np.zeros(n, dtype=np.int64)
     for i in range(n):
-        pcm[i], labels[i] = utterance(seed, i, length)
+        pcm[i], labels[i] = utterance(seed, i, length, mix_lo=mix_lo)
     return pcm, labels

@@ -261,18 +261,19 @@ def test_conv2d_winograd(ops, cfg):
     xd = x.double().requires_grad_(True)
     y = F.conv2d(xd, w.double(), None, 1, 1)
     got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1)
-    # fp32 Winograd: the input transform subtracts neighbours, so it is a few times noisier than
-    # the direct f32 MFMA chain (measured 1e-6 of the output scale); still fp32-grade
-    close(got, y, rtol=1e-5, name="winograd fwd")
+    # fp32 Winograd F(4x4,3x3) (conv_wino4.hip; F(2x2,3x3) below W = 4): the transforms carry constants up
+    # to 8 and 1/24, so it is noisier than the direct f32 MFMA chain - measured 2e-6 .. 1.05e-5 of the output
+    # scale on these shapes (F(2x2,3x3): 1e-6; direct: 1e-6 .. 3e-6), bounded by the 2e-5 of every conv test
+    close(got, y, rtol=2e-5, name="winograd fwd")
     got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1, residual=res.cuda())
-    close(got, y + res.double(), rtol=1e-5, name="winograd fwd + residual")
+    close(got, y + res.double(), rtol=2e-5, name="winograd fwd + residual")
     dy = synth_feat((B, Cout, H, W), 14)
     y.backward(dy.double())
     got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1)
-    close(got, xd.grad, rtol=1e-5, name="winograd dgrad")
+    close(got, xd.grad, rtol=2e-5, name="winograd dgrad")
     acc = synth_feat((B, Cin, H, W), 15)
     got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda())
-    close(got, xd.grad + acc.double(), rtol=1e-5, name="winograd dgrad + accumulate")
+    close(got, xd.grad + acc.double(), rtol=2e-5, name="winograd dgrad + accumulate")
     # weight gradient: Winograd F(3x3,2x2) when both channel counts are multiples of 64
     wd = w.double().requires_grad_(True)
     F.conv2d(x.double(), wd, None, 1, 1).backward(dy.double())
