@@ -10,6 +10,7 @@ device (Philox4x32-10, seeded per module); tests pass an explicit mask to replay
 import ctypes
 
 import torch
+import torch.distributed as td
 import torch.nn as nn
 import torch.nn.init as init
 
@@ -215,6 +216,10 @@ class AdversarialTrainer(Trainer):
         counts = (n_channels,) if isinstance(n_channels, int) else tuple(n_channels)
         enc_dim = self.loss.feat_dim
         self.classifiers = [ChannelClassifier(enc_dim, n, lambda_).to(self.device) for n in counts]
+        if self.world > 1:  # same classifier replicas everywhere (the encoder is synchronised by Trainer)
+            for c in self.classifiers:
+                for t in list(c.parameters()) + list(c.buffers()):
+                    td.broadcast(t.data, src=0)
         self.classifier_optimizers = [TensorAdam(c, lr=lr_d) for c in self.classifiers]
         self.criterion = CrossEntropyLoss()
         self.lr_d = lr_d
@@ -252,7 +257,7 @@ class AdversarialTrainer(Trainer):
             feat_loss = feat_loss + adv
         feat_loss.backward()
         scale = 1.0
-        if self.world > 1:  # encoder + centre gradients are averaged over ranks; classifiers stay per-rank
+        if self.world > 1:  # encoder + centre gradients are averaged over ranks
             air_dist.allreduce_grads(self.model, self.loss)
             scale = 1.0 / self.world
         self.feat_optimizer.step(grad_scale=scale)
@@ -268,7 +273,14 @@ class AdversarialTrainer(Trainer):
             lc = self.criterion(c(feats2.detach()), tgt)
             opt.zero_grad()
             lc.backward()
-            opt.step()
+            if self.world > 1:
+                # the classifiers are replicas too: without this every rank would train its own, and the
+                # gradient-reversal term each rank feeds its encoder would drift apart
+                works = [td.all_reduce(p.grad, op=td.ReduceOp.SUM, async_op=True)
+                         for p in c.parameters() if p.grad is not None]
+                for w in works:
+                    w.wait()
+            opt.step(grad_scale=scale)
             closs.append(lc.detach())
         self.last = {"adv_loss": None if adv is None else adv.detach(), "classifier_loss": closs}
         return loss.detach(), neg_scores

@@ -30,13 +30,13 @@ __device__ __forceinline__ void atomic_max_pos(unsigned* p, float v) {
 __global__ __launch_bounds__(FIR_NT) void fir_kernel(const float* __restrict__ x, int L,
                                                      const float* __restrict__ irs, int H,
                                                      const int* __restrict__ idx, float* __restrict__ y,
-                                                     unsigned* __restrict__ peaks) {
+                                                     unsigned* __restrict__ peaks, int n_ir) {
   __shared__ __attribute__((aligned(16))) float xs[FIR_GROUPS * FIR_GS];
   __shared__ __attribute__((aligned(16))) float hs[FIR_KC];
   const int b = blockIdx.y, n0 = blockIdx.x * FIR_BLK, t = threadIdx.x;
   const float* __restrict__ xb = x + (size_t)b * L;
   float* __restrict__ yb = y + (size_t)b * L;
-  const int ir = idx ? idx[b] : 0;
+  const int ir = idx ? min(idx[b], n_ir - 1) : 0;  // indices are caller data: never read past the IR table
   if (ir < 0) {  // pass-through utterance
     for (int i = t; i < FIR_BLK; i += FIR_NT)
       if (n0 + i < L) yb[n0 + i] = xb[n0 + i];
@@ -133,7 +133,7 @@ int air_ir_convolve(const float* x, int B, int L, const float* irs, int n_ir, in
   unsigned* peaks = normalize ? reinterpret_cast<unsigned*>(ws) : nullptr;
   if (peaks && hipMemsetAsync(peaks, 0, (size_t)B * 2 * sizeof(unsigned), st) != hipSuccess) return AIR_ELAUNCH;
   const dim3 grid((L + FIR_BLK - 1) / FIR_BLK, B);
-  hipLaunchKernelGGL(fir_kernel, grid, dim3(FIR_NT), 0, st, x, L, irs, H, ir_idx, y, peaks);
+  hipLaunchKernelGGL(fir_kernel, grid, dim3(FIR_NT), 0, st, x, L, irs, H, ir_idx, y, peaks, n_ir);
   AIR_CHECK_LAUNCH();
   if (normalize) {
     hipLaunchKernelGGL(fir_rescale_kernel, dim3(16, B), dim3(256), 0, st, y, L, ir_idx, peaks);

@@ -152,7 +152,8 @@ struct LfccArgs {
   float* out;
   const LfccPlan* plan;
   const int* start;  // padded mode: per-utterance crop start (may be null)
-  int L, T, tiles, flags, feat_len;
+  const float* silence;  // padded mode, AIR_PAD_SILENCE: the D-float frame to prepend (dataset.py:13-16)
+  int L, T, tiles, flags, feat_len, pad_mode;
 };
 
 constexpr int FLAG_EMPH = AIR_LFCC_EMPHASIS;
@@ -355,8 +356,11 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
   } else {
     // (B, D, feat_len): frame t lands on t' = t - start (+ k T when repeating)
     const int flen = a.feat_len;
-    const int start = (a.start != nullptr && T > flen) ? a.start[b] : 0;
+    // crop start clamped to the valid range: a bad offset must not leave columns unwritten
+    const int start = (a.start != nullptr && T > flen) ? min(max(a.start[b], 0), T - flen) : 0;
     float* __restrict__ obase = a.out + (size_t)b * D * flen;
+    const int npad = flen - T;  // > 0: pad (dataset.py:72-79)
+    const int shift = (npad > 0 && a.pad_mode == AIR_PAD_SILENCE) ? npad : 0;  // silence is PREPENDED (:528)
     for (int e = tid; e < FOUT * D; e += NTHREADS) {
       const int c = e / FOUT, fo = e - c * FOUT;
       const int t = t0 + fo;
@@ -365,8 +369,19 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
       if (T >= flen) {
         const int tp = t - start;
         if (tp >= 0 && tp < flen) obase[(size_t)c * flen + tp] = v;
-      } else {
+      } else if (a.pad_mode == AIR_PAD_REPEAT) {
         for (int tp = t; tp < flen; tp += T) obase[(size_t)c * flen + tp] = v;
+      } else {
+        obase[(size_t)c * flen + t + shift] = v;
+      }
+    }
+    if (npad > 0 && a.pad_mode != AIR_PAD_REPEAT) {
+      // the npad constant frames (zeros appended, :513-517, or the silence frame prepended, :524-528),
+      // shared out over the utterance's tiles
+      const int lo = a.pad_mode == AIR_PAD_SILENCE ? 0 : T;
+      for (int e = tile * NTHREADS + tid; e < npad * D; e += a.tiles * NTHREADS) {
+        const int c = e / npad, k = e - c * npad;
+        obase[(size_t)c * flen + lo + k] = a.pad_mode == AIR_PAD_SILENCE ? a.silence[c] : 0.0f;
       }
     }
   }
@@ -400,18 +415,23 @@ __global__ __launch_bounds__(256) void preemph_apply_kernel(float* x, int L, int
 // ---- (B,T,D) -> (B,D,feat_len): repeat-pad / chop + transpose ----------------
 __global__ __launch_bounds__(256) void pad_transpose_kernel(const float* feat, int T, int D,
                                                             float* out, int flen,
-                                                            const int* start) {
+                                                            const int* start, int pad_mode,
+                                                            const float* silence) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
   const int tp0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int st = (start != nullptr && T > flen) ? start[b] : 0;
+  const int st = (start != nullptr && T > flen) ? min(max(start[b], 0), T - flen) : 0;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {  // r: frame within tile, tx: coefficient
     const int tp = tp0 + r, c = c0 + tx;
     float v = 0.0f;
     if (tp < flen && c < D) {
-      const int t = (T >= flen) ? tp + st : tp % T;
-      v = feat[((size_t)b * T + t) * D + c];
+      int t;  // source frame, or -1 = zero, -2 = the silence frame
+      if (T >= flen) t = tp + st;
+      else if (pad_mode == AIR_PAD_REPEAT) t = tp % T;
+      else if (pad_mode == AIR_PAD_ZERO) t = tp < T ? tp : -1;
+      else t = tp >= flen - T ? tp - (flen - T) : -2;
+      v = t >= 0 ? feat[((size_t)b * T + t) * D + c] : (t == -2 ? silence[c] : 0.0f);
     }
     tile[r][tx] = v;
   }
@@ -423,8 +443,11 @@ __global__ __launch_bounds__(256) void pad_transpose_kernel(const float* feat, i
 }
 
 int lfcc_launch(const float* pcm, const short* pcm16, int B, int L, float* out, int feat_len, const int* start,
-                const void* plan_dev, int flags, hipStream_t stream) {
+                const void* plan_dev, int flags, hipStream_t stream, int pad_mode = AIR_PAD_REPEAT,
+                const float* silence = nullptr) {
   if ((!pcm && !pcm16) || !out || !plan_dev || B <= 0 || L <= 0) return AIR_EINVAL;
+  if (pad_mode < AIR_PAD_REPEAT || pad_mode > AIR_PAD_SILENCE) return AIR_EINVAL;  // dataset.py:79 raises ValueError
+  if (pad_mode == AIR_PAD_SILENCE && !silence) return AIR_EINVAL;
   const int T = 1 + L / FS;
   LfccArgs a;
   a.pcm = pcm;
@@ -432,6 +455,8 @@ int lfcc_launch(const float* pcm, const short* pcm16, int B, int L, float* out, 
   a.out = out;
   a.plan = reinterpret_cast<const LfccPlan*>(plan_dev);
   a.start = start;
+  a.silence = silence;
+  a.pad_mode = pad_mode;
   a.L = L;
   a.T = T;
   a.tiles = (T + FOUT - 1) / FOUT;
@@ -519,6 +544,15 @@ int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len
                      air_stream(stream));
 }
 
+int air_lfcc_fwd_padded_ex(const float* pcm, const int16_t* pcm16, int B, int L, float* out, int feat_len,
+                           const int* start_dev, const void* plan_dev, int flags, int pad_mode,
+                           const float* silence_dev, air_stream_t stream) {
+  if (feat_len <= 0 || (pcm != nullptr) == (pcm16 != nullptr)) return AIR_EINVAL;
+  return lfcc_launch(pcm, reinterpret_cast<const short*>(pcm16), B, L, out, feat_len, start_dev, plan_dev,
+                     (flags & (AIR_LFCC_EMPHASIS | AIR_LFCC_DELTA)) | FLAG_PADDED, air_stream(stream), pad_mode,
+                     silence_dev);
+}
+
 int air_lfcc_fwd_padded_i16(const int16_t* pcm16, int B, int L, float* out, int feat_len,
                             const int* start_dev, const void* plan_dev, int flags, air_stream_t stream) {
   // feat_len <= 0: the (B, T, D) layout of air_lfcc_fwd
@@ -549,14 +583,21 @@ int air_preemph_inplace(float* pcm, int B, int L, float coef, void* ws, size_t w
   return AIR_OK;
 }
 
-int air_pad_transpose(const float* feat, int B, int T, int D, float* out, int feat_len,
-                      const int* start_dev, air_stream_t stream) {
+int air_pad_transpose_ex(const float* feat, int B, int T, int D, float* out, int feat_len,
+                         const int* start_dev, int pad_mode, const float* silence_dev, air_stream_t stream) {
   if (!feat || !out || B <= 0 || T <= 0 || D <= 0 || feat_len <= 0) return AIR_EINVAL;
+  if (pad_mode < AIR_PAD_REPEAT || pad_mode > AIR_PAD_SILENCE) return AIR_EINVAL;
+  if (pad_mode == AIR_PAD_SILENCE && !silence_dev) return AIR_EINVAL;
   dim3 grid((feat_len + 63) / 64, (D + 63) / 64, B);
   hipLaunchKernelGGL(pad_transpose_kernel, grid, dim3(256), 0, air_stream(stream), feat, T, D,
-                     out, feat_len, start_dev);
+                     out, feat_len, start_dev, pad_mode, silence_dev);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_pad_transpose(const float* feat, int B, int T, int D, float* out, int feat_len,
+                      const int* start_dev, air_stream_t stream) {
+  return air_pad_transpose_ex(feat, B, T, D, out, feat_len, start_dev, AIR_PAD_REPEAT, nullptr, stream);
 }
 
 }  // extern "C"

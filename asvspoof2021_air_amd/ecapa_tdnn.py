@@ -332,6 +332,13 @@ class Res2Net2(nn.Module):
     def _backward_impl(self, S, dfeat, dout):
         arena = self.arena()
         G = arena.grad_views()
+        # gradient accumulation (a second backward without zero_grad): p.grad already IS the arena view, so
+        # autograd's "p.grad += returned view" would double the NEW gradient instead of adding the old one.
+        # Keep the old sums aside, fold them back in at the end and return None for the aliased entries
+        # (same protocol as ResNet._backward_impl).
+        accumulating = any(p.grad is not None and p.grad.data_ptr() == G[n].data_ptr()
+                           for n, p, _, _ in arena.entries)
+        old = arena.grad.clone() if accumulating else None
         det = lambda p: p.detach()
         bf = self.compute_dtype == "bf16"
         B, _, T = S["x"].shape
@@ -387,7 +394,7 @@ class Res2Net2(nn.Module):
         ops.sum_rows(rows, out=G["layer4.bias"])
         ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf)
         # data parallel: everything from layer4.weight to the end of the gradient arena is final
-        bucketer = getattr(self, "_bucketer", None)
+        bucketer = None if accumulating else getattr(self, "_bucketer", None)
         offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
 
         def grads_final_from(first_param):
@@ -412,4 +419,11 @@ class Res2Net2(nn.Module):
                                dbias=G["conv1.bias"])
         ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
         arena.tail_has_grad = have_tail
+        if accumulating:
+            if not have_tail:  # the tail got no new gradient: its old sums must survive the add below unchanged
+                arena.grad[arena.head_total:].zero_()
+            ops.add_(arena.grad, old)
+            arena.tail_has_grad = True  # old tail sums may be live; the optimiser covers the whole arena
+            return [None if (p.grad is not None and p.grad.data_ptr() == G[n].data_ptr())
+                    else (G[n] if (have_tail or n not in tail) else None) for n, p, _, _ in arena.entries]
         return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]

@@ -66,6 +66,16 @@ def delta(x):
     return xp[:, 2:] - xp[:, :-2]
 
 
+PAD_MODES = {"repeat": 0, "zero": 1, "silence": 2}
+
+
+def pad_mode_id(padding):
+    """--padding choice -> AIR_PAD_* (include/air_hip.h); the reference's error for anything else (dataset.py:79)."""
+    if padding not in PAD_MODES:
+        raise ValueError("Padding should be zero or repeat!")
+    return PAD_MODES[padding]
+
+
 class LFCC(nn.Module):
     """LFCC(fl, fs, fn, sr, filter_num, with_energy=False, with_emphasis=True, with_delta=True)."""
 
@@ -140,22 +150,42 @@ class LFCC(nn.Module):
                 x.copy_(src)
         return out
 
-    def forward_padded(self, x, feat_len=750, start=None):
-        """Fused LFCC -> repeat-pad/chop -> transpose: (B, L) -> (B, out_dim, feat_len),
-        i.e. what dataset.py:66-79 + main_train.py:338 build on the host.  Does not
-        mutate ``x``.  ``start``: optional int32 (B,) crop offsets for T > feat_len."""
+    def silence_row(self, device):
+        """The frame the reference prepends under ``--padding silence``: frame 0 of the LFCC of 3200 zero
+        samples (dataset.py:13-16), computed once per device by this module's own kernel."""
+        key = (str(device), self._plan_key)
+        if getattr(self, "_silence", None) is None or self._silence_key != key:
+            mut, self.mutate_input = self.mutate_input, False
+            try:
+                row = self.forward(torch.zeros(1, 3200, device=device))[0, 0].contiguous()
+            finally:
+                self.mutate_input = mut
+            self._silence, self._silence_key = row, (str(device), self._plan_key)
+        return self._silence
+
+    def forward_padded(self, x, feat_len=750, start=None, padding="repeat"):
+        """Fused LFCC -> pad/chop -> transpose: (B, L) -> (B, out_dim, feat_len), i.e. what
+        dataset.py:66-79 + main_train.py:338 build on the host.  Does not mutate ``x``.
+        ``start``: optional int32 (B,) crop offsets for T > feat_len.  ``padding``: the reference's
+        ``--padding`` choices 'repeat' | 'zero' | 'silence' (main_train.py:45); anything else raises
+        ValueError like dataset.py:79."""
         self._check(x)
+        mode = pad_mode_id(padding)
         B, L = x.shape
-        if x.dtype == torch.int16:
-            return self._forward_i16(x, feat_len, start)
-        src = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        i16 = x.dtype == torch.int16
+        src = x.contiguous() if i16 else (x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous())
         out = torch.empty((B, self.out_dim, feat_len), device=x.device, dtype=torch.float32)
+        sil = self.silence_row(x.device) if mode == 2 else None
         lib = _hip.lib()
-        _hip.check(lib.air_lfcc_fwd_padded(_hip.dptr(src), _hip.ci(B), _hip.ci(L), _hip.dptr(out),
-                                           _hip.ci(feat_len), _hip.dptr(start, torch.int32, True),
-                                           _hip.dptr(self.plan(x.device), torch.uint8),
-                                           _hip.ci(self._flags()), _hip.stream()),
-                   "air_lfcc_fwd_padded")
+        null = _hip.dptr(None, allow_none=True)
+        _hip.check(lib.air_lfcc_fwd_padded_ex(null if i16 else _hip.dptr(src),
+                                              _hip.dptr(src, torch.int16) if i16 else null,
+                                              _hip.ci(B), _hip.ci(L), _hip.dptr(out),
+                                              _hip.ci(feat_len), _hip.dptr(start, torch.int32, True),
+                                              _hip.dptr(self.plan(x.device), torch.uint8),
+                                              _hip.ci(self._flags()), _hip.ci(mode), _hip.dptr(sil, allow_none=True),
+                                              _hip.stream()),
+                   "air_lfcc_fwd_padded_ex")
         return out
 
     def _forward_i16(self, x, feat_len, start):

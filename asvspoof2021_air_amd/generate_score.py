@@ -20,6 +20,7 @@ import os
 
 import torch
 
+from . import ops
 from .feature_extraction import LFCC
 
 
@@ -37,7 +38,7 @@ def batch_scores(model, lfcc, loss_model=None, add_loss=None):
     reference calls ``score`` (the file gets ``-score``)."""
     feats, outputs = model(lfcc)
     if add_loss is None:
-        return -torch.softmax(outputs, dim=1)[:, 0]  # :102
+        return -ops.softmax_rows(outputs)[:, 0]  # :102
     if add_loss == "ocsoftmax":
         labels = torch.zeros(lfcc.shape[0], dtype=torch.int64, device=lfcc.device)  # :96
         _, score = loss_model(feats, labels)  # :104-105

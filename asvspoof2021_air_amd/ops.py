@@ -456,3 +456,17 @@ def asp_bwd(x, w, out, dout, dx, accumulate=False, rowsum=None):
                                       ci(1 if accumulate else 0), dptr(rowsum, allow_none=True), stream()),
                "air_asp_bwd")
     return dx
+
+
+def softmax_rows(logits):
+    """softmax over dim 1 of (B, C) logits (generate_score.py:102) on the softmax / cross-entropy kernel."""
+    B, C = logits.shape
+    logits = logits.float().contiguous()
+    probs = torch.empty_like(logits)
+    labels = torch.zeros(B, dtype=torch.int64, device=logits.device)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    correct = torch.empty((), device=logits.device, dtype=torch.int32)
+    _hip.check(_hip.lib().air_softmax_ce_fwd(_hip.dptr(logits), _hip.dptr(labels, torch.int64), _hip.ci(B), _hip.ci(C),
+                                             _hip.dptr(probs), _hip.dptr(loss), _hip.dptr(correct, torch.int32),
+                                             _hip.stream()), "air_softmax_ce_fwd")
+    return probs

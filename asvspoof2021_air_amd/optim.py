@@ -14,6 +14,7 @@ class FusedAdam:
         self.model = model
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
         self.step_count = 0
+        self.tail_steps = 0
         self.m = None
         self.v = None
 
@@ -22,16 +23,33 @@ class FusedAdam:
             p.grad = None
 
     def step(self, grad_scale=1.0):
+        """One Adam step over the gradient arena.  Like torch.optim.Adam, tensors without a gradient are left
+        alone: a step() with no backward since zero_grad() is a no-op (the arena still holds the previous
+        step's sums, which must not be applied twice)."""
         import torch
+        params = list(self.model.parameters())
+        if any(not p.requires_grad for p in params):
+            raise RuntimeError("FusedAdam updates the whole parameter arena in one launch: frozen parameters "
+                               "(requires_grad=False) are not supported")
+        if all(p.grad is None for p in params):
+            return
         arena = self.model.arena()
         if self.m is None or self.m.device != arena.flat.device:
             self.m = torch.zeros_like(arena.flat)
             self.v = torch.zeros_like(arena.flat)
+            self.tail_steps = 0
         g = self.param_groups[0]
         self.step_count += 1
-        n = arena.total if arena.tail_has_grad else arena.head_total
+        n = arena.head_total
         ops.adam_step(arena.flat[:n], arena.grad[:n], self.m[:n], self.v[:n], self.step_count,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
+        if arena.tail_has_grad and arena.total > n:
+            # the tail (fc_mu.* / fc7.*, bn7.*: gradients only under the CE base loss) keeps its own step
+            # count, so its bias correction matches torch.optim.Adam's per-tensor state when it receives
+            # gradients only some of the time
+            self.tail_steps += 1
+            ops.adam_step(arena.flat[n:], arena.grad[n:], self.m[n:], self.v[n:], self.tail_steps,
+                          g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale)
 
 
 class FusedSGD:

@@ -103,6 +103,8 @@ class _ResNetFn(torch.autograd.Function):
 
 
 class ResNet(nn.Module):
+    MAX_POOL_FRAMES = 148  # csrc/pool_head.hip: (256 (T' + 1) + 2 T') floats <= 150 KB of LDS
+
     def __init__(self, num_nodes, enc_dim, resnet_type="18", nclasses=2):
         self.in_planes = 16
         super().__init__()
@@ -220,6 +222,15 @@ class ResNet(nn.Module):
             raise ValueError("ResNet expects (B, 1, F, T), got %s" % (tuple(x.shape),))
         if x.shape[0] == 1 and self.training:
             pass  # the reference special-cases B==1 in SelfAttention (resnet.py:28-30); same maths here
+        ta = x.shape[3]
+        for _ in range(3):  # the three stride-2 stages (resnet.py:136-138)
+            ta = (ta - 1) // 2 + 1
+        if ta > self.MAX_POOL_FRAMES:
+            # checked up front (not in the middle of a scoring run): the attention pooling kernel keeps one
+            # utterance's (256, T') map in LDS
+            raise ValueError("ResNet HIP path: %d input frames give %d pooled frames; the SelfAttention pooling "
+                             "kernel holds at most %d (about %d input frames, feat_len 750 = 94)" % (
+                                 x.shape[3], ta, self.MAX_POOL_FRAMES, 8 * self.MAX_POOL_FRAMES))
         x = x.float().contiguous()  # main_train.py:338 hands over a transposed view
         arena = self.arena()
         # eval-mode forward never records a graph (backward through running-stat BN is not

@@ -10,7 +10,9 @@ zero_grad x2, loss.backward(), feat_optimizer.step(), ang_iso_optimizer.step()
 """
 import os
 
+import numpy as np
 import torch
+import torch.distributed as td
 
 from . import dist as air_dist
 from .feature_extraction import LFCC
@@ -29,7 +31,7 @@ def adjust_learning_rate(lr0, optimizer, epoch_num, lr_decay=0.5, interval=30):
 class Trainer:
     def __init__(self, model, enc_dim=256, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, r_real=0.9,
                  r_fake=0.2, alpha=20.0, weight_loss=1.0, feat_len=750, device="cuda", ecapa=False,
-                 loss_module=None, augment=None):
+                 loss_module=None, augment=None, padding="repeat"):
         self.device = torch.device(device)
         self.model = model.to(self.device)
         self.loss = (loss_module if loss_module is not None else
@@ -43,6 +45,12 @@ class Trainer:
         self.feat_len = feat_len
         self.ecapa = ecapa
         self.world = air_dist.world_size()
+        self.padding = padding
+        self.out_fold = None
+        self.prev_loss = 1e8       # best validation loss so far (main_train.py:280)
+        self.early_stop_cnt = 0    # main_train.py:279
+        if self.world > 1:
+            self.sync_from_rank0()
         # data parallel: start the gradient all-reduce inside backward where the model supports it
         if self.world > 1 and hasattr(self.model, "enable_ddp_overlap") and os.environ.get("AIR_DDP_OVERLAP", "1") == "1":
             self.model.enable_ddp_overlap()
@@ -50,13 +58,95 @@ class Trainer:
         # of the LFCC kernel (BASELINE configs[4]; replaces channel_simulation/*.py's offline pass)
         self.augment = augment
 
+    # ------------------------------------------------------------------ data parallel
+    def sync_from_rank0(self):
+        """Same replica everywhere: broadcast rank 0's parameter arena, the loss parameters and every module
+        buffer (BatchNorm running statistics, num_batches_tracked).  Called at construction when world > 1 -
+        ranks that built their model from a different seed or checkpoint would otherwise train diverged
+        replicas without any error - and before a checkpoint is written."""
+        if self.world == 1:
+            return
+        td.broadcast(self.model.arena().flat, src=0)
+        for p in self.loss.parameters():
+            td.broadcast(p.data, src=0)
+        self.sync_buffers_from_rank0()
+
+    def sync_buffers_from_rank0(self):
+        """Per-rank BatchNorm statistics are the reference's semantics (per-GPU batch == its batch, no SyncBN:
+        SURVEY.md 8e); what is SAVED is rank 0's running statistics."""
+        if self.world == 1:
+            return
+        for b in self.model.buffers():
+            td.broadcast(b.data, src=0)
+
+    # ------------------------------------------------------------------ logs and checkpoints
+    def set_out_fold(self, out_fold, fresh=True):
+        """main_train.py:104-121: the output folder with its ``checkpoint`` sub-folder.  ``fresh``: start the
+        logs over (the reference deletes and recreates the folder on a new run)."""
+        self.out_fold = out_fold
+        if air_dist.rank() == 0:
+            os.makedirs(os.path.join(out_fold, "checkpoint"), exist_ok=True)
+            if fresh:
+                for name in ("train_loss.log", "dev_loss.log", "test_loss.log"):
+                    path = os.path.join(out_fold, name)
+                    if os.path.exists(path):
+                        os.remove(path)
+        return self
+
+    def log_step(self, epoch_num, i, loss, adv=None):
+        """One line of ``train_loss.log`` exactly as main_train.py:479-481 appends it per iteration:
+        ``str(epoch) \\t str(i) \\t str(loss) \\n`` with ``loss`` the Python float of ``.item()``.  ``adv``:
+        the (adv_loss, acc_1, acc_2) triple of the ``--ADV_AUG`` variant (main_train.py:470-476)."""
+        if self.out_fold is None or air_dist.rank() != 0:
+            return
+        val = float(loss.item()) if torch.is_tensor(loss) else float(loss)
+        with open(os.path.join(self.out_fold, "train_loss.log"), "a") as log:
+            if adv is not None and epoch_num > 0:
+                log.write(str(epoch_num) + "\t" + str(i) + "\t" + str(float(adv[0])) + "\t" + str(float(adv[1])) +
+                          "\t" + str(float(adv[2])) + "\t" + str(val) + "\n")
+            else:
+                log.write(str(epoch_num) + "\t" + str(i) + "\t" + str(val) + "\n")
+
+    def log_eval(self, epoch_num, losses, eer, name="test_loss.log"):
+        """``str(epoch) \\t str(np.nanmean(losses)) \\t str(eer) \\n`` (main_train.py:666-667; the dev log of
+        :596-598 has the same layout)."""
+        if self.out_fold is None or air_dist.rank() != 0:
+            return
+        with open(os.path.join(self.out_fold, name), "a") as log:
+            log.write(str(epoch_num) + "\t" + str(np.nanmean(losses)) + "\t" + str(eer) + "\n")
+
+    def save_checkpoint(self, epoch_num, val_loss=None):
+        """End-of-epoch checkpoints with the reference's file names and whole-module pickles
+        (main_train.py:671-709): ``checkpoint/anti-spoofing_feat_model_%d.pt`` and
+        ``checkpoint/anti-spoofing_loss_model_%d.pt`` every epoch (numbered epoch_num + 1), and
+        ``anti-spoofing_feat_model.pt`` / ``anti-spoofing_loss_model.pt`` whenever the validation loss
+        improves.  generate_score.py:46-48 loads these with torch.load.  Returns True when the best pair
+        was written.  With world > 1 rank 0's BatchNorm statistics go to every rank first."""
+        if self.out_fold is None:
+            raise RuntimeError("call set_out_fold() first")
+        self.sync_buffers_from_rank0()
+        improved = val_loss is not None and val_loss < self.prev_loss
+        if air_dist.rank() == 0:
+            ck = os.path.join(self.out_fold, "checkpoint")
+            torch.save(self.model, os.path.join(ck, "anti-spoofing_feat_model_%d.pt" % (epoch_num + 1)))
+            torch.save(self.loss, os.path.join(ck, "anti-spoofing_loss_model_%d.pt" % (epoch_num + 1)))
+            if improved:
+                torch.save(self.model, os.path.join(self.out_fold, "anti-spoofing_feat_model.pt"))
+                torch.save(self.loss, os.path.join(self.out_fold, "anti-spoofing_loss_model.pt"))
+        if improved:
+            self.prev_loss = val_loss
+            self.early_stop_cnt = 0
+        elif val_loss is not None:
+            self.early_stop_cnt += 1
+        return improved
+
     def set_epoch(self, epoch_num, lr_decay=0.5, interval=30):
         adjust_learning_rate(self.lr0, self.feat_optimizer, epoch_num, lr_decay, interval)
         adjust_learning_rate(self.lr0, self.loss_optimizer, epoch_num, lr_decay, interval)
 
     def features(self, pcm, start=None):
         """(B, L) PCM -> model input, fused on the GPU (dataset.py:66-79 + main_train.py:338,:347)."""
-        feat = self.lfcc.forward_padded(pcm, self.feat_len, start)  # (B, 60, feat_len)
+        feat = self.lfcc.forward_padded(pcm, self.feat_len, start, self.padding)  # (B, 60, feat_len)
         return feat if self.ecapa else feat.unsqueeze(1)
 
     def step_features(self, feat, labels):

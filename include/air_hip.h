@@ -59,6 +59,19 @@ int air_lfcc_fwd(const float* pcm, int B, int L, float* out, const void* plan_de
  * T >= feat_len (chop; start_dev may be NULL = 0).  */
 int air_lfcc_fwd_padded(const float* pcm, int B, int L, float* out, int feat_len,
                         const int* start_dev, const void* plan_dev, int flags, air_stream_t stream);
+/* All three pad modes of the reference's --padding flag (main_train.py:45, dataset.py:72-79) for inputs
+ * shorter than feat_len; longer inputs are chopped at start[b] (clamped to [0, T - feat_len]) whatever the mode:
+ *   AIR_PAD_REPEAT  tile the frames (dataset.py:519-522)
+ *   AIR_PAD_ZERO    append zero frames (dataset.py:513-517)
+ *   AIR_PAD_SILENCE PREPEND silence_dev (D floats: the LFCC frame of digital silence, dataset.py:13-16, :524-528)
+ * Exactly one of pcm (fp32) / pcm16 (16-bit PCM) is non-NULL.  Any other pad_mode: AIR_EINVAL (the reference
+ * raises ValueError, dataset.py:79). */
+#define AIR_PAD_REPEAT 0
+#define AIR_PAD_ZERO 1
+#define AIR_PAD_SILENCE 2
+int air_lfcc_fwd_padded_ex(const float* pcm, const int16_t* pcm16, int B, int L, float* out, int feat_len,
+                           const int* start_dev, const void* plan_dev, int flags, int pad_mode,
+                           const float* silence_dev, air_stream_t stream);
 /* Same from 16-bit PCM as stored in the corpus' wav/flac files: the kernel converts s -> s / 32768 (exact, what
  * soundfile/librosa hand the reference, preprocess.py:239-241), so the features are bit-identical to the fp32
  * entry points on the converted samples while the kernel reads half the bytes (128 KB instead of 256 KB per
@@ -73,6 +86,9 @@ int air_preemph_inplace(float* pcm, int B, int L, float coef, void* ws, size_t w
 /* (B,T,D) -> (B,D,feat_len) repeat-pad / chop + transpose (dataset.py:66-79, main_train.py:338). */
 int air_pad_transpose(const float* feat, int B, int T, int D, float* out, int feat_len,
                       const int* start_dev, air_stream_t stream);
+/* ... with the pad mode of air_lfcc_fwd_padded_ex (dataset.py:513-528). */
+int air_pad_transpose_ex(const float* feat, int B, int T, int D, float* out, int feat_len,
+                         const int* start_dev, int pad_mode, const float* silence_dev, air_stream_t stream);
 
 /* --------------------------------------------------------------- conv2d --
  * Replaces nn.Conv2d forward/backward as used by resnet.py:131,56-61,140

@@ -393,59 +393,7 @@ def main():
     ec["g_center"] = lossmod.center.grad
     save("ecapa.npz", **ec)
 
-    # ---------------------------------------------------------------- G9 synthetic-corpus EER
-    print("G9 EER on the synthetic corpus (reference LFCC + ResNet + AngularIsoLoss + torch.optim)")
-    from asvspoof2021_air_amd.synth import corpus
-    L9, B9, NTR, NHO, EPOCHS = 16000, 32, 384, 256, 4
-    pcm_tr, lab_tr = corpus(688, NTR, L9)
-    pcm_ho, lab_ho = corpus(689, NHO, L9)
-    lf = ref_fe.LFCC(320, 160, 512, 16000, 20, with_energy=False)
-
-    def feats_of(pcm):
-        with torch.no_grad():
-            f = lf(torch.from_numpy(pcm.copy()))  # (n, 101, 60)
-        return f.unsqueeze(1).transpose(2, 3).contiguous()  # (n, 1, 60, 101), main_train.py:338
-
-    xtr, xho = feats_of(pcm_tr), feats_of(pcm_ho)
-    net = ref_resnet.ResNet(3, 256, resnet_type="18", nclasses=2)
-    fill_module_(net)
-    lossmod = ref_loss.AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
-    fill_module_(lossmod)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005)
-    opt2 = torch.optim.SGD(lossmod.parameters(), lr=5e-4)
-    ltr = torch.from_numpy(lab_tr)
-    epoch_loss = []
-    step = 0
-    for ep in range(EPOCHS):
-        net.train()
-        tot = 0.0
-        for i in range(0, NTR, B9):
-            torch.manual_seed(9000 + step)  # the host-side attention noise (resnet.py:38)
-            feat, _ = net(xtr[i:i + B9])
-            loss, _ = lossmod(feat, ltr[i:i + B9])
-            opt.zero_grad()
-            opt2.zero_grad()
-            loss.backward()
-            opt.step()
-            opt2.step()
-            tot += loss.item()
-            step += 1
-        epoch_loss.append(tot / (NTR // B9))
-    net.eval()
-    scores = []
-    with torch.no_grad():
-        for i in range(0, NHO, B9):
-            torch.manual_seed(9500 + i // B9)
-            feat, _ = net(xho[i:i + B9])
-            _, neg = lossmod(feat, torch.zeros(B9, dtype=torch.long))
-            scores.append(-neg)  # generate_score.py:116 writes +cos similarity
-    scores = torch.cat(scores).numpy()
-    eer = min(ref_em.compute_eer(scores[lab_ho == 0], scores[lab_ho == 1])[0],
-              ref_em.compute_eer(-scores[lab_ho == 0], -scores[lab_ho == 1])[0])
-    print("  epoch losses", epoch_loss, " held-out EER %.4f" % eer)
-    save("synth_eer.npz", epoch_loss=np.array(epoch_loss), scores=scores, labels=lab_ho, eer=np.array(eer),
-         cfg=np.array([L9, B9, NTR, NHO, EPOCHS]), pcm_sum=np.array([pcm_tr.astype(np.float64).sum(),
-                                                                      pcm_ho.astype(np.float64).sum()]))
+    # G9 (EER on the synthetic corpus): tests/golden/make_golden_eer2.py (separable regime, seeded construction)
     print("done")
 
 

@@ -33,12 +33,16 @@ SEED = 688
 
 
 def checksums(sd):
-    names, vals = [], []
+    """per tensor: (sum, sum |.|, first element, numel) as float64 and the int64 sum of the raw 32-bit
+    patterns (integer addition is associative: a bit-exact, order-independent checksum)."""
+    names, vals, bits = [], [], []
     for k, v in sd.items():
-        v = v.detach().double().reshape(-1)
+        raw = v.detach().reshape(-1)
+        v = raw.double()
         names.append(k)
         vals.append([float(v.sum()), float(v.abs().sum()), float(v[0]) if v.numel() else 0.0, float(v.numel())])
-    return np.array(names), np.array(vals, dtype=np.float64)
+        bits.append(int(raw.contiguous().view(torch.int32).long().sum()) if raw.dtype == torch.float32 else int(raw.long().sum()))
+    return np.array(names), np.array(vals, dtype=np.float64), np.array(bits, dtype=np.int64)
 
 
 def build(which):
@@ -122,8 +126,8 @@ def init():
     out = {}
     for which in ("resnet", "ecapa"):
         net, lossmod = build(which)
-        n, v = checksums(net.state_dict())
-        out[which + "_names"], out[which + "_vals"] = n, v
+        n, v, bits = checksums(net.state_dict())
+        out[which + "_names"], out[which + "_vals"], out[which + "_bits"] = n, v, bits
         out[which + "_center"] = lossmod.center.detach().numpy().copy()
     save("init_checksums.npz", seed=np.array(SEED), **out)
 

@@ -123,7 +123,9 @@ def test_adversarial_step_gradients_and_two_phase_update():
         ref = sd[k].grad.numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         gap = np.abs(plain.numpy() - ref).max() / np.abs(ref).max()  # what dropping the adversarial term would cost
-        assert err <= 2e-3 and gap > 20 * err, (k, err, gap)
+        # 6e-3: the Winograd F(4x4,3x3) convolutions round at up to 1e-5 of a layer's output scale (F(2x2): 1e-6),
+        # which this filler-initialised net amplifies to 4.3e-3 of max on conv1.weight (measured; F(2x2): 8e-4)
+        assert err <= 6e-3 and gap > 20 * err, (k, err, gap)
     np.testing.assert_allclose(float(tr.last["adv_loss"]), l_adv.item(), rtol=1e-4)
     # epoch 0: no adversarial term (main_train.py:377), classifiers still train in phase 2
     tr0 = make(False)

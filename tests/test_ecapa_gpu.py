@@ -204,3 +204,39 @@ def test_whole_module_pickle_roundtrip(tmp_path):
     m2.eval()
     with torch.no_grad():
         assert torch.equal(m(x)[0], m2(x)[0])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gradient_accumulation_two_backwards(dtype):
+    """backward twice without zero_grad: p.grad (a view of the gradient arena) must end as the SUM of both
+    gradients, like torch's AccumulateGrad - not twice the second one (ECAPA had no guard)."""
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    torch.manual_seed(688)
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60).cuda().train().set_compute_dtype(dtype)
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0).cuda()
+    xa, xb = synth_feat((4, 60, 96), seed=1).cuda(), synth_feat((4, 60, 96), seed=2).cuda()
+    labels = torch.tensor([0, 1, 1, 0]).cuda()
+
+    def grads_of(x):
+        for p in m.parameters():
+            p.grad = None
+        m.bn1.running_mean.zero_()  # (forward state does not matter for the gradients; keep runs comparable)
+        feat, _ = m(x)
+        lossm(feat, labels)[0].backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    ga, gb = grads_of(xa), grads_of(xb)
+    for p in m.parameters():
+        p.grad = None
+    for x in (xa, xb):
+        feat, _ = m(x)
+        lossm(feat, labels)[0].backward()
+    arena = m.arena()
+    for k, p in m.named_parameters():
+        if k not in ga:
+            continue
+        want = ga[k] + gb[k]
+        assert p.grad.data_ptr() == arena.grad_view(k).data_ptr()  # still the zero-copy arena view
+        tol = 1e-6 * float(want.abs().max()) + 1e-12
+        assert float((p.grad - want).abs().max()) <= tol, k

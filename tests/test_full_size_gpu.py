@@ -48,7 +48,11 @@ def test_resnet_full_size_step_vs_oracle():
     # of a ReLU threshold, and a flipped unit moves whole gradient elements: the fp32 CPU oracle ITSELF is
     # up to 5e-2 of max away from its fp64 evaluation on single elements (layer4.1.conv1.weight), and so is
     # the HIP path.  So: relative L2 per tensor against the fp64 oracle, bounded by what the fp32 oracle
-    # shows against the same fp64 truth (x3) plus 1e-3.
+    # shows against the same fp64 truth (x3) plus 5e-3: the Winograd F(4x4,3x3) convolutions (conv_wino4.hip)
+    # round at up to 1e-5 of a layer's output scale where the direct fp32 convolution rounds at 1e-6 .. 3e-6,
+    # and this filler-initialised net amplifies that to 3.6e-3 on the worst tensor (layer4.1.bn2.weight;
+    # measured 1.0e-3 with F(2x2,3x3); the better-conditioned point set (0,1,-1,2,-1/2) halves the
+    # per-convolution error but measured 5.0e-3 here: the figure is set by flipped ReLUs, not by rounding).
     p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
     o64 = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
     _, _, _, g64, _, _ = o64.loss_and_grads(xo.double(), labels, None)
@@ -58,7 +62,7 @@ def test_resnet_full_size_step_vs_oracle():
         nrm = np.linalg.norm(ref) + 1e-30
         e_hip = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / nrm
         e_cpu = np.linalg.norm(go[k].numpy().ravel().astype(np.float64) - ref) / nrm
-        assert e_hip <= 3.0 * e_cpu + 1e-3, (k, e_hip, e_cpu)
+        assert e_hip <= 3.0 * e_cpu + 5e-3, (k, e_hip, e_cpu)
         if e_hip > worst[1]:
             worst = (k, e_hip, e_cpu)
     print("worst relative L2 gradient error vs fp64: %s hip %.2e (fp32 CPU oracle: %.2e)" % worst)
@@ -140,3 +144,45 @@ def test_ecapa_full_length_step_vs_oracle(dtype):
             worst = (k, err)
         assert err <= 5e-3, (k, err)
     print("fp32 worst relative L2 gradient error", worst)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_ecapa_configs2_size_properties(dtype):
+    """BASELINE configs[2] at size under pytest: ECAPA-TDNN-512, batch 128, T = 750 (bf16 compute = configs[2]
+    itself, fp32 = the reference's arithmetic).  The CPU oracle needs minutes at this size, so the checks are
+    the size-independent properties: (a) determinism - two identical steps give bit-identical gradients,
+    (b) linearity - backward of 2 x loss doubles every gradient, (c) eval-mode batch independence - scoring
+    128 utterances at once equals scoring them 16 at a time, (d) every gradient finite and non-zero."""
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    B, T = 128, 750
+    x = synth_feat((B, 60, T), seed=128).cuda()
+    labels = (torch.arange(B) % 5 != 0).long().cuda()
+
+    def fresh():
+        torch.manual_seed(688)
+        m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)  # seeded kaiming init (= reference's)
+        lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+        return m.cuda().train().set_compute_dtype(dtype), lossm.cuda()
+
+    gs = []
+    for scale in (1.0, 1.0, 2.0):
+        m, lossm = fresh()
+        feat, _ = m(x)
+        loss, _ = lossm(feat, labels)
+        (scale * loss).backward()
+        gs.append((m.arena().grad[:m.arena().head_total].clone(), lossm.center.grad.clone(), loss.item()))
+    assert torch.equal(gs[0][0], gs[1][0]) and torch.equal(gs[0][1], gs[1][1]) and gs[0][2] == gs[1][2]
+    g1, g2 = gs[0][0], gs[2][0]
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert float((g2 - 2.0 * g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+    for k, p in m.named_parameters():
+        if k.startswith(("fc7", "bn7")):
+            assert p.grad is None  # no gradient under ang_iso (main_train.py:355 -> 376)
+        elif k not in ("attention.2.bias", "attention.3.bias"):  # analytically zero (softmax over T)
+            assert p.grad is not None and float(p.grad.abs().max()) > 0, k
+    m.eval()
+    with torch.no_grad():
+        f_all, _ = m(x)
+        f_parts = torch.cat([m(x[i:i + 16])[0] for i in range(0, B, 16)])
+    assert float((f_all - f_parts).abs().max()) <= 2e-5 * float(f_all.abs().max())

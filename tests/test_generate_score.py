@@ -146,3 +146,36 @@ def test_graphed_batch1_scoring_equals_eager(tmp_path, kind):
     r_graph = rate(lambda: gs(x))
     print("%s batch-1 scoring at T=750: eager %.0f utt/s, hipGraph replay %.0f utt/s" % (kind, r_eager, r_graph))
     assert r_graph > 0.9 * r_eager
+
+
+@pytest.mark.gpu
+def test_trainer_checkpoints_feed_generate_score(tmp_path):
+    """Trainer.save_checkpoint() writes the reference's files (main_train.py:675-704); loading them the way
+    generate_score.py:46-48 does (torch.load of whole-module pickles) scores exactly like the live modules."""
+    from asvspoof2021_air_amd.generate_score import test_on_dataset
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    torch.manual_seed(688)
+    tr = Trainer(ResNet(3, 256, resnet_type="18", nclasses=2), feat_len=96).set_out_fold(str(tmp_path / "run"))
+    feats, names, labels = _items(6, 96, True)
+    x = feats.transpose(2, 3).contiguous().cuda()
+    for step in range(2):  # two real optimisation steps so the checkpoint is not the initial state
+        loss, _ = tr.step_features(x, labels.cuda())
+        tr.log_step(0, step, loss)
+    assert tr.save_checkpoint(0, val_loss=float(loss)) is True
+    lines = (tmp_path / "run" / "train_loss.log").read_text().splitlines()
+    assert len(lines) == 2 and lines[1].split("\t")[:2] == ["0", "1"] and float(lines[1].split("\t")[2]) == float(loss)
+    feat_model = torch.load(tmp_path / "run" / "anti-spoofing_feat_model.pt", weights_only=False).cuda()
+    loss_model = torch.load(tmp_path / "run" / "anti-spoofing_loss_model.pt", weights_only=False).cuda()
+    per_epoch = torch.load(tmp_path / "run" / "checkpoint" / "anti-spoofing_feat_model_1.pt", weights_only=False)
+    assert list(per_epoch.state_dict().keys()) == list(tr.model.state_dict().keys())
+    for (k, a), b in zip(feat_model.state_dict().items(), tr.model.state_dict().values()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    tags = torch.zeros(6)
+    batches = [(feats[i:i + 3], names[i:i + 3], tags[i:i + 3], labels[i:i + 3]) for i in range(0, 6, 3)]
+    tr.model.set_attention_noise(None)
+    feat_model.set_attention_noise(None)
+    fa, fb = tmp_path / "live.txt", tmp_path / "loaded.txt"
+    test_on_dataset(tr.model, batches, str(fa), tr.loss, "ocsoftmax", task="19eval")
+    test_on_dataset(feat_model, batches, str(fb), loss_model, "ocsoftmax", task="19eval")
+    assert fa.read_text() == fb.read_text() and len(fa.read_text().splitlines()) == 6

@@ -117,6 +117,56 @@ def test_lfcc_padded_layout(lfcc, L, feat_len):
     np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
 
 
+@pytest.mark.parametrize("padding", ["zero", "silence", "repeat"])
+@pytest.mark.parametrize("L,feat_len", [(16000, 750), (3200, 64), (64000, 750), (120000, 750)])
+def test_lfcc_pad_modes(golden, lfcc, L, feat_len, padding):
+    """All three --padding choices (main_train.py:45) of the fused front-end and of pad_transpose vs the oracle
+    (oracle/pad.py, pinned to dataset.py:513-528 by tests/golden/pad.npz): zero frames APPENDED, the
+    LFCC-of-silence frame PREPENDED; longer inputs are chopped whatever the mode; int16 PCM gives the same."""
+    from asvspoof2021_air_amd import dataset as ds
+    B = 2
+    x = synth_pcm(B, L, seed=177 + L)
+    T = 1 + L // 160
+    sil = lfcc.silence_row(torch.device("cuda"))
+    sil_o = torch.from_numpy(o_lfcc.lfcc_forward(np.zeros((1, 3200), np.float32)))[:, 0, :]  # dataset.py:13-16
+    np.testing.assert_allclose(sil.cpu().numpy(), sil_o[0].numpy(), atol=TOL)
+    np.testing.assert_allclose(sil_o[0].numpy(), golden("pad.npz")["silence_row"].reshape(-1), atol=1e-5)
+    start = torch.tensor([1, T - feat_len - 1], dtype=torch.int32) if T > feat_len else None
+    y = lfcc.forward_padded(x.cuda(), feat_len, None if start is None else start.cuda(), padding)
+    yo = torch.from_numpy(o_lfcc.lfcc_forward(x.numpy().copy()))
+    rows = []
+    for b in range(B):
+        f = yo[b:b + 1]
+        if T > feat_len:
+            f = f[:, int(start[b]):int(start[b]) + feat_len]
+        elif T < feat_len:
+            f = {"zero": lambda: o_pad.zero_pad(f, feat_len), "repeat": lambda: o_pad.repeat_pad(f, feat_len),
+                 "silence": lambda: o_pad.silence_pad(f, feat_len, sil_o)}[padding]()
+        rows.append(f)
+    want = o_pad.to_model_input(torch.stack(rows))[:, 0]
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), atol=TOL)
+    if padding == "zero" and T < feat_len:
+        assert torch.count_nonzero(y[:, :, T:]) == 0          # appended, exact zeros
+    if padding == "silence" and T < feat_len:
+        assert torch.equal(y[:, :, 0], sil.expand(B, -1))      # prepended, the frame itself
+    y2 = ds.pad_transpose(lfcc_noinplace(lfcc, x), feat_len, None if start is None else start.cuda(), padding, sil)
+    np.testing.assert_array_equal(y2.cpu().numpy(), y.cpu().numpy())
+    x16 = (x * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
+    y16 = lfcc.forward_padded(x16.cuda(), feat_len, None if start is None else start.cuda(), padding)
+    y16f = lfcc.forward_padded((x16.float() / 32768.0).cuda(), feat_len, None if start is None else start.cuda(), padding)
+    assert torch.equal(y16, y16f)
+
+
+def test_lfcc_pad_mode_errors_and_clamped_start(lfcc):
+    x = synth_pcm(2, 16000, seed=5).cuda()
+    with pytest.raises(ValueError, match="Padding should be zero or repeat!"):  # dataset.py:79
+        lfcc.forward_padded(x, 750, None, "reflect")
+    # crop offsets are caller data: out-of-range values are clamped on the device, every column is written
+    bad = torch.tensor([-5, 10 ** 6], dtype=torch.int32).cuda()
+    good = torch.tensor([0, 101 - 64], dtype=torch.int32).cuda()
+    assert torch.equal(lfcc.forward_padded(x, 64, bad), lfcc.forward_padded(x, 64, good))
+
+
 def lfcc_noinplace(lfcc, x):
     lfcc.mutate_input = False
     try:

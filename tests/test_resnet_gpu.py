@@ -102,7 +102,7 @@ def test_grads_vs_oracle_small(golden):
         assert err < 5e-3, "%s: relative L2 grad err %.3g" % (k, err)
         assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max(), k
         np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=5e-3)
-    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=1e-5)
     # gradients live in the flat arena (zero-copy views)
     arena = m.arena()
     assert m.conv1.weight.grad.data_ptr() == arena.grad_view("conv1.weight").data_ptr()
@@ -114,8 +114,8 @@ def test_trajectory_vs_golden(golden):
     losses.  Step 1 is pre-update (tight); later steps sit on Adam's sign-SGD noise floor
     (see tests/golden/make_golden.py): the first Adam updates are lr * sign(g), so rounding-level
     gradient differences flip whole updates of near-zero-gradient weights.  There the fp32 and
-    fp64 oracles differ by 1e-4, the direct-conv kernels by 1e-4, and the Winograd convs (input
-    transform subtracts neighbours: ~1e-6 of scale per conv instead of ~1e-7) by 2e-3."""
+    fp64 oracles differ by 1e-4, the direct-conv kernels by 1e-4, and the Winograd convs (F(4x4,3x3):
+    up to 1e-5 of scale per conv instead of 1e-6) by 3e-4 at step 2 and 2e-3 at step 3."""
     g = golden("trajectory.npz")
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     from asvspoof2021_air_amd.train import Trainer
@@ -132,7 +132,7 @@ def test_trajectory_vs_golden(golden):
         loss, _ = tr.step_features(xb, labels)
         losses.append(loss.item())
     np.testing.assert_allclose(losses[0], g["losses"][0], rtol=2e-5)
-    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=1e-4)
+    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=5e-4)
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-3)
     sd = m.state_dict()
     assert np.abs(sd["conv1.weight"].cpu().numpy() - g["conv1_w"]).max() <= 3 * 2 * 5e-4 + 1e-6
@@ -196,3 +196,31 @@ def test_whole_module_pickle_roundtrip(tmp_path):
     # and the loaded module trains (arena rebuilt on first use)
     tr2 = Trainer(m2, loss_module=l2, feat_len=96)
     tr2.step_features(x, torch.tensor([0, 1, 1, 0]).cuda())
+
+
+def test_optimizer_skips_without_gradients_and_rejects_frozen():
+    """torch.optim.Adam semantics on the arena: a step() with no backward since zero_grad() changes nothing
+    (the arena still holds the previous sums - applying them again would be a second step), frozen parameters
+    are refused, and the tail (fc_mu.*) keeps its own step count."""
+    from asvspoof2021_air_amd.optim import FusedAdam
+    m = make_model()
+    opt = FusedAdam(m, lr=5e-4)
+    xb = synth_feat((4, 1, 60, 96), seed=9).cuda()
+    m.set_attention_noise(None)
+    feat, mu = m(xb)
+    (feat.square().mean() + mu.square().mean()).backward()  # the CE-style branch: fc_mu gets gradients too
+    opt.step()
+    w1 = m.arena().flat.clone()
+    assert opt.step_count == 1 and opt.tail_steps == 1
+    opt.zero_grad()
+    opt.step()  # nothing to apply
+    assert torch.equal(m.arena().flat, w1) and opt.step_count == 1
+    feat, _ = m(xb)
+    feat.square().mean().backward()  # ang_iso-style: no gradient for fc_mu
+    fc_mu = m.fc_mu.weight.detach().clone()
+    opt.step()
+    assert opt.step_count == 2 and opt.tail_steps == 1 and torch.equal(m.fc_mu.weight.detach(), fc_mu)
+    assert not torch.equal(m.arena().flat, w1)
+    m.conv1.weight.requires_grad_(False)
+    with pytest.raises(RuntimeError, match="frozen"):
+        opt.step()
