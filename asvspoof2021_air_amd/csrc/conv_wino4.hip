@@ -661,7 +661,7 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
     return ok;
   }();
   if (!attr_ok) return AIR_ELAUNCH;
-  AirProfScope ps(AIR_K_CONV_WINO, flops, st);
+  AirProfScope ps(AIR_K_CONV_WINO4, flops, st);
   if (a.trace != nullptr) {
     if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, true>), dim3(nblk), dim3(256), ldsb, st, a);
     else hipLaunchKernelGGL((wino4_conv_kernel<1, true>), dim3(nblk), dim3(256), ldsb, st, a);

@@ -34,6 +34,8 @@ FEAT_LEN = 750      # reference default --feat_len (main_train.py:43), padding='
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0
+WINO_ISSUE = {"wino_conv_kernel": 16.0 / 36.0, "wino_wgrad_kernel": 16.0 / 36.0, "wino4_conv_kernel": 36.0 / 144.0}
+PMC_FILE = "r02_pmc_traffic.json"
 
 
 def synth_batch(step, rank, device):
@@ -72,31 +74,35 @@ def roofline_leg(trainer, batches):
     lib.air_prof_enable(0)
     convs = [r for r in rows if r["kernel"].startswith(("conv", "wino", "c1b"))]
     dom = max(convs, key=lambda r: r["total_ms"])
-    achieved = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
+    algorithmic = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
     all_flops = sum(r["work"] for r in convs)
     all_ms = sum(r["total_ms"] for r in convs)
     # the bf16 pointwise kernels (ECAPA, --dtype bf16) are priced against the bf16 MFMA peak
     peak = PEAK_BF16_MFMA_TFLOPS if dom["kernel"].startswith("c1b") else PEAK_F32_MFMA_TFLOPS
+    # FLOPs a kernel puts through the matrix pipe per algorithmic FLOP (2 * MACs of the direct convolution,
+    # SURVEY.md 8d): the Winograd kernels multiply 16 (F(2x2,3x3)) / 36 (F(4x4,3x3)) transformed values per
+    # 2x2 / 4x4 output tile where the direct algorithm multiplies 36 / 144.  "achieved" and "frac" are the
+    # ISSUED rate against the MFMA peak - a fraction of the roofline, never above 1 - and the
+    # algorithmic-equivalent rate (what a direct kernel would have to sustain) is reported beside it.
+    issue = WINO_ISSUE.get(dom["kernel"], 1.0)
+    achieved = algorithmic * issue
     out = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
            "traffic": None,
-           # "achieved" counts ALGORITHMIC FLOPs (2 * MACs of the direct convolution, SURVEY.md
-           # 8d).  The Winograd kernels issue 36/16 = 2.25x fewer MFMA FLOPs than that (plus
-           # tile padding), so their algorithmic rate may exceed the MFMA peak; the FLOPs they
-           # actually issue to the matrix pipe are reported beside it.
-           "mfma_issued": (round(achieved / 2.25, 2) if dom["kernel"].startswith("wino") else round(achieved, 2)),
+           "algorithmic_equivalent": round(algorithmic, 2), "issued_per_algorithmic_flop": round(issue, 4),
            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches_per_step": dom["launches"] // 2,
-           "all_conv_kernels": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+           "all_conv_kernels": {"algorithmic_equivalent": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                 "ms_per_step": round(all_ms / 2, 3)}}
-    # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command: profiles/r01_n_pmc_traffic.md)
+    # HBM-side bytes per launch of the dominant kernel from this round's committed PMC passes (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, tools/profile_round.sh +
+    # tools/pmc_traffic.py); null when the file does not cover this kernel / configuration
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
             pmc = json.load(fh)
         model_key = "ecapa" if dom["kernel"].startswith("c1b") else "resnet"
         if BATCH == (128 if model_key == "ecapa" else 64) and FEAT_LEN == 750:  # the measured configuration only
-            out["traffic"] = round(pmc[model_key][dom["kernel"]]["traffic_bytes_per_launch"])
-            out["traffic_source"] = "profiles/r01_n_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)"
+            out["traffic"] = round(pmc[model_key + "_family"][dom["kernel"]]["traffic_bytes_per_launch"])
+            out["traffic_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)" % PMC_FILE
     except (OSError, KeyError, ValueError):
         pass
     if dom["kernel"] == "c1b_fwd_kernel":
@@ -114,7 +120,9 @@ def roofline_leg(trainer, batches):
                               "avg_launch_ms": round(lf[0]["total_ms"] / lf[0]["launches"], 4)}
     out["per_kernel"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // 2,
                           "ms_per_step": round(r["total_ms"] / 2, 3),
-                          "rate": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2)} for r in rows]
+                          "algorithmic_rate": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2),
+                          "issued_rate": round(WINO_ISSUE.get(r["kernel"], 1.0) * r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2)}
+                         for r in rows]
     return out
 
 
@@ -140,19 +148,21 @@ def cpu_baseline_leg():
     tr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
     times = []
     t_start = time.perf_counter()
-    for it in range(8):
+    for it in range(13):  # 3 warm-up + 10 timed, median
         t0 = time.perf_counter()
         tr.step(x, labels, None)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > 25.0 and len(times) >= 2:  # bounded sample
+        if time.perf_counter() - t_start > 30.0 and len(times) >= 4:  # bounded sample
             break
     warm = min(3, len(times) - 1)
     step = float(np.median(times[warm:]))
     per_utt = t_lfcc / 64 + step / 8
-    return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
+            "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
                       "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, 3 warm-up + "
-                      "5 timed, median %.3f s/step" % (1e3 * t_lfcc / 64, step),
+                      "%d timed, median %.3f s/step; threads capped at 16 of %d (PyTorch-CPU conv backward "
+                      "collapses when oversubscribed)" % (1e3 * t_lfcc / 64, len(times) - warm, step, os.cpu_count() or 1),
             "lfcc_utt_per_s": round(64 / t_lfcc, 1), "train_step_utt_per_s": round(8 / step, 2)}
 
 
@@ -176,6 +186,8 @@ def main():
                          "(BASELINE configs[4]; 30 synthetic 1024-tap IRs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="default run only: skip the ECAPA-TDNN-512 bf16 leg (BASELINE configs[2]) reported under 'configs'")
     args = ap.parse_args()
 
     from asvspoof2021_air_amd import dist as air_dist
@@ -196,31 +208,6 @@ def main():
     from asvspoof2021_air_amd.train import Trainer
     global BATCH, FEAT_LEN
     FEAT_LEN = args.feat_len
-    torch.manual_seed(688)
-    if args.model == "resnet":
-        from asvspoof2021_air_amd.resnet import ResNet
-        model = ResNet(3, 256, resnet_type="18", nclasses=2)
-        BATCH = args.batch or 64
-    else:
-        from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
-        model = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
-        model.set_compute_dtype(args.dtype or "bf16")
-        BATCH = args.batch or 128
-    trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
-                      feat_len=FEAT_LEN, device=device, ecapa=(args.model == "ecapa"))
-    if args.augment:
-        from asvspoof2021_air_amd.augment import ChannelAugment
-        trainer.augment = ChannelAugment(p=1.0, seed=688 + rank, device=device)
-    if world > 1:  # same initial weights everywhere
-        arena = model.arena()
-        td.broadcast(arena.flat, src=0)
-        for p in trainer.loss.parameters():
-            td.broadcast(p.data, src=0)
-
-    nb = max(2, min(4, args.steps + args.warmup))
-    batches = [synth_batch(i, rank, device) for i in range(nb)]  # inputs resident in HBM
-    for i in range(args.warmup):
-        trainer.step(*batches[i % nb])
 
     def fence():
         torch.cuda.synchronize()
@@ -228,40 +215,94 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last, _ = trainer.step(*batches[i % nb])
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
-    loss_val = float(last.item())
+    def run_config(model_name, dtype, batch, steps, warmup, augment, want_roofline):
+        """W untimed + K timed train steps of one configuration (barrier + synchronize fences, MAX over ranks),
+        then the instrumented roofline steps.  Returns (model, dict)."""
+        global BATCH
+        torch.manual_seed(688)
+        if model_name == "resnet":
+            from asvspoof2021_air_amd.resnet import ResNet
+            model = ResNet(3, 256, resnet_type="18", nclasses=2)
+            BATCH = batch or 64
+        else:
+            from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+            model = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+            model.set_compute_dtype(dtype or "bf16")
+            BATCH = batch or 128
+        # (Trainer broadcasts rank 0's weights, loss centre and BatchNorm buffers when world > 1)
+        trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
+                          feat_len=FEAT_LEN, device=device, ecapa=(model_name == "ecapa"))
+        if augment:
+            from asvspoof2021_air_amd.augment import ChannelAugment
+            trainer.augment = ChannelAugment(p=1.0, seed=688 + rank, device=device)
+        nb = max(2, min(4, steps + warmup))
+        batches = [synth_batch(i, rank, device) for i in range(nb)]  # inputs resident in HBM
+        for i in range(warmup):
+            trainer.step(*batches[i % nb])
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last, _ = trainer.step(*batches[i % nb])
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            dt = float(t.item())
+        res = {"value": round(world * BATCH * steps / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(1e3 * dt / steps, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
+               "final_loss": round(float(last.item()), 5)}
+        # The instrumented roofline steps are ordinary train steps: with world > 1 they contain the gradient
+        # all-reduce, so EVERY rank runs them (rank 0 alone would wait for its peers forever); only rank 0 reports.
+        if want_roofline:
+            res["roofline"] = roofline_leg(trainer, batches)
+        bucketer = getattr(model, "_bucketer", None)
+        res["ddp"] = {"device": "cuda:%d" % local, "world": world,
+                      "buckets_in_backward": (bucketer.total_launched if bucketer is not None else 0)}
+        return model, res
 
-    # The instrumented roofline steps are ordinary train steps: with world > 1 they contain the gradient
-    # all-reduce, so EVERY rank runs them (rank 0 alone would wait for its peers forever); only rank 0 reports.
-    roofline = None if args.no_roofline else roofline_leg(trainer, batches)
+    model, main_res = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup, args.augment,
+                                 not args.no_roofline)
+    dt_unused = None
+    roofline = main_res.pop("roofline", None)
+    main_batch = BATCH
+    # BASELINE configs[2] (ECAPA-TDNN-512, bf16 compute, batch 128 per GPU) rides along in the default run so
+    # that the driver's bench line carries a measured number for it too
+    extra = {}
+    if args.model == "resnet" and not args.no_extra_configs and args.batch == 0 and not args.augment:
+        del model
+        torch.cuda.empty_cache()
+        _, e = run_config("ecapa", "bf16", 0, max(2, min(args.steps, 8)), min(args.warmup, 2), False, not args.no_roofline)
+        e["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
+        e["dtype"] = "bf16"
+        e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16 compute "
+                         "(pointwise and dilated convs on v_mfma_f32_32x32x16_bf16, fp32 accumulate), T=401 "
+                         "repeat-padded to %d" % FEAT_LEN)
+        extra["ecapa_bf16_b128"] = e
+        if args.model == "resnet":
+            from asvspoof2021_air_amd.resnet import ResNet  # noqa: F401  (model for the line below)
+        model = None
+    BATCH = main_batch
 
     if rank == 0:
         line = {
             "metric": "utterances/sec (LFCC+ResNet-OCSoftmax train step, 4 s@16 kHz)",
-            "value": round(world * BATCH * args.steps / dt, 2), "unit": "utt/s",
+            "value": main_res["value"], "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: fused HIP LFCC(320,160,512,20 filters) + ResNet-18 + "
                                    "OC-Softmax(ang_iso) fp32 train step (fwd+bwd+Adam+SGD), 4 s @ 16 kHz PCM in HBM, "
                                    "T=401 frames repeat-padded to feat_len=%d" % FEAT_LEN,
                        "global_batch": world * BATCH, "per_gpu_batch": BATCH, "feat_len": FEAT_LEN,
                        "parallelism": "dp%d" % world},
-            "final_loss": round(loss_val, 5),
+            "final_loss": main_res["final_loss"],
+            "ddp": main_res["ddp"],
         }
         if args.model == "ecapa":
             line["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
-            dt = model.compute_dtype
+            dt = args.dtype or "bf16"
             line["dtype"] = "bf16" if dt == "bf16" else "f32"
             line["config"]["workload"] = (
                 "BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, T=401 repeat-padded to "
@@ -272,6 +313,8 @@ def main():
             line["config"]["workload"] += "; + on-the-fly IR convolution (1024 taps) of every utterance ahead of LFCC"
         if roofline is not None:
             line["roofline"] = roofline
+        if extra:
+            line["configs"] = extra
         if world == 1 and not args.no_cpu_baseline and args.model == "resnet":
             line["cpu_baseline"] = cpu_baseline_leg()
         print(json.dumps(line), flush=True)

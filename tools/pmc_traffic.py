@@ -13,7 +13,7 @@ src = "gpurun_out/%s" % tag
 def load(path):
     d = {}
     for ln in open(path):
-        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=(\d+)\s+avg=([\d.e+-]+)", ln)
+        m = re.match(r"(.+?)\s+(FETCH_SIZE|WRITE_SIZE|SQ_VALU_MFMA_BUSY_CYCLES|GRBM_GUI_ACTIVE)\s+n=(\d+)\s+avg=([\d.e+-]+)", ln)
         if m:
             d[m.group(1).strip()] = (int(m.group(3)), float(m.group(4)))
     return d
@@ -34,10 +34,33 @@ for model in ("resnet", "ecapa"):
         rows.append((model, k, n, fk, wk, traffic))
         out.setdefault(model, {})[k] = {"launches": n, "fetch_kb": fk, "write_kb": wk,
                                         "traffic_bytes_per_launch": traffic}
-ks = [k for k in out["resnet"] if k.startswith("wino_conv_kernel")]
-n = sum(out["resnet"][k]["launches"] for k in ks)
-out["resnet"]["wino_conv_kernel"] = {"launches": n, "traffic_bytes_per_launch": sum(
-    out["resnet"][k]["launches"] * out["resnet"][k]["traffic_bytes_per_launch"] for k in ks) / n}
+# per-family aggregates (all template instances of a kernel, launch-weighted) live under their OWN top-level
+# key: inside out[model] they would be summed a second time by anyone adding up the per-kernel rows
+fam = {}
+for model in out:
+    for base in ("wino4_conv_kernel", "wino_conv_kernel", "wino_wgrad_kernel", "c1b_gemm_kernel", "c1b_fwd_kernel"):
+        ks = [k for k in out[model] if k.startswith(base)]
+        n = sum(out[model][k]["launches"] for k in ks)
+        if n:
+            fam.setdefault(model, {})[base] = {"launches": n, "traffic_bytes_per_launch": sum(
+                out[model][k]["launches"] * out[model][k]["traffic_bytes_per_launch"] for k in ks) / n}
+# MFMA-pipe busy fraction per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+busy_rows = []
+for model in ("resnet", "ecapa"):
+    try:
+        mb = load("%s/pmc_%s_SQ_VALU_MFMA_BUSY_CYCLES.txt" % (src, model))
+        ga = load("%s/pmc_%s_GRBM_GUI_ACTIVE.txt" % (src, model))
+    except OSError:
+        continue
+    for k in sorted(mb):
+        if k in ga and ga[k][1] > 0:
+            frac = mb[k][1] / (1024.0 * ga[k][1] / 8.0)
+            if frac > 0.01:
+                busy_rows.append((model, k, mb[k][0], frac))
+                out.setdefault(model, {}).setdefault(k, {})["mfma_busy"] = frac
+for model in fam:
+    for base, v in fam[model].items():
+        out[model + "_family"] = fam[model]
 json.dump(out, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1, sort_keys=True)
 with open("profiles/%s_pmc_traffic.md" % tag, "w") as fh:
     fh.write("# PMC HBM-side traffic per launch (%s), `tools/profile_round.sh` + `tools/pmc_traffic.py`\n\n"
@@ -52,4 +75,10 @@ with open("profiles/%s_pmc_traffic.md" % tag, "w") as fh:
     for model, k, n, fk, wk, t in rows:
         if t > 5e6:
             fh.write("| %s | %s | %d | %.4g | %.4g | %.1f |\n" % (model, k[:60], n, fk, wk, t / 1e6))
-print(out["resnet"]["wino_conv_kernel"], out["ecapa"].get("c1b_gemm_kernel"))
+    if busy_rows:
+        fh.write("\n## MFMA pipe busy (separate `--pmc SQ_VALU_MFMA_BUSY_CYCLES` / `--pmc GRBM_GUI_ACTIVE` passes of the same command)\n\n"
+                 "busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), launch average.\n\n"
+                 "| model | kernel | launches | MFMA busy |\n|---|---|---|---|\n")
+        for model, k, n, frac in busy_rows:
+            fh.write("| %s | %s | %d | %.2f |\n" % (model, k[:60], n, frac))
+print(fam)

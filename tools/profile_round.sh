@@ -2,29 +2,29 @@
 # Run on the GPU box (gpurun): bench lines, rocprofv3 kernel traces and PMC traffic passes.
 # Usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r01_final}
+TAG=${1:-r02_final}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 timeout 300 python bench.py > $OUT/bench_resnet.json 2> $OUT/bench_resnet.err
-timeout 300 python bench.py --feat-len 401 --no-cpu-baseline > $OUT/bench_resnet_t401.json 2>> $OUT/bench_resnet.err
+timeout 300 python bench.py --feat-len 401 --no-cpu-baseline --no-extra-configs > $OUT/bench_resnet_t401.json 2>> $OUT/bench_resnet.err
 timeout 300 python bench.py --model ecapa --steps 8 > $OUT/bench_ecapa_bf16.json 2> $OUT/bench_ecapa.err
 timeout 300 python bench.py --model ecapa --steps 8 --feat-len 401 > $OUT/bench_ecapa_bf16_t401.json 2>> $OUT/bench_ecapa.err
 timeout 300 python bench.py --model ecapa --steps 8 --augment --no-roofline > $OUT/bench_ecapa_bf16_aug.json 2>> $OUT/bench_ecapa.err
 timeout 300 python bench.py --model ecapa --dtype fp32 --steps 8 --no-roofline > $OUT/bench_ecapa_fp32.json 2>> $OUT/bench_ecapa.err
 for m in resnet ecapa; do
   rm -rf $OUT/prof_$m
-  timeout 400 rocprofv3 --kernel-trace -d $OUT/prof_$m -o $m -- python bench.py --model $m --no-cpu-baseline > $OUT/prof_$m.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace -d $OUT/prof_$m -o $m -- python bench.py --model $m --no-cpu-baseline --no-extra-configs > $OUT/prof_$m.log 2>&1
   DB=$(find $OUT/prof_$m -name "*.db" | head -1)
   python tools/prof_summary.py $DB $OUT/${m}_kernel_stats.md > /dev/null
   find $OUT/prof_$m -name "*.db" -delete
 done
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   for m in resnet ecapa; do
     rm -rf $OUT/pmc_${m}_$c
-    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${m}_$c -o pmc -- python bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_${m}_$c.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_${m}_$c -o pmc -- python bench.py --model $m --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra-configs > $OUT/pmc_${m}_$c.log 2>&1
     DB=$(find $OUT/pmc_${m}_$c -name "*.db" | head -1)
     python tools/pmc_query.py $DB > $OUT/pmc_${m}_$c.txt 2>&1
     find $OUT/pmc_${m}_$c -name "*.db" -delete
