@@ -29,6 +29,7 @@
 // so short images (layer4: 3 x 94) fill the 16-tile MFMA width with tiles of two images.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "air_common.h"
@@ -133,7 +134,9 @@ struct W4Args {
   int ngroups;            // GRR * TWG
   int ncot;               // Cout / 32
   int nitems;             // work items: ceil(ngroups / 4) * ncot, numbered cot-fastest
-  int stagger;            // rotate each workgroup's k-step stream (see the kernel)
+  int split;              // cut the k-step stream evenly over the workgroups (see the kernel)
+  unsigned* flags;        // split: one word per workgroup, raised to `epoch` when its tail sums are in y
+  unsigned epoch;
   long long* trace;       // debug: cycle totals of workgroup 0 (null in production)
 };
 
@@ -199,25 +202,38 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   const int wrem = a.W & 3;  // pixels of the chunk that straddles the right edge
 
   const int lw = xcd_remap(blockIdx.x, gridDim.x);
-  const int i0 = (int)((long long)lw * a.nitems / (int)gridDim.x);
-  const int i1 = (int)((long long)(lw + 1) * a.nitems / (int)gridDim.x);
-  if (i0 >= i1) return;
+  // Work = the global stream of nitems * nchunk k-steps.  Unsplit (a.split == 0), workgroup lw takes whole
+  // items [lw nitems / n, (lw + 1) nitems / n).  Split, it takes k-steps [lw G / n, (lw + 1) G / n) wherever
+  // they fall: 384 items over 256 workgroups (layer4) are 1.5 each instead of two rounds of one, and the
+  // workgroups reach their epilogues at different times instead of bursting 128 KB per CU into HBM together.
+  // An item cut in two is summed through y: the workgroup that owns its TAIL chunks [c, nchunk) meets it as
+  // its FIRST segment, stores the partial sums and raises its flag; the owner of the HEAD chunks [0, c)
+  // meets it as its LAST segment, waits for the successor's flag (set long before), adds the stored sums
+  // and the residual and stores the result.  Needs >= nchunk k-steps per workgroup (an item is cut at most
+  // once); no dependency cycle whatever the dispatch order (a workgroup publishes before it ever waits).
+  int fi, fc, nseg, last_end, S;
+  if (a.split) {
+    const long long G = (long long)a.nitems * nchunk;
+    const long long g0 = (long long)lw * G / (int)gridDim.x, g1 = (long long)(lw + 1) * G / (int)gridDim.x;
+    if (g0 >= g1) return;
+    fi = (int)(g0 / nchunk);
+    fc = (int)(g0 - (long long)fi * nchunk);
+    const int li = (int)((g1 - 1) / nchunk);
+    last_end = (int)((g1 - 1) - (long long)li * nchunk) + 1;
+    nseg = li - fi + 1;
+    S = (int)(g1 - g0);
+  } else {
+    const int i0 = (int)((long long)lw * a.nitems / (int)gridDim.x);
+    const int i1 = (int)((long long)(lw + 1) * a.nitems / (int)gridDim.x);
+    if (i0 >= i1) return;
+    fi = i0; fc = 0; nseg = i1 - i0; last_end = nchunk;
+    S = nseg * nchunk;
+  }
   long long tk0 = 0, tw0 = 0;
   if (TRACE) { tk0 = clock64(); tw0 = wall_clock64(); }
-  const int S = (i1 - i0) * nchunk;  // k-steps in this workgroup's stream
-  // The stream is ROTATED by c0 k-steps: segment 0 = the first item's chunks [c0, nchunk) (its partial sums
-  // are stored to y), segments 1 .. n-1 = the other items whole, segment n = the first item's chunks
-  // [0, c0) (loads the partial sums back, adds the residual, stores).  c0 differs from workgroup to
-  // workgroup, so the workgroups reach their epilogues at different times: in lockstep, all 256 CUs burst
-  // their 128 KB of outputs at once, the HBM write rate (not the store issue) bounds the epilogue at
-  // 12-16k cycles per item, and the memory system idles in between.  Measured: epilogues 12.5k -> 8.5k
-  // cycles, but the extra partial-sum round trip of the first item costs more than that saves at 7-8 items
-  // per workgroup (layer1: 0.33 -> 0.36 ms), so it is OFF by default (AIR_WINO4_STAGGER=1).
-  const int nit = i1 - i0;
-  const int c0 = a.stagger ? (int)(((unsigned)lw % 8u) * (unsigned)nchunk / 8u) : 0;
-  const int nseg = nit + (c0 > 0 ? 1 : 0);
-  auto seg_item = [&](int seg) { return seg == nit ? i0 : i0 + seg; };
-  auto seg_end = [&](int seg) { return seg == nit ? c0 : nchunk; };
+  const int i0 = fi, c0 = fc;
+  auto seg_item = [&](int seg) { return fi + seg; };
+  auto seg_end = [&](int seg) { return seg == nseg - 1 ? last_end : nchunk; };
 
   float* const ldsU = lds;
   float* const ldsP = lds + W4_NBUF * W4_ULDS;
@@ -588,19 +604,39 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     e_cur = e_nxt;
     long long ce = 0;
     if (tracing) { ce = clock64(); tL += ce - cl; }
-    epilogue(item, seg == 0 && c0 > 0, seg == nit);
+    const bool tail_part = seg == 0 && fc > 0;                        // -> partial sums into y
+    const bool head_part = seg == nseg - 1 && last_end < nchunk;      // <- the successor's partial sums
+    if (head_part) {
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.flags + lw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch &&
+               ++spins < (1u << 24))
+          __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    }
+    epilogue(item, tail_part, head_part);
     if (tracing) tE += clock64() - ce;
     // Compiler-visible vmcnt(0): whatever it spilled around the epilogue has come back, so it puts no
-    // vmcnt waits (which would also drain the DMAs in flight) into the k-step loop.  It also orders a
-    // rotated stream's partial sums in front of their reload by the same workgroup.
+    // vmcnt waits (which would also drain the DMAs in flight) into the k-step loop; the tail sums are out.
     long long cd = 0;
     if (tracing) cd = clock64();
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (tracing) tDr += clock64() - cd;
+    if (tail_part) {  // publish: every wave's stores are done (above); one agent-scope release, then the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.flags + lw, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   if (tracing && (tid & 63) == 0) {
     long long* o = a.trace + wave * 8;
-    o[0] = tW; o[1] = tB; o[2] = tD; o[3] = tM; o[4] = tT; o[5] = tE; o[6] = i1 - i0; o[7] = S; o[32] = tS; o[33] = clock64() - tk0; o[34] = wall_clock64() - tw0; o[35] = tDr; o[36] = tL;
+    o[0] = tW; o[1] = tB; o[2] = tD; o[3] = tM; o[4] = tT; o[5] = tE; o[6] = nseg; o[7] = S; o[32] = tS; o[33] = clock64() - tk0; o[34] = wall_clock64() - tw0; o[35] = tDr; o[36] = tL;
   }
 }
 
@@ -646,9 +682,32 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   a.ncot = M / W4_CO;
   a.nitems = (a.ngroups + 3) / 4 * a.ncot;
   a.trace = g_wino4_trace;
-  static const int stagger = getenv("AIR_WINO4_STAGGER") ? atoi(getenv("AIR_WINO4_STAGGER")) : 0;
-  a.stagger = stagger && a.Cin / W4_CK >= 8;
-  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  // split streams: only when every workgroup gets at least one item's worth of k-steps, not under stream
+  // capture (the per-launch epoch would be frozen into the graph), and when it changes the balance
+  static const int split_on = getenv("AIR_WINO4_SPLIT") ? atoi(getenv("AIR_WINO4_SPLIT")) : 1;
+  a.split = 0; a.flags = nullptr; a.epoch = 0;
+  // (an item cut in two costs an extra round trip of its 128 KB of sums: measured a gain only when whole
+  // items leave the last round more than 15 % empty - layer4: 384 items, 0.49 -> 0.41 ms; layer1: 1920
+  // items, 0.33 -> 0.35 ms)
+  const double fill = (double)a.nitems / (256.0 * ((a.nitems + 255) / 256));
+  if (split_on && a.nitems >= 256 && (fill < 0.87 || split_on > 1)) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
+    static unsigned* flag_ring = [] {  // 64 launches' worth of 257 words, zeroed once; epochs never repeat
+      unsigned* p = nullptr;
+      if (hipMalloc(&p, 64 * 320 * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+      if (hipMemset(p, 0, 64 * 320 * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
+      return p;
+    }();
+    static std::atomic<unsigned> next_epoch{1};
+    if (cap == hipStreamCaptureStatusNone && flag_ring != nullptr) {
+      a.epoch = next_epoch.fetch_add(1);
+      if (a.epoch == 0) a.epoch = next_epoch.fetch_add(1);
+      a.flags = flag_ring + (a.epoch % 64) * 320;
+      a.split = 1;
+    }
+  }
   const size_t ldsb = (size_t)W4_NBUF * (W4_ULDS + W4_PATCHF) * sizeof(float);
   static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
     const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, false>),
