@@ -571,21 +571,49 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // dw[e] = sum_k partial[k][e]; with taps > 1 the partials are [tap][co*ci] and dw is [co*ci][tap].
-// 4 lanes share one output and stride the split axis, so a 256-way split costs 64 dependent
-// loads per lane instead of 256 (the small layer1 reductions are latency-bound).
+// A workgroup owns 64 consecutive outputs; its 4 waves take the split index k = w, w + 4, ... (so every load
+// instruction is one coalesced 256-byte row segment, 8 in flight per wave) and their 4 sums meet in LDS in a
+// fixed order: deterministic, whatever the split count.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
                                                               float* __restrict__ dw, size_t n,
                                                               int nsplit, int taps) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nth = (size_t)gridDim.x * blockDim.x;
-  const int sub = (int)(gid & 3);
-  for (size_t e = gid >> 2; e < ((n + 63) / 64) * 64; e += nth >> 2) {
-    float s = 0.0f;
-    if (e < n)
-      for (int k = sub; k < nsplit; k += 4) s += partial[(size_t)k * n + e];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (sub == 0 && e < n) {
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (nsplit <= 16) {
+    // few splits over many outputs (the wide layers): one output per thread, all its loads in flight at once
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = k < nsplit ? partial[(size_t)k * n + e] : 0.0f;
+      float s = v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) s += v[k];
+      if (taps > 1) {
+        const size_t plane = n / taps;
+        const size_t t = e / plane, cc = e - t * plane;
+        dw[cc * taps + t] = s;
+      } else {
+        dw[e] = s;
+      }
+    }
+    return;
+  }
+  const size_t nblk = (n + 63) / 64;
+  for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const size_t e = blk * 64 + lane;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < n) {
+      int k = w;
+      for (; k + 28 < nsplit; k += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += partial[(size_t)(k + 4 * u) * n + e];
+      }
+      for (int u = 0; k < nsplit; k += 4, ++u) acc[u] += partial[(size_t)k * n + e];
+    }
+    s_part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && e < n) {
+      const float s = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
       if (taps > 1) {
         const size_t plane = n / taps;  // Cout*Cin
         const size_t t = e / plane, cc = e - t * plane;
@@ -594,6 +622,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         dw[e] = s;
       }
     }
+    __syncthreads();
   }
 }
 
@@ -671,6 +700,12 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(DirectArgs a) {
     if (lane == 0) a.partial[(size_t)row * a.Cout * K + e] = s;
   }
   (void)red;
+}
+
+// reduce_partials_kernel: one workgroup per 64 outputs, at most 8 per CU
+int reduce_grid(size_t n, int nsplit) {
+  const size_t g = nsplit <= 16 ? (n + 255) / 256 : (n + 63) / 64;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
 int grid_for(size_t n, int per_block = 256, int cap = 256 * 16) {
@@ -890,7 +925,7 @@ int run_wgrad(const WgradGeom& g, const float* x, const float* dy, float* dw, co
       hipLaunchKernelGGL((conv_wgrad_kernel<KH_, KW_, S_, CT_, 0, DIL_>), dim3(nblk), dim3(256), \
                          0, st, a);                                                              \
     AIR_CHECK_LAUNCH();                                                                          \
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,        \
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, a.nsplit)), dim3(256), 0, st, \
                        reinterpret_cast<const float*>(ws), dw, wsz, a.nsplit, g.KH * g.KW);      \
     AIR_CHECK_LAUNCH();                                                                          \
     return AIR_OK;                                                                               \
@@ -1123,7 +1158,7 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
                     p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
     hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
     AIR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, rows)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, rows, 1);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
@@ -1136,7 +1171,7 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     int rc = air_wino_wgrad_partials(x, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H, p->W,
                                      p->Cout, conv_flops(p), st);
     if (rc != AIR_OK) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(wsz * 4)), dim3(256), 0, st,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nsplit)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, nsplit, 9);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
@@ -1156,7 +1191,7 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     AIR_CHECK_LAUNCH();
     int rc = air_wino_wgrad_partials(xpad, dy, partial, p->B, 64, p->H, p->W, p->Cout, conv_flops(p), st);
     if (rc != AIR_OK) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid_for(w64 * 4)), dim3(256), 0, st, partial, dw64, w64, nsplit, 9);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(w64, nsplit)), dim3(256), 0, st, partial, dw64, w64, nsplit, 9);
     AIR_CHECK_LAUNCH();
     // dw[co][ci < Cin][tap] = dw64[co][ci][tap]: the first Cin * 9 floats of every 64 * 9 row
     hipLaunchKernelGGL(copy_rows_kernel, dim3(1, p->Cout), dim3(256), 0, st, dw, (size_t)p->Cin * 9, dw64,
