@@ -19,5 +19,6 @@ for name, (Cin, H, W, Cout) in CFG.items():
     tf = timeit(lambda: ops.conv2d_fwd(x, w, 1, 1))
     tr = timeit(lambda: ops.conv2d_fwd(x, w, 1, 1, residual=res))
     td = timeit(lambda: ops.conv2d_dgrad(dy, w, x.shape, 1, 1))
-    print("%-4s B=%d  fwd %.3f ms %.1f TF | fwd+res %.3f ms %.1f TF | dgrad %.3f ms %.1f TF" % (
-        name, B, tf, fl / tf / 1e9, tr, fl / tr / 1e9, td, fl / td / 1e9), flush=True)
+    tw = timeit(lambda: ops.conv2d_wgrad(x, dy, w.shape, 1, 1))
+    print("%-4s B=%d  fwd %.3f ms %.1f TF | fwd+res %.3f ms %.1f TF | dgrad %.3f ms %.1f TF | wgrad %.3f ms %.1f TF" % (
+        name, B, tf, fl / tf / 1e9, tr, fl / tr / 1e9, td, fl / td / 1e9, tw, fl / tw / 1e9), flush=True)
