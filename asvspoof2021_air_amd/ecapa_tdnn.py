@@ -325,9 +325,8 @@ class Res2Net2(nn.Module):
                                relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"),
                                dbias=gv("conv1.bias"))
         ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf)
-        dinp = ops.conv1d_dgrad(dc1, det(blk.conv1.weight), bf16=bf)
-        ops.add_strided(dinp, dinp, dout)  # residual branch (ecapa_tdnn.py:93)
-        return dinp
+        # + dout: the residual branch (ecapa_tdnn.py:93), added in the dgrad epilogue
+        return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf)
 
     def _backward_impl(self, S, dfeat, dout):
         arena = self.arena()

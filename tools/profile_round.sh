@@ -21,6 +21,13 @@ for m in resnet ecapa; do
   python tools/prof_summary.py $DB $OUT/${m}_kernel_stats.md > /dev/null
   find $OUT/prof_$m -name "*.db" -delete
 done
+# the same command with the side-stream overlap of the weight-gradient kernels off: kernels run one at a time,
+# which is what bench.py's roofline leg times (compare avg us here with roofline.avg_launch_ms)
+rm -rf $OUT/prof_resnet_serial
+AIR_OVERLAP_WGRAD=0 timeout 400 rocprofv3 --kernel-trace -d $OUT/prof_resnet_serial -o resnet -- python bench.py --no-cpu-baseline --no-extra-configs > $OUT/prof_resnet_serial.log 2>&1
+DB=$(find $OUT/prof_resnet_serial -name "*.db" | head -1)
+python tools/prof_summary.py $DB $OUT/resnet_serial_kernel_stats.md > /dev/null
+find $OUT/prof_resnet_serial -name "*.db" -delete
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   for m in resnet ecapa; do
     rm -rf $OUT/pmc_${m}_$c
