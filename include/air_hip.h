@@ -96,8 +96,10 @@ int air_pad_transpose_ex(const float* feat, int B, int T, int D, float* out, int
  * Optional fused prologue: per-input-channel y = max(0, x*scale[c]+shift[c])
  * (BatchNorm apply + ReLU of the pre-activation block, resnet.py:64,67)
  * applied while staging the input; optional epilogue residual add
- * (resnet.py:68) and per-output-channel sum / sum-of-squares partials for
- * the next BatchNorm's batch statistics.
+ * (resnet.py:68).  3x3 / stride 1 / pad 1 layers without the fused prologue run
+ * as Winograd F(4x4,3x3) (forward, dgrad: csrc/conv_wino4.hip) and F(3x3,2x2)
+ * (wgrad: csrc/conv_wino.hip); results within 2e-5 of the output scale of the
+ * fp64 convolution (direct kernels: 3e-6).
  */
 typedef struct AirConv2d {
   int B, Cin, H, W;       /* input */
@@ -108,8 +110,11 @@ typedef struct AirConv2d {
 
 size_t air_conv2d_ws_bytes(const AirConv2d* p);
 /* y = conv(act(x), w) [+ residual].  in_scale/in_shift NULL = identity prologue.
- * relu: apply max(0,.) after the affine prologue.  stats: NULL or (2, Cout) fp64
- * accumulators receiving sum and sum of squares of y (zeroed by the caller). */
+ * relu: apply max(0,.) after the affine prologue.  stats: RESERVED, must be NULL (AIR_EUNSUPPORTED
+ * otherwise).  Per-channel sum / sum of squares of y from the conv epilogue was costed on MI355X and not
+ * built: 12 of the step's 18 BatchNorm statistics passes follow a Winograd conv (0.3 ms in all), and the
+ * per-lane reduction over its 4x4 output tiles adds about 400 VALU instructions to an epilogue that is
+ * already the kernel's serial part (0.1 ms); the statistics stay in air_bn_stats' own pass. */
 int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
                    const float* in_scale, const float* in_shift, int relu,
                    const float* residual, double* stats, void* ws, size_t ws_bytes,
@@ -203,8 +208,8 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
  */
 /* Batch statistics -> mean/invstd, fused scale/shift for the apply, running
  * stat update (momentum 0.1, unbiased var) when running_* non-NULL.
- * stats_in: optional (2,C) fp64 sum/sumsq already accumulated by a conv
- * epilogue; when NULL the kernel reduces x itself. */
+ * stats_in: RESERVED, must be NULL (AIR_EUNSUPPORTED otherwise; see air_conv2d_fwd): the kernel reduces x
+ * itself (shifted sums, fp64 two-stage, fixed order). */
 size_t air_bn_ws_bytes(int B, int C, int S);
 int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in,
                  const float* gamma, const float* beta, float eps, float momentum,
