@@ -192,6 +192,275 @@ __global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same contraction, persistent and with producer waves (the kernel that runs; the one above
+// remains for odd T).  Measured on c1b_fwd_kernel (B = 128, T = 750, 512 -> 512: 0.172 ms):
+// staging alone 0.076 ms, MFMA + stores alone 0.097 ms, 3072 workgroup launches alone 0.038 ms - the
+// phases ADD UP, and rocprofv3 shows why: 17.6 M L2 requests per launch (13.2 M reads: the 64-byte
+// A rows use half of every 128-byte line, the X tile is fetched by all four Cout tiles, 512-byte row
+// pieces at 8-byte alignment span 5 lines; 4.4 M writes of 44 bytes on average), 565 cycles mean
+// L2 latency, the per-CU L1 stalled on pending misses 60 % of the time.  The tile is REQUEST-bound,
+// so this kernel is built around the request count:
+//   * 256 (Cout) x 128 (frames) tile when Cout % 256 == 0: an X tile is fetched by two workgroups
+//     instead of four (8 consumer waves, each 64 x 64 = 2 x 2 MFMA 32x32x16 tiles);
+//   * A is packed stage-major, [K/32][M][32 k]: a stage's A tile is ONE contiguous block of full
+//     lines, copied lane-linearly (the bank swizzle is baked into the packed layout);
+//   * workgroups stay resident (one or two per CU) and walk their XCD's work items in the old order
+//     (neighbours in time share X tiles in that XCD's L2);
+//   * two extra waves are PRODUCERS: one issues every `buffer_load_dwordx4 ... lds` of the fp32 X
+//     stage [32 k][128 t], the other those of the A stage, into a 3-deep LDS ring, two stages
+//     ahead, across tile boundaries - and only they count vmcnt for them.  The consumer waves never
+//     wait on a DMA: one s_barrier per stage tells them the stage has landed (and tells the
+//     producers the slot two behind is free), so their epilogue stores drain underneath the next
+//     tile's MFMAs without disturbing a counted wait (loads and stores of ONE wave may retire out of
+//     order with respect to each other, so a wave that did both could only wait for vmcnt(0));
+//   * the fp32 -> bf16 rounding (v_cvt_pk_bf16_f32, as before) moves to the reader: a lane of the
+//     32x32x16 MFMA needs 8 consecutive k at its t = 4 ds_read2st64_b32 down the k rows.
+// Frames >= T of a row's last tile read the next row / utterance or, behind the tensor, the
+// descriptor's zeros: they only ever reach output columns that are not stored.
+constexpr int FD_NS = 3;
+constexpr int FD_XB = BK * BN * 4;   // 16 KB: X stage, fp32 [k][t]
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 fd_rsrc(const void* base, unsigned bytes) {
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(size_t)base);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((size_t)base >> 32));  // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void fd_dma16(i32x4 rsrc, unsigned soff, unsigned m0v, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %0, %2 offen lds"
+               :: "s"(rsrc), "s"(m0v), "s"(soff), "v"(voff) : "memory", "m0");
+}
+
+// fp32 weights -> bf16, stage-major: 16-byte chunk o = (ks * M + m) * 4 + pc holds k = ks * 32 + c * 8 .. + 7 of
+// row m with c = pc ^ ((m >> 2) & 3) (the reader's bank swizzle).  transpose = 1: A[m][k] = w[k][m] (dgrad).
+__global__ __launch_bounds__(256) void c1b_pack_stage_kernel(const float* __restrict__ w, uint4* __restrict__ a,
+                                                             int M, int K, int transpose) {
+  const size_t n = (size_t)M * K / 8;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
+    const int pc = (int)(o & 3), m = (int)((o >> 2) % M), ks = (int)((o >> 2) / M);
+    const int k0 = ks * BK + ((pc ^ ((m >> 2) & 3)) * 8);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = transpose ? w[(size_t)(k0 + j) * M + m] : w[(size_t)m * K + k0 + j];
+    uint4 q;
+    q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
+    a[o] = q;
+  }
+}
+
+struct FdTile {
+  int b, m0, t0;
+};
+template <int TBM>
+__device__ __forceinline__ FdTile fd_tile(const C1bFwd& p, int work) {
+  FdTile t;
+  const int mt = work % p.tiles_m, rest = work / p.tiles_m;
+  t.m0 = mt * TBM;
+  t.t0 = (rest % p.tiles_t) * BN;
+  t.b = rest / p.tiles_t;
+  return t;
+}
+
+// WM = wave rows of 64 output channels: tile = 64 WM x 128, 2 WM consumer waves + 2 producers
+template <int WM>
+__global__ __launch_bounds__(128 * WM + 128) void c1b_fwd_ps_kernel(const C1bFwd p) {
+  constexpr int TBM = 64 * WM;
+  constexpr int AB = TBM * BK * 2;  // A stage bytes
+  constexpr int SB = FD_XB + AB;
+  constexpr int NCONS = 2 * WM;
+  constexpr int RP = WM == 4 ? 16 : 8;  // epilogue rows per pass (LDS: 256 RP bytes per consumer wave)
+  extern __shared__ __attribute__((aligned(16))) char fd_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // work items of this XCD: [w_lo, w_hi); this workgroup takes every nwg-th of them
+  const int nwg = gridDim.x / NXCD;
+  const int w_lo = (blockIdx.x % NXCD) * p.per_xcd, first = w_lo + blockIdx.x / NXCD;
+  const int w_hi = w_lo + p.per_xcd < p.total ? w_lo + p.per_xcd : p.total;
+  if (first >= w_hi) return;
+  const int nmy = (w_hi - first + nwg - 1) / nwg;
+  const int nk = p.K / BK;
+  const int G = nmy * nk;
+
+  if (wave >= NCONS) {
+    // ---------------------------------------------------------------- producers
+    const bool px = wave == NCONS;  // X producer; the other one stages A
+    const i32x4 rs = px ? fd_rsrc(p.x, (unsigned)(((size_t)(p.B - 1) * p.x_bs + (size_t)p.K * p.T) * 4u))
+                        : fd_rsrc(p.a, (unsigned)p.M * p.K * 2u);
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)fd_lds;
+    // X: instruction i covers k rows 2 i, 2 i + 1 (lane >> 5), 32 chunks each; rows 8 .. 15 and 24 .. 31 hold
+    // their chunks XOR 8.  A: instruction q copies bytes 1024 q .. + 1023 of the stage's block.
+    const unsigned xrow = ((unsigned)(lane >> 5) * p.T) * 4u;
+    const unsigned xv0 = xrow + (lane & 31) * 16u, xv1 = xrow + ((lane & 31) ^ 8) * 16u;
+    const unsigned av = lane * 16u;
+    const unsigned xrow2 = 2u * p.T * 4u;
+    int it = 0, is = 0, islot = 0;  // next stage to issue: tile index, k stage, ring slot
+    FdTile tl = fd_tile<TBM>(p, first);
+    auto issue = [&]() {
+      const unsigned base = lds0 + islot * SB;
+      if (px) {
+        const unsigned xo = (unsigned)(((size_t)tl.b * p.x_bs + tl.t0) * 4u) + (unsigned)is * BK * p.T * 4u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fd_dma16(rs, xo + i * xrow2, base + i * 1024, (i & 4) ? xv1 : xv0);
+      } else {
+        const unsigned ao = ((unsigned)is * p.M + tl.m0) * (BK * 2u);
+#pragma unroll
+        for (int q = 0; q < AB / 1024; ++q) fd_dma16(rs, ao + q * 1024, base + FD_XB + q * 1024, av);
+      }
+      islot = islot + 1 == FD_NS ? 0 : islot + 1;
+      if (++is == nk) {
+        is = 0;
+        ++it;
+        if (it < nmy) tl = fd_tile<TBM>(p, first + it * nwg);
+      }
+    };
+    issue();
+    if (G > 1) issue();
+    for (int g = 0; g < G; ++g) {
+      // the younger stage may stay in flight: 16 (X) or AB / 1024 (A) DMAs
+      if (g + 1 < G) {
+        if (px) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AB / 1024) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (g + 2 < G) issue();
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumers
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, kg = lane >> 5;
+  unsigned ao[2], bo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ao[i] = FD_XB + (wm * 64 + i * 32 + r) * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bo[j] = (kg * 8) * 512 + (((wn * 64 + j * 32 + r) ^ (kg << 5)) * 4);
+  const int asw = (r >> 2) & 3;
+
+  f32x16 acc[2][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  };
+  zero();
+  int it = 0, ks = 0, slot = 0;
+  for (int g = 0; g < G; ++g) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* st = fd_lds + slot * SB;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(st + ao[i] + (((kk * 2 + kg) ^ asw) * 16));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* col = reinterpret_cast<const float*>(st + bo[j] + kk * 16 * 512);
+        uint4 v;
+        v.x = pack2(col[0 * 128], col[1 * 128]);
+        v.y = pack2(col[2 * 128], col[3 * 128]);
+        v.z = pack2(col[4 * 128], col[5 * 128]);
+        v.w = pack2(col[6 * 128], col[7 * 128]);
+        fb[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    slot = slot + 1 == FD_NS ? 0 : slot + 1;
+    if (++ks == nk) {
+      ks = 0;
+      const FdTile tl = fd_tile<TBM>(p, first + it * nwg);
+      ++it;
+      // Epilogue.  The MFMA leaves a lane with ONE frame of 16 rows; stored directly that is 64 dword stores
+      // per lane whose 128-byte row pieces (8-byte aligned) become 4.4 M L2 write requests of 44 bytes.  Each
+      // wave turns RP rows x 64 frames at a time through its own 4 / 2 KB of LDS (no barrier: one wave, LDS
+      // operations of a wave execute in order) and stores 16 bytes per lane, 256-byte row pieces.
+      float* __restrict__ yb = p.y + (size_t)tl.b * p.y_bs;
+      const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.b * p.y_bs : nullptr;
+      float* tile = reinterpret_cast<float*>(fd_lds + FD_NS * SB) + wave * (RP * 64);
+      const int c4 = (lane & 15) * 4, lrow = lane >> 4;
+      const int t = tl.t0 + wn * 64 + c4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int hp = 0; hp < 32 / RP; ++hp) {
+#pragma unroll
+          for (int e = 0; e < RP / 2; ++e) {
+            const int rr = hp * (RP / 2) + e;
+            const int row = (rr & 3) + 8 * ((rr >> 2) - hp * (RP / 8)) + 4 * kg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tile[row * 64 + j * 32 + r] = acc[i][j][rr];
+          }
+#pragma unroll
+          for (int q = 0; q < RP / 4; ++q) {
+            const int row = lrow + 4 * q;
+            const int m = tl.m0 + wm * 64 + i * 32 + hp * RP + row;
+            float4 v = *reinterpret_cast<const float4*>(&tile[row * 64 + c4]);
+            float add = 0.0f;
+            if (p.bias) add += p.bias[m];
+            if (p.bias_bc) add += p.bias_bc[(size_t)tl.b * p.M + m];
+            const size_t o = (size_t)m * p.T + t;
+            if (t + 3 < p.T) {
+              if (ab) {
+                const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab + o);
+                v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
+              }
+              f32x4a8 out = {v.x + add, v.y + add, v.z + add, v.w + add};
+              if (p.relu) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) out[k4] = fmaxf(out[k4], 0.0f);
+              }
+              *reinterpret_cast<f32x4a8*>(yb + o) = out;
+            } else if (t + 1 < p.T) {  // T is even: a row's last piece holds 4 or 2 frames
+              if (ab) {
+                const f32x2 u = *reinterpret_cast<const f32x2*>(ab + o);
+                v.x += u[0]; v.y += u[1];
+              }
+              f32x2 out = {v.x + add, v.y + add};
+              if (p.relu) {
+                out[0] = fmaxf(out[0], 0.0f);
+                out[1] = fmaxf(out[1], 0.0f);
+              }
+              *reinterpret_cast<f32x2*>(yb + o) = out;
+            }
+          }
+        }
+      }
+      zero();
+    }
+  }
+}
+
+template <int WM>
+int fd_launch(C1bFwd& p, hipStream_t st) {
+  constexpr int lds = FD_NS * (FD_XB + 64 * WM * BK * 2) + 2 * WM * (WM == 4 ? 16 : 8) * 256;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_fwd_ps_kernel<WM>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  if (!attr_ok) return AIR_ELAUNCH;
+  p.tiles_m = p.M / (64 * WM);
+  p.total = p.B * p.tiles_t * p.tiles_m;
+  p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  // resident workgroups: 128 KB of LDS -> one per CU, 80 KB -> two
+  hipLaunchKernelGGL(c1b_fwd_ps_kernel<WM>, dim3(WM == 4 ? 256 : 512), dim3(128 * WM + 128), lds, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 // dw[e] = sum_s partial[s][e], fixed order (deterministic)
 __global__ __launch_bounds__(256) void c1b_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                          size_t n, int nsplit) {
@@ -573,9 +842,6 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
             const float* bias_bc, const float* acc, int relu, int B, int M, int K, int T, void* ws, double flops,
             hipStream_t st) {
   unsigned short* a = reinterpret_cast<unsigned short*>(ws);
-  const size_t n2 = (size_t)M * K / 2;
-  hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, transpose);
-  AIR_CHECK_LAUNCH();
   C1bFwd p;
   p.x = x; p.a = a; p.y = y; p.bias = bias; p.bias_bc = bias_bc; p.acc = acc;
   p.x_bs = x_bs; p.y_bs = y_bs;
@@ -584,6 +850,23 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  static const int use_ps = getenv("AIR_C1B_PS") ? atoi(getenv("AIR_C1B_PS")) : 3;
+  // the DMA moves 16-byte chunks: frame rows have to start on 8-byte boundaries (even T and strides),
+  // and every byte offset has to fit the descriptor's 32 bits
+  const bool ps_ok = use_ps && T % 2 == 0 && x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0 &&
+                     ((size_t)(B - 1) * x_bs + (size_t)K * T) * 4 < ((size_t)1 << 32) &&
+                     (size_t)M * K * 2 < ((size_t)1 << 32);
+  if (ps_ok) {
+    const size_t n8 = (size_t)M * K / 8;
+    hipLaunchKernelGGL(c1b_pack_stage_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, w,
+                       reinterpret_cast<uint4*>(a), M, K, transpose);
+    AIR_CHECK_LAUNCH();
+    AirProfScope prof(AIR_K_C1B_FWD, flops, st);
+    return (M % 256 == 0 && (use_ps & 2)) ? fd_launch<4>(p, st) : fd_launch<2>(p, st);
+  }
+  const size_t n2 = (size_t)M * K / 2;
+  hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, transpose);
+  AIR_CHECK_LAUNCH();
   AirProfScope prof(AIR_K_C1B_FWD, flops, st);
   hipLaunchKernelGGL(c1b_fwd_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
