@@ -4,7 +4,11 @@
 // and nn.BatchNorm1d in ecapa_tdnn.py.
 //
 // Layout: a (b, c) plane is S contiguous floats, so every kernel walks whole
-// planes with consecutive lanes on consecutive addresses (float4 when S % 4 == 0).
+// planes with consecutive lanes on consecutive addresses, 16 bytes per lane from the plane's first
+// 8-byte boundary on (planes start on 8-byte boundaries when S is even - ECAPA's T = 750 - and on
+// alternating 4 / 8-byte boundaries when it is odd - the ResNet's 9 x 375 maps: one head element is
+// peeled, kernels instantiated with PEEL); the floats behind the last full quad are one 8-byte access (even
+// S) or single accesses (PEEL).
 // Reductions are two-stage and deterministic: per-(channel, split) partials in
 // fp64, then one finalize block per launch.  No atomics.
 #include "air_common.h"
@@ -12,6 +16,14 @@
 namespace {
 
 constexpr int NT = 256;
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+// floats in front of p's next 8-byte boundary (0 or 1); -1 when the pointers disagree
+__device__ __forceinline__ int head8(const void* p) { return (int)((((size_t)p) >> 2) & 1); }
+__device__ __forceinline__ int head8(const void* p, const void* q) {
+  const int h = head8(p);
+  return q == nullptr || head8(q) == h ? h : -1;
+}
 
 __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   v = air_wave_sum_d(v);
@@ -32,6 +44,7 @@ int splits_for(int B, int C) {
 }
 
 // partial[(c*nsplit + split)*2 + {0,1}] = sum, sum of squares over images [b0,b1)
+template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __restrict__ x, int B,
                                                               int C, int S, int nsplit,
                                                               double* __restrict__ partial) {
@@ -46,13 +59,33 @@ __global__ __launch_bounds__(NT) void bn_partial_stats_kernel(const float* __res
   double d1 = 0.0, d2 = 0.0;
   for (int b = b0; b < b1; ++b) {
     const float* __restrict__ p = x + ((size_t)b * C + c) * S;
-    if ((S & 3) == 0 && ((((size_t)p) & 15) == 0)) {
-      const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
-      for (int i = threadIdx.x; i < S / 4; i += NT) {
-        float4 v = p4[i];
-        v.x -= K; v.y -= K; v.z -= K; v.w -= K;
-        s1 += (v.x + v.y) + (v.z + v.w);
-        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    const int h = PEEL ? head8(p) : 0;
+    if (PEEL || ((S & 1) == 0 && head8(p) == 0)) {
+      const int nq = (S - h) >> 2;
+      for (int i = threadIdx.x; i < nq; i += NT) {
+        f4a8 v = *reinterpret_cast<const f4a8*>(p + h + 4 * i);
+        v -= K;
+        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+      if (threadIdx.x == NT - 1) {
+        if (PEEL) {  // head element and the 0 - 3 behind the last quad
+          for (int i = 0; i < h; ++i) {
+            const float v = p[i] - K;
+            s1 += v;
+            s2 += v * v;
+          }
+          for (int i = h + 4 * nq; i < S; ++i) {
+            const float v = p[i] - K;
+            s1 += v;
+            s2 += v * v;
+          }
+        } else if (S & 2) {
+          f2a8 v = *reinterpret_cast<const f2a8*>(p + S - 2);
+          v -= K;
+          s1 += v[0] + v[1];
+          s2 += v[0] * v[0] + v[1] * v[1];
+        }
       }
     } else {
       for (int i = threadIdx.x; i < S; i += NT) {
@@ -118,6 +151,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // grid: (B*C planes, chunks of S)
+template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int C, int S,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
@@ -127,21 +161,37 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   const float sc = scale[c], sh = shift[c];
   const float* __restrict__ p = x + (size_t)plane * S;
   float* __restrict__ q = y + (size_t)plane * S;
-  const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
-  if (i0 >= S) return;
-  if (i0 + 3 < S && ((((size_t)(p + i0)) | ((size_t)(q + i0))) & 15) == 0) {
-    float4 v = *reinterpret_cast<const float4*>(p + i0);
-    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-    if (relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(q + i0) = v;
-  } else {
-    for (int i = i0; i < min(S, i0 + 4); ++i) {
+  // thread qi owns the quad at h + 4 qi (h = floats in front of the first 8-byte boundary: 0 unless PEEL);
+  // PEEL: thread 0 also owns the head, the thread of the last, incomplete quad walks it element by element
+  const int qi = blockIdx.y * NT + threadIdx.x;
+  const int h = PEEL ? head8(p, q) : (head8(p) | head8(q) ? -1 : 0);
+  const int i0 = h < 0 ? 4 * qi : h + 4 * qi;
+  auto scalar = [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i) {
       float v = p[i] * sc + sh;
       if (relu) v = fmaxf(v, 0.f);
       q[i] = v;
     }
+  };
+  if (h >= 0 && i0 + 3 < S) {
+    if (PEEL && qi == 0) scalar(0, h);
+    f4a8 v = *reinterpret_cast<const f4a8*>(p + i0);
+    v = v * sc + sh;
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *reinterpret_cast<f4a8*>(q + i0) = v;
+  } else if (!PEEL && h >= 0 && i0 + 2 == S) {
+    f2a8 v = *reinterpret_cast<const f2a8*>(p + i0);
+    v = v * sc + sh;
+    if (relu) {
+      v[0] = fmaxf(v[0], 0.f);
+      v[1] = fmaxf(v[1], 0.f);
+    }
+    *reinterpret_cast<f2a8*>(q + i0) = v;
+  } else {
+    scalar((PEEL && h > 0 && qi == 0) ? 0 : i0, min(S, i0 + 4));
   }
 }
 
@@ -151,6 +201,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
 // gradient of the conv BIAS, sum_{b,s} dx, in closed form, so no pass over dx is needed for it:
 //   dx = [x > 0] * gamma*invstd * (g - dbeta/N - xhat * dgamma/N).
 constexpr int NACC = 6;
+template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, size_t dy_bs, const float* __restrict__ dy2,
     size_t dy2_bs, const float* __restrict__ rowbias, float rb_scale, int B, int C, int S, int nsplit,
@@ -171,38 +222,43 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(
     const float* __restrict__ pg2 = dy2 ? dy2 + (size_t)b * dy2_bs + (size_t)c * S : nullptr;
     const float rb = rowbias ? rowbias[(size_t)b * C + c] * rb_scale : 0.0f;
     float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
-    if (!want_bias && pg2 == nullptr && (S & 3) == 0 && ((((size_t)px) | ((size_t)pg)) & 15) == 0) {
-      const float4* __restrict__ px4 = reinterpret_cast<const float4*>(px);
-      const float4* __restrict__ pg4 = reinterpret_cast<const float4*>(pg);
-      for (int i = threadIdx.x; i < S / 4; i += NT) {
-        const float4 xv = px4[i];
-        float4 g = pg4[i];
-        g.x += rb; g.y += rb; g.z += rb; g.w += rb;
-        if (relu) {
-          if (!(xv.x * sc + shf > 0.0f)) g.x = 0.0f;
-          if (!(xv.y * sc + shf > 0.0f)) g.y = 0.0f;
-          if (!(xv.z * sc + shf > 0.0f)) g.z = 0.0f;
-          if (!(xv.w * sc + shf > 0.0f)) g.w = 0.0f;
+    auto one = [&](float xv, float g) {
+      g += rb;
+      if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+      const float xh = (xv - mu) * is;
+      s1 += g;
+      s2 += g * xh;
+      if (want_bias && xv > 0.0f) {
+        s3 += g;
+        s4 += 1.0f;
+        s5 += xh;
+      }
+    };
+    int h = head8(px, pg) == head8(px, pg2) ? head8(px, pg) : -1;
+    if (!PEEL && (h != 0 || (S & 1))) h = -1;
+    if (h >= 0) {
+      const int nq = (S - h) >> 2;
+      for (int i = threadIdx.x; i < nq; i += NT) {
+        const f4a8 xv = *reinterpret_cast<const f4a8*>(px + h + 4 * i);
+        f4a8 g = *reinterpret_cast<const f4a8*>(pg + h + 4 * i);
+        if (pg2) g += *reinterpret_cast<const f4a8*>(pg2 + h + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) one(xv[e], g[e]);
+      }
+      if (threadIdx.x == NT - 1) {
+        if (PEEL) {  // head element and the 0 - 3 behind the last quad
+          for (int i = 0; i < h; ++i) one(px[i], pg[i] + (pg2 ? pg2[i] : 0.0f));
+          for (int i = h + 4 * nq; i < S; ++i) one(px[i], pg[i] + (pg2 ? pg2[i] : 0.0f));
+        } else if (S & 2) {
+          const f2a8 xv = *reinterpret_cast<const f2a8*>(px + S - 2);
+          f2a8 g = *reinterpret_cast<const f2a8*>(pg + S - 2);
+          if (pg2) g += *reinterpret_cast<const f2a8*>(pg2 + S - 2);
+          one(xv[0], g[0]);
+          one(xv[1], g[1]);
         }
-        s1 += (g.x + g.y) + (g.z + g.w);
-        s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) +
-              (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
       }
     } else {
-      for (int i = threadIdx.x; i < S; i += NT) {
-        const float xv = px[i];
-        float g = pg[i] + rb;
-        if (pg2) g += pg2[i];
-        if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
-        const float xh = (xv - mu) * is;
-        s1 += g;
-        s2 += g * xh;
-        if (want_bias && xv > 0.0f) {
-          s3 += g;
-          s4 += 1.0f;
-          s5 += xh;
-        }
-      }
+      for (int i = threadIdx.x; i < S; i += NT) one(px[i], pg[i] + (pg2 ? pg2[i] : 0.0f));
     }
     d1 += (double)s1;
     d2 += (double)s2;
@@ -245,6 +301,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
 
 // backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
 // (dy and dx may alias: the in-place gradient joins of resnet.py / ecapa_tdnn.py)
+template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* dy, size_t dy_bs, const float* dy2, size_t dy2_bs,
     const float* __restrict__ rowbias, float rb_scale, int C, int S, float invN,
@@ -263,8 +320,6 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   const int bb = plane / C;
   const float* pdy = dy + (size_t)bb * dy_bs + (size_t)c * S;               // may alias dx (in-place joins)
   const float* pdy2 = dy2 ? dy2 + (size_t)bb * dy2_bs + (size_t)c * S : nullptr;
-  const int i0 = (blockIdx.y * NT + threadIdx.x) * 4;
-  if (i0 >= S) return;
   auto one = [&](float xv, float g, float old) -> float {
     g += rb;
     if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
@@ -273,21 +328,39 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     if (relu_in && !(xv > 0.0f)) r = 0.0f;  // x = relu(c): no gradient where the ReLU clipped
     return accum ? r + old : r;
   };
-  if (pdy2 == nullptr && i0 + 3 < S && ((base + i0) & 3) == 0 &&
-      ((((size_t)x) | ((size_t)(pdy + i0)) | ((size_t)dx)) & 15) == 0) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + base + i0);
-    const float4 gv = *reinterpret_cast<const float4*>(pdy + i0);
-    float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (accum) ov = *reinterpret_cast<const float4*>(dx + base + i0);
-    float4 r;
-    r.x = one(xv.x, gv.x, ov.x);
-    r.y = one(xv.y, gv.y, ov.y);
-    r.z = one(xv.z, gv.z, ov.z);
-    r.w = one(xv.w, gv.w, ov.w);
-    *reinterpret_cast<float4*>(dx + base + i0) = r;
-  } else {
-    for (int i = i0; i < min(S, i0 + 4); ++i)
+  // quads from the plane's first 8-byte boundary on, as in bn_apply_kernel
+  const int qi = blockIdx.y * NT + threadIdx.x;
+  int h = head8(x + base, pdy);
+  if (h != head8(dx + base, pdy2)) h = -1;
+  if (!PEEL && h != 0) h = -1;
+  const int i0 = h < 0 ? 4 * qi : h + 4 * qi;
+  auto scalar = [&](int lo, int hi) {
+    for (int i = lo; i < hi; ++i)
       dx[base + i] = one(x[base + i], pdy[i] + (pdy2 ? pdy2[i] : 0.0f), accum ? dx[base + i] : 0.0f);
+  };
+  if (h >= 0 && i0 + 3 < S) {
+    if (PEEL && qi == 0) scalar(0, h);
+    const f4a8 xv = *reinterpret_cast<const f4a8*>(x + base + i0);
+    f4a8 gv = *reinterpret_cast<const f4a8*>(pdy + i0);
+    if (pdy2) gv += *reinterpret_cast<const f4a8*>(pdy2 + i0);
+    f4a8 ov = {0.f, 0.f, 0.f, 0.f};
+    if (accum) ov = *reinterpret_cast<const f4a8*>(dx + base + i0);
+    f4a8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = one(xv[e], gv[e], ov[e]);
+    *reinterpret_cast<f4a8*>(dx + base + i0) = r;
+  } else if (!PEEL && h >= 0 && i0 + 2 == S) {
+    const f2a8 xv = *reinterpret_cast<const f2a8*>(x + base + i0);
+    f2a8 gv = *reinterpret_cast<const f2a8*>(pdy + i0);
+    if (pdy2) gv += *reinterpret_cast<const f2a8*>(pdy2 + i0);
+    f2a8 ov = {0.f, 0.f};
+    if (accum) ov = *reinterpret_cast<const f2a8*>(dx + base + i0);
+    f2a8 r;
+    r[0] = one(xv[0], gv[0], ov[0]);
+    r[1] = one(xv[1], gv[1], ov[1]);
+    *reinterpret_cast<f2a8*>(dx + base + i0) = r;
+  } else {
+    scalar((PEEL && h > 0 && qi == 0) ? 0 : i0, min(S, i0 + 4));
   }
 }
 
@@ -318,8 +391,10 @@ int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, co
   hipStream_t st = air_stream(stream);
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_partial_stats_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S,
-                     nsplit, partial);
+  if (S & 1)
+    hipLaunchKernelGGL(bn_partial_stats_kernel<true>, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
+  else
+    hipLaunchKernelGGL(bn_partial_stats_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, x, S, partial, nsplit, C,
                      (double)B * (double)S, gamma, beta, eps, momentum, running_mean, running_var,
@@ -343,8 +418,10 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
                  int relu, float* y, air_stream_t stream) {
   if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale,
-                     shift, relu, y);
+  if (S & 1)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -364,16 +441,23 @@ int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const floa
   const double invN = 1.0 / ((double)B * (double)S);
   const size_t dense = (size_t)C * S;
   const size_t dbs = dy_bstride ? dy_bstride : dense, d2bs = dy2_bstride ? dy2_bstride : dense;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
-                     rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
+  if (S & 1)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
+                       rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
+                       rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   AIR_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C, (double)(float)invN,
                      gamma, invstd, dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale, C, S,
-                     (float)invN,
-                     mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
+  if (S & 1)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale,
+                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale,
+                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
