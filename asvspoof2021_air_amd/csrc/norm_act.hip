@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int NT = 256;
+constexpr int FLAT_S = 32;  // planes shorter than this: flat-indexed kernels (below)
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
 // floats in front of p's next 8-byte boundary (0 or 1); -1 when the pointers disagree
@@ -364,6 +365,114 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short planes (S < 32: BatchNorm1d over (B, C) features - the SE bottleneck, bn5 on the pooled
+// 3072 statistics, bn7 - where S = 1): a workgroup per plane would be a workgroup per ELEMENT
+// (393 k of them for bn5).  These variants index the (b, s) positions of a channel, or all elements,
+// flat; same sums, same order of the fp64 folds.
+__global__ __launch_bounds__(NT) void bn_partial_stats_flat_kernel(const float* __restrict__ x, int B, int C, int S,
+                                                                   int nsplit, double* __restrict__ partial) {
+  __shared__ double sh[NT / 64];
+  const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
+  const int per = (B + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(B, b0 + per);
+  const float K = x[(size_t)c * S];
+  double d1 = 0.0, d2 = 0.0;
+  for (int i = threadIdx.x; i < (b1 - b0) * S; i += NT) {
+    const int b = b0 + i / S, sidx = i % S;
+    const float v = x[((size_t)b * C + c) * S + sidx] - K;
+    d1 += (double)v;
+    d2 += (double)(v * v);
+  }
+  d1 = block_sum_d(d1, sh);
+  d2 = block_sum_d(d2, sh);
+  if (threadIdx.x == 0) {
+    partial[(size_t)blockIdx.x * 2] = d1;
+    partial[(size_t)blockIdx.x * 2 + 1] = d2;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_apply_flat_kernel(const float* __restrict__ x, int C, int S, size_t n,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)((i / S) % C);
+  float v = x[i] * scale[c] + shift[c];
+  if (relu) v = fmaxf(v, 0.f);
+  y[i] = v;
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_partial_flat_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, size_t dy_bs, const float* __restrict__ dy2,
+    size_t dy2_bs, const float* __restrict__ rowbias, float rb_scale, int B, int C, int S, int nsplit,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int want_bias,
+    double* __restrict__ partial) {
+  __shared__ double sh[NT / 64];
+  const int c = blockIdx.x / nsplit, split = blockIdx.x - c * nsplit;
+  const int per = (B + nsplit - 1) / nsplit;
+  const int b0 = split * per, b1 = min(B, b0 + per);
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is;
+  const float shf = beta[c] - mu * sc;
+  double d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+  for (int i = threadIdx.x; i < (b1 - b0) * S; i += NT) {
+    const int b = b0 + i / S, sidx = i % S;
+    const float xv = x[((size_t)b * C + c) * S + sidx];
+    float g = dy[(size_t)b * dy_bs + (size_t)c * S + sidx];
+    if (dy2) g += dy2[(size_t)b * dy2_bs + (size_t)c * S + sidx];
+    if (rowbias) g += rowbias[(size_t)b * C + c] * rb_scale;
+    if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+    const float xh = (xv - mu) * is;
+    d1 += (double)g;
+    d2 += (double)(g * xh);
+    if (want_bias && xv > 0.0f) {
+      d3 += (double)g;
+      d4 += 1.0;
+      d5 += (double)xh;
+    }
+  }
+  d1 = block_sum_d(d1, sh);
+  d2 = block_sum_d(d2, sh);
+  if (want_bias) {
+    d3 = block_sum_d(d3, sh);
+    d4 = block_sum_d(d4, sh);
+    d5 = block_sum_d(d5, sh);
+  }
+  if (threadIdx.x == 0) {
+    double* o = partial + (size_t)blockIdx.x * NACC;
+    o[0] = d1; o[1] = d2; o[2] = d3; o[3] = d4; o[4] = d5;
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply_flat_kernel(
+    const float* __restrict__ x, const float* dy, size_t dy_bs, const float* dy2, size_t dy2_bs,
+    const float* __restrict__ rowbias, float rb_scale, int C, int S, size_t n, float invN,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
+    int relu_in, float* dx) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  const size_t plane = i / S;
+  const int sidx = (int)(i - plane * S), c = (int)(plane % C);
+  const size_t b = plane / C;
+  const float mu = mean[c], is = invstd[c];
+  const float sc = gamma[c] * is;
+  const float shf = beta[c] - mu * sc;
+  const float xv = x[i];
+  float g = dy[b * dy_bs + (size_t)c * S + sidx];
+  if (dy2) g += dy2[b * dy2_bs + (size_t)c * S + sidx];
+  if (rowbias) g += rowbias[plane] * rb_scale;
+  if (relu && !(xv * sc + shf > 0.0f)) g = 0.0f;
+  const float xh = (xv - mu) * is;
+  float r = sc * (g - dbeta[c] * invN - xh * (dgamma[c] * invN));
+  if (relu_in && !(xv > 0.0f)) r = 0.0f;
+  dx[i] = accum ? r + dx[i] : r;
+}
+
 __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
@@ -391,7 +500,9 @@ int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, co
   hipStream_t st = air_stream(stream);
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
-  if (S & 1)
+  if (S < FLAT_S)
+    hipLaunchKernelGGL(bn_partial_stats_flat_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
+  else if (S & 1)
     hipLaunchKernelGGL(bn_partial_stats_kernel<true>, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
   else
     hipLaunchKernelGGL(bn_partial_stats_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
@@ -418,7 +529,11 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
                  int relu, float* y, air_stream_t stream) {
   if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  if (S & 1)
+  const size_t n = (size_t)B * C * S;
+  if (S < FLAT_S)
+    hipLaunchKernelGGL(bn_apply_flat_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, air_stream(stream), x, C, S,
+                       n, scale, shift, relu, y);
+  else if (S & 1)
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
@@ -441,7 +556,10 @@ int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const floa
   const double invN = 1.0 / ((double)B * (double)S);
   const size_t dense = (size_t)C * S;
   const size_t dbs = dy_bstride ? dy_bstride : dense, d2bs = dy2_bstride ? dy2_bstride : dense;
-  if (S & 1)
+  if (S < FLAT_S)
+    hipLaunchKernelGGL(bn_bwd_partial_flat_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
+                       rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
+  else if (S & 1)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
                        rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   else
@@ -452,7 +570,12 @@ int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const floa
                      gamma, invstd, dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
-  if (S & 1)
+  const size_t n = (size_t)B * C * S;
+  if (S < FLAT_S)
+    hipLaunchKernelGGL(bn_bwd_apply_flat_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs,
+                       dy_rowbias, rowbias_scale, C, S, n, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1,
+                       dx_accum, (relu >> 1) & 1, dx);
+  else if (S & 1)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale,
                        C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
   else
