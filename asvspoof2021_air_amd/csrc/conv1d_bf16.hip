@@ -650,6 +650,174 @@ __global__ __launch_bounds__(256) void c1b_gemm_kernel(const NtGemm p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The same NT GEMM, persistent, 256 x 256 tiles (used whenever M % 256 == 0 and N % 256 == 0; the kernel
+// above serves the 128-row operands of the attention layers).  rocprofv3 on c1b_gemm_kernel, layer4
+// forward (0.71 ms, 640 TF): 54 M L2 requests, 36 % of them misses (the 4.7 MB of weights plus the X
+// tiles of the workgroups in flight do not fit an XCD's 4 MB), 535 cycles mean read latency, ~50 lines
+// outstanding per CU all the time: the tile is bound by what one CU's L1 can have in flight, i.e. by
+// L2 -> LDS BYTES, and a 128 x 128 tile moves 1 byte per 64 FLOP.  256 x 256 halves that.
+// 8 waves, each 128 x 64 of the tile = 4 x 2 MFMA 32x32x16 tiles (128 accumulator registers, two waves
+// per SIMD); every wave issues its eighth of the stage's 64 `buffer_load_dwordx4 ... lds` (K = 64: full
+// 128-byte lines per row) one stage ahead into a 2-deep ring (128 KB), one barrier per stage.  A wave
+// that mixes DMA loads and epilogue stores can only wait for vmcnt(0) (they retire out of order with
+// respect to each other) - that is exactly what the loop does: at its top only the next stage's DMAs
+// (and, once per tile, the epilogue's stores) are outstanding.  Resident workgroups (one per CU) walk
+// their XCD's tiles; wave-private transposed epilogue as in c1b_fwd_ps_kernel.
+constexpr int G2_BM = 256, G2_BN = 256;
+constexpr int G2_AB = G2_BM * GK * 2;  // 32 KB
+constexpr int G2_BB = G2_BN * GK * 2;  // 32 KB
+constexpr int G2_SB = G2_AB + G2_BB;
+constexpr int G2_RP = 8;
+constexpr int G2_LDS = 2 * G2_SB + 8 * G2_RP * 256;
+
+struct G2Tile {
+  int batch, m0, n0, nseg;
+};
+__device__ __forceinline__ G2Tile g2_tile(const NtGemm& p, int work) {
+  G2Tile t;
+  const int mt = work % p.tiles_m, rest = work / p.tiles_m;
+  t.m0 = mt * G2_BM;
+  t.n0 = (rest % p.tiles_n) * G2_BN;
+  t.batch = rest / p.tiles_n;
+  t.nseg = min(p.nseg_per_batch, p.nseg_total - t.batch * p.nseg_per_batch);
+  return t;
+}
+
+__global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsigned a_bytes, unsigned b_bytes) {
+  extern __shared__ __attribute__((aligned(1024))) char g2_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x / NXCD;
+  const int w_lo = (blockIdx.x % NXCD) * p.per_xcd, first = w_lo + blockIdx.x / NXCD;
+  const int w_hi = w_lo + p.per_xcd < p.total ? w_lo + p.per_xcd : p.total;
+  if (first >= w_hi) return;
+  const int nmy = (w_hi - first + nwg - 1) / nwg;
+  const int kst = p.kseg / GK;  // stages per segment
+
+  // DMA roles: wave w stages tile rows 32 w .. 32 w + 31 of A and of B, 4 + 4 instructions per stage;
+  // instruction q covers 8 rows (lane >> 3), LDS chunk position lane & 7 holds source chunk pos ^ ((row >> 1) & 7)
+  const i32x4 ars = fd_rsrc(p.a, a_bytes), brs = fd_rsrc(p.b, b_bytes);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)g2_lds;
+  const int r8 = lane >> 3, pos = lane & 7;
+  const unsigned av0 = (unsigned)((r8 * p.a_rs + ((pos ^ (r8 >> 1)) * 8)) * 2);
+  const unsigned av1 = (unsigned)((r8 * p.a_rs + ((pos ^ (r8 >> 1) ^ 4) * 8)) * 2);
+  const unsigned bv0 = (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1)) * 8)) * 2);
+  const unsigned bv1 = (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1) ^ 4) * 8)) * 2);
+  const unsigned arow8 = (unsigned)(8 * p.a_rs * 2), brow8 = (unsigned)(8 * p.b_rs * 2);
+  int it_i = 0, iseg = 0, ik = 0, islot = 0;  // next stage to issue
+  G2Tile ti = g2_tile(p, first);
+  auto issue = [&]() {
+    const unsigned base = lds0 + islot * G2_SB + wave * 4096;
+    const size_t koff = (size_t)iseg * p.a_ss + (size_t)ik * GK, koffb = (size_t)iseg * p.b_ss + (size_t)ik * GK;
+    const unsigned ao = (unsigned)(((size_t)ti.batch * p.a_bs + (size_t)(ti.m0 + 32 * wave) * p.a_rs + koff) * 2);
+    const unsigned bo = (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + 32 * wave) * p.b_rs + koffb) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fd_dma16(ars, ao + q * arow8, base + q * 1024, (q & 1) ? av1 : av0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fd_dma16(brs, bo + q * brow8, base + G2_AB + q * 1024, (q & 1) ? bv1 : bv0);
+    islot ^= 1;
+    if (++ik == kst) {
+      ik = 0;
+      if (++iseg == ti.nseg) {
+        iseg = 0;
+        ++it_i;
+        if (it_i < nmy) ti = g2_tile(p, first + it_i * nwg);
+      }
+    }
+  };
+
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r = lane & 31, kg = lane >> 5;
+  const int sw = (r >> 1) & 7;
+  f32x16 acc[4][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  };
+  zero();
+  issue();
+  int slot = 0;
+  for (int it = 0; it < nmy; ++it) {
+    const G2Tile tl = g2_tile(p, first + it * nwg);
+    const int ng = tl.nseg * kst;
+    for (int g = 0; g < ng; ++g) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // this stage has landed everywhere; everyone is done with the previous one
+      if (g + 1 < ng || it + 1 < nmy) issue();
+      const unsigned short* sA = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB);
+      const unsigned short* sB = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB + G2_AB);
+#pragma unroll
+      for (int kk = 0; kk < GK / 16; ++kk) {
+        const int cpos = ((kk * 2 + kg) ^ sw) * 8;
+        bf16x8 fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 32 + r) * GK + cpos);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      slot ^= 1;
+    }
+    // epilogue: RP rows x 64 columns at a time through this wave's own 2 KB of LDS, 16-byte stores
+    float* __restrict__ ob = p.out + (size_t)tl.batch * p.o_bs;
+    const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.batch * p.o_bs : nullptr;
+    float* tile = reinterpret_cast<float*>(g2_lds + 2 * G2_SB) + wave * (G2_RP * 64);
+    const int c4 = (lane & 15) * 4, lrow = lane >> 4;
+    const int n = tl.n0 + wn * 64 + c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int hp = 0; hp < 32 / G2_RP; ++hp) {
+#pragma unroll
+        for (int e = 0; e < G2_RP / 2; ++e) {
+          const int rr = hp * (G2_RP / 2) + e;
+          const int row = (rr & 3) + 8 * ((rr >> 2) - hp * (G2_RP / 8)) + 4 * kg;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) tile[row * 64 + j * 32 + r] = acc[i][j][rr];
+        }
+#pragma unroll
+        for (int q = 0; q < G2_RP / 4; ++q) {
+          const int row = lrow + 4 * q;
+          const int m = tl.m0 + wm * 128 + i * 32 + hp * G2_RP + row;
+          const float4 v = *reinterpret_cast<const float4*>(&tile[row * 64 + c4]);
+          float add = 0.0f;
+          if (p.bias) add += p.bias[m];
+          if (p.bias_bc) add += p.bias_bc[(size_t)tl.batch * p.M + m];
+          const size_t o = (size_t)m * p.o_rs + n;
+          float vv[4] = {v.x + add, v.y + add, v.z + add, v.w + add};
+          if (n + 3 < p.n_valid && ((o & 1) == 0)) {
+            if (ab) {
+              const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vv[e] += u[e];
+            }
+            f32x4a8 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = p.relu ? fmaxf(vv[e], 0.0f) : vv[e];
+            *reinterpret_cast<f32x4a8*>(ob + o) = out;
+          } else {
+            for (int e = 0; e < 4 && n + e < p.n_valid; ++e) {
+              float w1 = vv[e];
+              if (ab) w1 += ab[o + e];
+              ob[o + e] = p.relu ? fmaxf(w1, 0.0f) : w1;
+            }
+          }
+        }
+      }
+    }
+    zero();
+  }
+}
+
 // ===================================================================================
 // Path 3: the dilated K = 3 convs of the Res2 branches (ecapa_tdnn.py:46: width -> width channels,
 // dilation 2 / 3 / 4, padding = dilation), forward and dgrad.  7 of them run back to back per block
@@ -828,9 +996,11 @@ bool shape_ok(const AirConv1d* p) {
 size_t xbs(const AirConv1d* p) { return p->x_bstride ? p->x_bstride : (size_t)p->Cin * p->T; }
 size_t ybs(const AirConv1d* p) { return p->y_bstride ? p->y_bstride : (size_t)p->Cout * p->T; }
 
+bool gemm_ps_ok(int M);
 int wgrad_nsplit(const AirConv1d* p, int* b_per_split) {
-  const int tiles = (p->Cout / BM) * (p->Cin / BN);
-  int want = 512 / tiles;
+  const bool ps = gemm_ps_ok(p->Cout) && p->Cin % 256 == 0;
+  const int tiles = ps ? (p->Cout / 256) * (p->Cin / 256) : (p->Cout / BM) * (p->Cin / BN);
+  int want = (ps ? 256 : 512) / tiles;  // resident workgroups: one (256 x 256 kernel) or two per CU
   if (want < 1) want = 1;
   if (want > p->B) want = p->B;
   const int per = (p->B + want - 1) / want;
@@ -874,7 +1044,27 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
 }
 
 
-int launch_gemm(NtGemm& g, int nbatch, int n_padded, int kid, double flops, hipStream_t st) {
+bool gemm_ps_ok(int M) {
+  static const int use = getenv("AIR_C1B_GEMM_PS") ? atoi(getenv("AIR_C1B_GEMM_PS")) : 1;
+  return use && M % G2_BM == 0;
+}
+
+int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_bytes, int kid, double flops,
+                hipStream_t st) {
+  if (gemm_ps_ok(g.M) && n_padded % G2_BN == 0 && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) &&
+      ((size_t)g.out & 7) == 0 && g.o_bs % 2 == 0) {
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) == hipSuccess;
+    if (!attr_ok) return AIR_ELAUNCH;
+    g.tiles_m = g.M / G2_BM;
+    g.tiles_n = n_padded / G2_BN;
+    g.total = g.tiles_m * g.tiles_n * nbatch;
+    g.per_xcd = (g.total + NXCD - 1) / NXCD;
+    AirProfScope prof(kid, flops, st);
+    hipLaunchKernelGGL(c1b_gemm_ps_kernel, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
   g.tiles_m = g.M / BM;
   g.tiles_n = n_padded / BN;
   g.total = g.tiles_m * g.tiles_n * nbatch;
@@ -911,7 +1101,7 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   g.b_rs = K; g.b_ss = 0; g.b_bs = (size_t)Tp * K;
   g.o_rs = T; g.o_bs = y_bs;
   g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
-  return launch_gemm(g, B, Tp, AIR_K_C1B_GEMM, flops, st);
+  return launch_gemm(g, B, Tp, (size_t)M * K * 2, (size_t)B * Tp * K * 2, AIR_K_C1B_GEMM, flops, st);
 }
 
 }  // namespace
@@ -1014,7 +1204,8 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
   g.b_rs = Tp; g.b_ss = (size_t)N * Tp; g.b_bs = (size_t)per * g.b_ss;
   g.o_rs = N; g.o_bs = (size_t)M * N;
   g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
-  int rc = launch_gemm(g, nsplit, N, AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
+  int rc = launch_gemm(g, nsplit, N, (size_t)B * Tp * M * 2, (size_t)B * Tp * N * 2, AIR_K_C1B_GEMM,
+                       2.0 * B * T * (double)M * N, st);
   if (rc != AIR_OK) return rc;
   if (nsplit > 1) {
     const size_t n = (size_t)M * N;

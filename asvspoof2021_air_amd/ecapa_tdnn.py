@@ -77,7 +77,7 @@ def _bn(x3, bn, training):
     if training:
         st = ops.bn_stats(x3, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                           bn.eps, bn.momentum)
-        bn.num_batches_tracked += 1
+        ops.bn_tick(bn.num_batches_tracked)
         return st
     scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                       bn.running_var, bn.eps)
@@ -273,6 +273,7 @@ class Res2Net2(nn.Module):
             S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
+        ops.bn_flush()
         return feat, out, S
 
     # ----------------------------------------------------------------- backward

@@ -470,3 +470,18 @@ def softmax_rows(logits):
                                              _hip.dptr(probs), _hip.dptr(loss), _hip.dptr(correct, torch.int32),
                                              _hip.stream()), "air_softmax_ce_fwd")
     return probs
+
+
+# BatchNorm's num_batches_tracked counters: one multi-tensor add per forward instead of one 4 us ATen launch per
+# layer (34 per ECAPA step).  bn_tick() queues a counter, bn_flush() adds 1 to everything queued since the last flush.
+_TICKS = []
+
+
+def bn_tick(counter):
+    _TICKS.append(counter)
+
+
+def bn_flush():
+    if _TICKS:
+        torch._foreach_add_(_TICKS, 1)
+        del _TICKS[:]

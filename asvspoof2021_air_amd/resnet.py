@@ -78,7 +78,7 @@ def _bn_train_coeffs(x, bn, training):
         mean, invstd, scale, shift = ops.bn_stats(x, bn.weight.detach(), bn.bias.detach(),
                                                   bn.running_mean, bn.running_var, bn.eps,
                                                   bn.momentum)
-        bn.num_batches_tracked += 1
+        ops.bn_tick(bn.num_batches_tracked)
         return mean, invstd, scale, shift
     scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                       bn.running_var, bn.eps)
@@ -290,6 +290,7 @@ class ResNet(nn.Module):
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
             S.update(l4=cur, c5=c5, st5=st5, a5v=a5v, noise=nz, pooled=pooled, alpha=alpha, feat=feat)
+        ops.bn_flush()
         return feat, mu, S
 
     # ----------------------------------------------------------------- backward
