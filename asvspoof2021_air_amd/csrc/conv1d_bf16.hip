@@ -553,6 +553,8 @@ struct NtGemm {
   const float* bias;        // [M]
   const float* bias_bc;     // [batch][M]
   const float* acc;         // addressed like out
+  unsigned short* out_bf;   // optional bf16 copy of out: out_bf + (batch * M + m) * out_bf_rs + n (c1b_gemm_ps_kernel only)
+  int out_bf_rs;
   size_t a_rs, a_ss, a_bs, b_rs, b_ss, b_bs, o_rs, o_bs;
   int M, n_valid, kseg, nseg_per_batch, nseg_total, relu, tiles_m, tiles_n, total, per_xcd;
 };
@@ -804,11 +806,17 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[e] = p.relu ? fmaxf(vv[e], 0.0f) : vv[e];
             *reinterpret_cast<f32x4a8*>(ob + o) = out;
+            if (p.out_bf)
+              *reinterpret_cast<uint2*>(p.out_bf + ((size_t)tl.batch * p.M + m) * p.out_bf_rs + n) =
+                  make_uint2(pack2(out[0], out[1]), pack2(out[2], out[3]));
           } else {
             for (int e = 0; e < 4 && n + e < p.n_valid; ++e) {
               float w1 = vv[e];
               if (ab) w1 += ab[o + e];
-              ob[o + e] = p.relu ? fmaxf(w1, 0.0f) : w1;
+              w1 = p.relu ? fmaxf(w1, 0.0f) : w1;
+              ob[o + e] = w1;
+              if (p.out_bf)
+                p.out_bf[((size_t)tl.batch * p.M + m) * p.out_bf_rs + n + e] = (unsigned short)(pack2(w1, 0.0f) & 0xffffu);
             }
           }
         }
@@ -997,6 +1005,7 @@ size_t xbs(const AirConv1d* p) { return p->x_bstride ? p->x_bstride : (size_t)p-
 size_t ybs(const AirConv1d* p) { return p->y_bstride ? p->y_bstride : (size_t)p->Cout * p->T; }
 
 bool gemm_ps_ok(int M);
+int launch_cvt_s(const float* x, size_t x_bs, int B, int C, int T, unsigned short* out, hipStream_t st);
 int wgrad_nsplit(const AirConv1d* p, int* b_per_split) {
   const bool ps = gemm_ps_ok(p->Cout) && p->Cin % 256 == 0;
   const int tiles = ps ? (p->Cout / 256) * (p->Cin / 256) : (p->Cout / BM) * (p->Cin / BN);
@@ -1049,8 +1058,10 @@ bool gemm_ps_ok(int M) {
   return use && M % G2_BM == 0;
 }
 
+// *bf_done (optional): set when the kernel that ran wrote g.out_bf itself
 int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_bytes, int kid, double flops,
-                hipStream_t st) {
+                hipStream_t st, bool* bf_done = nullptr) {
+  if (bf_done) *bf_done = false;
   if (gemm_ps_ok(g.M) && n_padded % G2_BN == 0 && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) &&
       ((size_t)g.out & 7) == 0 && g.o_bs % 2 == 0) {
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel),
@@ -1063,6 +1074,7 @@ int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_by
     AirProfScope prof(kid, flops, st);
     hipLaunchKernelGGL(c1b_gemm_ps_kernel, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
     AIR_CHECK_LAUNCH();
+    if (bf_done) *bf_done = g.out_bf != nullptr;
     return AIR_OK;
   }
   g.tiles_m = g.M / BM;
@@ -1086,7 +1098,7 @@ size_t gemm_fwd_ws(int B, int M, int K, int T) {
 // forward / dgrad through the GEMM: y_b[m][t] = sum_k A[m][k] x_b[k][t]
 int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, float* y, size_t y_bs, const float* bias,
                  const float* bias_bc, const float* acc, int relu, int B, int M, int K, int T, void* ws, double flops,
-                 hipStream_t st) {
+                 hipStream_t st, unsigned short* y_bf = nullptr, bool* bf_done = nullptr) {
   unsigned short* a = reinterpret_cast<unsigned short*>(ws);
   unsigned short* xt = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + align256((size_t)M * K * 2));
   const int Tp = round_up(T, TP_ALIGN);
@@ -1097,11 +1109,12 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   AIR_CHECK_LAUNCH();
   NtGemm g;
   g.a = a; g.b = xt; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = acc;
+  g.out_bf = y_bf; g.out_bf_rs = Tp;
   g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
   g.b_rs = K; g.b_ss = 0; g.b_bs = (size_t)Tp * K;
   g.o_rs = T; g.o_bs = y_bs;
   g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
-  return launch_gemm(g, B, Tp, (size_t)M * K * 2, (size_t)B * Tp * K * 2, AIR_K_C1B_GEMM, flops, st);
+  return launch_gemm(g, B, Tp, (size_t)M * K * 2, (size_t)B * Tp * K * 2, AIR_K_C1B_GEMM, flops, st, bf_done);
 }
 
 }  // namespace
@@ -1142,21 +1155,34 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
   return n + 256;
 }
 
-int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
-                        int relu, float* y, void* ws, size_t ws_bytes, air_stream_t stream) {
+int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
+                           int relu, float* y, unsigned short* y_bf16, void* ws, size_t ws_bytes, air_stream_t stream) {
   if ((!shape_ok(p) && !tap_ok(p)) || !x || !w || !y) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 0)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  int rc;
+  bool bf_done = false;
   if (p->K == 3) {
     if (bias_bc) return AIR_EUNSUPPORTED;
-    return run_tap(x, xbs(p), w, 0, y, ybs(p), bias, nullptr, relu, p->B, p->Cout, p->Cin, p->T, p->dil, ws,
-                   air_stream(stream));
+    rc = run_tap(x, xbs(p), w, 0, y, ybs(p), bias, nullptr, relu, p->B, p->Cout, p->Cin, p->T, p->dil, ws, st);
+  } else if (wide(p->Cout, p->Cin) && p->Cin % 64 == 0) {
+    rc = run_fwd_gemm(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
+                      2.0 * p->B * p->T * (double)p->Cout * p->Cin, st, y_bf16, &bf_done);
+  } else {
+    rc = run_fwd(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
+                 2.0 * p->B * p->T * (double)p->Cout * p->Cin, st);
   }
-  if (wide(p->Cout, p->Cin) && p->Cin % 64 == 0)
-    return run_fwd_gemm(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
-                        2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
-  return run_fwd(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
-                 2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
+  if (rc != AIR_OK) return rc;
+  // y_bf16: the output's bf16 copy in the weight-gradient operand layout - from the GEMM's epilogue when that
+  // kernel ran, by a conversion pass otherwise
+  if (y_bf16 && !bf_done) return launch_cvt_s(y, ybs(p), p->B, p->Cout, p->T, y_bf16, st);
+  return AIR_OK;
+}
+
+int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
+                        int relu, float* y, void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_conv1d_fwd_bf16_ex(p, x, w, bias, bias_bc, relu, y, nullptr, ws, ws_bytes, stream);
 }
 
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
@@ -1175,13 +1201,33 @@ int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, f
                  2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
 }
 
-int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                          air_stream_t stream) {
-  if (!shape_ok(p) || !x || !dy || !dw) return AIR_EINVAL;
+namespace {
+int launch_cvt_s(const float* x, size_t x_bs, int B, int C, int T, unsigned short* out, hipStream_t st) {
+  const int Tp = round_up(T, TP_ALIGN);
+  const int vec = T % 2 == 0 && x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0;
+  const size_t ch = (size_t)B * C * Tp / 8;
+  hipLaunchKernelGGL(c1b_cvt_s_kernel, dim3((unsigned)((ch + 255) / 256)), dim3(256), 0, st, x, x_bs, C, T, Tp, ch, vec, out);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+}  // namespace
+
+int air_conv1d_bf16_tp(int T) { return T > 0 ? round_up(T, TP_ALIGN) : 0; }
+
+int air_conv1d_cvt_bf16(const float* x, size_t x_bstride, int B, int C, int T, unsigned short* out, air_stream_t stream) {
+  if (!x || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  return launch_cvt_s(x, x_bstride ? x_bstride : (size_t)C * T, B, C, T, out, air_stream(stream));
+}
+
+int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* dy, const unsigned short* x_bf16,
+                              size_t x_bf16_bstride, const unsigned short* dy_bf16, size_t dy_bf16_bstride, float* dw,
+                              void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!shape_ok(p) || (!x && !x_bf16) || (!dy && !dy_bf16) || !dw) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 2)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
-  // bf16 copies of both operands ([row][(b, Tp)], zero-padded frames), then the split-K GEMM
+  // bf16 copies of both operands ([b][row][Tp], zero-padded frames) - made here unless the caller holds them
+  // already (written by the tensor's producer, or converted once for several layers) - then the split-K GEMM
   const int B = p->B, M = p->Cout, N = p->Cin, T = p->T, Tp = round_up(T, TP_ALIGN);
   int per;
   const int nsplit = wgrad_nsplit(p, &per);
@@ -1189,23 +1235,30 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
   float* partial = reinterpret_cast<float*>(base);
   unsigned short* dys = reinterpret_cast<unsigned short*>(base + align256((size_t)nsplit * M * N * sizeof(float)));
   unsigned short* xs = dys + align256((size_t)B * Tp * M * 2) / 2;
-  const int vec_y = T % 2 == 0 && ybs(p) % 2 == 0 && (reinterpret_cast<size_t>(dy) & 7) == 0;
-  const int vec_x = T % 2 == 0 && xbs(p) % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0;
-  const size_t chy = (size_t)B * M * Tp / 8, chx = (size_t)B * N * Tp / 8;
-  hipLaunchKernelGGL(c1b_cvt_s_kernel, dim3((unsigned)((chy + 255) / 256)), dim3(256), 0, st, dy, ybs(p), M, T, Tp, chy,
-                     vec_y, dys);
-  AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(c1b_cvt_s_kernel, dim3((unsigned)((chx + 255) / 256)), dim3(256), 0, st, x, xbs(p), N, T, Tp, chx,
-                     vec_x, xs);
-  AIR_CHECK_LAUNCH();
+  size_t a_ss = (size_t)M * Tp, b_ss = (size_t)N * Tp;
+  if (dy_bf16) {
+    dys = const_cast<unsigned short*>(dy_bf16);
+    if (dy_bf16_bstride) a_ss = dy_bf16_bstride;
+  } else {
+    const int rc = launch_cvt_s(dy, ybs(p), B, M, T, dys, st);
+    if (rc != AIR_OK) return rc;
+  }
+  if (x_bf16) {
+    xs = const_cast<unsigned short*>(x_bf16);
+    if (x_bf16_bstride) b_ss = x_bf16_bstride;
+  } else {
+    const int rc = launch_cvt_s(x, xbs(p), B, N, T, xs, st);
+    if (rc != AIR_OK) return rc;
+  }
   NtGemm g;
   g.a = dys; g.b = xs; g.out = nsplit > 1 ? partial : dw; g.bias = nullptr; g.bias_bc = nullptr; g.acc = nullptr;
-  g.a_rs = Tp; g.a_ss = (size_t)M * Tp; g.a_bs = (size_t)per * g.a_ss;
-  g.b_rs = Tp; g.b_ss = (size_t)N * Tp; g.b_bs = (size_t)per * g.b_ss;
+  g.out_bf = nullptr; g.out_bf_rs = 0;
+  g.a_rs = Tp; g.a_ss = a_ss; g.a_bs = (size_t)per * g.a_ss;
+  g.b_rs = Tp; g.b_ss = b_ss; g.b_bs = (size_t)per * g.b_ss;
   g.o_rs = N; g.o_bs = (size_t)M * N;
   g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
-  int rc = launch_gemm(g, nsplit, N, (size_t)B * Tp * M * 2, (size_t)B * Tp * N * 2, AIR_K_C1B_GEMM,
-                       2.0 * B * T * (double)M * N, st);
+  int rc = launch_gemm(g, nsplit, N, ((size_t)(B - 1) * a_ss + (size_t)M * Tp) * 2, ((size_t)(B - 1) * b_ss + (size_t)N * Tp) * 2,
+                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
   if (rc != AIR_OK) return rc;
   if (nsplit > 1) {
     const size_t n = (size_t)M * N;
@@ -1214,6 +1267,12 @@ int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, f
     AIR_CHECK_LAUNCH();
   }
   return AIR_OK;
+}
+
+int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                          air_stream_t stream) {
+  if (!x || !dy) return AIR_EINVAL;
+  return air_conv1d_wgrad_bf16_pre(p, x, dy, nullptr, 0, nullptr, 0, dw, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -9,6 +9,14 @@ namespace {
 
 constexpr int NT = 256;
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// float -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32: the rounding of conv1d_bf16.hip)
+__device__ __forceinline__ unsigned short bf16_bits(float a) {
+  const f32x2_t v = {a, 0.0f};
+  return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)) & 0xffffu);
+}
+
 __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   v = air_wave_sum_d(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(NT) void row_stats_bwd_kernel(
     const float* __restrict__ x, size_t rows, int T, const float* __restrict__ mean,
     const float* __restrict__ std_, const float* __restrict__ dmean,
     const float* __restrict__ dstd, float clamp_min, float* __restrict__ dx, int accumulate, int relu_mask,
-    float* __restrict__ rowsum) {
+    float* __restrict__ rowsum, unsigned short* __restrict__ bf, int Tp) {
   const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -138,6 +146,7 @@ __global__ __launch_bounds__(NT) void row_stats_bwd_kernel(
     if (accumulate) v += dx[row * T + t];
     if (relu_mask && !(xv > 0.0f)) v = 0.0f;
     dx[row * T + t] = v;
+    if (bf) bf[row * Tp + t] = bf16_bits(v);  // bf16 copy [row][Tp]: the weight-gradient GEMM's operand
     s += v;
   }
   if (rowsum != nullptr) {
@@ -264,7 +273,8 @@ __global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ out,
                                                      const float* __restrict__ dout,
                                                      float* __restrict__ dx, int accumulate,
-                                                     float* __restrict__ rowsum, size_t rows) {
+                                                     float* __restrict__ rowsum, size_t rows,
+                                                     unsigned short* __restrict__ bf, int Tp) {
   const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x
         dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
         const float da = wv[k] * (dwv - dot);  // softmax backward
         pw[t] = da;
+        if (bf) bf[row * Tp + t] = bf16_bits(da);  // bf16 copy [row][Tp]: the weight-gradient GEMM's operand
         rs += da;
       }
     }
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(NT) void asp_bwd_kernel(const float* __restrict__ x
       dx[row * T + t] = accumulate ? dx[row * T + t] + g : g;
       const float da = wv * (dwv - dot);  // softmax backward
       pw[t] = da;
+      if (bf) bf[row * Tp + t] = bf16_bits(da);
       rs += da;
     }
   }
@@ -426,17 +438,26 @@ int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_o
   return AIR_OK;
 }
 
-int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
-                      const float* dmean, const float* dstd, float clamp_min, float* dx,
-                      int accumulate, int relu_mask, float* rowsum, air_stream_t stream) {
+int air_row_stats_bwd_ex(const float* x, int B, int C, int T, const float* mean, const float* std_,
+                         const float* dmean, const float* dstd, float clamp_min, float* dx,
+                         int accumulate, int relu_mask, float* rowsum, unsigned short* dx_bf16, int dx_bf16_tp,
+                         air_stream_t stream) {
   if (!x || !mean || !dx || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
+  if (dx_bf16 && dx_bf16_tp < T) return AIR_EINVAL;
   if (dstd != nullptr && std_ == nullptr) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(row_stats_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
                      air_stream(stream), x, rows, T, mean, std_, dmean, dstd, clamp_min, dx,
-                     accumulate, relu_mask, rowsum);
+                     accumulate, relu_mask, rowsum, dx_bf16, dx_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
+                      const float* dmean, const float* dstd, float clamp_min, float* dx,
+                      int accumulate, int relu_mask, float* rowsum, air_stream_t stream) {
+  return air_row_stats_bwd_ex(x, B, C, T, mean, std_, dmean, dstd, clamp_min, dx, accumulate, relu_mask, rowsum,
+                              nullptr, 0, stream);
 }
 
 int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
@@ -475,18 +496,27 @@ int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* 
   return AIR_OK;
 }
 
-int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
-                const float* dout, float* dx, int accumulate, float* rowsum, air_stream_t stream) {
+int air_asp_bwd_ex(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
+                   const float* dout, float* dx, int accumulate, float* rowsum, unsigned short* dlogits_bf16,
+                   int dlogits_bf16_tp, air_stream_t stream) {
   if (!x || !w_to_dlogits || !out || !dout || !dx || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  if (dlogits_bf16 && dlogits_bf16_tp < T) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
   if (T <= 64 * ASP_R)
     hipLaunchKernelGGL(asp_bwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
-                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows);
+                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows, dlogits_bf16,
+                       dlogits_bf16_tp);
   else
     hipLaunchKernelGGL(asp_bwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
-                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows);
+                       air_stream(stream), x, w_to_dlogits, C, T, out, dout, dx, accumulate, rowsum, rows, dlogits_bf16,
+                       dlogits_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
+                const float* dout, float* dx, int accumulate, float* rowsum, air_stream_t stream) {
+  return air_asp_bwd_ex(x, w_to_dlogits, B, C, T, out, dout, dx, accumulate, rowsum, nullptr, 0, stream);
 }
 
 }  // extern "C"

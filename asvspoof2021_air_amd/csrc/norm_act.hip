@@ -19,6 +19,13 @@ constexpr int NT = 256;
 constexpr int FLAT_S = 32;  // planes shorter than this: flat-indexed kernels (below)
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32: the rounding of conv1d_bf16.hip)
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 // floats in front of p's next 8-byte boundary (0 or 1); -1 when the pointers disagree
 __device__ __forceinline__ int head8(const void* p) { return (int)((((size_t)p) >> 2) & 1); }
 __device__ __forceinline__ int head8(const void* p, const void* q) {
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int accum,
-    int relu_in, float* dx) {
+    int relu_in, float* dx, unsigned short* __restrict__ bf, int Tp) {
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float mu = mean[c], is = invstd[c];
@@ -335,9 +342,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   if (h != head8(dx + base, pdy2)) h = -1;
   if (!PEEL && h != 0) h = -1;
   const int i0 = h < 0 ? 4 * qi : h + 4 * qi;
+  // bf: optional bf16 copy of dx, [plane][Tp] (the weight-gradient GEMM's operand layout, conv1d_bf16.hip)
+  unsigned short* __restrict__ pbf = bf ? bf + (size_t)plane * Tp : nullptr;
   auto scalar = [&](int lo, int hi) {
-    for (int i = lo; i < hi; ++i)
-      dx[base + i] = one(x[base + i], pdy[i] + (pdy2 ? pdy2[i] : 0.0f), accum ? dx[base + i] : 0.0f);
+    for (int i = lo; i < hi; ++i) {
+      const float r = one(x[base + i], pdy[i] + (pdy2 ? pdy2[i] : 0.0f), accum ? dx[base + i] : 0.0f);
+      dx[base + i] = r;
+      if (pbf) pbf[i] = (unsigned short)(bf16_pack2(r, 0.0f) & 0xffffu);
+    }
   };
   if (h >= 0 && i0 + 3 < S) {
     if (PEEL && qi == 0) scalar(0, h);
@@ -350,6 +362,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = one(xv[e], gv[e], ov[e]);
     *reinterpret_cast<f4a8*>(dx + base + i0) = r;
+    if (pbf) {
+      if (!PEEL) {
+        *reinterpret_cast<uint2*>(pbf + i0) = make_uint2(bf16_pack2(r[0], r[1]), bf16_pack2(r[2], r[3]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pbf[i0 + e] = (unsigned short)(bf16_pack2(r[e], 0.0f) & 0xffffu);
+      }
+    }
   } else if (!PEEL && h >= 0 && i0 + 2 == S) {
     const f2a8 xv = *reinterpret_cast<const f2a8*>(x + base + i0);
     f2a8 gv = *reinterpret_cast<const f2a8*>(pdy + i0);
@@ -360,6 +380,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     r[0] = one(xv[0], gv[0], ov[0]);
     r[1] = one(xv[1], gv[1], ov[1]);
     *reinterpret_cast<f2a8*>(dx + base + i0) = r;
+    if (pbf) *reinterpret_cast<unsigned*>(pbf + i0) = bf16_pack2(r[0], r[1]);
   } else {
     scalar((PEEL && h > 0 && qi == 0) ? 0 : i0, min(S, i0 + 4));
   }
@@ -541,10 +562,13 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
   return AIR_OK;
 }
 
-int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
-                  const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
-                  const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
-                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, air_stream_t stream) {
+int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                   const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                   float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp, void* ws,
+                   size_t ws_bytes, air_stream_t stream) {
+  if (dx_bf16 && (S < FLAT_S || dx_bf16_tp < S || (dx_bf16_tp & 3) || (reinterpret_cast<size_t>(dx_bf16) & 7)))
+    return AIR_EINVAL;
   if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 ||
       C <= 0 || S <= 0)
     return AIR_EINVAL;
@@ -577,12 +601,21 @@ int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const floa
                        dx_accum, (relu >> 1) & 1, dx);
   else if (S & 1)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale,
-                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
+                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx, dx_bf16, dx_bf16_tp);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias, rowbias_scale,
-                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx);
+                       C, S, (float)invN, mean, invstd, gamma, beta, dgamma, dbeta, relu & 1, dx_accum, (relu >> 1) & 1, dx,
+                       dx_bf16, dx_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                  const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                  const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_bn_bwd_ex2(x, dy, dy_bstride, dy2, dy2_bstride, dy_rowbias, rowbias_scale, B, C, S, mean, invstd, gamma, beta,
+                        relu, dx, dx_accum, dgamma, dbeta, dbias, nullptr, 0, ws, ws_bytes, stream);
 }
 
 int air_bn_bwd(const float* x, const float* dy, int B, int C, int S, const float* mean,

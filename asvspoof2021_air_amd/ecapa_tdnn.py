@@ -242,7 +242,11 @@ class Res2Net2(nn.Module):
             out = cat123[:, k * C:(k + 1) * C]
             blocks.append(self._block_fwd(blk, inp, out, training, save))
             inp = out
-        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf)  # :172-173
+        # bf16 training: layer4's GEMM epilogue also writes x4's bf16 copy, the X operand of attention.0's weight
+        # gradient (kept until backward like x4 itself)
+        x4_bf = ops.bf16_rows(None, B, self.layer4.out_channels, T, x.device) if (bf and save) else None
+        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf,
+                            y_bf=x4_bf)  # :172-173
         mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178)
         ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
         a0, a3 = self.attention[0], self.attention[3]
@@ -270,15 +274,16 @@ class Res2Net2(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
+            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean, std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
         ops.bn_flush()
         return feat, out, S
 
     # ----------------------------------------------------------------- backward
-    def _block_bwd(self, S, dout, G, pre):
-        """dout: gradient w.r.t. the block output (dense (B,C,T)).  Returns d(inp) dense."""
+    def _block_bwd(self, S, dout, G, pre, inp_bf=None):
+        """dout: gradient w.r.t. the block output (dense (B,C,T)).  Returns d(inp) dense.
+        inp_bf: bf16 copy of the block input when the caller holds one (a slice of the concat's copy)."""
         blk = S["blk"]
         det = lambda p: p.detach()
         bf = self.compute_dtype == "bf16"
@@ -300,10 +305,13 @@ class Res2Net2(nn.Module):
         # the SE squeeze's gradient (d mean_T / d o3 = 1/T, ecapa_tdnn.py:19) enters bn3's backward as a
         # per-(b, c) constant on the incoming gradient; the conv bias gradient comes out of the same pass
         st3 = S["st3"]
+        # bf16 path: the BatchNorm backward writes the weight-gradient GEMM's dY operand itself (one buffer for
+        # every 512-channel gradient of the model: same stream, so each copy is consumed before the next is made)
+        dy_bf = ops.bf16_rows("ecapa.dy", B, C, T, do3.device) if bf else None
         dc3, _, _ = ops.bn_bwd(S["r3"], do3, st3[0], st3[1], det(blk.bn3.weight), det(blk.bn3.bias),
                                relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"),
-                               rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"))
-        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf)
+                               rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"), dx_bf16=dy_bf)
+        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf, dy_bf=dy_bf)
         dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight), bf16=bf)
         do1 = torch.empty_like(dcat)
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
@@ -324,8 +332,9 @@ class Res2Net2(nn.Module):
         st1 = S["st1"]
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),
                                relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"),
-                               dbias=gv("conv1.bias"))
-        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf)
+                               dbias=gv("conv1.bias"), dx_bf16=dy_bf)
+        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf, dy_bf=dy_bf,
+                         x_bf=inp_bf)
         # + dout: the residual branch (ecapa_tdnn.py:93), added in the dgrad epilogue
         return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf)
 
@@ -368,18 +377,23 @@ class Res2Net2(nn.Module):
         x4, wts = S["x4"], S["wts"]
         dx4 = torch.empty_like(x4)
         rows3 = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
-        ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False, rowsum=rows3)  # wts -> dlogits
+        # one (B, 1536, Tp) bf16 buffer serves d(logits) and, later, d(x4): each is consumed by its weight-gradient
+        # GEMM (same stream) before the next one is written
+        wide_bf = ops.bf16_rows("ecapa.dy1536", B, x4.shape[1], T, x4.device) if bf else None
+        ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False, rowsum=rows3,
+                    dlogits_bf16=wide_bf)  # wts -> dlogits
         a0, a3 = self.attention[0], self.attention[3]
         ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
-        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf)
+        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf, dy_bf=wide_bf)
         da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
         stA = S["stA"]
+        da1_bf = ops.bf16_rows("ecapa.da1", B, 128, T, x4.device) if bf else None
         da1, _, _ = ops.bn_bwd(S["a1"], da1n, stA[0], stA[1], det(self.attention[2].weight),
                                det(self.attention[2].bias), relu_in=True, dx=da1n,
                                dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"],
-                               dbias=G["attention.0.bias"])
+                               dbias=G["attention.0.bias"], dx_bf16=da1_bf)
         gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
-        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf)
+        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf, dy_bf=da1_bf, x_bf=S["x4_bf"])
         ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
         ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4, bf16=bf)
         dctxb = ops.row_sum(da1)  # (B,128)
@@ -390,9 +404,14 @@ class Res2Net2(nn.Module):
         # context-statistics gradient, the ReLU after layer4 (:173) and the per-row sums for the bias
         # gradient in ONE pass over the (B, 1536, T) tensor
         rows = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
-        ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows)
+        ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows,
+                          dx_bf16=wide_bf)
         ops.sum_rows(rows, out=G["layer4.bias"])
-        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf)
+        # the concat's bf16 copy is made once: layer4's weight gradient reads all of it, the conv1 weight gradients
+        # of blocks 2 and 3 read the channel slices that were their inputs
+        cat_bf = ops.conv1d_cvt_bf16(S["cat123"], ops.bf16_rows("ecapa.cat123", B, 3 * C, T, dx4.device)) if bf else None
+        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf, x_bf=cat_bf,
+                         dy_bf=wide_bf)
         # data parallel: everything from layer4.weight to the end of the gradient arena is final
         bucketer = None if accumulating else getattr(self, "_bucketer", None)
         offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
@@ -411,7 +430,8 @@ class Res2Net2(nn.Module):
         for k in (2, 1, 0):
             dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
             ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
-            dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1))
+            dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1),
+                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),

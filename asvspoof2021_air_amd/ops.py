@@ -120,12 +120,14 @@ def bn_apply(x, scale, shift, relu=False, out=None):
 
 
 def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=False,
-           dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None, dy2=None):
+           dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None, dy2=None,
+           dx_bf16=None):
     """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta).
     relu_in: x is itself a ReLU output (conv -> ReLU -> BN); dx is then the gradient
     w.r.t. the pre-ReLU tensor.  rowbias (B, C): the incoming gradient is dy + rowbias_scale *
     rowbias[b, c] (broadcast over time).  dbias (C,): receives sum_{b,t} dx, the conv-bias gradient.
-    dy (and the optional second gradient dy2, added on the fly) may be channel-slice views."""
+    dy (and the optional second gradient dy2, added on the fly) may be channel-slice views.
+    dx_bf16: (B, C, Tp) int16 buffer from bf16_rows(): receives dx rounded to bf16, the operand of conv1d_wgrad."""
     B, C, S = _bcs(x)
     if dy.dim() == 3 and (dy2 is not None or not dy.is_contiguous()):
         dyp, dyb = vptr(dy)
@@ -143,13 +145,17 @@ def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=Fal
     lib = _hip.lib()
     n = lib.air_bn_ws_bytes(ci(B), ci(C), ci(S))
     ws = workspace(n, x.device)
-    _hip.check(lib.air_bn_bwd_ex(dptr(x), dyp, csz(dyb), dy2p, csz(dy2b), dptr(rowbias, allow_none=True),
-                                 cf(rowbias_scale), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma),
-                                 dptr(beta),
-                                 ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
-                                 ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
-                                 dptr(dbias, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()),
-               "air_bn_bwd_ex")
+    if dx_bf16 is not None and tuple(dx_bf16.shape[:2]) != (B, C):
+        raise _hip.AirError("bn_bwd: dx_bf16 must be (B, C, Tp)")
+    _hip.check(lib.air_bn_bwd_ex2(dptr(x), dyp, csz(dyb), dy2p, csz(dy2b), dptr(rowbias, allow_none=True),
+                                  cf(rowbias_scale), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma),
+                                  dptr(beta),
+                                  ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
+                                  ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
+                                  dptr(dbias, allow_none=True), dptr(dx_bf16, torch.int16, allow_none=True),
+                                  ci(dx_bf16.shape[2] if dx_bf16 is not None else 0),
+                                  dptr(ws, torch.uint8), csz(n), stream()),
+               "air_bn_bwd_ex2")
     return dx, dgamma, dbeta
 
 
@@ -288,9 +294,10 @@ def _c1d_bf16(d, device, which):
     return workspace(n, device), n
 
 
-def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None, bf16=False):
+def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None, bf16=False, y_bf=None):
     """y = relu?(conv1d(x, w) + bias + bias_bc[b]); x / out may be channel-slice views.
-    bf16: pointwise layers run on the bf16 matrix cores (operands rounded, fp32 accumulate)."""
+    bf16: pointwise layers run on the bf16 matrix cores (operands rounded, fp32 accumulate); y_bf (bf16_rows
+    buffer, bf16 path only) also receives y rounded to bf16 - the X operand of a later conv1d_wgrad."""
     Cout, Cin, K = w.shape
     B, _, T = x.shape
     y = out if out is not None else torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
@@ -298,11 +305,14 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
     if bf16:
         wsb, nb = _c1d_bf16(d, x.device, 0)
         if wsb is not None:
-            _hip.check(_hip.lib().air_conv1d_fwd_bf16(
+            _hip.check(_hip.lib().air_conv1d_fwd_bf16_ex(
                 ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
                 dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
-                dptr(wsb, torch.uint8), csz(nb), stream()), "air_conv1d_fwd_bf16")
+                dptr(y_bf, torch.int16, allow_none=True),
+                dptr(wsb, torch.uint8), csz(nb), stream()), "air_conv1d_fwd_bf16_ex")
             return y
+    if y_bf is not None:
+        raise _hip.AirError("conv1d_fwd: y_bf needs the bf16 path")
     _hip.check(_hip.lib().air_conv1d_fwd(ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
                                          dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
                                          dptr(ws, torch.uint8), csz(n), stream()), "air_conv1d_fwd")
@@ -332,7 +342,47 @@ def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False):
     return dx
 
 
-def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None, bf16=False):
+_BF_ROWS = {}
+
+
+def bf16_rows(tag, B, C, T, device):
+    """Zero-padded (B, C, Tp) int16 buffer for a bf16 operand copy (Tp = air_conv1d_bf16_tp(T)).  With a tag: one
+    persistent buffer per (tag, shape), for copies made and consumed inside one backward pass - writers only
+    touch frames < T, so the padding stays zero for as long as the buffer lives.  tag None: fresh memory."""
+    Tp = int(_hip.lib().air_conv1d_bf16_tp(ci(T)))
+    if tag is None:  # a copy that outlives the call sequence (saved for backward): its own memory, padding zeroed
+        buf = torch.empty((B, C, Tp), device=device, dtype=torch.int16)
+        if Tp > T:
+            buf[:, :, T:].zero_()
+        return buf
+    key = (tag, B, C, Tp, device.type, device.index)
+    buf = _BF_ROWS.get(key)
+    if buf is None:
+        buf = _BF_ROWS[key] = torch.zeros((B, C, Tp), device=device, dtype=torch.int16)
+    return buf
+
+
+def conv1d_cvt_bf16(x, out):
+    """out (B, C, Tp) int16 <- bf16(x) for a (B, C, T) fp32 tensor or channel-slice view."""
+    B, C, T = x.shape
+    xp, xb = vptr(x)
+    _hip.check(_hip.lib().air_conv1d_cvt_bf16(xp, csz(xb), ci(B), ci(C), ci(T), dptr(out, torch.int16), stream()),
+               "air_conv1d_cvt_bf16")
+    return out
+
+
+def _bf_view(t):
+    """(pointer, batch stride in elements) of a (B, C, Tp) int16 copy or a channel-slice view of one."""
+    if t is None:
+        return ctypes.c_void_p(0), 0
+    if t.dtype != torch.int16 or not t.is_cuda or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        raise _hip.AirError("bf16 operand copy must be a (B, C, Tp) int16 GPU tensor (or a channel slice of one)")
+    return ctypes.c_void_p(t.data_ptr()), t.stride(0)
+
+
+def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None, bf16=False, x_bf=None, dy_bf=None):
+    """x_bf / dy_bf (bf16 path only): operand copies the caller already holds (bf16_rows buffers filled by
+    bn_bwd(dx_bf16=...) or conv1d_cvt_bf16), skipping the conversion pass inside."""
     Cout, Cin, K = w_shape
     B, _, T = x.shape
     dw = out if out is not None else torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32)
@@ -342,9 +392,11 @@ def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None, bf16=False):
     if bf16:
         wsb, nb = _c1d_bf16(d, x.device, 2)
         if wsb is not None:
-            _hip.check(_hip.lib().air_conv1d_wgrad_bf16(ctypes.byref(d), xp, yp, dptr(dw),
-                                                        dptr(wsb, torch.uint8), csz(nb), stream()),
-                       "air_conv1d_wgrad_bf16")
+            xfp, xfb = _bf_view(x_bf)
+            yfp, yfb = _bf_view(dy_bf)
+            _hip.check(_hip.lib().air_conv1d_wgrad_bf16_pre(ctypes.byref(d), xp, yp, xfp, csz(xfb), yfp, csz(yfb),
+                                                            dptr(dw), dptr(wsb, torch.uint8), csz(nb), stream()),
+                       "air_conv1d_wgrad_bf16_pre")
             return dw
     n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
     ws = workspace(n, x.device)
@@ -397,15 +449,18 @@ def row_stats(x, want_std=True, clamp_min=1e-4, mean_out=None, std_out=None):
     return mean, std
 
 
-def row_stats_bwd(x, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4, relu_mask=False, rowsum=None):
+def row_stats_bwd(x, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4, relu_mask=False, rowsum=None,
+                  dx_bf16=None):
     """dx (+)= gradient of the per-row mean / std statistics; relu_mask zeroes the result where x == 0;
-    rowsum (B, C) receives the time sums of the result rows."""
+    rowsum (B, C) receives the time sums of the result rows; dx_bf16 (bf16_rows buffer) its bf16 copy."""
     B, C, T = x.shape
-    _hip.check(_hip.lib().air_row_stats_bwd(dptr(x), ci(B), ci(C), ci(T), dptr(mean), dptr(std, allow_none=True),
-                                            dptr(dmean, allow_none=True), dptr(dstd, allow_none=True),
-                                            cf(clamp_min), dptr(dx), ci(1 if accumulate else 0),
-                                            ci(1 if relu_mask else 0), dptr(rowsum, allow_none=True), stream()),
-               "air_row_stats_bwd")
+    _hip.check(_hip.lib().air_row_stats_bwd_ex(dptr(x), ci(B), ci(C), ci(T), dptr(mean), dptr(std, allow_none=True),
+                                               dptr(dmean, allow_none=True), dptr(dstd, allow_none=True),
+                                               cf(clamp_min), dptr(dx), ci(1 if accumulate else 0),
+                                               ci(1 if relu_mask else 0), dptr(rowsum, allow_none=True),
+                                               dptr(dx_bf16, torch.int16, allow_none=True),
+                                               ci(dx_bf16.shape[2] if dx_bf16 is not None else 0), stream()),
+               "air_row_stats_bwd_ex")
     return dx
 
 
@@ -449,12 +504,15 @@ def asp_fwd(x, logits):
     return out
 
 
-def asp_bwd(x, w, out, dout, dx, accumulate=False, rowsum=None):
-    """Overwrites ``w`` with d(logits); writes / accumulates dx; rowsum (B, C) receives sum_t d(logits)."""
+def asp_bwd(x, w, out, dout, dx, accumulate=False, rowsum=None, dlogits_bf16=None):
+    """Overwrites ``w`` with d(logits); writes / accumulates dx; rowsum (B, C) receives sum_t d(logits);
+    dlogits_bf16 (bf16_rows buffer) the bf16 copy of d(logits)."""
     B, C, T = x.shape
-    _hip.check(_hip.lib().air_asp_bwd(dptr(x), dptr(w), ci(B), ci(C), ci(T), dptr(out), dptr(dout), dptr(dx),
-                                      ci(1 if accumulate else 0), dptr(rowsum, allow_none=True), stream()),
-               "air_asp_bwd")
+    _hip.check(_hip.lib().air_asp_bwd_ex(dptr(x), dptr(w), ci(B), ci(C), ci(T), dptr(out), dptr(dout), dptr(dx),
+                                         ci(1 if accumulate else 0), dptr(rowsum, allow_none=True),
+                                         dptr(dlogits_bf16, torch.int16, allow_none=True),
+                                         ci(dlogits_bf16.shape[2] if dlogits_bf16 is not None else 0), stream()),
+               "air_asp_bwd_ex")
     return dx
 
 

@@ -197,10 +197,30 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p);
 int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias,
                         const float* bias_bc, int relu, float* y, void* ws, size_t ws_bytes,
                         air_stream_t stream);
+/* Same, and y is also written as bf16 (nearest even) into y_bf16[(b*Cout + c) * air_conv1d_bf16_tp(T) + t], the
+ * operand layout of air_conv1d_wgrad_bf16_pre (from the GEMM's epilogue for the wide layers, by a conversion
+ * pass otherwise); NULL = air_conv1d_fwd_bf16. */
+int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const float* bias,
+                           const float* bias_bc, int relu, float* y, unsigned short* y_bf16, void* ws,
+                           size_t ws_bytes, air_stream_t stream);
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx,
                           const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
 int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
                           size_t ws_bytes, air_stream_t stream);
+/* The weight-gradient GEMM runs on bf16 copies of its operands, [b][channel][Tp] with
+ * Tp = air_conv1d_bf16_tp(T) frames per row and zeros for t >= T; air_conv1d_wgrad_bf16 makes them in its
+ * workspace, one HBM pass per operand.  A caller that already holds a copy - written by the tensor's producer
+ * (air_bn_bwd_ex2's dx_bf16) or converted once with air_conv1d_cvt_bf16 for several layers (ECAPA's (B, 1536, T)
+ * concat feeds layer4 and, as channel slices, two Bottle2neck conv1 layers: ecapa_tdnn.py:118,39) - passes it to
+ * air_conv1d_wgrad_bf16_pre: x_bf16 / dy_bf16 with their batch strides in ELEMENTS (0 = dense; a channel slice
+ * of a wider copy keeps the wide stride), NULL = convert the fp32 tensor as before.  Same rounding (nearest
+ * even) everywhere, so results are bit-identical to air_conv1d_wgrad_bf16. */
+int air_conv1d_bf16_tp(int T);
+int air_conv1d_cvt_bf16(const float* x, size_t x_bstride, int B, int C, int T, unsigned short* out,
+                        air_stream_t stream);
+int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* dy, const unsigned short* x_bf16,
+                              size_t x_bf16_bstride, const unsigned short* dy_bf16, size_t dy_bf16_bstride,
+                              float* dw, void* ws, size_t ws_bytes, air_stream_t stream);
 
 /* ------------------------------------------------------- batchnorm/relu --
  * nn.BatchNorm2d/1d (+ F.relu) as used at resnet.py:55-67,132,142 and
@@ -245,6 +265,14 @@ int air_bn_bwd_ex(const float* x, const float* dy, size_t dy_bstride, const floa
                   const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
                   const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
                   float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes, air_stream_t stream);
+/* Same, and dx is also written as bf16 (nearest even) into dx_bf16[(b*C + c) * dx_bf16_tp + s] - the operand
+ * layout of air_conv1d_wgrad_bf16_pre (dx_bf16_tp = air_conv1d_bf16_tp(S); the caller keeps the frames
+ * s >= S zero).  dx_bf16 NULL = air_bn_bwd_ex. */
+int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                   const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                   float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp, void* ws,
+                   size_t ws_bytes, air_stream_t stream);
 
 /* ------------------------------------------------------------- pooling ---
  * SelfAttention.forward (resnet.py:23-46) on x (B, C, T) (the squeezed conv5
@@ -304,6 +332,12 @@ int air_row_stats(const float* x, int B, int C, int T, float* mean, float* std_o
 int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, const float* std_,
                       const float* dmean, const float* dstd, float clamp_min, float* dx,
                       int accumulate, int relu_mask, float* rowsum_or_null, air_stream_t stream);
+/* Same, and the result is also written as bf16 into dx_bf16[(b*C + c) * dx_bf16_tp + t] (operand layout of
+ * air_conv1d_wgrad_bf16_pre; NULL = air_row_stats_bwd). */
+int air_row_stats_bwd_ex(const float* x, int B, int C, int T, const float* mean, const float* std_,
+                         const float* dmean, const float* dstd, float clamp_min, float* dx,
+                         int accumulate, int relu_mask, float* rowsum_or_null, unsigned short* dx_bf16,
+                         int dx_bf16_tp, air_stream_t stream);
 /* dx *= (y > 0): backward of the stand-alone ReLU after layer4 (ecapa_tdnn.py:173). */
 int air_relu_mask(float* dx, const float* y, size_t n, air_stream_t stream);
 /* out[b][c] = sum_t x[b][c][t]: gradient of a per-utterance bias. */
@@ -321,6 +355,10 @@ int air_asp_fwd(const float* x, float* logits_to_w, int B, int C, int T, float* 
 /* rowsum_or_null (B*C): sum over time of each d(logits) row (summed over b: attention.3's bias gradient). */
 int air_asp_bwd(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
                 const float* dout, float* dx, int accumulate, float* rowsum_or_null, air_stream_t stream);
+/* Same, and d(logits) is also written as bf16 into dlogits_bf16[(b*C + c) * dlogits_bf16_tp + t] (NULL = air_asp_bwd). */
+int air_asp_bwd_ex(const float* x, float* w_to_dlogits, int B, int C, int T, const float* out,
+                   const float* dout, float* dx, int accumulate, float* rowsum_or_null,
+                   unsigned short* dlogits_bf16, int dlogits_bf16_tp, air_stream_t stream);
 
 /* ----------------------------------------------------------- OC-Softmax ---
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
