@@ -74,8 +74,9 @@ struct C1bFwd {
   float* y;
   const float* bias;
   const float* bias_bc;
-  const float* acc;
-  size_t x_bs, y_bs;
+  const float* acc;   // accumulate operands: y += acc (batch stride acc_bs) + acc2 (batch stride acc2_bs)
+  const float* acc2;
+  size_t x_bs, y_bs, acc_bs, acc2_bs;
   int B, M, K, T, relu, tiles_m, tiles_t, total, per_xcd;
 };
 
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
 
   const int col = lane & 31, half = lane >> 5;
   float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
-  const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
+  const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.acc_bs : nullptr;
+  const float* __restrict__ ab2 = p.acc2 ? p.acc2 + (size_t)b * p.acc2_bs : nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void c1b_fwd_kernel(const C1bFwd p) {
         if (t < p.T) {
           float v = acc[i][j][r] + add;
           if (ab) v += ab[(size_t)m * p.T + t];
+          if (ab2) v += ab2[(size_t)m * p.T + t];
           if (p.relu) v = fmaxf(v, 0.0f);
           yb[(size_t)m * p.T + t] = v;
         }
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(128 * WM + 128) void c1b_fwd_ps_kernel(const C1bFwd
       // wave turns RP rows x 64 frames at a time through its own 4 / 2 KB of LDS (no barrier: one wave, LDS
       // operations of a wave execute in order) and stores 16 bytes per lane, 256-byte row pieces.
       float* __restrict__ yb = p.y + (size_t)tl.b * p.y_bs;
-      const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.b * p.y_bs : nullptr;
+      const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.b * p.acc_bs : nullptr;
+      const float* __restrict__ ab2 = p.acc2 ? p.acc2 + (size_t)tl.b * p.acc2_bs : nullptr;
       float* tile = reinterpret_cast<float*>(fd_lds + FD_NS * SB) + wave * (RP * 64);
       const int c4 = (lane & 15) * 4, lrow = lane >> 4;
       const int t = tl.t0 + wn * 64 + c4;
@@ -420,6 +424,10 @@ __global__ __launch_bounds__(128 * WM + 128) void c1b_fwd_ps_kernel(const C1bFwd
                 const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab + o);
                 v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
               }
+              if (ab2) {
+                const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab2 + o);
+                v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
+              }
               f32x4a8 out = {v.x + add, v.y + add, v.z + add, v.w + add};
               if (p.relu) {
 #pragma unroll
@@ -429,6 +437,10 @@ __global__ __launch_bounds__(128 * WM + 128) void c1b_fwd_ps_kernel(const C1bFwd
             } else if (t + 1 < p.T) {  // T is even: a row's last piece holds 4 or 2 frames
               if (ab) {
                 const f32x2 u = *reinterpret_cast<const f32x2*>(ab + o);
+                v.x += u[0]; v.y += u[1];
+              }
+              if (ab2) {
+                const f32x2 u = *reinterpret_cast<const f32x2*>(ab2 + o);
                 v.x += u[0]; v.y += u[1];
               }
               f32x2 out = {v.x + add, v.y + add};
@@ -1019,11 +1031,13 @@ int wgrad_nsplit(const AirConv1d* p, int* b_per_split) {
 
 int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y, size_t y_bs, const float* bias,
             const float* bias_bc, const float* acc, int relu, int B, int M, int K, int T, void* ws, double flops,
-            hipStream_t st) {
+            hipStream_t st, size_t acc_bs = 0, const float* acc2 = nullptr, size_t acc2_bs = 0) {
   unsigned short* a = reinterpret_cast<unsigned short*>(ws);
   C1bFwd p;
-  p.x = x; p.a = a; p.y = y; p.bias = bias; p.bias_bc = bias_bc; p.acc = acc;
+  p.x = x; p.a = a; p.y = y; p.bias = bias; p.bias_bc = bias_bc; p.acc = acc; p.acc2 = acc2;
   p.x_bs = x_bs; p.y_bs = y_bs;
+  p.acc_bs = acc_bs ? acc_bs : y_bs;
+  p.acc2_bs = acc2_bs ? acc2_bs : y_bs;
   p.B = B; p.M = M; p.K = K; p.T = T; p.relu = relu;
   p.tiles_m = M / BM;
   p.tiles_t = (T + BN - 1) / BN;
@@ -1032,7 +1046,9 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   static const int use_ps = getenv("AIR_C1B_PS") ? atoi(getenv("AIR_C1B_PS")) : 3;
   // the DMA moves 16-byte chunks: frame rows have to start on 8-byte boundaries (even T and strides),
   // and every byte offset has to fit the descriptor's 32 bits
-  const bool ps_ok = use_ps && T % 2 == 0 && x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0 &&
+  const bool acc_al = ((reinterpret_cast<size_t>(acc) | reinterpret_cast<size_t>(acc2)) & 7) == 0 && p.acc_bs % 2 == 0 &&
+                      p.acc2_bs % 2 == 0 && (reinterpret_cast<size_t>(y) & 7) == 0 && y_bs % 2 == 0;
+  const bool ps_ok = use_ps && acc_al && T % 2 == 0 && x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0 &&
                      ((size_t)(B - 1) * x_bs + (size_t)K * T) * 4 < ((size_t)1 << 32) &&
                      (size_t)M * K * 2 < ((size_t)1 << 32);
   if (ps_ok) {
@@ -1185,20 +1201,31 @@ int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, cons
   return air_conv1d_fwd_bf16_ex(p, x, w, bias, bias_bc, relu, y, nullptr, ws, ws_bytes, stream);
 }
 
-int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
-                          void* ws, size_t ws_bytes, air_stream_t stream) {
+int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
+                             size_t acc_bstride, const float* accumulate2, size_t acc2_bstride, void* ws,
+                             size_t ws_bytes, air_stream_t stream) {
   if ((!shape_ok(p) && !tap_ok(p)) || !dy || !w || !dx) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, 1)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
-  if (p->K == 3)
+  const bool plain = !accumulate2 && (acc_bstride == 0 || acc_bstride == xbs(p));
+  if (p->K == 3) {
+    if (!plain) return AIR_EUNSUPPORTED;
     return run_tap(dy, ybs(p), w, 1, dx, xbs(p), nullptr, accumulate, 0, p->B, p->Cout, p->Cin, p->T, p->dil, ws,
                    air_stream(stream));
+  }
   // A = W^T: w is (Cout, Cin) = [k][m]
-  if (wide(p->Cin, p->Cout) && p->Cout % 64 == 0)
+  if (wide(p->Cin, p->Cout) && p->Cout % 64 == 0) {
+    if (!plain) return AIR_EUNSUPPORTED;
     return run_fwd_gemm(dy, ybs(p), w, 1, dx, xbs(p), nullptr, nullptr, accumulate, 0, p->B, p->Cin, p->Cout, p->T, ws,
                         2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
+  }
   return run_fwd(dy, ybs(p), w, 1, dx, xbs(p), nullptr, nullptr, accumulate, 0, p->B, p->Cin, p->Cout, p->T, ws,
-                 2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream));
+                 2.0 * p->B * p->T * (double)p->Cout * p->Cin, air_stream(stream), acc_bstride, accumulate2, acc2_bstride);
+}
+
+int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
+                          void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_conv1d_dgrad_bf16_ex(p, dy, w, dx, accumulate, 0, nullptr, 0, ws, ws_bytes, stream);
 }
 
 namespace {

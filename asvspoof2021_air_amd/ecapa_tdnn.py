@@ -281,9 +281,10 @@ class Res2Net2(nn.Module):
         return feat, out, S
 
     # ----------------------------------------------------------------- backward
-    def _block_bwd(self, S, dout, G, pre, inp_bf=None):
-        """dout: gradient w.r.t. the block output (dense (B,C,T)).  Returns d(inp) dense.
-        inp_bf: bf16 copy of the block input when the caller holds one (a slice of the concat's copy)."""
+    def _block_bwd(self, S, dout, G, pre, inp_bf=None, add2=None):
+        """dout: gradient w.r.t. the block output ((B,C,T), dense or a channel slice).  Returns d(inp) (+ add2) dense.
+        inp_bf: bf16 copy of the block input when the caller holds one (a slice of the concat's copy).
+        add2: a second tensor to fold into the returned gradient (bf16 path: the same epilogue)."""
         blk = S["blk"]
         det = lambda p: p.detach()
         bf = self.compute_dtype == "bf16"
@@ -336,7 +337,7 @@ class Res2Net2(nn.Module):
         ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf, dy_bf=dy_bf,
                          x_bf=inp_bf)
         # + dout: the residual branch (ecapa_tdnn.py:93), added in the dgrad epilogue
-        return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf)
+        return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf, accumulate2=add2)
 
     def _backward_impl(self, S, dfeat, dout):
         arena = self.arena()
@@ -427,11 +428,19 @@ class Res2Net2(nn.Module):
         grads_final_from("layer4.weight")
         dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None
+        fold = bf and T % 2 == 0  # the two-operand dgrad epilogue (bf16 pointwise path, 8-byte aligned rows)
         for k in (2, 1, 0):
-            dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
-            ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
+            if fold:
+                # d(block k output) = its slice of the concat gradient + d(block k + 1 input): block k + 1's last
+                # dgrad already added this block's slice (add2), block 3 reads its slice in place
+                dblk = dcat123[:, k * C:(k + 1) * C] if dnext is None else dnext
+                add2 = dcat123[:, (k - 1) * C:k * C] if k > 0 else None
+            else:
+                dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
+                ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
+                add2 = None
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1),
-                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None)
+                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None, add2=add2)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),

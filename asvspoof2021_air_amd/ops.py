@@ -319,22 +319,26 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
     return y
 
 
-def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False):
-    """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out)."""
+def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False, accumulate2=None):
+    """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out).  bf16 pointwise path: accumulate may be a
+    channel-slice view and a second operand accumulate2 (view or dense) is added in the same epilogue."""
     Cout, Cin, K = w.shape
     B, _, T = dy.shape
     dx = out if out is not None else torch.empty((B, Cin, T), device=dy.device, dtype=torch.float32)
     xp, xb = vptr(dx)
     yp, yb = vptr(dy)
     d = AirConv1d(B, Cin, T, Cout, K, dil, pad, xb, yb)
-    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
+    acc, accb = vptr(accumulate) if accumulate is not None else (ctypes.c_void_p(0), 0)
     if bf16:
         wsb, nb = _c1d_bf16(d, dy.device, 1)
         if wsb is not None:
-            _hip.check(_hip.lib().air_conv1d_dgrad_bf16(ctypes.byref(d), yp, dptr(w), xp, acc,
-                                                        dptr(wsb, torch.uint8), csz(nb), stream()),
-                       "air_conv1d_dgrad_bf16")
+            acc2, acc2b = vptr(accumulate2) if accumulate2 is not None else (ctypes.c_void_p(0), 0)
+            _hip.check(_hip.lib().air_conv1d_dgrad_bf16_ex(ctypes.byref(d), yp, dptr(w), xp, acc, csz(accb), acc2,
+                                                           csz(acc2b), dptr(wsb, torch.uint8), csz(nb), stream()),
+                       "air_conv1d_dgrad_bf16_ex")
             return dx
+    if accumulate2 is not None or (accumulate is not None and accb != xb):
+        raise _hip.AirError("conv1d_dgrad: a second / strided accumulate operand needs the bf16 pointwise path")
     n = _hip.lib().air_conv1d_ws_bytes(ctypes.byref(d))
     ws = workspace(n, dy.device)
     _hip.check(_hip.lib().air_conv1d_dgrad(ctypes.byref(d), yp, dptr(w), xp, acc, dptr(ws, torch.uint8),

@@ -205,6 +205,13 @@ int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, c
                            size_t ws_bytes, air_stream_t stream);
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx,
                           const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+/* Same with up to two accumulate operands, each with its own batch stride in floats (0 = dx's): dx = dgrad +
+ * accumulate + accumulate2.  ECAPA's block input gradient = dgrad(conv1) + d(block output) [the residual,
+ * ecapa_tdnn.py:93] + the (B, 1536, T) concat gradient's slice for the previous block [:170] in one epilogue.
+ * AIR_EUNSUPPORTED for the K = 3 and the wide-layer paths when a second operand or a foreign stride is given. */
+int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, float* dx,
+                             const float* accumulate, size_t acc_bstride, const float* accumulate2,
+                             size_t acc2_bstride, void* ws, size_t ws_bytes, air_stream_t stream);
 int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
                           size_t ws_bytes, air_stream_t stream);
 /* The weight-gradient GEMM runs on bf16 copies of its operands, [b][channel][Tp] with
