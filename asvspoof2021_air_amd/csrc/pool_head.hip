@@ -208,33 +208,48 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
   }
 }
 
-// dx[m][k] = sum_n dy[m][n] w[n][k].  grid (ceil(K/256), ceil(M/8)): a thread owns one k for 8 rows
-// m, so every weight row is streamed once per 8 rows (coalesced along k); the 8 dy rows sit in LDS
-// and are read as broadcasts.  Per (m, k) the sum runs over n in ascending order.
+// dx[m][k] = sum_n dy[m][n] w[n][k]: a lane owns one k for 8 rows m, so every weight row is streamed once per
+// 8 rows (coalesced along k); the 8 dy rows sit in LDS and are read as broadcasts.
 constexpr int LIN_RB = 8;
+// grid (ceil(K / 64), ceil(M / 8)): lane = one k of 64, the workgroup's four waves split the sum over n into four
+// contiguous quarters (the SE layers have K = 128: a thread per k with the whole sum was 16 workgroups walking
+// 512 dependent loads each) and fold them through LDS in quarter order - still a fixed summation order.
 __global__ __launch_bounds__(NT) void linear_dx_kernel(const float* __restrict__ dy,
                                                        const float* __restrict__ w, int M, int K, int N,
                                                        float* __restrict__ dx) {
-  extern __shared__ __attribute__((aligned(16))) float ds[];  // [LIN_RB][N]
+  extern __shared__ __attribute__((aligned(16))) float ds[];  // [LIN_RB][N], then [4][LIN_RB][64] partial sums
+  __shared__ float part[4][LIN_RB][64];
   const int m0 = blockIdx.y * LIN_RB;
   for (int i = threadIdx.x; i < LIN_RB * N; i += NT) {
     const int r = i / N, n = i - r * N;
     ds[i] = m0 + r < M ? dy[(size_t)(m0 + r) * N + n] : 0.0f;
   }
   __syncthreads();
-  const int k = blockIdx.x * NT + threadIdx.x;
-  if (k >= K) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int nq = (N + 3) / 4, n_lo = wave * nq, n_hi = min(N, n_lo + nq);
   float s[LIN_RB];
 #pragma unroll
   for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
-  for (int n = 0; n < N; ++n) {
-    const float wv = w[(size_t)n * K + k];
+  if (k < K) {
+#pragma unroll 4
+    for (int n = n_lo; n < n_hi; ++n) {
+      const float wv = w[(size_t)n * K + k];
 #pragma unroll
-    for (int r = 0; r < LIN_RB; ++r) s[r] = fmaf(ds[r * N + n], wv, s[r]);
+      for (int r = 0; r < LIN_RB; ++r) s[r] = fmaf(ds[r * N + n], wv, s[r]);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < LIN_RB; ++r)
-    if (m0 + r < M) dx[(size_t)(m0 + r) * K + k] = s[r];
+  for (int r = 0; r < LIN_RB; ++r) part[wave][r][lane] = s[r];
+  __syncthreads();
+  // wave w finishes rows 2 w, 2 w + 1
+  if (k < K) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = wave * 2 + rr;
+      if (m0 + r < M) dx[(size_t)(m0 + r) * K + k] = ((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane];
+    }
+  }
 }
 
 // dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n].  grid (ceil(K/256), ceil(N/8)): a thread
@@ -399,7 +414,7 @@ int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K
   if ((size_t)N * LIN_RB * sizeof(float) > 64 * 1024 || (size_t)M * LIN_RB * sizeof(float) > 64 * 1024)
     return AIR_EUNSUPPORTED;
   if (dx != nullptr) {
-    hipLaunchKernelGGL(linear_dx_kernel, dim3((K + NT - 1) / NT, (M + LIN_RB - 1) / LIN_RB), dim3(NT),
+    hipLaunchKernelGGL(linear_dx_kernel, dim3((K + 63) / 64, (M + LIN_RB - 1) / LIN_RB), dim3(NT),
                        (size_t)N * LIN_RB * sizeof(float), air_stream(stream), dy, w, M, K, N, dx);
     AIR_CHECK_LAUNCH();
   }
