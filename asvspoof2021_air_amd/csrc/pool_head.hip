@@ -252,32 +252,45 @@ __global__ __launch_bounds__(NT) void linear_dx_kernel(const float* __restrict__
   }
 }
 
-// dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n].  grid (ceil(K/256), ceil(N/8)): a thread
-// owns one k for 8 outputs n, so x is streamed once per 8 outputs; sums run over m ascending.
+// dw[n][k] = sum_m dy[m][n] x[m][k]; db[n] = sum_m dy[m][n].  grid (ceil(K/64), ceil(N/8)): a lane
+// owns one k for 8 outputs n, so x is streamed once per 8 outputs.
 __global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__ x,
                                                        const float* __restrict__ dy, int M, int K,
                                                        int N, float* __restrict__ dw,
                                                        float* __restrict__ db) {
   extern __shared__ __attribute__((aligned(16))) float ds[];  // [M][LIN_RB]
+  __shared__ float part[4][LIN_RB][64];
   const int n0 = blockIdx.y * LIN_RB;
   for (int i = threadIdx.x; i < M * LIN_RB; i += NT) {
     const int m = i / LIN_RB, r = i - m * LIN_RB;
     ds[i] = n0 + r < N ? dy[(size_t)m * N + n0 + r] : 0.0f;
   }
   __syncthreads();
-  const int k = blockIdx.x * NT + threadIdx.x;
-  if (k < K) {
-    float s[LIN_RB];
+  // lane = one k of 64; the four waves take contiguous quarters of the rows m and fold in quarter order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int mq = (M + 3) / 4, m_lo = wave * mq, m_hi = min(M, m_lo + mq);
+  float s[LIN_RB];
 #pragma unroll
-    for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
-    for (int m = 0; m < M; ++m) {
+  for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
+  if (k < K) {
+#pragma unroll 4
+    for (int m = m_lo; m < m_hi; ++m) {
       const float xv = x[(size_t)m * K + k];
 #pragma unroll
       for (int r = 0; r < LIN_RB; ++r) s[r] = fmaf(ds[m * LIN_RB + r], xv, s[r]);
     }
+  }
 #pragma unroll
-    for (int r = 0; r < LIN_RB; ++r)
-      if (n0 + r < N) dw[(size_t)(n0 + r) * K + k] = s[r];
+  for (int r = 0; r < LIN_RB; ++r) part[wave][r][lane] = s[r];
+  __syncthreads();
+  if (k < K) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = wave * 2 + rr;
+      if (n0 + r < N)
+        dw[(size_t)(n0 + r) * K + k] = ((part[0][r][lane] + part[1][r][lane]) + part[2][r][lane]) + part[3][r][lane];
+    }
   }
   if (db != nullptr && blockIdx.x == 0 && threadIdx.x < LIN_RB && n0 + threadIdx.x < N) {
     float t = 0.0f;
@@ -286,13 +299,22 @@ __global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__
   }
 }
 
-// out[n] = sum_m x[m][n]  (e.g. per-utterance attention-vector partials -> gradient)
-__global__ void sum_rows_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// out[n] = sum_m x[m][n]  (e.g. per-utterance attention-vector partials -> gradient).  Lane = one n of 64; the
+// workgroup's four waves take contiguous quarters of the rows (eight loads in flight each) and fold their sums
+// in quarter order - a fixed summation order (a thread per column with the whole sum was M dependent loads).
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int mq = (M + 3) / 4, m_lo = wave * mq, m_hi = min(M, m_lo + mq);
   float s = 0.0f;
-  for (int m = 0; m < M; ++m) s += x[(size_t)m * N + n];
-  out[n] = s;
+  if (n < N) {
+#pragma unroll 8
+    for (int m = m_lo; m < m_hi; ++m) s += x[(size_t)m * N + n];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) out[n] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 // Philox4x32-10 counter-based generator -> N(0,1) via Box-Muller, scaled.
@@ -341,8 +363,7 @@ extern "C" {
 
 int air_sum_rows(const float* x, int M, int N, float* out, air_stream_t stream) {
   if (!x || !out || M <= 0 || N <= 0) return AIR_EINVAL;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, air_stream(stream), x,
-                     M, N, out);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((N + 63) / 64), dim3(256), 0, air_stream(stream), x, M, N, out);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -419,7 +440,7 @@ int air_linear_bwd(const float* x, const float* w, const float* dy, int M, int K
     AIR_CHECK_LAUNCH();
   }
   if (dw != nullptr) {
-    hipLaunchKernelGGL(linear_dw_kernel, dim3((K + NT - 1) / NT, (N + LIN_RB - 1) / LIN_RB), dim3(NT),
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((K + 63) / 64, (N + LIN_RB - 1) / LIN_RB), dim3(NT),
                        (size_t)M * LIN_RB * sizeof(float), air_stream(stream), x, dy, M, K, N, dw, db);
     AIR_CHECK_LAUNCH();
   }
