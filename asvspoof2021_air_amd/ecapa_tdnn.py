@@ -20,6 +20,8 @@ K=3 Res2 convs; tensors in HBM, BatchNorm, pooling and the K=3 weight gradients 
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -137,6 +139,10 @@ class Res2Net2(nn.Module):
         self._arena = None
         self.compute_dtype = "fp32"
         self._bucketer = None  # dist.GradBucketer when the all-reduce is overlapped with backward
+        # weight gradients on a side HIP stream (they feed nothing until the optimiser): the MFMA-bound GEMMs and the
+        # small K = 3 kernels overlap the HBM-bound BatchNorm / pooling backward passes of the main stream
+        self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
+        self._side_stream = None
 
     def enable_ddp_overlap(self, bucket_bytes=8 << 20):
         """Launch the gradient all-reduce from inside backward (one process per GPU, world size > 1):
@@ -151,6 +157,7 @@ class Res2Net2(nn.Module):
         st = dict(self.__dict__)
         st["_arena"] = None
         st["_bucketer"] = None
+        st["_side_stream"] = None
         return st
 
     def set_compute_dtype(self, dtype):
@@ -281,10 +288,13 @@ class Res2Net2(nn.Module):
         return feat, out, S
 
     # ----------------------------------------------------------------- backward
-    def _block_bwd(self, S, dout, G, pre, inp_bf=None, add2=None):
+    def _block_bwd(self, S, dout, G, pre, inp_bf=None, add2=None, on_side=None):
         """dout: gradient w.r.t. the block output ((B,C,T), dense or a channel slice).  Returns d(inp) (+ add2) dense.
         inp_bf: bf16 copy of the block input when the caller holds one (a slice of the concat's copy).
-        add2: a second tensor to fold into the returned gradient (bf16 path: the same epilogue)."""
+        add2: a second tensor to fold into the returned gradient (bf16 path: the same epilogue).
+        on_side(fn, *reads): runs a weight-gradient launch sequence (on the side stream when overlap is on)."""
+        if on_side is None:
+            on_side = lambda fn, *reads: fn()
         blk = S["blk"]
         det = lambda p: p.detach()
         bf = self.compute_dtype == "bf16"
@@ -308,11 +318,12 @@ class Res2Net2(nn.Module):
         st3 = S["st3"]
         # bf16 path: the BatchNorm backward writes the weight-gradient GEMM's dY operand itself (one buffer for
         # every 512-channel gradient of the model: same stream, so each copy is consumed before the next is made)
-        dy_bf = ops.bf16_rows("ecapa.dy", B, C, T, do3.device) if bf else None
+        dy_bf = ops.bf16_rows(pre + "dc3", B, C, T, do3.device) if bf else None
         dc3, _, _ = ops.bn_bwd(S["r3"], do3, st3[0], st3[1], det(blk.bn3.weight), det(blk.bn3.bias),
                                relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"),
                                rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"), dx_bf16=dy_bf)
-        ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf, dy_bf=dy_bf)
+        on_side(lambda: ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf,
+                                         dy_bf=dy_bf), dc3)
         dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight), bf16=bf)
         do1 = torch.empty_like(dcat)
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
@@ -326,16 +337,18 @@ class Res2Net2(nn.Module):
                        det(blk.bns[i].bias), relu_in=True, dx=dc_i, dy2=din_next,
                        dgamma=gv("bns.%d.weight" % i), dbeta=gv("bns.%d.bias" % i),
                        dbias=gv("convs.%d.bias" % i))
-            ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d, out=gv("convs.%d.weight" % i))
+            on_side(lambda dc_i=dc_i, i=i: ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d,
+                                                            out=gv("convs.%d.weight" % i)), dc_i)
             # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
             din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf)
             din_next = din if i > 0 else None
         st1 = S["st1"]
+        dy_bf = ops.bf16_rows(pre + "dc1", B, C, T, do3.device) if bf else None
         dc1, _, _ = ops.bn_bwd(S["r1"], do1, st1[0], st1[1], det(blk.bn1.weight), det(blk.bn1.bias),
                                relu_in=True, dx=do1, dgamma=gv("bn1.weight"), dbeta=gv("bn1.bias"),
                                dbias=gv("conv1.bias"), dx_bf16=dy_bf)
-        ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf, dy_bf=dy_bf,
-                         x_bf=inp_bf)
+        on_side(lambda: ops.conv1d_wgrad(S["inp"], dc1, blk.conv1.weight.shape, out=gv("conv1.weight"), bf16=bf,
+                                         dy_bf=dy_bf, x_bf=inp_bf), dc1)
         # + dout: the residual branch (ecapa_tdnn.py:93), added in the dgrad epilogue
         return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf, accumulate2=add2)
 
@@ -355,6 +368,27 @@ class Res2Net2(nn.Module):
         C = self.C
         tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")
         have_tail = dout is not None
+        # Weight gradients on the side stream (see __init__).  Ordering: a weight gradient starts after the event that
+        # marks its operands ready; tensors it reads are kept alive until the join (the caching allocator would hand
+        # their memory back to the main stream); every bf16 operand copy has its own buffer; the main stream joins
+        # the side stream before the gradients are used.
+        main = torch.cuda.current_stream()
+        use_side = self.overlap_wgrad and not accumulating
+        if use_side and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=main.device)
+        side = self._side_stream if use_side else main
+        keep = []
+
+        def on_side(fn, *reads):
+            if not use_side:
+                fn()
+                return
+            keep.extend(reads)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
         if dfeat is None:
             dfeat = torch.zeros_like(S["feat"])
         dfeat = dfeat.contiguous()
@@ -378,14 +412,13 @@ class Res2Net2(nn.Module):
         x4, wts = S["x4"], S["wts"]
         dx4 = torch.empty_like(x4)
         rows3 = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
-        # one (B, 1536, Tp) bf16 buffer serves d(logits) and, later, d(x4): each is consumed by its weight-gradient
-        # GEMM (same stream) before the next one is written
-        wide_bf = ops.bf16_rows("ecapa.dy1536", B, x4.shape[1], T, x4.device) if bf else None
+        wide_bf = ops.bf16_rows("ecapa.dlogits", B, x4.shape[1], T, x4.device) if bf else None
         ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False, rowsum=rows3,
                     dlogits_bf16=wide_bf)  # wts -> dlogits
         a0, a3 = self.attention[0], self.attention[3]
         ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
-        ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf, dy_bf=wide_bf)
+        on_side(lambda: ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf,
+                                         dy_bf=wide_bf), wts)
         da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
         stA = S["stA"]
         da1_bf = ops.bf16_rows("ecapa.da1", B, 128, T, x4.device) if bf else None
@@ -394,8 +427,12 @@ class Res2Net2(nn.Module):
                                dgamma=G["attention.2.weight"], dbeta=G["attention.2.bias"],
                                dbias=G["attention.0.bias"], dx_bf16=da1_bf)
         gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
-        dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf, dy_bf=da1_bf, x_bf=S["x4_bf"])
-        ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
+
+        def att0_wgrad():
+            dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf, dy_bf=da1_bf, x_bf=S["x4_bf"])
+            ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
+
+        on_side(att0_wgrad, da1)
         ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4, bf16=bf)
         dctxb = ops.row_sum(da1)  # (B,128)
         dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb, True, need_db=False)
@@ -405,23 +442,33 @@ class Res2Net2(nn.Module):
         # context-statistics gradient, the ReLU after layer4 (:173) and the per-row sums for the bias
         # gradient in ONE pass over the (B, 1536, T) tensor
         rows = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
+        dx4_bf = ops.bf16_rows("ecapa.dx4", B, x4.shape[1], T, x4.device) if bf else None
         ops.row_stats_bwd(x4, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows,
-                          dx_bf16=wide_bf)
+                          dx_bf16=dx4_bf)
         ops.sum_rows(rows, out=G["layer4.bias"])
         # the concat's bf16 copy is made once: layer4's weight gradient reads all of it, the conv1 weight gradients
         # of blocks 2 and 3 read the channel slices that were their inputs
-        cat_bf = ops.conv1d_cvt_bf16(S["cat123"], ops.bf16_rows("ecapa.cat123", B, 3 * C, T, dx4.device)) if bf else None
-        ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf, x_bf=cat_bf,
-                         dy_bf=wide_bf)
+        cat_bf = ops.bf16_rows("ecapa.cat123", B, 3 * C, T, dx4.device) if bf else None
+
+        def layer4_wgrad():
+            if bf:
+                ops.conv1d_cvt_bf16(S["cat123"], cat_bf)
+            ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf, x_bf=cat_bf,
+                             dy_bf=dx4_bf)
+
+        on_side(layer4_wgrad, dx4)
         # data parallel: everything from layer4.weight to the end of the gradient arena is final
         bucketer = None if accumulating else getattr(self, "_bucketer", None)
         offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
 
         def grads_final_from(first_param):
             if bucketer is not None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                bucketer.ready(offsets[first_param], [ev])
+                evs = [torch.cuda.Event()]
+                evs[0].record(main)
+                if use_side:
+                    evs.append(torch.cuda.Event())
+                    evs[1].record(side)
+                bucketer.ready(offsets[first_param], evs)
 
         if bucketer is not None:
             bucketer.reset(arena.grad, arena.head_total)
@@ -440,13 +487,17 @@ class Res2Net2(nn.Module):
                 ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
                 add2 = None
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1),
-                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None, add2=add2)
+                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None, add2=add2,
+                                    on_side=on_side)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),
                                relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"],
                                dbias=G["conv1.bias"])
         ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
+        if use_side:
+            main.wait_stream(side)  # join: every weight gradient is in the arena
+        del keep[:]
         arena.tail_has_grad = have_tail
         if accumulating:
             if not have_tail:  # the tail got no new gradient: its old sums must survive the add below unchanged
