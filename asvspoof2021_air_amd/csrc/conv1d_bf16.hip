@@ -458,6 +458,202 @@ __global__ __launch_bounds__(128 * WM + 128) void c1b_fwd_ps_kernel(const C1bFwd
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 (Cout) x 256 (frames) tile of the same contraction, for M % 256 == 0: 1.5 KB of L2 -> LDS traffic per k
+// for 131 kFLOP (85 FLOP per byte; the 256 x 128 tile above: 64), and the X tile is shared by two workgroups
+// per 512 output channels as before.  8 waves, each 128 x 64 = 4 x 2 MFMA tiles (128 accumulator registers,
+// two waves per SIMD, no producer waves: they would push the kernel to three waves per SIMD and 168
+// registers); every wave issues its 6 of the stage's 48 DMAs two stages ahead into a 3-deep ring (144 KB)
+// and waits with counted vmcnt.  Its epilogue stores would break that count (loads and stores retire out of
+// order with respect to each other), so the first wait of the next tile is vmcnt(0) - once per 16 stages.
+// The epilogue's transposition stage lives in the ring slot the tile's last stage just vacated.
+constexpr int F2_XB = BK * 256 * 4;  // 32 KB: X stage, fp32 [32 k][256 t]
+constexpr int F2_AB = 256 * BK * 2;  // 16 KB: A stage, bf16 [256 m][32 k]
+constexpr int F2_SB = F2_XB + F2_AB;
+constexpr int F2_LDS = FD_NS * F2_SB;
+
+__global__ __launch_bounds__(512) void c1b_fwd_ps2_kernel(const C1bFwd p) {
+  extern __shared__ __attribute__((aligned(16))) char fd_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x / NXCD;
+  const int w_lo = (blockIdx.x % NXCD) * p.per_xcd, first = w_lo + blockIdx.x / NXCD;
+  const int w_hi = w_lo + p.per_xcd < p.total ? w_lo + p.per_xcd : p.total;
+  if (first >= w_hi) return;
+  const int nmy = (w_hi - first + nwg - 1) / nwg;
+  const int nk = p.K / BK;
+  const int G = nmy * nk;
+
+  auto tile_of = [&](int work) {
+    FdTile t;
+    const int mt = work % p.tiles_m, rest = work / p.tiles_m;
+    t.m0 = mt * 256;
+    t.t0 = (rest % p.tiles_t) * 256;
+    t.b = rest / p.tiles_t;
+    return t;
+  };
+
+  // DMA roles: wave w stages X rows 4 w .. 4 w + 3 (one 1 KB row per instruction) and 2 KB of the A block
+  const i32x4 xrs = fd_rsrc(p.x, (unsigned)(((size_t)(p.B - 1) * p.x_bs + (size_t)p.K * p.T) * 4u));
+  const i32x4 ars = fd_rsrc(p.a, (unsigned)p.M * p.K * 2u);
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)fd_lds;
+  const unsigned lv = lane * 16u;
+  const unsigned xrow = (unsigned)p.T * 4u;
+  int it_i = 0, is = 0, islot = 0;
+  FdTile ti = tile_of(first);
+  auto issue = [&]() {
+    const unsigned base = lds0 + islot * F2_SB;
+    const unsigned xo = __builtin_amdgcn_readfirstlane(
+        (unsigned)(((size_t)ti.b * p.x_bs + ti.t0) * 4u) + (unsigned)(is * BK + 4 * wave) * xrow);
+    const unsigned ao = __builtin_amdgcn_readfirstlane(((unsigned)is * p.M + ti.m0) * (BK * 2u) + wave * 2048u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fd_dma16(xrs, xo + q * xrow, base + (4 * wave + q) * 1024, lv);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fd_dma16(ars, ao + q * 1024, base + F2_XB + wave * 2048 + q * 1024, lv);
+    islot = islot + 1 == FD_NS ? 0 : islot + 1;
+    if (++is == nk) {
+      is = 0;
+      ++it_i;
+      if (it_i < nmy) ti = tile_of(first + it_i * nwg);
+    }
+  };
+
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r = lane & 31, kg = lane >> 5;
+  const int asw = (r >> 2) & 3;
+  unsigned ao4[4], bo2[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ao4[i] = F2_XB + (wm * 128 + i * 32 + r) * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bo2[j] = (kg * 8) * 1024 + (wn * 64 + j * 32 + r) * 4;
+
+  f32x16 acc[4][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  };
+  zero();
+  issue();
+  if (G > 1) issue();
+  int slot = 0, g = 0;
+  for (int it = 0; it < nmy; ++it) {
+    const FdTile tl = tile_of(first + it * nwg);
+    const int b = tl.b, m0 = tl.m0, t0 = tl.t0;
+    for (int ks = 0; ks < nk; ++ks, ++g) {
+      if (g + 1 < G && !(ks == 0 && it > 0)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (g + 2 < G) issue();
+      const char* st = fd_lds + slot * F2_SB;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          fa[i] = *reinterpret_cast<const bf16x8*>(st + ao4[i] + (((kk * 2 + kg) ^ asw) * 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float* col = reinterpret_cast<const float*>(st + bo2[j] + kk * 16 * 1024);
+          uint4 v;
+          v.x = pack2(col[0 * 256], col[1 * 256]);
+          v.y = pack2(col[2 * 256], col[3 * 256]);
+          v.z = pack2(col[4 * 256], col[5 * 256]);
+          v.w = pack2(col[6 * 256], col[7 * 256]);
+          fb[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (ks + 1 < nk) slot = slot + 1 == FD_NS ? 0 : slot + 1;
+    }
+    // epilogue through the slot the last stage just vacated (nothing is issued into it before the next
+    // iteration's barrier): 16 rows x 64 frames per wave and pass, 16-byte stores
+    __syncthreads();
+    float* tile = reinterpret_cast<float*>(fd_lds + slot * F2_SB) + wave * (16 * 64);
+    slot = slot + 1 == FD_NS ? 0 : slot + 1;
+    float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
+    const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.acc_bs : nullptr;
+    const float* __restrict__ ab2 = p.acc2 ? p.acc2 + (size_t)b * p.acc2_bs : nullptr;
+    const int c4 = (lane & 15) * 4, lrow = lane >> 4;
+    const int t = t0 + wn * 64 + c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int rr = hp * 8 + e;
+          const int row = (rr & 3) + 8 * ((rr >> 2) - hp * 2) + 4 * kg;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) tile[row * 64 + j * 32 + r] = acc[i][j][rr];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = lrow + 4 * q;
+          const int m = m0 + wm * 128 + i * 32 + hp * 16 + row;
+          float4 v = *reinterpret_cast<const float4*>(&tile[row * 64 + c4]);
+          float add = 0.0f;
+          if (p.bias) add += p.bias[m];
+          if (p.bias_bc) add += p.bias_bc[(size_t)b * p.M + m];
+          const size_t o = (size_t)m * p.T + t;
+          if (t + 3 < p.T) {
+            if (ab) {
+              const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab + o);
+              v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
+            }
+            if (ab2) {
+              const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab2 + o);
+              v.x += u[0]; v.y += u[1]; v.z += u[2]; v.w += u[3];
+            }
+            f32x4a8 out = {v.x + add, v.y + add, v.z + add, v.w + add};
+            if (p.relu) {
+#pragma unroll
+              for (int k4 = 0; k4 < 4; ++k4) out[k4] = fmaxf(out[k4], 0.0f);
+            }
+            *reinterpret_cast<f32x4a8*>(yb + o) = out;
+          } else if (t + 1 < p.T) {  // T is even: a row's last piece holds 4 or 2 frames
+            if (ab) {
+              const f32x2 u = *reinterpret_cast<const f32x2*>(ab + o);
+              v.x += u[0]; v.y += u[1];
+            }
+            if (ab2) {
+              const f32x2 u = *reinterpret_cast<const f32x2*>(ab2 + o);
+              v.x += u[0]; v.y += u[1];
+            }
+            f32x2 out = {v.x + add, v.y + add};
+            if (p.relu) {
+              out[0] = fmaxf(out[0], 0.0f);
+              out[1] = fmaxf(out[1], 0.0f);
+            }
+            *reinterpret_cast<f32x2*>(yb + o) = out;
+          }
+        }
+      }
+    }
+    zero();
+  }
+}
+
+int fd_launch2(C1bFwd& p, hipStream_t st) {
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_fwd_ps2_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, F2_LDS) == hipSuccess;
+  if (!attr_ok) return AIR_ELAUNCH;
+  p.tiles_m = p.M / 256;
+  p.tiles_t = (p.T + 255) / 256;
+  p.total = p.B * p.tiles_t * p.tiles_m;
+  p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  hipLaunchKernelGGL(c1b_fwd_ps2_kernel, dim3(256), dim3(512), F2_LDS, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 template <int WM>
 int fd_launch(C1bFwd& p, hipStream_t st) {
   constexpr int lds = FD_NS * (FD_XB + 64 * WM * BK * 2) + 2 * WM * (WM == 4 ? 16 : 8) * 256;
@@ -1043,7 +1239,7 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
-  static const int use_ps = getenv("AIR_C1B_PS") ? atoi(getenv("AIR_C1B_PS")) : 3;
+  static const int use_ps = getenv("AIR_C1B_PS") ? atoi(getenv("AIR_C1B_PS")) : 7;
   // the DMA moves 16-byte chunks: frame rows have to start on 8-byte boundaries (even T and strides),
   // and every byte offset has to fit the descriptor's 32 bits
   const bool acc_al = ((reinterpret_cast<size_t>(acc) | reinterpret_cast<size_t>(acc2)) & 7) == 0 && p.acc_bs % 2 == 0 &&
@@ -1057,6 +1253,7 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
                        reinterpret_cast<uint4*>(a), M, K, transpose);
     AIR_CHECK_LAUNCH();
     AirProfScope prof(AIR_K_C1B_FWD, flops, st);
+    if (M % 256 == 0 && (use_ps & 4)) return fd_launch2(p, st);
     return (M % 256 == 0 && (use_ps & 2)) ? fd_launch<4>(p, st) : fd_launch<2>(p, st);
   }
   const size_t n2 = (size_t)M * K / 2;
