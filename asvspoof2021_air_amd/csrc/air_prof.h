@@ -18,8 +18,8 @@ enum AirKernelId {
   AIR_K_LFCC,              // lfcc_kernel
   AIR_K_CONV_WINO,         // wino_conv_kernel: 3x3 s1 forward and dgrad, Winograd F(2x2,3x3)
   AIR_K_CONV_WINO_WG,      // wino_wgrad_kernel: 3x3 s1 weight gradient, Winograd F(3x3,2x2)
-  AIR_K_C1B_FWD,           // c1b_fwd_kernel: fused bf16 pointwise conv1d forward / dgrad (ECAPA 512-channel layers)
-  AIR_K_C1B_GEMM,          // c1b_gemm_kernel: LDS-DMA bf16 GEMM (ECAPA layer4 forward / dgrad, every pointwise wgrad)
+  AIR_K_C1B_FWD,           // c1b_fwd_kernel / c1b_fwd_ps_kernel<WM> / c1b_fwd_ps2_kernel: bf16 pointwise conv1d forward / dgrad on fp32 tensors
+  AIR_K_C1B_GEMM,          // c1b_gemm_kernel / c1b_gemm_ps_kernel: LDS-DMA bf16 GEMM (ECAPA layer4 forward / dgrad, every pointwise wgrad)
   AIR_K_C1B_TAP,           // c1b_tap_kernel: bf16 dilated K=3 Res2 convs, forward / dgrad (ECAPA)
   AIR_K_CONV_WINO4,        // wino4_conv_kernel: 3x3 s1 forward and dgrad, Winograd F(4x4,3x3)
   AIR_K_COUNT

@@ -38,8 +38,11 @@ for model in ("resnet", "ecapa"):
 # key: inside out[model] they would be summed a second time by anyone adding up the per-kernel rows
 fam = {}
 for model in out:
-    for base in ("wino4_conv_kernel", "wino_conv_kernel", "wino_wgrad_kernel", "c1b_gemm_kernel", "c1b_fwd_kernel"):
-        ks = [k for k in out[model] if k.startswith(base)]
+    # family (= the profiling id's name, csrc/air_prof.h) -> kernel-name prefix of its template instances / variants
+    for base, prefix in (("wino4_conv_kernel", "wino4_conv_kernel"), ("wino_conv_kernel", "wino_conv_kernel"),
+                         ("wino_wgrad_kernel", "wino_wgrad_kernel"), ("c1b_gemm_kernel", "c1b_gemm"),
+                         ("c1b_fwd_kernel", "c1b_fwd")):
+        ks = [k for k in out[model] if k.startswith(prefix)]
         n = sum(out[model][k]["launches"] for k in ks)
         if n:
             fam.setdefault(model, {})[base] = {"launches": n, "traffic_bytes_per_launch": sum(
