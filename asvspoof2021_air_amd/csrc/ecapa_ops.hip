@@ -98,7 +98,10 @@ __global__ __launch_bounds__(NT) void channel_sum_final_kernel(const double* __r
 }
 
 // per (b,c) row over T: mean and std = sqrt(clamp(unbiased var, 1e-4)) (ecapa_tdnn.py:178);
-// one wave per row.  std may be null (SE squeeze only needs the mean, ecapa_tdnn.py:19).
+// one wave per row.  std may be null (SE squeeze only needs the mean, ecapa_tdnn.py:19).  Rows of up to
+// 64 * ROW_R frames (the reference's 750 fits) stay in registers between the mean and the variance pass: the
+// (B, 1536, T) context tensor is read once, not twice (0.28 -> 0.13 ms).
+constexpr int ROW_R = 16;
 __global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__ x, size_t rows,
                                                        int T, float* __restrict__ mean,
                                                        float* __restrict__ std_, float clamp_min) {
@@ -106,6 +109,33 @@ __global__ __launch_bounds__(NT) void row_stats_kernel(const float* __restrict__
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* __restrict__ p = x + row * T;
+  if (std_ != nullptr && T <= 64 * ROW_R) {
+    float v[ROW_R];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ROW_R; ++k) {
+      const int t = lane + 64 * k;
+      v[k] = t < T ? p[t] : 0.0f;
+    }
+    // same order of additions per lane as the loop below: t = lane, lane + 64, ...
+#pragma unroll
+    for (int k = 0; k < ROW_R; ++k)
+      if (lane + 64 * k < T) s += v[k];
+    const float m = air_wave_sum(s) / (float)T;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ROW_R; ++k)
+      if (lane + 64 * k < T) {
+        const float d = v[k] - m;
+        q = fmaf(d, d, q);
+      }
+    q = air_wave_sum(q) / (float)(T - 1);
+    if (lane == 0) {
+      mean[row] = m;
+      std_[row] = sqrtf(fmaxf(q, clamp_min));
+    }
+    return;
+  }
   float s = 0.0f;
   for (int t = lane; t < T; t += 64) s += p[t];
   const float m = air_wave_sum(s) / (float)T;
