@@ -734,24 +734,51 @@ __global__ __launch_bounds__(256) void c1b_cvt_s_kernel(const float* __restrict_
   }
 }
 
-// X (B, C, T) fp32 -> Xt bf16 [B][Tp][C] (channels contiguous), zeros for t >= T.  A thread reads 16
-// channel rows at ITS frame (coalesced along t) and writes 32 contiguous bytes of the transposed row.
-// grid (Tp / 64, C / 64, B), 256 threads = 64 frames x 4 channel groups of 16.
+// X (B, C, T) fp32 -> Xt bf16 [B][Tp][C] (channels contiguous), zeros for t >= T, through an LDS transposition so
+// that BOTH sides move full lines: a workgroup owns 64 channels x 64 frames; reads are 16 bytes per lane along t
+// (a wave: 4 channel rows x 256 B), the rounded values go to LDS as [t][c] bf16 (rows padded to 132 bytes), and
+// each lane writes 32 contiguous bytes of a transposed row - 4 lanes cover the tile's 128-byte row piece, a wave
+// 16 rows.  (Round 1's version wrote 32-byte pieces straight from registers: four partial requests per line.)
+// grid (Tp / 64, C / 64, B), 256 threads.
 __global__ __launch_bounds__(256) void c1b_cvt_t_kernel(const float* __restrict__ x, size_t xbs, int C, int T, int Tp,
-                                                        unsigned short* __restrict__ out) {
-  const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int c0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+                                                        int vec_ok, unsigned short* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 66];  // [t][c], 66 elements per row
+  const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const size_t b = blockIdx.z;
-  const float* __restrict__ src = x + b * xbs + (size_t)c0 * T + t;
-  float v[16];
+  const int tid = threadIdx.x;
+  {
+    const int q = tid & 15, cr = tid >> 4;  // quad of frames, channel row (+ 16 j)
+    const int t = t0 + 4 * q;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = t < T ? src[(size_t)i * T] : 0.0f;
-  uint4 o0, o1;
-  o0.x = pack2(v[0], v[1]); o0.y = pack2(v[2], v[3]); o0.z = pack2(v[4], v[5]); o0.w = pack2(v[6], v[7]);
-  o1.x = pack2(v[8], v[9]); o1.y = pack2(v[10], v[11]); o1.z = pack2(v[12], v[13]); o1.w = pack2(v[14], v[15]);
-  uint4* dst = reinterpret_cast<uint4*>(out + (b * Tp + t) * (size_t)C + c0);
-  dst[0] = o0;
-  dst[1] = o1;
+    for (int j = 0; j < 4; ++j) {
+      const int c = cr + 16 * j;
+      const float* __restrict__ src = x + b * xbs + (size_t)(c0 + c) * T + t;
+      float v[4];
+      if (vec_ok && t + 3 < T) {
+        const f32x4a8 w = *reinterpret_cast<const f32x4a8*>(src);
+        v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t + e < T ? src[e] : 0.0f;
+      }
+      const unsigned p01 = pack2(v[0], v[1]), p23 = pack2(v[2], v[3]);
+      tile[(4 * q + 0) * 66 + c] = (unsigned short)(p01 & 0xffffu);
+      tile[(4 * q + 1) * 66 + c] = (unsigned short)(p01 >> 16);
+      tile[(4 * q + 2) * 66 + c] = (unsigned short)(p23 & 0xffffu);
+      tile[(4 * q + 3) * 66 + c] = (unsigned short)(p23 >> 16);
+    }
+  }
+  __syncthreads();
+  {
+    const int tr = tid >> 2, cq = (tid & 3) * 16;  // frame row, 16-channel piece
+    const unsigned* __restrict__ row = reinterpret_cast<const unsigned*>(&tile[tr * 66 + cq]);
+    uint4 o0, o1;
+    o0.x = row[0]; o0.y = row[1]; o0.z = row[2]; o0.w = row[3];
+    o1.x = row[4]; o1.y = row[5]; o1.z = row[6]; o1.w = row[7];
+    uint4* dst = reinterpret_cast<uint4*>(out + (b * Tp + t0 + tr) * (size_t)C + c0 + cq);
+    dst[0] = o0;
+    dst[1] = o1;
+  }
 }
 
 struct NtGemm {
@@ -1318,7 +1345,8 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   const size_t n2 = (size_t)M * K / 2;
   hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, transpose);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(c1b_cvt_t_kernel, dim3(Tp / 64, K / 64, B), dim3(256), 0, st, x, x_bs, K, T, Tp, xt);
+  const int vec_t = T % 2 == 0 && x_bs % 2 == 0 && (reinterpret_cast<size_t>(x) & 7) == 0;
+  hipLaunchKernelGGL(c1b_cvt_t_kernel, dim3(Tp / 64, K / 64, B), dim3(256), 0, st, x, x_bs, K, T, Tp, vec_t, xt);
   AIR_CHECK_LAUNCH();
   NtGemm g;
   g.a = a; g.b = xt; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = acc;
