@@ -1084,10 +1084,13 @@ struct C1bTap {
 
 // fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
 // transpose = 1: m = ci, k = co, taps flipped (dgrad: dx[t] = sum_k w[..][2 - k'] dy[t + (k' - 1) d]).
+// blockIdx.y = layer of a batch of equally shaped convs (w_stride floats / 3 M K packed elements apart)
 __global__ __launch_bounds__(256) void c1b_pack3_kernel(const float* __restrict__ w, unsigned short* __restrict__ a,
-                                                        int Cout, int Cin, int transpose) {
+                                                        int Cout, int Cin, int transpose, size_t w_stride) {
   const int M = transpose ? Cin : Cout, K = transpose ? Cout : Cin;
   const size_t n = (size_t)3 * M * K;
+  w += (size_t)blockIdx.y * w_stride;
+  a += (size_t)blockIdx.y * n;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int k = (int)(e % K);
     const int m = (int)((e / K) % M);
@@ -1211,12 +1214,18 @@ bool tap_ok(const AirConv1d* p) {
 }
 
 int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y, size_t y_bs, const float* bias,
-            const float* acc, int relu, int B, int Cout, int Cin, int T, int dil, void* ws, hipStream_t st) {
+            const float* acc, int relu, int B, int Cout, int Cin, int T, int dil, void* ws, hipStream_t st,
+            const unsigned short* w_packed = nullptr) {
   const int M = transpose ? Cin : Cout, K = transpose ? Cout : Cin;
-  unsigned short* a = reinterpret_cast<unsigned short*>(ws);
-  const size_t n = (size_t)3 * M * K;
-  hipLaunchKernelGGL(c1b_pack3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, a, Cout, Cin, transpose);
-  AIR_CHECK_LAUNCH();
+  const unsigned short* a = w_packed;
+  if (a == nullptr) {
+    unsigned short* pa = reinterpret_cast<unsigned short*>(ws);
+    const size_t n = (size_t)3 * M * K;
+    hipLaunchKernelGGL(c1b_pack3_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, w, pa, Cout, Cin,
+                       transpose, (size_t)0);
+    AIR_CHECK_LAUNCH();
+    a = pa;
+  }
   C1bTap p;
   p.x = x; p.a = a; p.y = y; p.bias = bias; p.acc = acc; p.x_bs = x_bs; p.y_bs = y_bs;
   p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu;
@@ -1396,9 +1405,11 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
   return n + 256;
 }
 
-int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
-                           int relu, float* y, unsigned short* y_bf16, void* ws, size_t ws_bytes, air_stream_t stream) {
-  if ((!shape_ok(p) && !tap_ok(p)) || !x || !w || !y) return AIR_EINVAL;
+int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const unsigned short* w_packed,
+                           const float* bias, const float* bias_bc, int relu, float* y, unsigned short* y_bf16, void* ws,
+                           size_t ws_bytes, air_stream_t stream) {
+  if ((!shape_ok(p) && !tap_ok(p)) || !x || (!w && !(w_packed && p->K == 3)) || !y) return AIR_EINVAL;
+  if (w_packed && p->K != 3) return AIR_EUNSUPPORTED;
   if (!air_conv1d_bf16_supported(p, 0)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
@@ -1406,7 +1417,7 @@ int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, c
   bool bf_done = false;
   if (p->K == 3) {
     if (bias_bc) return AIR_EUNSUPPORTED;
-    rc = run_tap(x, xbs(p), w, 0, y, ybs(p), bias, nullptr, relu, p->B, p->Cout, p->Cin, p->T, p->dil, ws, st);
+    rc = run_tap(x, xbs(p), w, 0, y, ybs(p), bias, nullptr, relu, p->B, p->Cout, p->Cin, p->T, p->dil, ws, st, w_packed);
   } else if (wide(p->Cout, p->Cin) && p->Cin % 64 == 0) {
     rc = run_fwd_gemm(x, xbs(p), w, 0, y, ybs(p), bias, bias_bc, nullptr, relu, p->B, p->Cout, p->Cin, p->T, ws,
                       2.0 * p->B * p->T * (double)p->Cout * p->Cin, st, y_bf16, &bf_done);
@@ -1423,20 +1434,21 @@ int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, c
 
 int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, const float* bias, const float* bias_bc,
                         int relu, float* y, void* ws, size_t ws_bytes, air_stream_t stream) {
-  return air_conv1d_fwd_bf16_ex(p, x, w, bias, bias_bc, relu, y, nullptr, ws, ws_bytes, stream);
+  return air_conv1d_fwd_bf16_ex(p, x, w, nullptr, bias, bias_bc, relu, y, nullptr, ws, ws_bytes, stream);
 }
 
-int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
-                             size_t acc_bstride, const float* accumulate2, size_t acc2_bstride, void* ws,
-                             size_t ws_bytes, air_stream_t stream) {
-  if ((!shape_ok(p) && !tap_ok(p)) || !dy || !w || !dx) return AIR_EINVAL;
+int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, const unsigned short* w_packed,
+                             float* dx, const float* accumulate, size_t acc_bstride, const float* accumulate2,
+                             size_t acc2_bstride, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if ((!shape_ok(p) && !tap_ok(p)) || !dy || (!w && !(w_packed && p->K == 3)) || !dx) return AIR_EINVAL;
+  if (w_packed && p->K != 3) return AIR_EUNSUPPORTED;
   if (!air_conv1d_bf16_supported(p, 1)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
   const bool plain = !accumulate2 && (acc_bstride == 0 || acc_bstride == xbs(p));
   if (p->K == 3) {
     if (!plain) return AIR_EUNSUPPORTED;
     return run_tap(dy, ybs(p), w, 1, dx, xbs(p), nullptr, accumulate, 0, p->B, p->Cout, p->Cin, p->T, p->dil, ws,
-                   air_stream(stream));
+                   air_stream(stream), w_packed);
   }
   // A = W^T: w is (Cout, Cin) = [k][m]
   if (wide(p->Cin, p->Cout) && p->Cout % 64 == 0) {
@@ -1450,7 +1462,7 @@ int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w
 
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx, const float* accumulate,
                           void* ws, size_t ws_bytes, air_stream_t stream) {
-  return air_conv1d_dgrad_bf16_ex(p, dy, w, dx, accumulate, 0, nullptr, 0, ws, ws_bytes, stream);
+  return air_conv1d_dgrad_bf16_ex(p, dy, w, nullptr, dx, accumulate, 0, nullptr, 0, ws, ws_bytes, stream);
 }
 
 namespace {
@@ -1465,6 +1477,18 @@ int launch_cvt_s(const float* x, size_t x_bs, int B, int C, int T, unsigned shor
 }  // namespace
 
 int air_conv1d_bf16_tp(int T) { return T > 0 ? round_up(T, TP_ALIGN) : 0; }
+
+size_t air_conv1d_tap_pack_elems(int Cout, int Cin) { return (size_t)3 * Cout * Cin; }
+
+int air_conv1d_tap_pack_bf16(const float* w, size_t w_stride, int n_layers, int Cout, int Cin, int transpose,
+                             unsigned short* out, air_stream_t stream) {
+  if (!w || !out || n_layers <= 0 || Cout <= 0 || Cin <= 0) return AIR_EINVAL;
+  const size_t n = (size_t)3 * Cout * Cin;
+  hipLaunchKernelGGL(c1b_pack3_kernel, dim3((unsigned)((n + 255) / 256), n_layers), dim3(256), 0, air_stream(stream), w, out,
+                     Cout, Cin, transpose, w_stride);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
 
 int air_conv1d_cvt_bf16(const float* x, size_t x_bstride, int B, int C, int T, unsigned short* out, air_stream_t stream) {
   if (!x || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;

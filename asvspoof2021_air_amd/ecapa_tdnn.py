@@ -201,9 +201,11 @@ class Res2Net2(nn.Module):
         cat = torch.empty_like(o1)
         t_list, r_list, st_list = [], [], []
         t_i = o1[:, :w]
+        # bf16: the seven branch weights (a regular stride apart in the parameter arena) are packed in one launch
+        wp = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=False) if bf else None
         for i in range(nums):
             r_i = ops.conv1d_fwd(t_i, det(blk.convs[i].weight), det(blk.convs[i].bias), relu=True,
-                                 dil=d, pad=d, bf16=bf)
+                                 dil=d, pad=d, bf16=bf, w_packed=wp[i] if wp is not None else None)
             st_i = _bn(r_i, blk.bns[i], training)
             # BN-apply, store into the concat slice and form the next branch's input in one pass
             if i + 1 < nums:
@@ -328,6 +330,7 @@ class Res2Net2(nn.Module):
         do1 = torch.empty_like(dcat)
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])
         din_next = None
+        wpt = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=True) if bf else None
         for i in reversed(range(nums)):
             # d(sp_i) = d(cat slice i) + d(input of branch i + 1): both are channel-slice views and the sum is
             # formed inside the BatchNorm backward passes
@@ -340,7 +343,8 @@ class Res2Net2(nn.Module):
             on_side(lambda dc_i=dc_i, i=i: ops.conv1d_wgrad(S["t"][i], dc_i, blk.convs[i].weight.shape, d, d,
                                                             out=gv("convs.%d.weight" % i)), dc_i)
             # the input gradient lands in its slice of d(o1); branch i - 1 reads it from there
-            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf)
+            din = ops.conv1d_dgrad(dc_i, det(blk.convs[i].weight), d, d, out=do1[:, i * w:(i + 1) * w], bf16=bf,
+                                   w_packed=wpt[i] if wpt is not None else None)
             din_next = din if i > 0 else None
         st1 = S["st1"]
         dy_bf = ops.bf16_rows(pre + "dc1", B, C, T, do3.device) if bf else None

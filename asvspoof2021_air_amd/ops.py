@@ -294,7 +294,30 @@ def _c1d_bf16(d, device, which):
     return workspace(n, device), n
 
 
-def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None, bf16=False, y_bf=None):
+def conv1d_tap_pack(weights, transpose, out=None):
+    """bf16 operand blocks of a list of equally shaped K = 3 conv weights that sit at a regular stride in memory
+    (the Res2 branch convs inside the parameter arena), packed in one launch.  Returns an (n, 3*Cout*Cin) int16
+    tensor whose rows are the w_packed arguments of conv1d_fwd / conv1d_dgrad, or None if the layout is irregular."""
+    w0 = weights[0]
+    n = len(weights)
+    stride = (weights[1].data_ptr() - w0.data_ptr()) // 4 if n > 1 else 0
+    for i, w in enumerate(weights):
+        if w.shape != w0.shape or not w.is_contiguous() or w.data_ptr() != w0.data_ptr() + 4 * stride * i:
+            return None
+    Cout, Cin, K = w0.shape
+    if K != 3 or (n > 1 and stride <= 0):
+        return None
+    per = Cout * Cin * 3
+    if out is None:
+        out = torch.empty((n, per), device=w0.device, dtype=torch.int16)
+    _hip.check(_hip.lib().air_conv1d_tap_pack_bf16(dptr(w0), csz(stride), ci(n), ci(Cout), ci(Cin),
+                                                   ci(1 if transpose else 0), dptr(out, torch.int16), stream()),
+               "air_conv1d_tap_pack_bf16")
+    return out
+
+
+def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None, bf16=False, y_bf=None,
+               w_packed=None):
     """y = relu?(conv1d(x, w) + bias + bias_bc[b]); x / out may be channel-slice views.
     bf16: pointwise layers run on the bf16 matrix cores (operands rounded, fp32 accumulate); y_bf (bf16_rows
     buffer, bf16 path only) also receives y rounded to bf16 - the X operand of a later conv1d_wgrad."""
@@ -306,7 +329,8 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
         wsb, nb = _c1d_bf16(d, x.device, 0)
         if wsb is not None:
             _hip.check(_hip.lib().air_conv1d_fwd_bf16_ex(
-                ctypes.byref(d), vptr(x)[0], dptr(w), dptr(bias, allow_none=True),
+                ctypes.byref(d), vptr(x)[0], dptr(w), dptr(w_packed, torch.int16, allow_none=True),
+                dptr(bias, allow_none=True),
                 dptr(bias_bc, allow_none=True), ci(1 if relu else 0), vptr(y)[0],
                 dptr(y_bf, torch.int16, allow_none=True),
                 dptr(wsb, torch.uint8), csz(nb), stream()), "air_conv1d_fwd_bf16_ex")
@@ -319,7 +343,7 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
     return y
 
 
-def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False, accumulate2=None):
+def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False, accumulate2=None, w_packed=None):
     """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out).  bf16 pointwise path: accumulate may be a
     channel-slice view and a second operand accumulate2 (view or dense) is added in the same epilogue."""
     Cout, Cin, K = w.shape
@@ -333,7 +357,9 @@ def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False, acc
         wsb, nb = _c1d_bf16(d, dy.device, 1)
         if wsb is not None:
             acc2, acc2b = vptr(accumulate2) if accumulate2 is not None else (ctypes.c_void_p(0), 0)
-            _hip.check(_hip.lib().air_conv1d_dgrad_bf16_ex(ctypes.byref(d), yp, dptr(w), xp, acc, csz(accb), acc2,
+            _hip.check(_hip.lib().air_conv1d_dgrad_bf16_ex(ctypes.byref(d), yp, dptr(w),
+                                                           dptr(w_packed, torch.int16, allow_none=True), xp, acc,
+                                                           csz(accb), acc2,
                                                            csz(acc2b), dptr(wsb, torch.uint8), csz(nb), stream()),
                        "air_conv1d_dgrad_bf16_ex")
             return dx

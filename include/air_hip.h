@@ -200,17 +200,25 @@ int air_conv1d_fwd_bf16(const AirConv1d* p, const float* x, const float* w, cons
 /* Same, and y is also written as bf16 (nearest even) into y_bf16[(b*Cout + c) * air_conv1d_bf16_tp(T) + t], the
  * operand layout of air_conv1d_wgrad_bf16_pre (from the GEMM's epilogue for the wide layers, by a conversion
  * pass otherwise); NULL = air_conv1d_fwd_bf16. */
-int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const float* bias,
-                           const float* bias_bc, int relu, float* y, unsigned short* y_bf16, void* ws,
-                           size_t ws_bytes, air_stream_t stream);
+int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const unsigned short* w_packed,
+                           const float* bias, const float* bias_bc, int relu, float* y, unsigned short* y_bf16,
+                           void* ws, size_t ws_bytes, air_stream_t stream);
+/* K = 3 layers: the kernels read the weights as bf16 [tap][m][k] (dgrad: transposed, taps flipped).  The
+ * _bf16 entry points pack them on every call; air_conv1d_tap_pack_bf16 packs n_layers equally shaped layers
+ * (weights w_stride floats apart, e.g. the seven Res2 branch convs of a Bottle2neck inside the parameter arena)
+ * in ONE launch, layer i at out + i * air_conv1d_tap_pack_elems(Cout, Cin); pass that block as w_packed (w may
+ * then be NULL).  w_packed must be NULL for K = 1 layers. */
+size_t air_conv1d_tap_pack_elems(int Cout, int Cin);
+int air_conv1d_tap_pack_bf16(const float* w, size_t w_stride, int n_layers, int Cout, int Cin, int transpose,
+                             unsigned short* out, air_stream_t stream);
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx,
                           const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
 /* Same with up to two accumulate operands, each with its own batch stride in floats (0 = dx's): dx = dgrad +
  * accumulate + accumulate2.  ECAPA's block input gradient = dgrad(conv1) + d(block output) [the residual,
  * ecapa_tdnn.py:93] + the (B, 1536, T) concat gradient's slice for the previous block [:170] in one epilogue.
  * AIR_EUNSUPPORTED for the K = 3 and the wide-layer paths when a second operand or a foreign stride is given. */
-int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, float* dx,
-                             const float* accumulate, size_t acc_bstride, const float* accumulate2,
+int air_conv1d_dgrad_bf16_ex(const AirConv1d* p, const float* dy, const float* w, const unsigned short* w_packed,
+                             float* dx, const float* accumulate, size_t acc_bstride, const float* accumulate2,
                              size_t acc2_bstride, void* ws, size_t ws_bytes, air_stream_t stream);
 int air_conv1d_wgrad_bf16(const AirConv1d* p, const float* x, const float* dy, float* dw, void* ws,
                           size_t ws_bytes, air_stream_t stream);

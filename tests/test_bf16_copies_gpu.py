@@ -173,3 +173,23 @@ def test_small_linear_and_row_sums(ops):
         close(dw, dy.double().t() @ x.double(), 2e-5, "linear dw")
         close(db, dy.double().sum(0), 2e-5, "linear db")
         close(ops.sum_rows(dy.cuda()), dy.double().sum(0), 2e-5, "sum_rows")
+
+
+def test_tap_weights_packed_in_one_launch(ops):
+    """Seven equally shaped K = 3 weights at a regular stride (as in the parameter arena), packed once: forward and
+    dgrad with the packed blocks are bit-identical to the calls that pack per layer."""
+    B, C, T, n = 2, 64, 300, 7
+    flat = (synth_feat((n * (C * C * 3 + C),), 1, scale=0.1)).cuda()
+    ws = [flat[i * (C * C * 3 + C):i * (C * C * 3 + C) + C * C * 3].view(C, C, 3) for i in range(n)]
+    x = synth_feat((B, C, T), 2).cuda()
+    wp = ops.conv1d_tap_pack(ws, transpose=False)
+    wpt = ops.conv1d_tap_pack(ws, transpose=True)
+    assert wp is not None and wp.shape == (n, 3 * C * C)
+    for i in (0, 3, 6):
+        y0 = ops.conv1d_fwd(x, ws[i], relu=True, dil=3, pad=3, bf16=True)
+        y1 = ops.conv1d_fwd(x, ws[i], relu=True, dil=3, pad=3, bf16=True, w_packed=wp[i])
+        assert torch.equal(y0, y1)
+        d0 = ops.conv1d_dgrad(x, ws[i], 3, 3, bf16=True)
+        d1 = ops.conv1d_dgrad(x, ws[i], 3, 3, bf16=True, w_packed=wpt[i])
+        assert torch.equal(d0, d1)
+    assert ops.conv1d_tap_pack([ws[0], ws[2], ws[1]], transpose=False) is None  # irregular stride: caller packs per layer
