@@ -158,12 +158,14 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
-// grid: (B*C planes, chunks of S)
+// grid: (B*C planes, chunks of S).  rowmean (optional, single-chunk planes only): mean over the plane of the
+// OUTPUT - the SE squeeze of ecapa_tdnn.py:19 taken while bn3's output is written, instead of a pass that re-reads it.
 template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int C, int S,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
-                                                      float* __restrict__ y) {
+                                                      float* __restrict__ y, float* __restrict__ rowmean) {
+  __shared__ float wsum[NT / 64];
   const int plane = blockIdx.x;
   const int c = plane % C;
   const float sc = scale[c], sh = shift[c];
@@ -174,11 +176,13 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   const int qi = blockIdx.y * NT + threadIdx.x;
   const int h = PEEL ? head8(p, q) : (head8(p) | head8(q) ? -1 : 0);
   const int i0 = h < 0 ? 4 * qi : h + 4 * qi;
+  float tsum = 0.0f;
   auto scalar = [&](int lo, int hi) {
     for (int i = lo; i < hi; ++i) {
       float v = p[i] * sc + sh;
       if (relu) v = fmaxf(v, 0.f);
       q[i] = v;
+      tsum += v;
     }
   };
   if (h >= 0 && i0 + 3 < S) {
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     *reinterpret_cast<f4a8*>(q + i0) = v;
+    tsum += (v[0] + v[1]) + (v[2] + v[3]);
   } else if (!PEEL && h >= 0 && i0 + 2 == S) {
     f2a8 v = *reinterpret_cast<const f2a8*>(p + i0);
     v = v * sc + sh;
@@ -198,8 +203,15 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       v[1] = fmaxf(v[1], 0.f);
     }
     *reinterpret_cast<f2a8*>(q + i0) = v;
+    tsum += v[0] + v[1];
   } else {
     scalar((PEEL && h > 0 && qi == 0) ? 0 : i0, min(S, i0 + 4));
+  }
+  if (rowmean != nullptr) {  // wave sums folded in wave order: a fixed summation order
+    tsum = air_wave_sum(tsum);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tsum;
+    __syncthreads();
+    if (threadIdx.x == 0) rowmean[plane] = (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) / (float)S;
   }
 }
 
@@ -546,20 +558,26 @@ int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
   return AIR_OK;
 }
 
-int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
-                 int relu, float* y, air_stream_t stream) {
+int air_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift,
+                    int relu, float* y, float* rowmean, air_stream_t stream) {
   if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
+  if (rowmean && (S < FLAT_S || grid.y != 1)) return AIR_EUNSUPPORTED;
   const size_t n = (size_t)B * C * S;
   if (S < FLAT_S)
     hipLaunchKernelGGL(bn_apply_flat_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, air_stream(stream), x, C, S,
                        n, scale, shift, relu, y);
   else if (S & 1)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
+                 int relu, float* y, air_stream_t stream) {
+  return air_bn_apply_ex(x, B, C, S, scale, shift, relu, y, nullptr, stream);
 }
 
 int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,

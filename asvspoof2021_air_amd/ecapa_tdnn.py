@@ -222,9 +222,13 @@ class Res2Net2(nn.Module):
         ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
         r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True, bf16=bf)
         st3 = _bn(r3, blk.bn3, training)
-        o3 = ops.bn_apply(r3, st3[2], st3[3])
         se = blk.se.se
-        m, _ = ops.row_stats(o3, want_std=False)
+        if 32 <= T <= 1024:  # the SE squeeze (mean over time) comes out of the pass that writes o3
+            m = torch.empty((B, C), device=inp.device, dtype=torch.float32)
+            o3 = ops.bn_apply(r3, st3[2], st3[3], rowmean=m)
+        else:
+            o3 = ops.bn_apply(r3, st3[2], st3[3])
+            m, _ = ops.row_stats(o3, want_std=False)
         z1 = ops.linear_fwd(m, det(se[1].weight).view(se[1].out_channels, -1), det(se[1].bias), relu=True)
         stS = _bn(z1.view(B, -1, 1), se[3], training)
         z1n = ops.bn_apply(z1.view(B, -1, 1), stS[2], stS[3]).view(B, -1)

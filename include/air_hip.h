@@ -258,6 +258,11 @@ int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* y = x*scale[c] + shift[c], optional ReLU. */
 int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
                  int relu, float* y, air_stream_t stream);
+/* Same, and rowmean[b*C + c] (B*C floats, may be NULL) receives the mean over s of the OUTPUT plane: the SE
+ * squeeze (ecapa_tdnn.py:19) of the tensor being written, without a pass that re-reads it.  rowmean needs
+ * 32 <= S <= 1024 (one workgroup per plane); AIR_EUNSUPPORTED otherwise. */
+int air_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift,
+                    int relu, float* y, float* rowmean, air_stream_t stream);
 /* Backward of y = relu?(bn(x)) in training mode.  dy: grad wrt y.  relu bit 0: a ReLU
  * follows the BN (resnet.py:64); bit 1: the BN input is itself a ReLU output
  * (conv -> ReLU -> BN, ecapa_tdnn.py:67-69), so dx is masked where x == 0 and is the

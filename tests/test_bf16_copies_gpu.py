@@ -193,3 +193,14 @@ def test_tap_weights_packed_in_one_launch(ops):
         d1 = ops.conv1d_dgrad(x, ws[i], 3, 3, bf16=True, w_packed=wpt[i])
         assert torch.equal(d0, d1)
     assert ops.conv1d_tap_pack([ws[0], ws[2], ws[1]], transpose=False) is None  # irregular stride: caller packs per layer
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 750), (3, 16, 375), (2, 8, 1024)])
+def test_bn_apply_rowmean(ops, shape):
+    B, C, S = shape
+    x = synth_feat(shape, 1).cuda()
+    scale, shift = (1.0 + 0.3 * synth_feat((C,), 2)).cuda(), (0.2 * synth_feat((C,), 3)).cuda()
+    m = torch.empty((B, C), device="cuda")
+    y = ops.bn_apply(x, scale, shift, relu=True, rowmean=m)
+    assert torch.equal(y, ops.bn_apply(x, scale, shift, relu=True))
+    close(m, y.double().mean(2), 2e-6, "row mean")
