@@ -9,6 +9,8 @@ namespace {
 
 constexpr int NT = 256;
 
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f2a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // float -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32: the rounding of conv1d_bf16.hip)
@@ -28,17 +30,26 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return r;
 }
 
-// out[b][c][s] = a[b][c][s] (+ b2[b][c][s]); each tensor has its own batch stride
+// out[b][c][s] = a[b][c][s] (+ b2[b][c][s]); each tensor has its own batch stride.  bf (optional): the result also
+// as bf16 at bf[b * bf_bs + c * Tp + s] (the weight-gradient GEMM's operand layout, conv1d_bf16.hip).
 __global__ __launch_bounds__(NT) void add_strided_kernel(float* __restrict__ out, size_t ob,
                                                          const float* __restrict__ a, size_t ab,
                                                          const float* __restrict__ b2, size_t bb,
-                                                         int CS) {
+                                                         int CS, int S, unsigned short* __restrict__ bf, size_t bf_bs,
+                                                         int Tp) {
   const int b = blockIdx.y;
   const float* __restrict__ pa = a + (size_t)b * ab;
   const float* __restrict__ pb = b2 ? b2 + (size_t)b * bb : nullptr;
   float* __restrict__ po = out + (size_t)b * ob;
-  for (int i = blockIdx.x * NT + threadIdx.x; i < CS; i += gridDim.x * NT)
-    po[i] = pb ? pa[i] + pb[i] : pa[i];
+  unsigned short* __restrict__ pf = bf ? bf + (size_t)b * bf_bs : nullptr;
+  for (int i = blockIdx.x * NT + threadIdx.x; i < CS; i += gridDim.x * NT) {
+    const float v = pb ? pa[i] + pb[i] : pa[i];
+    po[i] = v;
+    if (pf) {
+      const int c = i / S;
+      pf[(size_t)c * Tp + (i - c * S)] = bf16_bits(v);
+    }
+  }
 }
 
 // Res2 chain step (ecapa_tdnn.py:78-83): v = x * scale[c] + shift[c] (BatchNorm apply of branch i);
@@ -49,7 +60,8 @@ __global__ __launch_bounds__(NT) void res2_bn_apply_kernel(const float* __restri
                                                            const float* __restrict__ shift,
                                                            float* __restrict__ y1, size_t y1_bs,
                                                            const float* __restrict__ add, size_t add_bs,
-                                                           float* __restrict__ y2) {
+                                                           float* __restrict__ y2, unsigned short* __restrict__ bf,
+                                                           size_t bf_bs, int Tp) {
   const int plane = blockIdx.x;  // b * C + c
   const int b = plane / C, c = plane - b * C;
   const float sc = scale[c], sh = shift[c];
@@ -57,10 +69,36 @@ __global__ __launch_bounds__(NT) void res2_bn_apply_kernel(const float* __restri
   float* __restrict__ q1 = y1 + (size_t)b * y1_bs + (size_t)c * S;
   const float* __restrict__ pa = add ? add + (size_t)b * add_bs + (size_t)c * S : nullptr;
   float* __restrict__ q2 = y2 ? y2 + (size_t)plane * S : nullptr;
+  // bf (optional): y1 also as bf16, [b][c][Tp] with its own batch stride (the concat's copy, conv3's weight gradient)
+  unsigned short* __restrict__ qf = bf ? bf + (size_t)b * bf_bs + (size_t)c * Tp : nullptr;
+  const bool vec = (S & 1) == 0 && ((((size_t)p) | ((size_t)q1) | ((size_t)pa) | ((size_t)q2)) & 7) == 0;
+  if (vec) {  // 16 bytes per lane (planes start on 8-byte boundaries), a 2-float tail when S % 4 == 2
+    for (int i = 4 * (blockIdx.y * NT + threadIdx.x); i < S; i += 4 * gridDim.y * NT) {
+      if (i + 3 < S) {
+        const f4a8 v = *reinterpret_cast<const f4a8*>(p + i) * sc + sh;
+        *reinterpret_cast<f4a8*>(q1 + i) = v;
+        if (q2) *reinterpret_cast<f4a8*>(q2 + i) = v + *reinterpret_cast<const f4a8*>(pa + i);
+        if (qf) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qf[i + e] = bf16_bits(v[e]);
+        }
+      } else {
+        const f2a8 v = *reinterpret_cast<const f2a8*>(p + i) * sc + sh;
+        *reinterpret_cast<f2a8*>(q1 + i) = v;
+        if (q2) *reinterpret_cast<f2a8*>(q2 + i) = v + *reinterpret_cast<const f2a8*>(pa + i);
+        if (qf) {
+          qf[i] = bf16_bits(v[0]);
+          qf[i + 1] = bf16_bits(v[1]);
+        }
+      }
+    }
+    return;
+  }
   for (int i = blockIdx.y * NT + threadIdx.x; i < S; i += gridDim.y * NT) {
     const float v = p[i] * sc + sh;
     q1[i] = v;
     if (q2) q2[i] = v + pa[i];
+    if (qf) qf[i] = bf16_bits(v);
   }
 }
 
@@ -404,26 +442,42 @@ int air_row_sum(const float* x, int B, int C, int T, float* out, air_stream_t st
   return AIR_OK;
 }
 
-int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
-                    const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream) {
+int air_add_strided_ex(float* out, size_t out_bstride, const float* a, size_t a_bstride, const float* b,
+                       size_t b_bstride, int B, int C, int S, unsigned short* out_bf16, size_t out_bf16_bstride,
+                       int out_bf16_tp, air_stream_t stream) {
   if (!out || !a || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
+  if (out_bf16 && out_bf16_tp < S) return AIR_EINVAL;
   const int CS = C * S;
   dim3 grid(min((CS + NT - 1) / NT, 1024), B);
   hipLaunchKernelGGL(add_strided_kernel, grid, dim3(NT), 0, air_stream(stream), out, out_bstride,
-                     a, a_bstride, b, b_bstride, CS);
+                     a, a_bstride, b, b_bstride, CS, S, out_bf16,
+                     out_bf16_bstride ? out_bf16_bstride : (size_t)C * out_bf16_tp, out_bf16_tp);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bstride,
+                    const float* b, size_t b_bstride, int B, int C, int S, air_stream_t stream) {
+  return air_add_strided_ex(out, out_bstride, a, a_bstride, b, b_bstride, B, C, S, nullptr, 0, 0, stream);
+}
+
+int air_res2_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
+                         size_t y1_bstride, const float* add, size_t add_bstride, float* y2, unsigned short* y1_bf16,
+                         size_t y1_bf16_bstride, int y1_bf16_tp, air_stream_t stream) {
+  if (!x || !scale || !shift || !y1 || B <= 0 || C <= 0 || S <= 0 || ((add == nullptr) != (y2 == nullptr)))
+    return AIR_EINVAL;
+  if (y1_bf16 && y1_bf16_tp < S) return AIR_EINVAL;
+  hipLaunchKernelGGL(res2_bn_apply_kernel, dim3(B * C, (S + NT * 4 - 1) / (NT * 4)), dim3(NT), 0, air_stream(stream),
+                     x, C, S, scale, shift, y1, y1_bstride ? y1_bstride : (size_t)C * S, add,
+                     add_bstride ? add_bstride : (size_t)C * S, y2, y1_bf16,
+                     y1_bf16_bstride ? y1_bf16_bstride : (size_t)C * y1_bf16_tp, y1_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
 
 int air_res2_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
                       size_t y1_bstride, const float* add, size_t add_bstride, float* y2, air_stream_t stream) {
-  if (!x || !scale || !shift || !y1 || B <= 0 || C <= 0 || S <= 0 || ((add == nullptr) != (y2 == nullptr)))
-    return AIR_EINVAL;
-  hipLaunchKernelGGL(res2_bn_apply_kernel, dim3(B * C, (S + NT * 2 - 1) / (NT * 2)), dim3(NT), 0, air_stream(stream),
-                     x, C, S, scale, shift, y1, y1_bstride ? y1_bstride : (size_t)C * S, add,
-                     add_bstride ? add_bstride : (size_t)C * S, y2);
-  AIR_CHECK_LAUNCH();
-  return AIR_OK;
+  return air_res2_bn_apply_ex(x, B, C, S, scale, shift, y1, y1_bstride, add, add_bstride, y2, nullptr, 0, 0, stream);
 }
 
 static int channel_sum_split(int B, int C, int* b_per_split) {

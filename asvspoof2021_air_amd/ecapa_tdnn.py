@@ -199,6 +199,9 @@ class Res2Net2(nn.Module):
         st1 = _bn(r1, blk.bn1, training)
         o1 = ops.bn_apply(r1, st1[2], st1[3])
         cat = torch.empty_like(o1)
+        # bf16 training: the concat's bf16 copy (conv3's weight-gradient operand) is written by the passes that fill it
+        cat_bf = ops.bf16_rows(None, B, C, T, inp.device) if (bf and save) else None
+        cb = (lambda lo, hi: cat_bf[:, lo:hi]) if cat_bf is not None else (lambda lo, hi: None)
         t_list, r_list, st_list = [], [], []
         t_i = o1[:, :w]
         # bf16: the seven branch weights (a regular stride apart in the parameter arena) are packed in one launch
@@ -211,15 +214,15 @@ class Res2Net2(nn.Module):
             if i + 1 < nums:
                 t_next = torch.empty((B, w, T), device=inp.device, dtype=torch.float32)
                 ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w],
-                                  o1[:, (i + 1) * w:(i + 2) * w], t_next)
+                                  o1[:, (i + 1) * w:(i + 2) * w], t_next, y1_bf=cb(i * w, (i + 1) * w))
             else:
                 t_next = None
-                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
+                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w], y1_bf=cb(i * w, (i + 1) * w))
             t_list.append(t_i)
             r_list.append(r_i)
             st_list.append(st_i)
             t_i = t_next
-        ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
+        ops.add_strided(cat[:, nums * w:], o1[:, nums * w:], out_bf=cb(nums * w, C))
         r3 = ops.conv1d_fwd(cat, det(blk.conv3.weight), det(blk.conv3.bias), relu=True, bf16=bf)
         st3 = _bn(r3, blk.bn3, training)
         se = blk.se.se
@@ -235,7 +238,7 @@ class Res2Net2(nn.Module):
         z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
         ops.se_scale_fwd(o3, z2, inp, out)
         if save:
-            return dict(blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat,
+            return dict(blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat, cat_bf=cat_bf,
                         r3=r3, st3=st3, o3=o3, m=m, z1=z1, stS=stS, z1n=z1n, z2=z2)
         return None
 
@@ -329,7 +332,7 @@ class Res2Net2(nn.Module):
                                relu_in=True, dx=do3, dgamma=gv("bn3.weight"), dbeta=gv("bn3.bias"),
                                rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"), dx_bf16=dy_bf)
         on_side(lambda: ops.conv1d_wgrad(S["cat"], dc3, blk.conv3.weight.shape, out=gv("conv3.weight"), bf16=bf,
-                                         dy_bf=dy_bf), dc3)
+                                         dy_bf=dy_bf, x_bf=S["cat_bf"]), dc3)
         dcat = ops.conv1d_dgrad(dc3, det(blk.conv3.weight), bf16=bf)
         do1 = torch.empty_like(dcat)
         ops.add_strided(do1[:, nums * w:], dcat[:, nums * w:])

@@ -438,24 +438,31 @@ def conv1d_wgrad(x, dy, w_shape, dil=1, pad=0, out=None, bf16=False, x_bf=None, 
     return dw
 
 
-def add_strided(out, a, b=None):
-    """out = a (+ b) over (B, C, T) tensors / channel-slice views."""
+def add_strided(out, a, b=None, out_bf=None):
+    """out = a (+ b) over (B, C, T) tensors / channel-slice views; out_bf: (B, C, Tp) int16 copy (or a channel slice
+    of one) that also receives the result as bf16."""
     B, C, T = out.shape
     op, ob = vptr(out)
     ap, ab = vptr(a)
     bp, bb = vptr(b) if b is not None else (ctypes.c_void_p(0), 0)
-    _hip.check(_hip.lib().air_add_strided(op, csz(ob), ap, csz(ab), bp, csz(bb), ci(B), ci(C), ci(T),
-                                          stream()), "air_add_strided")
+    fp, fb = _bf_view(out_bf)
+    _hip.check(_hip.lib().air_add_strided_ex(op, csz(ob), ap, csz(ab), bp, csz(bb), ci(B), ci(C), ci(T), fp, csz(fb),
+                                             ci(out_bf.shape[2] if out_bf is not None else 0), stream()),
+               "air_add_strided_ex")
     return out
 
 
-def res2_bn_apply(x, scale, shift, y1, add=None, y2=None):
-    """y1 (channel-slice view) = x*scale + shift; y2 (dense) = that + add (channel-slice view)."""
+def res2_bn_apply(x, scale, shift, y1, add=None, y2=None, y1_bf=None):
+    """y1 (channel-slice view) = x*scale + shift; y2 (dense) = that + add (channel-slice view); y1_bf: channel slice
+    of a (B, C, Tp) int16 copy that also receives y1 as bf16."""
     B, C, T = x.shape
     y1p, y1b = vptr(y1)
     ap, ab = vptr(add) if add is not None else (ctypes.c_void_p(0), 0)
-    _hip.check(_hip.lib().air_res2_bn_apply(dptr(x), ci(B), ci(C), ci(T), dptr(scale), dptr(shift), y1p, csz(y1b),
-                                            ap, csz(ab), dptr(y2, allow_none=True), stream()), "air_res2_bn_apply")
+    fp, fb = _bf_view(y1_bf)
+    _hip.check(_hip.lib().air_res2_bn_apply_ex(dptr(x), ci(B), ci(C), ci(T), dptr(scale), dptr(shift), y1p, csz(y1b),
+                                               ap, csz(ab), dptr(y2, allow_none=True), fp, csz(fb),
+                                               ci(y1_bf.shape[2] if y1_bf is not None else 0), stream()),
+               "air_res2_bn_apply_ex")
     return y2
 
 

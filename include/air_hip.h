@@ -338,6 +338,16 @@ int air_add_strided(float* out, size_t out_bstride, const float* a, size_t a_bst
  * batch stride add_bstride): the next branch's input "sp + spx[i+1]".  add and y2 both NULL or both set. */
 int air_res2_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
                       size_t y1_bstride, const float* add, size_t add_bstride, float* y2, air_stream_t stream);
+/* Both with a bf16 copy of the result (out / y1) in the weight-gradient operand layout of
+ * air_conv1d_wgrad_bf16_pre: element (b, c, s) at bf16[b * bstride + c * tp + s], bstride in elements (0 = C * tp),
+ * tp = air_conv1d_bf16_tp(S); the seven branch outputs and the pass-through group of a Bottle2neck together fill
+ * the bf16 copy of its concat (conv3's X operand).  NULL = the plain entry points. */
+int air_add_strided_ex(float* out, size_t out_bstride, const float* a, size_t a_bstride, const float* b,
+                       size_t b_bstride, int B, int C, int S, unsigned short* out_bf16, size_t out_bf16_bstride,
+                       int out_bf16_tp, air_stream_t stream);
+int air_res2_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift, float* y1,
+                         size_t y1_bstride, const float* add, size_t add_bstride, float* y2, unsigned short* y1_bf16,
+                         size_t y1_bf16_bstride, int y1_bf16_tp, air_stream_t stream);
 /* out[c] = sum_{b,s} x[b][c][s]: conv bias gradients (fp64 partials, fixed order). */
 size_t air_channel_sum_ws_bytes(int B, int C);
 int air_channel_sum(const float* x, int B, int C, int S, size_t bstride, float* out, void* ws,

@@ -204,3 +204,25 @@ def test_bn_apply_rowmean(ops, shape):
     y = ops.bn_apply(x, scale, shift, relu=True, rowmean=m)
     assert torch.equal(y, ops.bn_apply(x, scale, shift, relu=True))
     close(m, y.double().mean(2), 2e-6, "row mean")
+
+
+@pytest.mark.parametrize("T", [750, 101])
+def test_res2_and_add_strided_write_bf16_slices(ops, T):
+    """The Res2 chain step and the pass-through copy fill channel slices of the concat AND of its bf16 copy."""
+    B, w, C = 3, 64, 192
+    r = synth_feat((B, w, T), 1).cuda()
+    o1 = synth_feat((B, C, T), 2).cuda()
+    scale, shift = (1.0 + 0.3 * synth_feat((w,), 3)).cuda(), (0.2 * synth_feat((w,), 4)).cuda()
+    cat0, cat1 = torch.zeros_like(o1), torch.zeros_like(o1)
+    cat_bf = ops.bf16_rows(None, B, C, T, r.device)
+    t0 = torch.empty_like(r); t1 = torch.empty_like(r)
+    ops.res2_bn_apply(r, scale, shift, cat0[:, w:2 * w], o1[:, 2 * w:], t0)
+    ops.res2_bn_apply(r, scale, shift, cat1[:, w:2 * w], o1[:, 2 * w:], t1, y1_bf=cat_bf[:, w:2 * w])
+    assert torch.equal(cat0, cat1) and torch.equal(t0, t1)
+    want = r.double() * scale.double().view(1, -1, 1) + shift.double().view(1, -1, 1)
+    close(cat1[:, w:2 * w], want, 1e-6, "res2 y1")
+    close(t1, want + o1[:, 2 * w:].double(), 1e-6, "res2 y2")
+    ops.add_strided(cat1[:, 2 * w:], o1[:, 2 * w:], out_bf=cat_bf[:, 2 * w:])
+    assert torch.equal(cat1[:, 2 * w:], o1[:, 2 * w:])
+    assert torch.equal(cat_bf[:, w:, :T].cpu(), bf16_bits(cat1[:, w:]))
+    assert int(cat_bf[:, :, T:].abs().max()) == 0 and int(cat_bf[:, :w].abs().max()) == 0
