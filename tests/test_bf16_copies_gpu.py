@@ -225,4 +225,4 @@ def test_res2_and_add_strided_write_bf16_slices(ops, T):
     ops.add_strided(cat1[:, 2 * w:], o1[:, 2 * w:], out_bf=cat_bf[:, 2 * w:])
     assert torch.equal(cat1[:, 2 * w:], o1[:, 2 * w:])
     assert torch.equal(cat_bf[:, w:, :T].cpu(), bf16_bits(cat1[:, w:]))
-    assert int(cat_bf[:, :, T:].abs().max()) == 0 and int(cat_bf[:, :w].abs().max()) == 0
+    assert int(cat_bf[:, :, T:].abs().max()) == 0  # (the first group was never written: fresh memory, only the padding is zeroed)
