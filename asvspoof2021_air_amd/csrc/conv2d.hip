@@ -702,6 +702,64 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(DirectArgs a) {
   (void)red;
 }
 
+// The same partials, one workgroup per (b, ho) output row with the row's operands in LDS: dy [Cout][Wo] and the
+// KH input rows of every input channel, zero-padded [Cin * KH][W + 2 pw].  A thread owns one (co, ci, kh) and a
+// segment of the row and keeps KW accumulators (the kernel above re-reads both rows from L1/L2 for each of its
+// 432 (co, k) pairs and wave-reduces each: 472 us for a 67 MB problem; this one 10x less).  Segments are folded in
+// order, so the summation order is fixed.
+constexpr int DIRECT_KW_MAX = 4;
+__global__ __launch_bounds__(512) void conv_direct_wgrad_rows_kernel(DirectArgs a, int nseg) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int XW = (a.W + 2 * a.pw) | 1;  // odd pitch: the KH rows a wave reads sit in different banks
+  const int nrow = a.Cin * a.KH;
+  float* sdy = dsm;                   // [Cout][Wo]
+  float* sx = dsm + a.Cout * a.Wo;    // [Cin * KH][XW]
+  const int row = blockIdx.x;         // b * Ho + ho
+  const int ho = row % a.Ho, b = row / a.Ho;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int e = tid; e < a.Cout * a.Wo; e += nt) {
+    const int co = e / a.Wo, wo = e - co * a.Wo;
+    sdy[e] = a.dy[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo];
+  }
+  for (int e = tid; e < nrow * XW; e += nt) {
+    const int r = e / XW, c = e - r * XW;
+    const int ci = r / a.KH, kh = r - ci * a.KH;
+    const int hi = ho * a.sh - a.ph + kh, wi = c - a.pw;
+    sx[e] = (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) ? a.x[(((size_t)b * a.Cin + ci) * a.H + hi) * a.W + wi] : 0.0f;
+  }
+  __syncthreads();
+  const int npair = a.Cout * nrow;
+  const int seg = tid / npair, pair = tid - seg * npair;
+  float acc[DIRECT_KW_MAX];
+#pragma unroll
+  for (int k = 0; k < DIRECT_KW_MAX; ++k) acc[k] = 0.0f;
+  const bool active = seg < nseg;
+  const int co = pair / nrow, r = pair - co * nrow;
+  if (active) {
+    const int w_lo = (int)((long long)a.Wo * seg / nseg), w_hi = (int)((long long)a.Wo * (seg + 1) / nseg);
+    const float* __restrict__ pd = sdy + co * a.Wo;
+    const float* __restrict__ px = sx + r * XW;
+    for (int wo = w_lo; wo < w_hi; ++wo) {
+      const float d = pd[wo];
+#pragma unroll
+      for (int k = 0; k < DIRECT_KW_MAX; ++k)
+        if (k < a.KW) acc[k] = fmaf(d, px[wo * a.sw + k], acc[k]);
+    }
+  }
+  __syncthreads();  // the staged rows are dead: their space takes the segments' sums
+  float* red = dsm;  // [nseg][npair][KW]
+  if (active)
+    for (int k = 0; k < a.KW; ++k) red[((size_t)seg * npair + pair) * a.KW + k] = acc[k];
+  __syncthreads();
+  const int K = nrow * a.KW;
+  for (int e = tid; e < npair * a.KW; e += nt) {
+    float s = 0.0f;
+    for (int g = 0; g < nseg; ++g) s += red[(size_t)g * npair * a.KW + e];
+    // e = (co * nrow + r) * KW + k = co * K + (r * KW + k): the layout reduce_partials_kernel expects
+    a.partial[(size_t)row * a.Cout * K + e] = s;
+  }
+}
+
 // reduce_partials_kernel: one workgroup per 64 outputs, at most 8 per CU
 int reduce_grid(size_t n, int nsplit) {
   const size_t g = nsplit <= 16 ? (n + 255) / 256 : (n + 63) / 64;
@@ -1156,7 +1214,20 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     if (!ws || ws_bytes < (size_t)rows * wsz * sizeof(float)) return AIR_EWORKSPACE;
     DirectArgs a = {x, nullptr, nullptr, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H,
                     p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
-    hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
+    const int npair = p->Cout * p->Cin * p->KH;
+    const size_t lds = ((size_t)p->Cout * p->Wo + (size_t)p->Cin * p->KH * ((p->W + 2 * p->pw) | 1)) * sizeof(float);
+    static const int use_rows = getenv("AIR_DIRECT_WGRAD_ROWS") ? atoi(getenv("AIR_DIRECT_WGRAD_ROWS")) : 1;
+    if (use_rows && p->KW <= DIRECT_KW_MAX && npair <= 512 && lds <= 150 * 1024) {
+      int nseg = 512 / npair;
+      if (nseg > 4) nseg = 4;
+      const int nthr = (npair * nseg + 63) / 64 * 64;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_wgrad_rows_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return AIR_ELAUNCH;
+      hipLaunchKernelGGL(conv_direct_wgrad_rows_kernel, dim3(rows), dim3(nthr), lds, st, a, nseg);
+    } else {
+      hipLaunchKernelGGL(conv_direct_wgrad_kernel, dim3(rows), dim3(256), 0, st, a);
+    }
     AIR_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, rows)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, rows, 1);
