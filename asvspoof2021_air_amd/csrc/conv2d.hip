@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(DirectArgs a) {
 // The same partials, one workgroup per (b, ho) output row with the row's operands in LDS: dy [Cout][Wo] and the
 // KH input rows of every input channel, zero-padded [Cin * KH][W + 2 pw].  A thread owns one (co, ci, kh) and a
 // segment of the row and keeps KW accumulators (the kernel above re-reads both rows from L1/L2 for each of its
-// 432 (co, k) pairs and wave-reduces each: 472 us for a 67 MB problem; this one 10x less).  Segments are folded in
+// 432 (co, k) pairs and wave-reduces each: 472 us for a 67 MB problem; this one 152 us).  Segments are folded in
 // order, so the summation order is fixed.
 constexpr int DIRECT_KW_MAX = 4;
 __global__ __launch_bounds__(512) void conv_direct_wgrad_rows_kernel(DirectArgs a, int nseg) {
@@ -717,15 +717,34 @@ __global__ __launch_bounds__(512) void conv_direct_wgrad_rows_kernel(DirectArgs 
   const int row = blockIdx.x;         // b * Ho + ho
   const int ho = row % a.Ho, b = row / a.Ho;
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int e = tid; e < a.Cout * a.Wo; e += nt) {
-    const int co = e / a.Wo, wo = e - co * a.Wo;
-    sdy[e] = a.dy[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo];
+  // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
+  const int ndy = a.Cout * a.Wo, nx = nrow * XW;
+  for (int e0 = tid; e0 < ndy; e0 += 8 * nt) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * nt;
+      const int co = e / a.Wo, wo = e - co * a.Wo;
+      v[u] = e < ndy ? a.dy[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * nt < ndy) sdy[e0 + u * nt] = v[u];
   }
-  for (int e = tid; e < nrow * XW; e += nt) {
-    const int r = e / XW, c = e - r * XW;
-    const int ci = r / a.KH, kh = r - ci * a.KH;
-    const int hi = ho * a.sh - a.ph + kh, wi = c - a.pw;
-    sx[e] = (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W) ? a.x[(((size_t)b * a.Cin + ci) * a.H + hi) * a.W + wi] : 0.0f;
+  for (int e0 = tid; e0 < nx; e0 += 8 * nt) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * nt;
+      const int r = e / XW, c = e - r * XW;
+      const int ci = r / a.KH, kh = r - ci * a.KH;
+      const int hi = ho * a.sh - a.ph + kh, wi = c - a.pw;
+      v[u] = (e < nx && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
+                 ? a.x[(((size_t)b * a.Cin + ci) * a.H + hi) * a.W + wi] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * nt < nx) sx[e0 + u * nt] = v[u];
   }
   __syncthreads();
   const int npair = a.Cout * nrow;
