@@ -408,7 +408,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
   const int HWi = a.H * a.W;
   const int HoWoi = a.Ho * a.Wo;
-  const size_t HW = (size_t)a.H * a.W;
   const size_t HoWo = (size_t)a.Ho * a.Wo;
 
   // this lane's channel for the B operand

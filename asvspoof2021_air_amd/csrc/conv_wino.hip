@@ -216,7 +216,6 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
   const int cw = wave & 1;   // channel half of the workgroup's 64
   const int gw = wave >> 1;  // tile group of the workgroup's 2
   const int HWi = a.H * a.W;
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
     }
   };
   stamp();
-  int cur = 0, p = 0;
+  int cur = 0;
   // one K chunk = 2 k-steps.  FIRST: the item's first chunk, whose step 0 starts the
   // accumulators from a zero C operand (no separate zeroing pass over 256 AGPRs).
   constexpr int NU1 = 8;  // DMAs issued in step 1 (slots 0, 2, .. 14); the rest in the next step 0
@@ -533,7 +532,6 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
       const long long c4 = clock64();
       tS0 += c1 - c0; tWait += c2 - c1; tBar += c3 - c2; tS1 += c4 - c3;
     }
-    ++p;
     cur = nxt;
   };
   for (int item = i0; item < i1; ++item) {
@@ -644,7 +642,6 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
   const unsigned mD0 = lds0 + WG_XF * 4u + wave * (16 * WG_DP * 4u);
 
   // stage geometry -> per-lane source offsets (one VGPR each) and the wave's channel bases
-  unsigned vox = OOB, vod = OOB, xs0 = 0, ds0 = 0;
   int edge_col = -1;  // staged column of image column W if a valid tile of the stage sees it
   auto set_stage = [&](int s, unsigned& vx, unsigned& vd, unsigned& xs, unsigned& dsf, int& ecol) {
     const int seg = s % a.NTS;

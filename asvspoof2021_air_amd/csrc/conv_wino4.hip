@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         res[cr][yy] = v;
       }
     };
-    const bool any_add = use_res || accum;
     load_res(0);
 #pragma unroll
     for (int cr = 0; cr < 8; ++cr) {
@@ -514,7 +513,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   transform();
 
   int cur = 0;
-  long long tW = 0, tB = 0, tD = 0, tR = 0, tM = 0, tT = 0, tE = 0;
+  long long tW = 0, tB = 0, tD = 0, tM = 0, tT = 0, tE = 0;
   auto kstep = [&](auto first_tag, int e_next) {
     constexpr bool FIRST = decltype(first_tag)::value;
     const int nxt = cur + 1 == W4_NBUF ? 0 : cur + 1;
