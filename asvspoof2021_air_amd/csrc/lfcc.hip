@@ -32,13 +32,15 @@ constexpr int MAXF = 32;          // filters supported (2 per lane of a 16-lane 
 constexpr int MAXW = 32;          // bins per filter supported
 constexpr int NW = 8;             // waves per workgroup
 constexpr int NTHREADS = NW * 64;
-constexpr int GPW = 2;                  // 4-frame groups per wave
-constexpr int FCOMP = NW * GPW * 4;     // 64 frames computed per workgroup
+constexpr int GPW = 1;                  // 4-frame groups per wave
+constexpr int FCOMP = NW * GPW * 4;     // 32 frames computed per workgroup
 constexpr int HALO = 2;                 // delta-delta reaches 2 frames each side
-constexpr int FOUT = FCOMP - 2 * HALO;  // 60 frames written per workgroup
-constexpr int NSAMP = FS * (FCOMP + 1); // 10,400 staged samples
+constexpr int FOUT = FCOMP - 2 * HALO;  // 28 frames written per workgroup
+constexpr int NSAMP = FS * (FCOMP + 1); // 5,280 staged samples
 constexpr int XROW = 17;                // padded transpose row (complex elements)
-constexpr int XCH_FLOATS = 4 * 16 * XROW * 2;  // wave-private exchange tile (2176 floats)
+// wave-private exchange tile: the 4 x 16 x 17 transposition (real and imaginary parts in two passes), then the 4
+// power rows + 4 x 32 filterbank outputs; 69.6 KB for the workgroup - two workgroups per CU (round 1: one)
+constexpr int XCH_FLOATS = 4 * 264 + 4 * 32;
 constexpr int PROW = 264;               // power-spectrum row stride (floats)
 constexpr int FBUF_OFF = 4 * PROW;      // filterbank outputs live after the 4 power rows
 
@@ -239,7 +241,6 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
   const int lo1 = plan->lo[j1 < MAXF ? j1 : 0];
   const int partner = (lane & 48) | ((16 - g) & 15);
   float* xch = s_xch + wave * XCH_FLOATS;
-  float2* xch2 = reinterpret_cast<float2*>(xch);
 
   __syncthreads();
 
@@ -263,15 +264,19 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
     fft16<true>(x);  // over m: Y[g][q]
 #pragma unroll
     for (int q = 1; q < 16; ++q) x[q] = cmul(x[q], tw[q]);
-    // transpose through LDS: row q, column g
+    // transpose through LDS: row q, column g - real parts, then imaginary parts through the same 4.3 KB
+    float xre[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xch2[(f * 16 + q) * XROW + g] = make_float2(x[q].re, x[q].im);
+    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].re;
     air_wave_lds_fence();
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-      const float2 v = xch2[(f * 16 + g) * XROW + l];
-      x[l] = cf{v.x, v.y};
-    }
+    for (int l = 0; l < 16; ++l) xre[l] = xch[(f * 16 + g) * XROW + l];
+    air_wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].im;
+    air_wave_lds_fence();
+#pragma unroll
+    for (int l = 0; l < 16; ++l) x[l] = cf{xre[l], xch[(f * 16 + g) * XROW + l]};
     fft16<false>(x);  // over l: Z[g + 16 p] = x[p]
     air_wave_lds_fence();  // exchange tile is reused for the power rows below
 
