@@ -640,9 +640,14 @@ struct DirectArgs {
 constexpr int DIRECT_MAX_W = 16 * 27;
 
 __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(DirectArgs a) {
-  __shared__ float sw_[DIRECT_MAX_W];
+  // weights as [k][16 co]: the 16 output channels of a tap are four 16-byte broadcast reads (one 4-byte read per
+  // (co, tap) made the LDS instruction stream the bound: 79 us for a 67 MB layer)
+  __shared__ __attribute__((aligned(16))) float sw_[DIRECT_MAX_W];
   const int K = a.Cin * a.KH * a.KW;
-  for (int e = threadIdx.x; e < a.Cout * K; e += 256) sw_[e] = a.w[e];
+  for (int e = threadIdx.x; e < 16 * K; e += 256) {
+    const int k = e >> 4, co = e & 15;
+    sw_[e] = co < a.Cout ? a.w[co * K + k] : 0.0f;
+  }
   __syncthreads();
   const size_t npx = (size_t)a.B * a.Ho * a.Wo;
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npx; p += (size_t)gridDim.x * 256) {
@@ -662,9 +667,15 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(DirectArgs a) {
           if (wi < 0 || wi >= a.W) continue;
           const float xv = a.x[(((size_t)b * a.Cin + ci) * a.H + hi) * a.W + wi];
           const int k = (ci * a.KH + kh) * a.KW + kw;
+          const float4* __restrict__ wk = reinterpret_cast<const float4*>(&sw_[k * 16]);
 #pragma unroll
-          for (int co = 0; co < 16; ++co)
-            if (co < a.Cout) acc[co] = fmaf(xv, sw_[co * K + k], acc[co]);
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 w4 = wk[c4];
+            acc[4 * c4 + 0] = fmaf(xv, w4.x, acc[4 * c4 + 0]);
+            acc[4 * c4 + 1] = fmaf(xv, w4.y, acc[4 * c4 + 1]);
+            acc[4 * c4 + 2] = fmaf(xv, w4.z, acc[4 * c4 + 2]);
+            acc[4 * c4 + 3] = fmaf(xv, w4.w, acc[4 * c4 + 3]);
+          }
         }
       }
 #pragma unroll
@@ -704,27 +715,30 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(DirectArgs a) {
 // The same partials, one workgroup per (b, ho) output row with the row's operands in LDS: dy [Cout][Wo] and the
 // KH input rows of every input channel, zero-padded [Cin * KH][W + 2 pw].  A thread owns one (co, ci, kh) and a
 // segment of the row and keeps KW accumulators (the kernel above re-reads both rows from L1/L2 for each of its
-// 432 (co, k) pairs and wave-reduces each: 472 us for a 67 MB problem; this one 152 us).  Segments are folded in
+// 432 (co, k) pairs and wave-reduces each: 472 us for a 67 MB problem; this one 69 us).  Segments are folded in
 // order, so the summation order is fixed.
 constexpr int DIRECT_KW_MAX = 4;
 __global__ __launch_bounds__(512) void conv_direct_wgrad_rows_kernel(DirectArgs a, int nseg) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  const int XW = (a.W + 2 * a.pw) | 1;  // odd pitch: the KH rows a wave reads sit in different banks
+  // pitches: multiples of 4 floats so that a thread can walk its row 4 pixels at a time with 16-byte reads (the
+  // padding is zero-filled: it contributes nothing); + 4 on x for the KW - 1 floats behind the last quad
+  const int DP = (a.Wo + 3) & ~3;
+  const int XW = ((a.W + 2 * a.pw + 3) & ~3) + 4;
   const int nrow = a.Cin * a.KH;
-  float* sdy = dsm;                   // [Cout][Wo]
-  float* sx = dsm + a.Cout * a.Wo;    // [Cin * KH][XW]
+  float* sdy = dsm;                   // [Cout][DP]
+  float* sx = dsm + a.Cout * DP;      // [Cin * KH][XW]
   const int row = blockIdx.x;         // b * Ho + ho
   const int ho = row % a.Ho, b = row / a.Ho;
   const int tid = threadIdx.x, nt = blockDim.x;
   // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
-  const int ndy = a.Cout * a.Wo, nx = nrow * XW;
+  const int ndy = a.Cout * DP, nx = nrow * XW;
   for (int e0 = tid; e0 < ndy; e0 += 8 * nt) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * nt;
-      const int co = e / a.Wo, wo = e - co * a.Wo;
-      v[u] = e < ndy ? a.dy[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo] : 0.0f;
+      const int co = e / DP, wo = e - co * DP;
+      v[u] = (e < ndy && wo < a.Wo) ? a.dy[(((size_t)b * a.Cout + co) * a.Ho + ho) * a.Wo + wo] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -754,14 +768,29 @@ __global__ __launch_bounds__(512) void conv_direct_wgrad_rows_kernel(DirectArgs 
   const bool active = seg < nseg;
   const int co = pair / nrow, r = pair - co * nrow;
   if (active) {
-    const int w_lo = (int)((long long)a.Wo * seg / nseg), w_hi = (int)((long long)a.Wo * (seg + 1) / nseg);
-    const float* __restrict__ pd = sdy + co * a.Wo;
+    const float* __restrict__ pd = sdy + co * DP;
     const float* __restrict__ px = sx + r * XW;
-    for (int wo = w_lo; wo < w_hi; ++wo) {
-      const float d = pd[wo];
+    if (a.sw == 1 && a.KW == 3) {
+      // four pixels per step: one 16-byte read of dy, one 16-byte + one 8-byte read of x, twelve FMAs
+      const int nq = DP / 4;
+      const int q_lo = (int)((long long)nq * seg / nseg), q_hi = (int)((long long)nq * (seg + 1) / nseg);
+      for (int q = q_lo; q < q_hi; ++q) {
+        const float4 d = *reinterpret_cast<const float4*>(pd + 4 * q);
+        const float4 x0 = *reinterpret_cast<const float4*>(px + 4 * q);
+        const float2 x1 = *reinterpret_cast<const float2*>(px + 4 * q + 4);
+        acc[0] = fmaf(d.x, x0.x, acc[0]); acc[1] = fmaf(d.x, x0.y, acc[1]); acc[2] = fmaf(d.x, x0.z, acc[2]);
+        acc[0] = fmaf(d.y, x0.y, acc[0]); acc[1] = fmaf(d.y, x0.z, acc[1]); acc[2] = fmaf(d.y, x0.w, acc[2]);
+        acc[0] = fmaf(d.z, x0.z, acc[0]); acc[1] = fmaf(d.z, x0.w, acc[1]); acc[2] = fmaf(d.z, x1.x, acc[2]);
+        acc[0] = fmaf(d.w, x0.w, acc[0]); acc[1] = fmaf(d.w, x1.x, acc[1]); acc[2] = fmaf(d.w, x1.y, acc[2]);
+      }
+    } else {
+      const int w_lo = (int)((long long)a.Wo * seg / nseg), w_hi = (int)((long long)a.Wo * (seg + 1) / nseg);
+      for (int wo = w_lo; wo < w_hi; ++wo) {
+        const float d = pd[wo];
 #pragma unroll
-      for (int k = 0; k < DIRECT_KW_MAX; ++k)
-        if (k < a.KW) acc[k] = fmaf(d, px[wo * a.sw + k], acc[k]);
+        for (int k = 0; k < DIRECT_KW_MAX; ++k)
+          if (k < a.KW) acc[k] = fmaf(d, px[wo * a.sw + k], acc[k]);
+      }
     }
   }
   __syncthreads();  // the staged rows are dead: their space takes the segments' sums
@@ -1233,7 +1262,8 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     DirectArgs a = {x, nullptr, nullptr, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H,
                     p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
     const int npair = p->Cout * p->Cin * p->KH;
-    const size_t lds = ((size_t)p->Cout * p->Wo + (size_t)p->Cin * p->KH * ((p->W + 2 * p->pw) | 1)) * sizeof(float);
+    const size_t lds = ((size_t)p->Cout * ((p->Wo + 3) & ~3) +
+                        (size_t)p->Cin * p->KH * (((p->W + 2 * p->pw + 3) & ~3) + 4)) * sizeof(float);
     static const int use_rows = getenv("AIR_DIRECT_WGRAD_ROWS") ? atoi(getenv("AIR_DIRECT_WGRAD_ROWS")) : 1;
     if (use_rows && p->KW <= DIRECT_KW_MAX && npair <= 512 && lds <= 150 * 1024) {
       int nseg = 512 / npair;
