@@ -44,14 +44,25 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
   float* ws = xs + (size_t)C * TP;
   const int b = blockIdx.x;
   const float* __restrict__ xb = x + (size_t)b * C * T;
-  for (int e = threadIdx.x; e < C * T; e += NT) {
-    const int c = e / T, t = e - c * T;
-    xs[c * TP + t] = xb[e];
+  // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
+  for (int e0 = threadIdx.x; e0 < C * T; e0 += 8 * NT) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = e0 + u * NT < C * T ? xb[e0 + u * NT] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NT;
+      if (e < C * T) {
+        const int c = e / T, t = e - c * T;
+        xs[c * TP + t] = v[u];
+      }
+    }
   }
   __syncthreads();
   // w_t = <x[:, t], a>   (torch.bmm, resnet.py:26)
   for (int t = threadIdx.x; t < T; t += NT) {
     float s = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) s = fmaf(xs[c * TP + t], att[c], s);
     ws[t] = tanhf(s);
   }
@@ -73,6 +84,7 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
   // weighted mean and unbiased std over T (resnet.py:37-42)
   for (int c = threadIdx.x; c < C; c += NT) {
     float avg = 0.0f, zs = 0.0f;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) {
       const float wv = xs[c * TP + t] * ws[t];
       avg += wv;
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
     }
     const float zm = zs / (float)T;
     float ss = 0.0f;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) {
       float z = xs[c * TP + t] * ws[t];
       if (noise) z += noise[((size_t)b * T + t) * C + c];
@@ -113,14 +126,25 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   const int b = blockIdx.x;
   const float* __restrict__ xb = x + (size_t)b * C * T;
   const float* __restrict__ nb = noise ? noise + (size_t)b * T * C : nullptr;
-  for (int e = threadIdx.x; e < C * T; e += NT) {
-    const int c = e / T, t = e - c * T;
-    xs[c * TP + t] = xb[e];
+  // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
+  for (int e0 = threadIdx.x; e0 < C * T; e0 += 8 * NT) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = e0 + u * NT < C * T ? xb[e0 + u * NT] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NT;
+      if (e < C * T) {
+        const int c = e / T, t = e - c * T;
+        xs[c * TP + t] = v[u];
+      }
+    }
   }
   for (int t = threadIdx.x; t < T; t += NT) al[t] = alpha[(size_t)b * T + t];
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += NT) {
     float zs = 0.0f;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) {
       float z = xs[c * TP + t] * al[t];
       if (nb) z += nb[(size_t)t * C + c];
@@ -133,10 +157,11 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
     dav[c] = dout[(size_t)b * 2 * C + c];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < T; t += NT) {
+  // a wave per frame, lanes over the channels: the noise rows (B, T, C) are read coalesced
+  for (int t = threadIdx.x >> 6; t < T; t += NT / 64) {
     float acc = 0.0f, s = 0.0f;
     const float a_t = al[t];
-    for (int c = 0; c < C; ++c) {
+    for (int c = threadIdx.x & 63; c < C; c += 64) {
       const float xv = xs[c * TP + t];
       float z = xv * a_t;
       if (nb) z += nb[(size_t)t * C + c];
@@ -144,9 +169,13 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
       acc = fmaf(g, xv, acc);
       s = fmaf(xv, att[c], s);
     }
-    dal[t] = acc;
-    const float u = tanhf(s);
-    dw[t] = 1.0f - u * u;  // finished below once <alpha, dalpha> is known
+    acc = air_wave_sum(acc);
+    s = air_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) {
+      dal[t] = acc;
+      const float u = tanhf(s);
+      dw[t] = 1.0f - u * u;  // finished below once <alpha, dalpha> is known
+    }
   }
   __syncthreads();
   float dot = 0.0f;
@@ -158,15 +187,23 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   for (int c = threadIdx.x; c < C; c += NT) {
     const float ac = att[c], cf = coef[c], dv = dav[c], zmc = zm[c];
     float da = 0.0f;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) {
       const float xv = xs[c * TP + t];
       float z = xv * al[t];
       if (nb) z += nb[(size_t)t * C + c];
       const float g = dv + cf * (z - zmc);
-      dx[((size_t)b * C + c) * T + t] = g * al[t] + dw[t] * ac;
+      xs[c * TP + t] = g * al[t] + dw[t] * ac;  // dx, staged: this thread is the only reader of its x row
       da = fmaf(dw[t], xv, da);
     }
     datt_partial[(size_t)b * C + c] = da;
+  }
+  __syncthreads();
+  // dx leaves with consecutive lanes on consecutive frames (a thread per channel row wrote 64 rows per store)
+  float* __restrict__ dxb = dx + (size_t)b * C * T;
+  for (int e = threadIdx.x; e < C * T; e += NT) {
+    const int c = e / T, t = e - c * T;
+    dxb[e] = xs[c * TP + t];
   }
 }
 
