@@ -921,6 +921,14 @@ __device__ __forceinline__ G2Tile g2_tile(const NtGemm& p, int work) {
   return t;
 }
 
+// BKM: the B operand is K-MAJOR - element (k, n) at b + k * b_rs + n, n contiguous - i.e. an activation's bf16 copy
+// [b][channel][Tp] as the producers write it and the weight gradient reads it; no transposed copy (c1b_cvt_t) is
+// made for the forward / dgrad GEMM.  Its stage is [64 k][256 n] (512-byte rows, 16-byte chunk c of row k at
+// position c ^ ((k & 3) << 2)) and a lane assembles its 8 consecutive k with two `ds_read_b64_tr_b16`: the 16
+// lanes of a group point at a [4 k][16 n] block, 4 contiguous n each, and receive one column of it
+// (tools/ubench/tr_read.hip prints the mapping).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool BKM>
 __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsigned a_bytes, unsigned b_bytes) {
   extern __shared__ __attribute__((aligned(1024))) char g2_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -939,16 +947,21 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
   const int r8 = lane >> 3, pos = lane & 7;
   const unsigned av0 = (unsigned)((r8 * p.a_rs + ((pos ^ (r8 >> 1)) * 8)) * 2);
   const unsigned av1 = (unsigned)((r8 * p.a_rs + ((pos ^ (r8 >> 1) ^ 4) * 8)) * 2);
-  const unsigned bv0 = (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1)) * 8)) * 2);
-  const unsigned bv1 = (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1) ^ 4) * 8)) * 2);
-  const unsigned arow8 = (unsigned)(8 * p.a_rs * 2), brow8 = (unsigned)(8 * p.b_rs * 2);
+  // B, K-major: instruction q of wave w covers k rows 8 w + 2 q + (lane >> 5), 32 chunks each
+  const unsigned bv0 = BKM ? (unsigned)((lane >> 5) * p.b_rs * 2 + (((lane & 31) ^ ((lane >> 5) << 2)) * 16))
+                           : (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1)) * 8)) * 2);
+  const unsigned bv1 = BKM ? (unsigned)((lane >> 5) * p.b_rs * 2 + (((lane & 31) ^ ((2 + (lane >> 5)) << 2)) * 16))
+                           : (unsigned)((r8 * p.b_rs + ((pos ^ (r8 >> 1) ^ 4) * 8)) * 2);
+  const unsigned arow8 = (unsigned)(8 * p.a_rs * 2), brow8 = (unsigned)((BKM ? 2 : 8) * p.b_rs * 2);
   int it_i = 0, iseg = 0, ik = 0, islot = 0;  // next stage to issue
   G2Tile ti = g2_tile(p, first);
   auto issue = [&]() {
     const unsigned base = lds0 + islot * G2_SB + wave * 4096;
     const size_t koff = (size_t)iseg * p.a_ss + (size_t)ik * GK, koffb = (size_t)iseg * p.b_ss + (size_t)ik * GK;
     const unsigned ao = (unsigned)(((size_t)ti.batch * p.a_bs + (size_t)(ti.m0 + 32 * wave) * p.a_rs + koff) * 2);
-    const unsigned bo = (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + 32 * wave) * p.b_rs + koffb) * 2);
+    const unsigned bo = BKM ? (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)iseg * p.b_ss +
+                                          ((size_t)ik * GK + 8 * wave) * p.b_rs + ti.n0) * 2)
+                            : (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + 32 * wave) * p.b_rs + koffb) * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) fd_dma16(ars, ao + q * arow8, base + q * 1024, (q & 1) ? av1 : av0);
 #pragma unroll
@@ -995,7 +1008,25 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 32 + r) * GK + cpos);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+        for (int j = 0; j < 2; ++j) {
+          if (BKM) {
+            const int i16 = lane & 15, gsel = (lane >> 4) & 1;
+            const int nl = wn * 64 + j * 32 + gsel * 16 + 4 * (i16 & 3);  // first of this lane's 4 columns
+            s16x4 h[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int row = kk * 16 + kg * 8 + 4 * hh + (i16 >> 2);
+              const unsigned short* src = sB + row * 256 + (((nl >> 3) ^ ((i16 >> 2) << 2)) << 3) + (nl & 4);
+              h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)src);
+            }
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 both = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+            fb[j] = __builtin_bit_cast(bf16x8, both);
+          } else {
+            fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1309,19 +1340,28 @@ bool gemm_ps_ok(int M) {
 
 // *bf_done (optional): set when the kernel that ran wrote g.out_bf itself
 int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_bytes, int kid, double flops,
-                hipStream_t st, bool* bf_done = nullptr) {
+                hipStream_t st, bool* bf_done = nullptr, bool b_kmajor = false) {
   if (bf_done) *bf_done = false;
+  if (b_kmajor && !(gemm_ps_ok(g.M) && n_padded % G2_BN == 0 && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) &&
+                    ((size_t)g.out & 7) == 0 && g.o_bs % 2 == 0 && g.b_rs % 8 == 0))
+    return AIR_EUNSUPPORTED;  // only the 256 x 256 kernel reads a K-major B
   if (gemm_ps_ok(g.M) && n_padded % G2_BN == 0 && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) &&
       ((size_t)g.out & 7) == 0 && g.o_bs % 2 == 0) {
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) == hipSuccess;
+    static const bool attr_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) == hipSuccess;
     if (!attr_ok) return AIR_ELAUNCH;
     g.tiles_m = g.M / G2_BM;
     g.tiles_n = n_padded / G2_BN;
     g.total = g.tiles_m * g.tiles_n * nbatch;
     g.per_xcd = (g.total + NXCD - 1) / NXCD;
     AirProfScope prof(kid, flops, st);
-    hipLaunchKernelGGL(c1b_gemm_ps_kernel, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
+    if (b_kmajor)
+      hipLaunchKernelGGL(c1b_gemm_ps_kernel<true>, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
+    else
+      hipLaunchKernelGGL(c1b_gemm_ps_kernel<false>, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
     AIR_CHECK_LAUNCH();
     if (bf_done) *bf_done = g.out_bf != nullptr;
     return AIR_OK;
@@ -1403,6 +1443,31 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
     if (part > n) n = part;
   }
   return n + 256;
+}
+
+int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* xb, size_t xb_bstride, const float* w,
+                                     int dgrad, const float* bias, const float* bias_bc, int relu, const float* accumulate,
+                                     float* y, unsigned short* y_bf16, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!shape_ok(p) || !xb || !w || !y) return AIR_EINVAL;
+  if (!air_conv1d_bf16_supported(p, dgrad ? 1 : 0)) return AIR_EUNSUPPORTED;
+  if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  const int M = dgrad ? p->Cin : p->Cout, K = dgrad ? p->Cout : p->Cin, B = p->B, T = p->T;
+  const int Tp = round_up(T, TP_ALIGN);
+  if (K % GK != 0) return AIR_EUNSUPPORTED;
+  unsigned short* a = reinterpret_cast<unsigned short*>(ws);
+  const size_t n2 = (size_t)M * K / 2;
+  hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, dgrad ? 1 : 0);
+  AIR_CHECK_LAUNCH();
+  NtGemm g;
+  g.a = a; g.b = xb; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = accumulate;
+  g.out_bf = y_bf16; g.out_bf_rs = Tp;
+  g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
+  g.b_rs = Tp; g.b_ss = 0; g.b_bs = xb_bstride ? xb_bstride : (size_t)K * Tp;
+  g.o_rs = T; g.o_bs = dgrad ? xbs(p) : ybs(p);
+  g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
+  return launch_gemm(g, B, Tp, (size_t)M * K * 2, ((size_t)(B - 1) * g.b_bs + (size_t)K * Tp) * 2, AIR_K_C1B_GEMM,
+                     2.0 * B * T * (double)p->Cout * p->Cin, st, nullptr, true);
 }
 
 int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const unsigned short* w_packed,

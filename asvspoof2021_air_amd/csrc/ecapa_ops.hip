@@ -228,7 +228,8 @@ __global__ __launch_bounds__(NT) void se_scale_kernel(const float* __restrict__ 
                                                       const float* __restrict__ z,
                                                       const float* __restrict__ res, size_t res_b,
                                                       int C, int T, float* __restrict__ out,
-                                                      size_t out_b, size_t rows) {
+                                                      size_t out_b, size_t rows, unsigned short* __restrict__ bf,
+                                                      size_t bf_b, int Tp) {
   const size_t row = (size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -237,7 +238,14 @@ __global__ __launch_bounds__(NT) void se_scale_kernel(const float* __restrict__ 
   const float* __restrict__ px = x + row * T;
   const float* __restrict__ pr = res + b * res_b + c * T;
   float* __restrict__ po = out + b * out_b + c * T;
-  for (int t = lane; t < T; t += 64) po[t] = fmaf(px[t], g, pr[t]);
+  // bf (optional): the result also as bf16 at bf[b * bf_b + c * Tp + t] - the block output's slice of the concat's
+  // bf16 copy, which layer4's GEMM and three weight gradients read
+  unsigned short* __restrict__ pf = bf ? bf + b * bf_b + c * (size_t)Tp : nullptr;
+  for (int t = lane; t < T; t += 64) {
+    const float v = fmaf(px[t], g, pr[t]);
+    po[t] = v;
+    if (pf) pf[t] = bf16_bits(v);
+  }
 }
 
 // backward: dx = dout * sigmoid(z); dz = s(1-s) * sum_t dout*x   (dres = dout, same tensor)
@@ -544,15 +552,23 @@ int air_row_stats_bwd(const float* x, int B, int C, int T, const float* mean, co
                               nullptr, 0, stream);
 }
 
-int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
-                     int C, int T, float* out, size_t out_bstride, air_stream_t stream) {
+int air_se_scale_fwd_ex(const float* x, const float* z, const float* res, size_t res_bstride, int B,
+                        int C, int T, float* out, size_t out_bstride, unsigned short* out_bf16, size_t out_bf16_bstride,
+                        int out_bf16_tp, air_stream_t stream) {
   if (!x || !z || !res || !out || B <= 0 || C <= 0 || T <= 0) return AIR_EINVAL;
+  if (out_bf16 && out_bf16_tp < T) return AIR_EINVAL;
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(NT), 0,
                      air_stream(stream), x, z, res, res_bstride ? res_bstride : (size_t)C * T, C, T,
-                     out, out_bstride ? out_bstride : (size_t)C * T, rows);
+                     out, out_bstride ? out_bstride : (size_t)C * T, rows, out_bf16,
+                     out_bf16_bstride ? out_bf16_bstride : (size_t)C * out_bf16_tp, out_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
+                     int C, int T, float* out, size_t out_bstride, air_stream_t stream) {
+  return air_se_scale_fwd_ex(x, z, res, res_bstride, B, C, T, out, out_bstride, nullptr, 0, 0, stream);
 }
 
 int air_se_scale_bwd(const float* x, const float* z, const float* dout, size_t dout_bstride, int B,

@@ -189,7 +189,7 @@ class Res2Net2(nn.Module):
         return feat, out
 
     # ------------------------------------------------------------------ forward
-    def _block_fwd(self, blk, inp, out, training, save):
+    def _block_fwd(self, blk, inp, out, training, save, out_bf=None):
         """Bottle2neck (ecapa_tdnn.py:64-95).  ``inp`` / ``out`` may be channel-slice views."""
         B, C, T = inp.shape
         w, d, nums = blk.width, blk.dilation, blk.nums
@@ -236,7 +236,7 @@ class Res2Net2(nn.Module):
         stS = _bn(z1.view(B, -1, 1), se[3], training)
         z1n = ops.bn_apply(z1.view(B, -1, 1), stS[2], stS[3]).view(B, -1)
         z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
-        ops.se_scale_fwd(o3, z2, inp, out)
+        ops.se_scale_fwd(o3, z2, inp, out, out_bf=out_bf)
         if save:
             return dict(blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat, cat_bf=cat_bf,
                         r3=r3, st3=st3, o3=o3, m=m, z1=z1, stS=stS, z1n=z1n, z2=z2)
@@ -252,17 +252,27 @@ class Res2Net2(nn.Module):
         st0 = _bn(r0, self.bn1, training)
         h = ops.bn_apply(r0, st0[2], st0[3])  # :161
         cat123 = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
+        # bf16 training: the concat's bf16 copy [b][1536][Tp] is written slice by slice by the blocks' last kernels;
+        # layer4's forward GEMM reads it K-major (no transposed copy), its weight gradient and the conv1 weight
+        # gradients of blocks 2 and 3 read it in backward
+        cat_bf = ops.bf16_rows(None, B, 3 * C, T, x.device) if (bf and save and T % 2 == 0) else None
         blocks = []
         inp = h
         for k, blk in enumerate((self.layer1, self.layer2, self.layer3)):
             out = cat123[:, k * C:(k + 1) * C]
-            blocks.append(self._block_fwd(blk, inp, out, training, save))
+            blocks.append(self._block_fwd(blk, inp, out, training, save,
+                                          out_bf=cat_bf[:, k * C:(k + 1) * C] if cat_bf is not None else None))
             inp = out
         # bf16 training: layer4's GEMM epilogue also writes x4's bf16 copy, the X operand of attention.0's weight
         # gradient (kept until backward like x4 itself)
         x4_bf = ops.bf16_rows(None, B, self.layer4.out_channels, T, x.device) if (bf and save) else None
-        x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf,
-                            y_bf=x4_bf)  # :172-173
+        x4 = None
+        if cat_bf is not None:
+            x4 = ops.conv1d_pointwise_kmajor(cat_bf, det(self.layer4.weight), T, bias=det(self.layer4.bias), relu=True,
+                                             y_bf=x4_bf)
+        if x4 is None:
+            x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf,
+                                y_bf=x4_bf)  # :172-173
         mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178)
         ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
         a0, a3 = self.attention[0], self.attention[3]
@@ -290,7 +300,8 @@ class Res2Net2(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean, std=std,
+            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
+                     std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
         ops.bn_flush()
@@ -459,10 +470,13 @@ class Res2Net2(nn.Module):
         ops.sum_rows(rows, out=G["layer4.bias"])
         # the concat's bf16 copy is made once: layer4's weight gradient reads all of it, the conv1 weight gradients
         # of blocks 2 and 3 read the channel slices that were their inputs
-        cat_bf = ops.bf16_rows("ecapa.cat123", B, 3 * C, T, dx4.device) if bf else None
+        cat_bf = S["cat_bf"]
+        made_here = bf and cat_bf is None
+        if made_here:
+            cat_bf = ops.bf16_rows("ecapa.cat123", B, 3 * C, T, dx4.device)
 
         def layer4_wgrad():
-            if bf:
+            if made_here:
                 ops.conv1d_cvt_bf16(S["cat123"], cat_bf)
             ops.conv1d_wgrad(S["cat123"], dx4, self.layer4.weight.shape, out=G["layer4.weight"], bf16=bf, x_bf=cat_bf,
                              dy_bf=dx4_bf)
@@ -484,7 +498,10 @@ class Res2Net2(nn.Module):
         if bucketer is not None:
             bucketer.reset(arena.grad, arena.head_total)
         grads_final_from("layer4.weight")
-        dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
+        # layer4's data gradient reads d(x4)'s bf16 copy (written by the context-statistics backward) K-major
+        dcat123 = ops.conv1d_pointwise_kmajor(dx4_bf, det(self.layer4.weight), T, dgrad=True) if dx4_bf is not None else None
+        if dcat123 is None:
+            dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None
         fold = bf and T % 2 == 0  # the two-operand dgrad epilogue (bf16 pointwise path, 8-byte aligned rows)
         for k in (2, 1, 0):

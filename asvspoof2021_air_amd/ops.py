@@ -346,6 +346,34 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
     return y
 
 
+def conv1d_pointwise_kmajor(xb, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, accumulate=None, out=None,
+                            y_bf=None):
+    """K = 1 forward (y = W . x) or data gradient (dx = W^T . dy + accumulate) straight from the bf16 copy ``xb``
+    ((B, C, Tp) int16, or a channel slice of one) of the input operand.  Returns None when the layer does not fit the
+    K-major GEMM (the caller falls back to conv1d_fwd / conv1d_dgrad on the fp32 tensor)."""
+    Cout, Cin, K = w.shape
+    B = xb.shape[0]
+    Cy = Cin if dgrad else Cout
+    if K != 1 or xb.shape[1] != (Cout if dgrad else Cin):
+        return None
+    y = out if out is not None else torch.empty((B, Cy, T), device=xb.device, dtype=torch.float32)
+    yp, yb = vptr(y)
+    d = AirConv1d(B, Cin, T, Cout, 1, 1, 0, yb if dgrad else 0, 0 if dgrad else yb)
+    wsb, nb = _c1d_bf16(d, xb.device, 1 if dgrad else 0)
+    if wsb is None:
+        return None
+    xp, xbs_ = _bf_view(xb)
+    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
+    rc = _hip.lib().air_conv1d_pointwise_bf16_kmajor(
+        ctypes.byref(d), xp, csz(xbs_), dptr(w), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+        dptr(bias_bc, allow_none=True), ci(1 if relu else 0), acc, yp, dptr(y_bf, torch.int16, allow_none=True),
+        dptr(wsb, torch.uint8), csz(nb), stream())
+    if rc == -2:  # AIR_EUNSUPPORTED: shape outside the K-major kernel
+        return None
+    _hip.check(rc, "air_conv1d_pointwise_bf16_kmajor")
+    return y
+
+
 def conv1d_dgrad(dy, w, dil=1, pad=0, accumulate=None, out=None, bf16=False, accumulate2=None, w_packed=None):
     """dx = conv1d_transpose(dy, w) (+ accumulate, addressed like out).  bf16 pointwise path: accumulate may be a
     channel-slice view and a second operand accumulate2 (view or dense) is added in the same epilogue."""
@@ -516,12 +544,15 @@ def relu_mask_(dx, y):
     return dx
 
 
-def se_scale_fwd(x, z, res, out):
+def se_scale_fwd(x, z, res, out, out_bf=None):
+    """out = x * sigmoid(z[b][c]) + res; out_bf: channel slice of a (B, C', Tp) int16 copy that also receives it as bf16."""
     B, C, T = x.shape
     rp, rb = vptr(res)
     op, ob = vptr(out)
-    _hip.check(_hip.lib().air_se_scale_fwd(dptr(x), dptr(z), rp, csz(rb), ci(B), ci(C), ci(T), op, csz(ob),
-                                           stream()), "air_se_scale_fwd")
+    fp, fb = _bf_view(out_bf)
+    _hip.check(_hip.lib().air_se_scale_fwd_ex(dptr(x), dptr(z), rp, csz(rb), ci(B), ci(C), ci(T), op, csz(ob), fp,
+                                              csz(fb), ci(out_bf.shape[2] if out_bf is not None else 0), stream()),
+               "air_se_scale_fwd_ex")
     return out
 
 

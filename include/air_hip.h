@@ -213,6 +213,16 @@ int air_conv1d_tap_pack_bf16(const float* w, size_t w_stride, int n_layers, int 
                              unsigned short* out, air_stream_t stream);
 int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, float* dx,
                           const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+/* Forward (dgrad = 0: y = W . x) or data gradient (dgrad = 1: dx = W^T . dy + accumulate) of a K = 1 layer whose INPUT
+ * operand the caller already holds as a bf16 copy in the weight-gradient layout [b][channel][Tp] (xb, batch stride
+ * xb_bstride in elements, 0 = dense): the 256 x 256 GEMM reads it K-major (ds_read_b64_tr_b16), so neither a
+ * conversion nor a transposed copy is made - the SAME copy serves this layer's forward, its data gradient's
+ * counterpart and the weight gradients around it.  Needs Cout % 256 == 0 (forward) / Cin % 256 == 0 (dgrad), the K
+ * dimension a multiple of 64 and Tp % 256 == 0; AIR_EUNSUPPORTED otherwise.  y_bf16 as in air_conv1d_fwd_bf16_ex. */
+int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* xb, size_t xb_bstride, const float* w,
+                                     int dgrad, const float* bias, const float* bias_bc, int relu,
+                                     const float* accumulate, float* y, unsigned short* y_bf16, void* ws,
+                                     size_t ws_bytes, air_stream_t stream);
 /* Same with up to two accumulate operands, each with its own batch stride in floats (0 = dx's): dx = dgrad +
  * accumulate + accumulate2.  ECAPA's block input gradient = dgrad(conv1) + d(block output) [the residual,
  * ecapa_tdnn.py:93] + the (B, 1536, T) concat gradient's slice for the previous block [:170] in one epilogue.
@@ -375,6 +385,11 @@ int air_row_sum(const float* x, int B, int C, int T, float* out, air_stream_t st
 /* SEModule gate + block residual (ecapa_tdnn.py:27-29,:93): out = x*sigmoid(z[b][c]) + res. */
 int air_se_scale_fwd(const float* x, const float* z, const float* res, size_t res_bstride, int B,
                      int C, int T, float* out, size_t out_bstride, air_stream_t stream);
+/* Same, with a bf16 copy of out at out_bf16[b * bstride + c * tp + t] (bstride in elements, 0 = C * tp): a block's
+ * output is a channel slice of the (B, 1536, T) concat, and this fills the matching slice of the concat's bf16 copy. */
+int air_se_scale_fwd_ex(const float* x, const float* z, const float* res, size_t res_bstride, int B,
+                        int C, int T, float* out, size_t out_bstride, unsigned short* out_bf16,
+                        size_t out_bf16_bstride, int out_bf16_tp, air_stream_t stream);
 int air_se_scale_bwd(const float* x, const float* z, const float* dout, size_t dout_bstride, int B,
                      int C, int T, float* dx, float* dz, air_stream_t stream);
 /* Attentive statistics pooling (ecapa_tdnn.py:143-185): softmax over T of the attention

@@ -226,3 +226,34 @@ def test_res2_and_add_strided_write_bf16_slices(ops, T):
     assert torch.equal(cat1[:, 2 * w:], o1[:, 2 * w:])
     assert torch.equal(cat_bf[:, w:, :T].cpu(), bf16_bits(cat1[:, w:]))
     assert int(cat_bf[:, :, T:].abs().max()) == 0  # (the first group was never written: fresh memory, only the padding is zeroed)
+
+
+@pytest.mark.parametrize("cfg", [(2, 1536, 1536, 750), (3, 512, 512, 750), (2, 512, 256, 200), (2, 256, 1536, 130)])
+def test_pointwise_from_kmajor_bf16_copy(ops, cfg):
+    """Forward and data gradient straight from the operand's bf16 copy [b][C][Tp] (K-major B operand read with
+    ds_read_b64_tr_b16) vs the kernels that start from the fp32 tensor: same rounding, same products."""
+    B, Cin, Cout, T = cfg
+    x = synth_feat((B, Cin, T), 1).cuda()
+    w = synth_feat((Cout, Cin, 1), 2, scale=0.05).cuda()
+    bias = synth_feat((Cout,), 3, scale=0.2).cuda()
+    dy = synth_feat((B, Cout, T), 4).cuda()
+    other = synth_feat((B, Cin, T), 5).cuda()
+    xb = ops.conv1d_cvt_bf16(x, ops.bf16_rows(None, B, Cin, T, x.device))
+    dyb = ops.conv1d_cvt_bf16(dy, ops.bf16_rows(None, B, Cout, T, x.device))
+    y_ref = ops.conv1d_fwd(x, w, bias, relu=True, bf16=True)
+    ybf = ops.bf16_rows(None, B, Cout, T, x.device)
+    y = ops.conv1d_pointwise_kmajor(xb, w, T, bias=bias, relu=True, y_bf=ybf)
+    if Cout % 256 == 0 and Cin % 64 == 0:
+        assert y is not None
+        close(y, y_ref, 2e-6, "kmajor fwd")
+        assert torch.equal(ybf[:, :, :T].cpu(), bf16_bits(y))
+    d_ref = ops.conv1d_dgrad(dy, w, bf16=True, accumulate=other)
+    d = ops.conv1d_pointwise_kmajor(dyb, w, T, dgrad=True, accumulate=other)
+    if Cin % 256 == 0 and Cout % 64 == 0:
+        assert d is not None
+        close(d, d_ref, 2e-6, "kmajor dgrad")
+    # a channel slice of a wider copy as the operand
+    wide = ops.conv1d_cvt_bf16(torch.cat((other, x), 1), ops.bf16_rows(None, B, 2 * Cin, T, x.device))
+    y2 = ops.conv1d_pointwise_kmajor(wide[:, Cin:], w, T, bias=bias, relu=True)
+    if y is not None:
+        assert torch.equal(y2, y)
