@@ -164,7 +164,8 @@ template <bool PEEL>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int C, int S,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
-                                                      float* __restrict__ y, float* __restrict__ rowmean) {
+                                                      float* __restrict__ y, float* __restrict__ rowmean,
+                                                      unsigned short* __restrict__ bf, int Tp) {
   __shared__ float wsum[NT / 64];
   const int plane = blockIdx.x;
   const int c = plane % C;
@@ -177,11 +178,14 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
   const int h = PEEL ? head8(p, q) : (head8(p) | head8(q) ? -1 : 0);
   const int i0 = h < 0 ? 4 * qi : h + 4 * qi;
   float tsum = 0.0f;
+  // bf (optional): y also as bf16, [plane][Tp] (a later weight gradient's operand, conv1d_bf16.hip)
+  unsigned short* __restrict__ pbf = bf ? bf + (size_t)plane * Tp : nullptr;
   auto scalar = [&](int lo, int hi) {
     for (int i = lo; i < hi; ++i) {
       float v = p[i] * sc + sh;
       if (relu) v = fmaxf(v, 0.f);
       q[i] = v;
+      if (pbf) pbf[i] = (unsigned short)(bf16_pack2(v, 0.0f) & 0xffffu);
       tsum += v;
     }
   };
@@ -194,6 +198,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     *reinterpret_cast<f4a8*>(q + i0) = v;
+    if (pbf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pbf[i0 + e] = (unsigned short)(bf16_pack2(v[e], 0.0f) & 0xffffu);
+    }
     tsum += (v[0] + v[1]) + (v[2] + v[3]);
   } else if (!PEEL && h >= 0 && i0 + 2 == S) {
     f2a8 v = *reinterpret_cast<const f2a8*>(p + i0);
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       v[1] = fmaxf(v[1], 0.f);
     }
     *reinterpret_cast<f2a8*>(q + i0) = v;
+    if (pbf) *reinterpret_cast<unsigned*>(pbf + i0) = bf16_pack2(v[0], v[1]);
     tsum += v[0] + v[1];
   } else {
     scalar((PEEL && h > 0 && qi == 0) ? 0 : i0, min(S, i0 + 4));
@@ -559,25 +568,28 @@ int air_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 }
 
 int air_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift,
-                    int relu, float* y, float* rowmean, air_stream_t stream) {
+                    int relu, float* y, float* rowmean, unsigned short* y_bf16, int y_bf16_tp, air_stream_t stream) {
   if (!x || !scale || !shift || !y || B <= 0 || C <= 0 || S <= 0) return AIR_EINVAL;
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
   if (rowmean && (S < FLAT_S || grid.y != 1)) return AIR_EUNSUPPORTED;
+  if (y_bf16 && (S < FLAT_S || y_bf16_tp < S || (y_bf16_tp & 1))) return AIR_EINVAL;
   const size_t n = (size_t)B * C * S;
   if (S < FLAT_S)
     hipLaunchKernelGGL(bn_apply_flat_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, air_stream(stream), x, C, S,
                        n, scale, shift, relu, y);
   else if (S & 1)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean,
+                       y_bf16, y_bf16_tp);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, air_stream(stream), x, C, S, scale, shift, relu, y, rowmean,
+                       y_bf16, y_bf16_tp);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
 
 int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const float* shift,
                  int relu, float* y, air_stream_t stream) {
-  return air_bn_apply_ex(x, B, C, S, scale, shift, relu, y, nullptr, stream);
+  return air_bn_apply_ex(x, B, C, S, scale, shift, relu, y, nullptr, nullptr, 0, stream);
 }
 
 int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,

@@ -250,7 +250,10 @@ class Res2Net2(nn.Module):
         C = self.C
         r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
         st0 = _bn(r0, self.bn1, training)
-        h = ops.bn_apply(r0, st0[2], st0[3])  # :161
+        # bf16 training: the first block's input and attention's hidden tensor leave their BatchNorm with a bf16 copy
+        # (X operands of the conv1 / attention.3 weight gradients)
+        h_bf = ops.bf16_rows(None, B, C, T, x.device) if (bf and save) else None
+        h = ops.bn_apply(r0, st0[2], st0[3], y_bf=h_bf)  # :161
         cat123 = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
         # bf16 training: the concat's bf16 copy [b][1536][Tp] is written slice by slice by the blocks' last kernels;
         # layer4's forward GEMM reads it K-major (no transposed copy), its weight gradient and the conv1 weight
@@ -284,7 +287,8 @@ class Res2Net2(nn.Module):
         ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std]
         a1 = ops.conv1d_fwd(x4, w_x, det(a0.bias), bias_bc=ctxb, relu=True, bf16=bf)  # attention.0 + ReLU
         stA = _bn(a1, self.attention[2], training)
-        a1n = ops.bn_apply(a1, stA[2], stA[3])
+        a1n_bf = ops.bf16_rows(None, B, a1.shape[1], T, x.device) if (bf and save) else None
+        a1n = ops.bn_apply(a1, stA[2], stA[3], y_bf=a1n_bf)
         wts = ops.conv1d_fwd(a1n, det(a3.weight), det(a3.bias), bf16=bf)  # logits -> softmax weights below
         pooled = ops.asp_fwd(x4, wts)  # :184-187 (mu | sg)
         st5 = _bn(pooled.view(B, -1, 1), self.bn5, training)
@@ -300,7 +304,7 @@ class Res2Net2(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S = dict(x=x, r0=r0, st0=st0, h=h, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
+            S = dict(x=x, r0=r0, st0=st0, h=h, h_bf=h_bf, a1n_bf=a1n_bf, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
                      std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
@@ -440,7 +444,7 @@ class Res2Net2(nn.Module):
         a0, a3 = self.attention[0], self.attention[3]
         ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
         on_side(lambda: ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf,
-                                         dy_bf=wide_bf), wts)
+                                         dy_bf=wide_bf, x_bf=S["a1n_bf"]), wts)
         da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
         stA = S["stA"]
         da1_bf = ops.bf16_rows("ecapa.da1", B, 128, T, x4.device) if bf else None
@@ -515,7 +519,7 @@ class Res2Net2(nn.Module):
                 ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
                 add2 = None
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1),
-                                    inp_bf=cat_bf[:, (k - 1) * C:k * C] if (bf and k > 0) else None, add2=add2,
+                                    inp_bf=(cat_bf[:, (k - 1) * C:k * C] if k > 0 else S["h_bf"]) if bf else None, add2=add2,
                                     on_side=on_side)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]

@@ -111,13 +111,15 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=1e-5):
     return coef[0], coef[1]
 
 
-def bn_apply(x, scale, shift, relu=False, out=None, rowmean=None):
+def bn_apply(x, scale, shift, relu=False, out=None, rowmean=None, y_bf=None):
     """y = x * scale[c] + shift[c] (+ ReLU); rowmean (B, C), 32 <= S <= 1024: also the mean over s of every
     output plane (the SE squeeze taken on the way out)."""
     B, C, S = _bcs(x)
     y = out if out is not None else torch.empty_like(x)
     _hip.check(_hip.lib().air_bn_apply_ex(dptr(x), ci(B), ci(C), ci(S), dptr(scale), dptr(shift),
-                                          ci(1 if relu else 0), dptr(y), dptr(rowmean, allow_none=True), stream()),
+                                          ci(1 if relu else 0), dptr(y), dptr(rowmean, allow_none=True),
+                                          dptr(y_bf, torch.int16, allow_none=True),
+                                          ci(y_bf.shape[2] if y_bf is not None else 0), stream()),
                "air_bn_apply_ex")
     return y
 

@@ -270,9 +270,10 @@ int air_bn_apply(const float* x, int B, int C, int S, const float* scale, const 
                  int relu, float* y, air_stream_t stream);
 /* Same, and rowmean[b*C + c] (B*C floats, may be NULL) receives the mean over s of the OUTPUT plane: the SE
  * squeeze (ecapa_tdnn.py:19) of the tensor being written, without a pass that re-reads it.  rowmean needs
- * 32 <= S <= 1024 (one workgroup per plane); AIR_EUNSUPPORTED otherwise. */
+ * 32 <= S <= 1024 (one workgroup per plane); AIR_EUNSUPPORTED otherwise.  y_bf16 (may be NULL): y also as bf16 at
+ * y_bf16[(b*C + c) * y_bf16_tp + s], the operand layout of air_conv1d_wgrad_bf16_pre. */
 int air_bn_apply_ex(const float* x, int B, int C, int S, const float* scale, const float* shift,
-                    int relu, float* y, float* rowmean, air_stream_t stream);
+                    int relu, float* y, float* rowmean, unsigned short* y_bf16, int y_bf16_tp, air_stream_t stream);
 /* Backward of y = relu?(bn(x)) in training mode.  dy: grad wrt y.  relu bit 0: a ReLU
  * follows the BN (resnet.py:64); bit 1: the BN input is itself a ReLU output
  * (conv -> ReLU -> BN, ecapa_tdnn.py:67-69), so dx is masked where x == 0 and is the

@@ -201,9 +201,11 @@ def test_bn_apply_rowmean(ops, shape):
     x = synth_feat(shape, 1).cuda()
     scale, shift = (1.0 + 0.3 * synth_feat((C,), 2)).cuda(), (0.2 * synth_feat((C,), 3)).cuda()
     m = torch.empty((B, C), device="cuda")
-    y = ops.bn_apply(x, scale, shift, relu=True, rowmean=m)
+    buf = ops.bf16_rows(None, B, C, S, x.device)
+    y = ops.bn_apply(x, scale, shift, relu=True, rowmean=m, y_bf=buf)
     assert torch.equal(y, ops.bn_apply(x, scale, shift, relu=True))
     close(m, y.double().mean(2), 2e-6, "row mean")
+    assert torch.equal(buf[:, :, :S].cpu(), bf16_bits(y))
 
 
 @pytest.mark.parametrize("T", [750, 101])
