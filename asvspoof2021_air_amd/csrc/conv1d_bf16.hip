@@ -787,7 +787,9 @@ struct NtGemm {
   float* out;               // out[batch][m][n]: out + batch * o_bs + m * o_rs + n
   const float* bias;        // [M]
   const float* bias_bc;     // [batch][M]
-  const float* acc;         // addressed like out
+  const float* acc;         // out += acc[batch * acc_bs + m * o_rs + n] (+ acc2 likewise; c1b_gemm_ps_kernel: own batch strides)
+  const float* acc2;
+  size_t acc_bs, acc2_bs;
   unsigned short* out_bf;   // optional bf16 copy of out: out_bf + (batch * M + m) * out_bf_rs + n (c1b_gemm_ps_kernel only)
   int out_bf_rs;
   size_t a_rs, a_ss, a_bs, b_rs, b_ss, b_bs, o_rs, o_bs;
@@ -1037,7 +1039,8 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
     }
     // epilogue: RP rows x 64 columns at a time through this wave's own 2 KB of LDS, 16-byte stores
     float* __restrict__ ob = p.out + (size_t)tl.batch * p.o_bs;
-    const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.batch * p.o_bs : nullptr;
+    const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.batch * p.acc_bs : nullptr;
+    const float* __restrict__ ab2 = p.acc2 ? p.acc2 + (size_t)tl.batch * p.acc2_bs : nullptr;
     float* tile = reinterpret_cast<float*>(g2_lds + 2 * G2_SB) + wave * (G2_RP * 64);
     const int c4 = (lane & 15) * 4, lrow = lane >> 4;
     const int n = tl.n0 + wn * 64 + c4;
@@ -1068,6 +1071,11 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
 #pragma unroll
               for (int e = 0; e < 4; ++e) vv[e] += u[e];
             }
+            if (ab2) {
+              const f32x4a8 u = *reinterpret_cast<const f32x4a8*>(ab2 + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vv[e] += u[e];
+            }
             f32x4a8 out;
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[e] = p.relu ? fmaxf(vv[e], 0.0f) : vv[e];
@@ -1079,6 +1087,7 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
             for (int e = 0; e < 4 && n + e < p.n_valid; ++e) {
               float w1 = vv[e];
               if (ab) w1 += ab[o + e];
+              if (ab2) w1 += ab2[o + e];
               w1 = p.relu ? fmaxf(w1, 0.0f) : w1;
               ob[o + e] = w1;
               if (p.out_bf)
@@ -1399,6 +1408,7 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   AIR_CHECK_LAUNCH();
   NtGemm g;
   g.a = a; g.b = xt; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = acc;
+  g.acc2 = nullptr; g.acc_bs = y_bs; g.acc2_bs = 0;
   g.out_bf = y_bf; g.out_bf_rs = Tp;
   g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
   g.b_rs = K; g.b_ss = 0; g.b_bs = (size_t)Tp * K;
@@ -1447,7 +1457,8 @@ size_t air_conv1d_bf16_ws_bytes(const AirConv1d* p) {
 
 int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* xb, size_t xb_bstride, const float* w,
                                      int dgrad, const float* bias, const float* bias_bc, int relu, const float* accumulate,
-                                     float* y, unsigned short* y_bf16, void* ws, size_t ws_bytes, air_stream_t stream) {
+                                     size_t acc_bstride, const float* accumulate2, size_t acc2_bstride, float* y,
+                                     unsigned short* y_bf16, void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!shape_ok(p) || !xb || !w || !y) return AIR_EINVAL;
   if (!air_conv1d_bf16_supported(p, dgrad ? 1 : 0)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_conv1d_bf16_ws_bytes(p)) return AIR_EWORKSPACE;
@@ -1460,11 +1471,15 @@ int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* x
   hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, dgrad ? 1 : 0);
   AIR_CHECK_LAUNCH();
   NtGemm g;
-  g.a = a; g.b = xb; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = accumulate;
+  g.a = a; g.b = xb; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = accumulate; g.acc2 = accumulate2;
   g.out_bf = y_bf16; g.out_bf_rs = Tp;
   g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
   g.b_rs = Tp; g.b_ss = 0; g.b_bs = xb_bstride ? xb_bstride : (size_t)K * Tp;
   g.o_rs = T; g.o_bs = dgrad ? xbs(p) : ybs(p);
+  g.acc_bs = acc_bstride ? acc_bstride : g.o_bs;
+  g.acc2_bs = acc2_bstride ? acc2_bstride : g.o_bs;
+  if (((reinterpret_cast<size_t>(accumulate) | reinterpret_cast<size_t>(accumulate2)) & 7) || g.acc_bs % 2 || g.acc2_bs % 2)
+    return AIR_EUNSUPPORTED;
   g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
   return launch_gemm(g, B, Tp, (size_t)M * K * 2, ((size_t)(B - 1) * g.b_bs + (size_t)K * Tp) * 2, AIR_K_C1B_GEMM,
                      2.0 * B * T * (double)p->Cout * p->Cin, st, nullptr, true);
@@ -1593,6 +1608,7 @@ int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* d
   }
   NtGemm g;
   g.a = dys; g.b = xs; g.out = nsplit > 1 ? partial : dw; g.bias = nullptr; g.bias_bc = nullptr; g.acc = nullptr;
+  g.acc2 = nullptr; g.acc_bs = 0; g.acc2_bs = 0;
   g.out_bf = nullptr; g.out_bf_rs = 0;
   g.a_rs = Tp; g.a_ss = a_ss; g.a_bs = (size_t)per * g.a_ss;
   g.b_rs = Tp; g.b_ss = b_ss; g.b_bs = (size_t)per * g.b_ss;

@@ -349,7 +349,7 @@ def conv1d_fwd(x, w, bias=None, bias_bc=None, relu=False, dil=1, pad=0, out=None
 
 
 def conv1d_pointwise_kmajor(xb, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, accumulate=None, out=None,
-                            y_bf=None):
+                            y_bf=None, accumulate2=None):
     """K = 1 forward (y = W . x) or data gradient (dx = W^T . dy + accumulate) straight from the bf16 copy ``xb``
     ((B, C, Tp) int16, or a channel slice of one) of the input operand.  Returns None when the layer does not fit the
     K-major GEMM (the caller falls back to conv1d_fwd / conv1d_dgrad on the fp32 tensor)."""
@@ -365,10 +365,12 @@ def conv1d_pointwise_kmajor(xb, w, T, dgrad=False, bias=None, bias_bc=None, relu
     if wsb is None:
         return None
     xp, xbs_ = _bf_view(xb)
-    acc = vptr(accumulate)[0] if accumulate is not None else ctypes.c_void_p(0)
+    acc, accb = vptr(accumulate) if accumulate is not None else (ctypes.c_void_p(0), 0)
+    acc2, acc2b = vptr(accumulate2) if accumulate2 is not None else (ctypes.c_void_p(0), 0)
     rc = _hip.lib().air_conv1d_pointwise_bf16_kmajor(
         ctypes.byref(d), xp, csz(xbs_), dptr(w), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
-        dptr(bias_bc, allow_none=True), ci(1 if relu else 0), acc, yp, dptr(y_bf, torch.int16, allow_none=True),
+        dptr(bias_bc, allow_none=True), ci(1 if relu else 0), acc, csz(accb), acc2, csz(acc2b), yp,
+        dptr(y_bf, torch.int16, allow_none=True),
         dptr(wsb, torch.uint8), csz(nb), stream())
     if rc == -2:  # AIR_EUNSUPPORTED: shape outside the K-major kernel
         return None

@@ -218,11 +218,14 @@ int air_conv1d_dgrad_bf16(const AirConv1d* p, const float* dy, const float* w, f
  * xb_bstride in elements, 0 = dense): the 256 x 256 GEMM reads it K-major (ds_read_b64_tr_b16), so neither a
  * conversion nor a transposed copy is made - the SAME copy serves this layer's forward, its data gradient's
  * counterpart and the weight gradients around it.  Needs Cout % 256 == 0 (forward) / Cin % 256 == 0 (dgrad), the K
- * dimension a multiple of 64 and Tp % 256 == 0; AIR_EUNSUPPORTED otherwise.  y_bf16 as in air_conv1d_fwd_bf16_ex. */
+ * dimension a multiple of 64 and Tp % 256 == 0; AIR_EUNSUPPORTED otherwise.  accumulate / accumulate2 (either may be
+ * NULL) with their batch strides in floats (0 = the output's), as in air_conv1d_dgrad_bf16_ex; y_bf16 as in
+ * air_conv1d_fwd_bf16_ex. */
 int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* xb, size_t xb_bstride, const float* w,
                                      int dgrad, const float* bias, const float* bias_bc, int relu,
-                                     const float* accumulate, float* y, unsigned short* y_bf16, void* ws,
-                                     size_t ws_bytes, air_stream_t stream);
+                                     const float* accumulate, size_t acc_bstride, const float* accumulate2,
+                                     size_t acc2_bstride, float* y, unsigned short* y_bf16, void* ws, size_t ws_bytes,
+                                     air_stream_t stream);
 /* Same with up to two accumulate operands, each with its own batch stride in floats (0 = dx's): dx = dgrad +
  * accumulate + accumulate2.  ECAPA's block input gradient = dgrad(conv1) + d(block output) [the residual,
  * ecapa_tdnn.py:93] + the (B, 1536, T) concat gradient's slice for the previous block [:170] in one epilogue.

@@ -254,6 +254,10 @@ def test_pointwise_from_kmajor_bf16_copy(ops, cfg):
     if Cin % 256 == 0 and Cout % 64 == 0:
         assert d is not None
         close(d, d_ref, 2e-6, "kmajor dgrad")
+        # two accumulate operands, one of them a channel slice of a wider tensor (its own batch stride)
+        wide_acc = torch.cat((other, other * 0.5), 1)
+        d2 = ops.conv1d_pointwise_kmajor(dyb, w, T, dgrad=True, accumulate=wide_acc[:, Cin:], accumulate2=other)
+        close(d2, d_ref.double() + 0.5 * other.double(), 2e-6, "kmajor dgrad + 2 operands")
     # a channel slice of a wider copy as the operand
     wide = ops.conv1d_cvt_bf16(torch.cat((other, x), 1), ops.bf16_rows(None, B, 2 * Cin, T, x.device))
     y2 = ops.conv1d_pointwise_kmajor(wide[:, Cin:], w, T, bias=bias, relu=True)
