@@ -1090,9 +1090,38 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   return m * sizeof(float) + 256;
 }
 
-int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
-                   const float* in_scale, const float* in_shift, int relu, const float* residual,
-                   double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
+// which Winograd kernel takes this 3x3 / stride 1 / pad 1 layer for `pass` (0 forward, 1 dgrad): 4, 2 or 0 (none)
+static int wino_kind(const AirConv2d* p, int pass) {
+  if (!wino_shape(p) || !generic_ok(p)) return 0;
+  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
+  if (air_wino4_ok(p->B, Kc, p->H, p->W, M)) return 4;
+  if (air_wino_ok(p->B, Kc, p->H, p->W, M)) return 2;
+  return 0;
+}
+
+size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
+  if (!p || !shape_ok(p)) return 0;
+  const int kind = wino_kind(p, pass);
+  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
+  if (kind == 4) return air_wino4_packed_elems(M, Kc) * sizeof(float);
+  if (kind == 2) return air_wino_packed_elems(M, Kc) * sizeof(float);
+  return 0;
+}
+
+int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes, air_stream_t stream) {
+  if (!p || !w || !out || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_prepack_bytes(p, pass);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  if (out_bytes < need) return AIR_EWORKSPACE;
+  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
+  float* up = reinterpret_cast<float*>(out);
+  return wino_kind(p, pass) == 4 ? air_wino4_weights(w, up, M, Kc, pass, air_stream(stream))
+                                 : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
+}
+
+int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
+                       const float* in_scale, const float* in_shift, int relu, const float* residual,
+                       double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!p || !x || !w || !y || !shape_ok(p)) return AIR_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
   if (stats != nullptr) return AIR_EUNSUPPORTED;  // fused BN statistics: not in this build
@@ -1115,11 +1144,17 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
   float* wp = reinterpret_cast<float*>(ws);
   if (in_scale == nullptr && wino_shape(p) && air_wino4_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
     if (ws_bytes < air_wino4_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)  // transformed earlier (air_conv2d_prepack): no weights kernel in front of the conv
+      return air_wino4_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
+                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
     return air_wino4_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
                           conv_flops(p), st);
   }
   if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
     if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
+                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
     return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
                          conv_flops(p), st);
   }
@@ -1137,8 +1172,14 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
                  ck, mt, conv_flops(p), st);
 }
 
-int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
-                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
+int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
+                   const float* in_scale, const float* in_shift, int relu, const float* residual,
+                   double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_conv2d_fwd_pre(p, x, w, nullptr, y, in_scale, in_shift, relu, residual, stats, ws, ws_bytes, stream);
+}
+
+int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
+                         const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!p || !dy || !w || !dx || !shape_ok(p)) return AIR_EINVAL;
   if (!generic_ok(p)) return AIR_EUNSUPPORTED;
   hipStream_t st = air_stream(stream);
@@ -1149,11 +1190,17 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
   // roles swap: "input" channels = Cout, "output" channels = Cin
   if (wino_shape(p) && air_wino4_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
     if (ws_bytes < air_wino4_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino4_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
+                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
     return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
                           conv_flops(p), st);
   }
   if (wino_shape(p) && air_wino_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
     if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
+                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
     return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
                          conv_flops(p), st);
   }
@@ -1246,6 +1293,11 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
     }
   }
   return AIR_OK;
+}
+
+int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
+                     const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_conv2d_dgrad_pre(p, dy, w, nullptr, dx, accumulate, ws, ws_bytes, stream);
 }
 
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

@@ -14,8 +14,10 @@ size_t air_wino_packed_elems(int M, int Kc);
 // y (B, M, H, W) = conv3x3_s1_p1(x (B, Kc, H, W), w) [+ residual].
 // dgrad == 0: w is (M, Kc, 3, 3).  dgrad == 1: w is (Kc, M, 3, 3) and taps are flipped, i.e. the
 // data gradient of the forward conv whose weight is w.  up: workspace of air_wino_packed_elems.
+// w == nullptr: `up` already holds the transformed weights (air_wino_weights ran earlier, e.g. on another stream).
 int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,
                   int H, int W, int M, int dgrad, float* up, double flops, hipStream_t st);
+int air_wino_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st);
 
 // Weight gradient of the same convolution (Winograd F(3x3,2x2)).  Writes K-split partial sums
 // partial[nsplit][9][Cout][Cin] (nsplit = air_wino_wgrad_nsplit) for reduce_partials_kernel.
@@ -30,3 +32,4 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M);
 size_t air_wino4_packed_elems(int M, int Kc);
 int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
                    int W, int M, int dgrad, float* up, double flops, hipStream_t st);
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st);

@@ -880,11 +880,19 @@ int air_wino_wgrad_partials(const float* x, const float* dy, float* partial, int
   return AIR_OK;
 }
 
-int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,
-                  int H, int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
+int air_wino_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st) {
   hipLaunchKernelGGL(wino_weights_kernel, dim3(grid_for((size_t)((M + WBM - 1) / WBM * WBM) * Kc)),
                      dim3(256), 0, st, w, up, M, Kc, dgrad);
   AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_wino_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc,
+                  int H, int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
+  if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino_weights)
+    const int rc = air_wino_weights(w, up, M, Kc, dgrad, st);
+    if (rc != AIR_OK) return rc;
+  }
   WinoArgs a;
   a.x = x; a.up = up; a.y = y; a.residual = residual;
   a.B = B; a.Cin = Kc; a.H = H; a.W = W; a.Cout = M;

@@ -662,11 +662,19 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
 
 size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)M * Kc * W4_NP + 1024; }
 
-int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
-                   int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st) {
   hipLaunchKernelGGL(wino4_weights_kernel, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc,
                      dgrad);
   AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
+                   int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
+  if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino4_weights)
+    const int rc = air_wino4_weights(w, up, M, Kc, dgrad, st);
+    if (rc != AIR_OK) return rc;
+  }
   W4Args a;
   a.x = x; a.up = up; a.y = y; a.residual = residual;
   a.B = B; a.Cin = Kc; a.H = H; a.W = W; a.Cout = M;

@@ -46,25 +46,42 @@ def _conv_ws(desc, device):
     return workspace(n, device), n
 
 
-def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=False, residual=None):
+def conv2d_prepack(w, x_shape, stride, padding, which, out=None):
+    """Transformed (Winograd) weights of a 3x3 / stride 1 / pad 1 layer for ``which`` (0 forward, 1 dgrad) into a
+    buffer the later conv2d_fwd / conv2d_dgrad call takes as ``w_packed``; None when the layer has no such form.
+    Runs on the current stream: call it under a side stream and order it with events."""
+    d = _conv_desc(x_shape, w.shape, stride, padding)
+    n = int(_hip.lib().air_conv2d_prepack_bytes(ctypes.byref(d), ci(which)))
+    if n == 0:
+        return None
+    if out is None or out.numel() < n:
+        out = torch.empty(n, dtype=torch.uint8, device=w.device)
+    _hip.check(_hip.lib().air_conv2d_prepack(ctypes.byref(d), dptr(w), ci(which), dptr(out, torch.uint8), csz(n),
+                                             stream()), "air_conv2d_prepack")
+    return out
+
+
+def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=False, residual=None, w_packed=None):
     """y = conv2d(act(x), w) (+ residual); act = optional per-channel affine + ReLU."""
     d = _conv_desc(x.shape, w.shape, stride, padding)
     y = torch.empty((d.B, d.Cout, d.Ho, d.Wo), device=x.device, dtype=torch.float32)
     ws, n = _conv_ws(d, x.device)
-    _hip.check(_hip.lib().air_conv2d_fwd(
-        ctypes.byref(d), dptr(x), dptr(w), dptr(y), dptr(in_scale, allow_none=True),
+    _hip.check(_hip.lib().air_conv2d_fwd_pre(
+        ctypes.byref(d), dptr(x), dptr(w), dptr(w_packed, torch.uint8, allow_none=True), dptr(y),
+        dptr(in_scale, allow_none=True),
         dptr(in_shift, allow_none=True), ci(1 if relu else 0), dptr(residual, allow_none=True),
-        ctypes.c_void_p(0), dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_fwd")
+        ctypes.c_void_p(0), dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_fwd_pre")
     return y
 
 
-def conv2d_dgrad(dy, w, x_shape, stride=1, padding=0, accumulate=None, out=None):
+def conv2d_dgrad(dy, w, x_shape, stride=1, padding=0, accumulate=None, out=None, w_packed=None):
     d = _conv_desc(x_shape, w.shape, stride, padding)
     dx = out if out is not None else torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
     ws, n = _conv_ws(d, dy.device)
-    _hip.check(_hip.lib().air_conv2d_dgrad(
-        ctypes.byref(d), dptr(dy), dptr(w), dptr(dx), dptr(accumulate, allow_none=True),
-        dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_dgrad")
+    _hip.check(_hip.lib().air_conv2d_dgrad_pre(
+        ctypes.byref(d), dptr(dy), dptr(w), dptr(w_packed, torch.uint8, allow_none=True), dptr(dx),
+        dptr(accumulate, allow_none=True),
+        dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_dgrad_pre")
     return dx
 
 

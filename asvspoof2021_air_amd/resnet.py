@@ -139,6 +139,13 @@ class ResNet(nn.Module):
         # weight gradients on a side HIP stream, overlapping the HBM-bound BN-backward passes
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self._side_stream = None
+        # Winograd weight transforms (a ~9 us kernel in front of each of the 16 + 16 forward / dgrad launches of the
+        # 3x3 stride-1 layers) depend on the weights only: from the second training step on they run on the side
+        # stream at the start of the step, under the front-end and the first layers (ops.conv2d_prepack)
+        self.prepack_weights = os.environ.get("AIR_PREPACK_WEIGHTS", "1") == "1"
+        self._geo = {}    # layer key -> (input shape, stride, padding) seen by the last training forward
+        self._packs = {}  # (layer key, pass) -> persistent buffer
+        self._pack_ev = [None, None]
         self._bucketer = None  # dist.GradBucketer when the all-reduce is overlapped with backward
 
     def enable_ddp_overlap(self, bucket_bytes=None):
@@ -153,6 +160,7 @@ class ResNet(nn.Module):
         st = dict(self.__dict__)
         st["_arena"] = None
         st["_side_stream"] = None
+        st["_geo"], st["_packs"], st["_pack_ev"] = {}, {}, [None, None]
         st["_bucketer"] = None
         st["_noise_tensor"] = None
         if st.get("noise_mode") == "tensor":
@@ -241,6 +249,37 @@ class ResNet(nn.Module):
         feat, mu, _ = self._forward_impl(x, None, save=False)
         return feat, mu
 
+    def _launch_prepack(self, fuse):
+        """Enqueue the Winograd weight transforms of every 3x3 stride-1 layer (forward unless the BatchNorm is fused
+        into the conv's operand read, dgrad always) on the side stream, for the layer geometries the previous
+        training forward saw.  Returns {(layer key, pass): buffer}; events in self._pack_ev."""
+        self._geo_live = {}
+        if not self._geo:
+            return {}
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=main.device)
+        side = self._side_stream
+        start = torch.cuda.Event()
+        start.record(main)  # the optimiser step that produced these weights is in front of it
+        side.wait_event(start)
+        live = {}
+        blocks = list(self.blocks())
+        with torch.cuda.stream(side):
+            for which in (0, 1):
+                if which == 0 and fuse:
+                    continue
+                for (bi, ci), (shape, s, pad) in self._geo.items():
+                    conv = blocks[bi].conv1 if ci == 1 else blocks[bi].conv2
+                    buf = ops.conv2d_prepack(conv.weight.detach(), shape, s, pad, which, out=self._packs.get(((bi, ci), which)))
+                    if buf is not None:
+                        self._packs[((bi, ci), which)] = buf
+                        live[((bi, ci), which)] = buf
+                        self._geo_live[(bi, ci)] = shape
+                self._pack_ev[which] = torch.cuda.Event()
+                self._pack_ev[which].record(side)
+        return live
+
     # ------------------------------------------------------------------ forward
     def _forward_impl(self, x, noise, save):
         training = self.training
@@ -253,8 +292,26 @@ class ResNet(nn.Module):
             S["x"], S["c1"], S["st1"] = x, c1, st1
             S["blocks"] = []
         fuse = self.fuse_bn_into_conv
-        for blk in self.blocks():
+        prepack = self.prepack_weights and save and training and self.overlap_wgrad
+        live = self._launch_prepack(fuse) if prepack else {}
+        waited = [False]
+
+        def packed(key, which, shape):
+            """Buffer of transformed weights for this call, or None (first step, other shapes, non-Winograd layer)."""
+            if prepack:
+                self._geo[key] = (tuple(shape), self._geo_sp[key][0], self._geo_sp[key][1])
+            buf = live.get((key, which))
+            if buf is None or self._geo_live.get(key) != tuple(shape):
+                return None
+            if which == 0 and not waited[0]:
+                torch.cuda.current_stream().wait_event(self._pack_ev[0])
+                waited[0] = True
+            return buf
+
+        self._geo_sp = {}
+        for bi, blk in enumerate(self.blocks()):
             s = blk.stride
+            self._geo_sp[(bi, 1)], self._geo_sp[(bi, 2)] = (s, 1), (1, 1)
             stA = _bn_train_coeffs(cur, blk.bn1, training)
             if fuse:  # BN-apply + ReLU folded into the conv's operand read (no activated tensor)
                 actA, pA = cur, dict(in_scale=stA[2], in_shift=stA[3], relu=True)
@@ -264,13 +321,13 @@ class ResNet(nn.Module):
                 sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, **pA)
             else:
                 sc = cur
-            h = ops.conv2d_fwd(actA, w(blk.conv1), s, 1, **pA)
+            h = ops.conv2d_fwd(actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
             stB = _bn_train_coeffs(h, blk.bn2, training)
             if fuse:
                 actB, pB = h, dict(in_scale=stB[2], in_shift=stB[3], relu=True)
             else:
                 actB, pB = ops.bn_apply(h, stB[2], stB[3], relu=True), {}
-            out = ops.conv2d_fwd(actB, w(blk.conv2), 1, 1, residual=sc, **pB)
+            out = ops.conv2d_fwd(actB, w(blk.conv2), 1, 1, residual=sc, w_packed=packed((bi, 2), 0, actB.shape), **pB)
             if save:
                 S["blocks"].append((blk, cur, stA, h, stB, actA, actB))
             cur = out
@@ -289,7 +346,9 @@ class ResNet(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S.update(l4=cur, c5=c5, st5=st5, a5v=a5v, noise=nz, pooled=pooled, alpha=alpha, feat=feat)
+            S.update(l4=cur, c5=c5, st5=st5, a5v=a5v, noise=nz, pooled=pooled, alpha=alpha, feat=feat,
+                     packs={k: v for k, v in live.items() if k[1] == 1 and self._geo_live.get(k[0]) is not None},
+                     pack_ev=self._pack_ev[1] if live else None)
         ops.bn_flush()
         return feat, mu, S
 
@@ -385,7 +444,12 @@ class ResNet(nn.Module):
         grads_final_from("conv5.weight")
         dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1))
         fuse = self.fuse_bn_into_conv
-        for blk, xin, stA, h, stB, actA, actB in reversed(S["blocks"]):
+        packs = S.get("packs") or {}
+        if packs and S.get("pack_ev") is not None:
+            main.wait_event(S["pack_ev"])  # the dgrad weight transforms enqueued on the side stream during forward
+        nblk = len(S["blocks"])
+        for ri, (blk, xin, stA, h, stB, actA, actB) in enumerate(reversed(S["blocks"])):
+            bi = nblk - 1 - ri
             s = blk.stride
             pre = nm(blk.conv1.weight)[:-len("conv1.weight")]
             pA = dict(in_scale=stA[2], in_shift=stA[3], relu=True) if fuse else {}
@@ -402,14 +466,14 @@ class ResNet(nn.Module):
                     ops.conv2d_wgrad(actA, dcur, blk.shortcut[0].weight.shape, s, 0, out=gsc, **pA)
 
             ev_dcur = on_side(wg_out, dcur)
-            d_actB = ops.conv2d_dgrad(dcur, w(blk.conv2), h.shape, 1, 1)
+            d_actB = ops.conv2d_dgrad(dcur, w(blk.conv2), h.shape, 1, 1, w_packed=packs.get(((bi, 2), 1)))
             dh, _, _ = ops.bn_bwd(h, d_actB, stB[0], stB[1], blk.bn2.weight.detach(),
                                   blk.bn2.bias.detach(), relu=True, dx=d_actB,
                                   dgamma=gv(pre + "bn2.weight"), dbeta=gv(pre + "bn2.bias"))
             g1 = gv(pre + "conv1.weight")
             on_side(lambda dh=dh, actA=actA, blk=blk, s=s, pA=pA, g1=g1:
                     ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=g1, **pA), dh)
-            d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1)
+            d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
             if has_sc:
                 ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
                                  out=d_actA)

@@ -124,6 +124,21 @@ int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
  * used to join the 1x1-shortcut and 3x3 branches of a PreActBlock). */
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
                      const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+/* Weight transforms off the critical path.  The 3x3 / stride 1 / pad 1 layers run as Winograd kernels whose
+ * transformed weights (G g G^T, packed) are otherwise produced by a small kernel in front of EVERY forward and dgrad
+ * launch (25 + 25 launches of ~9 us per ResNet-18 step, serialised with the convs).  They depend on the weights
+ * only: air_conv2d_prepack writes them for `pass` (0 forward, 1 dgrad) into a caller-owned buffer of
+ * air_conv2d_prepack_bytes(p, pass) bytes (0 = this layer / pass has no such form) - on any stream, e.g. a side
+ * stream at the start of the step - and the _pre entry points take that buffer as w_packed (NULL = transform here;
+ * layers that do not run as Winograd kernels ignore it). */
+size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass);
+int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes,
+                       air_stream_t stream);
+int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
+                       const float* in_scale, const float* in_shift, int relu, const float* residual,
+                       double* stats, void* ws, size_t ws_bytes, air_stream_t stream);
+int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
+                         const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
 /* dw = correlation(act(x), dy); same prologue as fwd so the activated tensor
  * is never materialised. */
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,
