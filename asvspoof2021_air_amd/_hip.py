@@ -47,6 +47,7 @@ def lib():
                 "(or __graft_entry__.build()). There is no CPU fallback." % _LIB_PATH)
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.air_version.restype = ctypes.c_char_p
+        _lib.air_option_name.restype = ctypes.c_char_p
         _lib.air_lfcc_plan_bytes.restype = ctypes.c_size_t
         _lib.air_preemph_ws_bytes.restype = ctypes.c_size_t
         for name in ("air_conv2d_ws_bytes", "air_bn_ws_bytes", "air_conv1d_ws_bytes", "air_conv1d_bf16_ws_bytes",
@@ -55,6 +56,38 @@ def lib():
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_size_t
     return _lib
+
+
+def set_option(name, value):
+    """Dispatch option of the library (include/air_hip.h, "dispatch options"); returns the previous value."""
+    L = lib()
+    old = ctypes.c_int(0)
+    check(L.air_get_option(name.encode(), ctypes.byref(old)), "air_get_option(%s)" % name)
+    check(L.air_set_option(name.encode(), ctypes.c_int(int(value))), "air_set_option(%s)" % name)
+    return old.value
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().air_get_option(name.encode(), ctypes.byref(v)), "air_get_option(%s)" % name)
+    return v.value
+
+
+class options:
+    """``with _hip.options(NO_WINOGRAD=3): ...`` - set dispatch options for a block, restore them after."""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc, what):

@@ -1,0 +1,24 @@
+// Dispatch options of the library: which of several equivalent kernels serves a call.  One table, one setter
+// (air_set_option in include/air_hip.h); each option is seeded once from the environment variable AIR_<NAME>
+// (the A/B switches of tools/ and the profiling scripts) and can be changed at run time, e.g. by the parity
+// tests that run the same assertion on the direct and on the Winograd kernels.  Options never change results
+// beyond the documented rounding of the kernel they select.
+#pragma once
+
+enum AirOption {
+  AIR_OPT_NO_WINO4 = 0,        // 1: 3x3/s1 forward+dgrad skip Winograd F(4x4,3x3) (-> F(2x2,3x3) or direct)
+  AIR_OPT_NO_WINOGRAD,         // bit 1: forward/dgrad on the direct f32 MFMA kernels; bit 2: weight gradients too
+                               // (3 = the strict-parity configuration: every convolution an fmaf chain)
+  AIR_OPT_WINO4_SPLIT,         // 0: never cut the k-step stream; 1: when the last round is > 13 % empty; 2: always
+  AIR_OPT_WINO4_TH3,           // 1: F(3x4,3x3) tiles where they waste fewer rows than F(4x4,3x3) (H = 9, 5, 3)
+  AIR_OPT_WINO4_XCD,           // 1: items dealt round-robin inside an XCD (shared x / U lines hit its L2)
+  AIR_OPT_CONV_MT,             // force the direct kernels' pixel-tile count (0 = heuristic)
+  AIR_OPT_WGRAD_WGS,           // workgroups of the split-K direct weight gradient
+  AIR_OPT_WINO_WGRAD_WGS,      // workgroups of the Winograd weight gradient
+  AIR_OPT_DIRECT_WGRAD_ROWS,   // 1: row-staged conv1 weight gradient
+  AIR_OPT_C1B_PS,              // bit mask: persistent bf16 pointwise kernels (1 = ps<4>, 2 = ps2, 4 = dgrad too)
+  AIR_OPT_C1B_GEMM_PS,         // 1: 256x256 persistent bf16 GEMM
+  AIR_OPT_COUNT
+};
+
+int air_opt(AirOption o);  // current value (thread-safe relaxed read)

@@ -1,7 +1,64 @@
-// Library identification for the C-ABI (include/air_hip.h).
+// Library identification and the dispatch-option table of the C-ABI (include/air_hip.h).
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
 #include "air_common.h"
+#include "air_options.h"
+
+namespace {
+struct OptDef {
+  const char* name;  // option name = environment variable without the AIR_ prefix
+  int def;
+};
+const OptDef kOpts[AIR_OPT_COUNT] = {
+    {"NO_WINO4", 0},   {"NO_WINOGRAD", 0},       {"WINO4_SPLIT", 1},       {"WINO4_TH3", 1},
+    {"WINO4_XCD", 1},  {"CONV_MT", 0},           {"WGRAD_WGS", 256},       {"WINO_WGRAD_WGS", 256},
+    {"DIRECT_WGRAD_ROWS", 1}, {"C1B_PS", 7},     {"C1B_GEMM_PS", 1},
+};
+std::atomic<int> g_val[AIR_OPT_COUNT];
+std::once_flag g_once;
+void init_opts() {
+  for (int i = 0; i < AIR_OPT_COUNT; ++i) {
+    char env[64] = "AIR_";
+    strncat(env, kOpts[i].name, sizeof(env) - 5);
+    const char* v = getenv(env);
+    g_val[i].store(v ? atoi(v) : kOpts[i].def, std::memory_order_relaxed);
+  }
+}
+int find_opt(const char* name) {
+  if (!name) return -1;
+  if (strncmp(name, "AIR_", 4) == 0) name += 4;
+  for (int i = 0; i < AIR_OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+int air_opt(AirOption o) {
+  std::call_once(g_once, init_opts);
+  return g_val[o].load(std::memory_order_relaxed);
+}
 
 extern "C" {
 const char* air_version(void) { return "air_hip gfx950 1"; }
 int air_abi_version(void) { return 1; }
+
+int air_set_option(const char* name, int value) {
+  const int i = find_opt(name);
+  if (i < 0) return AIR_EINVAL;
+  std::call_once(g_once, init_opts);
+  g_val[i].store(value, std::memory_order_relaxed);
+  return AIR_OK;
+}
+int air_get_option(const char* name, int* value) {
+  const int i = find_opt(name);
+  if (i < 0 || !value) return AIR_EINVAL;
+  *value = air_opt((AirOption)i);
+  return AIR_OK;
+}
+int air_option_count(void) { return AIR_OPT_COUNT; }
+const char* air_option_name(int index) { return index >= 0 && index < AIR_OPT_COUNT ? kOpts[index].name : nullptr; }
 }

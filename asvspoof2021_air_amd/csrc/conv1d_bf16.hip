@@ -26,6 +26,7 @@
 // Workgroups are numbered so the tiles sharing an X_b time tile (all Cout tiles) run
 // back-to-back on ONE XCD and re-read it from that XCD's L2.
 #include "air_common.h"
+#include "air_options.h"
 #include "air_prof.h"
 
 namespace {
@@ -1315,7 +1316,7 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.tiles_t = (T + BN - 1) / BN;
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
-  static const int use_ps = getenv("AIR_C1B_PS") ? atoi(getenv("AIR_C1B_PS")) : 7;
+  const int use_ps = air_opt(AIR_OPT_C1B_PS);
   // the DMA moves 16-byte chunks: frame rows have to start on 8-byte boundaries (even T and strides),
   // and every byte offset has to fit the descriptor's 32 bits
   const bool acc_al = ((reinterpret_cast<size_t>(acc) | reinterpret_cast<size_t>(acc2)) & 7) == 0 && p.acc_bs % 2 == 0 &&
@@ -1343,7 +1344,7 @@ int run_fwd(const float* x, size_t x_bs, const float* w, int transpose, float* y
 
 
 bool gemm_ps_ok(int M) {
-  static const int use = getenv("AIR_C1B_GEMM_PS") ? atoi(getenv("AIR_C1B_GEMM_PS")) : 1;
+  const int use = air_opt(AIR_OPT_C1B_GEMM_PS);
   return use && M % G2_BM == 0;
 }
 

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "air_common.h"
+#include "air_options.h"
 #include "air_prof.h"
 #include "air_lds_dma.h"
 #include "conv_wino.h"
@@ -899,7 +900,7 @@ int pick_mt(int ntiles, int cout) {
   const int npxg = (ntiles + NWAVE - 1) / NWAVE;
   const double r2 = npxg * ((cout + 63) / 64) / 512.0, r1 = npxg * ((cout + 31) / 32) / 768.0;
   const double eff2 = r2 / ceil(r2), eff1 = r1 / ceil(r1);
-  static const int force = getenv("AIR_CONV_MT") ? atoi(getenv("AIR_CONV_MT")) : 0;
+  const int force = air_opt(AIR_OPT_CONV_MT);
   if (force == 1 || force == 2) return force;
   return (eff1 > eff2 + 0.08) ? 1 : 2;
 }
@@ -978,7 +979,7 @@ int wgrad_nsplit(const AirConv2d* p) {
   const int ntiles = p->B * p->Ho * WT;
   const int ct = wgrad_ct(p);
   const int ncot = p->Cout / (ct == 32 ? 128 : 64), ncit = (p->Cin + ct - 1) / ct;
-  static const int total = getenv("AIR_WGRAD_WGS") ? atoi(getenv("AIR_WGRAD_WGS")) : 256;
+  const int total = air_opt(AIR_OPT_WGRAD_WGS);
   int target = total / (ncot * ncit);  // workgroups in flight over the whole chip
   if (target < 1) target = 1;
   if (target > ntiles) target = ntiles;
@@ -1011,7 +1012,7 @@ int run_wgrad(const WgradGeom& g, const float* x, const float* dy, float* dw, co
   const int ct = (g.S == 2 && g.Cout % 128 == 0) ? 32 : 64;
   a.ncot = g.Cout / (ct == 32 ? 128 : 64);
   a.ncit = (g.Cin + ct - 1) / ct;
-  static const int total = getenv("AIR_WGRAD_WGS") ? atoi(getenv("AIR_WGRAD_WGS")) : 256;
+  const int total = air_opt(AIR_OPT_WGRAD_WGS);
   int nsplit = total / (a.ncot * a.ncit);  // workgroups in flight over the whole chip
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
@@ -1314,12 +1315,16 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     DirectArgs a = {x, nullptr, nullptr, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H,
                     p->W, p->Cout, p->KH, p->KW, p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
     const int npair = p->Cout * p->Cin * p->KH;
-    const size_t lds = ((size_t)p->Cout * ((p->Wo + 3) & ~3) +
-                        (size_t)p->Cin * p->KH * (((p->W + 2 * p->pw + 3) & ~3) + 4)) * sizeof(float);
-    static const int use_rows = getenv("AIR_DIRECT_WGRAD_ROWS") ? atoi(getenv("AIR_DIRECT_WGRAD_ROWS")) : 1;
+    int nseg = npair > 0 && npair <= 512 ? 512 / npair : 1;
+    if (nseg > 4) nseg = 4;
+    // the staged rows and, once they are dead, the per-segment sums red[nseg][npair][KW] share the allocation:
+    // short rows (W <= 48 for the ResNet's conv1) make the sums the larger of the two
+    const size_t stage_f = (size_t)p->Cout * ((p->Wo + 3) & ~3) +
+                           (size_t)p->Cin * p->KH * (((p->W + 2 * p->pw + 3) & ~3) + 4);
+    const size_t red_f = (size_t)nseg * npair * p->KW;
+    const size_t lds = (stage_f > red_f ? stage_f : red_f) * sizeof(float);
+    const int use_rows = air_opt(AIR_OPT_DIRECT_WGRAD_ROWS);
     if (use_rows && p->KW <= DIRECT_KW_MAX && npair <= 512 && lds <= 150 * 1024) {
-      int nseg = 512 / npair;
-      if (nseg > 4) nseg = 4;
       const int nthr = (npair * nseg + 63) / 64 * 64;
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_wgrad_rows_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "air_common.h"
+#include "air_options.h"
 #include "air_lds_dma.h"
 #include "air_prof.h"
 #include "conv_wino.h"
@@ -829,8 +830,7 @@ static long long* g_wino_trace = nullptr;
 extern "C" void air_dbg_wino_trace(long long* p) { g_wino_trace = p; }
 
 bool air_wino_ok(int B, int Kc, int H, int W, int M) {
-  static const int off = getenv("AIR_NO_WINOGRAD") ? atoi(getenv("AIR_NO_WINOGRAD")) : 0;
-  if (off) return false;
+  if (air_opt(AIR_OPT_NO_WINOGRAD) & 1) return false;
   if (M < 32 || M % 32 != 0 || Kc < WCK || Kc % WCK != 0) return false;
   // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
   const double ein = (double)B * Kc * H * W;
@@ -843,8 +843,7 @@ size_t air_wino_packed_elems(int M, int Kc) {
 }
 
 bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout) {
-  static const int off = getenv("AIR_NO_WINOGRAD") ? atoi(getenv("AIR_NO_WINOGRAD")) : 0;
-  if (off & 2) return false;
+  if (air_opt(AIR_OPT_NO_WINOGRAD) & 2) return false;
   if (Cin % 64 != 0 || Cout % 64 != 0 || W < 2) return false;
   const double ein = (double)B * Cin * H * W, eout = (double)B * Cout * H * W;
   return ein * 4.0 < 2147483648.0 && eout * 4.0 < 2147483648.0;
@@ -852,7 +851,7 @@ bool air_wino_wgrad_ok(int B, int Cin, int H, int W, int Cout) {
 
 int air_wino_wgrad_nsplit(int B, int Cin, int H, int W, int Cout) {
   const int nseg = B * ((H + 1) / 2) * (((W + 1) / 2 + WG_SEG - 1) / WG_SEG);
-  static const int total = getenv("AIR_WINO_WGRAD_WGS") ? atoi(getenv("AIR_WINO_WGRAD_WGS")) : 256;
+  const int total = air_opt(AIR_OPT_WINO_WGRAD_WGS);
   int n = total / ((Cin / 64) * (Cout / 64));
   if (n < 1) n = 1;
   if (n > nseg) n = nseg;

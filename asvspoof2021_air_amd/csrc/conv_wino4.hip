@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "air_common.h"
+#include "air_options.h"
 #include "air_lds_dma.h"
 #include "air_prof.h"
 #include "conv_wino.h"
@@ -651,8 +652,7 @@ static long long* g_wino4_trace = nullptr;
 extern "C" void air_dbg_wino4_trace(long long* p) { g_wino4_trace = p; }
 
 bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
-  static const int off = getenv("AIR_NO_WINO4") ? atoi(getenv("AIR_NO_WINO4")) : 0;
-  if (off) return false;
+  if (air_opt(AIR_OPT_NO_WINO4) || (air_opt(AIR_OPT_NO_WINOGRAD) & 1)) return false;
   if (M < W4_CO || M % W4_CO != 0 || Kc < W4_CK || Kc % W4_CK != 0) return false;
   // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
   const double ein = (double)B * Kc * H * W, eout = (double)B * M * H * W;
@@ -692,7 +692,7 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
   // split streams: only when every workgroup gets at least one item's worth of k-steps, not under stream
   // capture (the per-launch epoch would be frozen into the graph), and when it changes the balance
-  static const int split_on = getenv("AIR_WINO4_SPLIT") ? atoi(getenv("AIR_WINO4_SPLIT")) : 1;
+  const int split_on = air_opt(AIR_OPT_WINO4_SPLIT);
   a.split = 0; a.flags = nullptr; a.epoch = 0;
   // (an item cut in two costs an extra round trip of its 128 KB of sums: measured a gain only when whole
   // items leave the last round more than 15 % empty - layer4: 384 items, 0.49 -> 0.41 ms; layer1: 1920

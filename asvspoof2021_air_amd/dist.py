@@ -39,6 +39,17 @@ def init_from_env(backend=None, device_index=None):
     return local
 
 
+def all_mean(value):
+    """Mean of a Python scalar over the ranks (validation loss before ``Trainer.save_checkpoint`` compares
+    it with the best so far: every rank must take the same early-stopping decision)."""
+    if world_size() == 1:
+        return float(value)
+    dev = "cuda" if td.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t.item()) / world_size()
+
+
 def bucket_slices(n_elems, bucket_bytes=BUCKET_BYTES):
     """Reverse-order (last layers first) [start, end) slices of a flat arena."""
     per = max(1, bucket_bytes // 4)

@@ -121,10 +121,15 @@ class Trainer:
         ``checkpoint/anti-spoofing_loss_model_%d.pt`` every epoch (numbered epoch_num + 1), and
         ``anti-spoofing_feat_model.pt`` / ``anti-spoofing_loss_model.pt`` whenever the validation loss
         improves.  generate_score.py:46-48 loads these with torch.load.  Returns True when the best pair
-        was written.  With world > 1 rank 0's BatchNorm statistics go to every rank first."""
+        was written.
+
+        No collective runs in here, so the usual ``if rank == 0: trainer.save_checkpoint(...)`` is safe with
+        world > 1 (round 2 broadcast the buffers first and deadlocked under that pattern): rank 0 writes its
+        OWN BatchNorm running statistics, which is what SURVEY.md 8e asks for, and the other ranks keep
+        theirs.  When every rank calls it, pass the same ``val_loss`` everywhere (``dist.all_mean``) so that
+        ``prev_loss`` / ``early_stop_cnt`` stay in step."""
         if self.out_fold is None:
             raise RuntimeError("call set_out_fold() first")
-        self.sync_buffers_from_rank0()
         improved = val_loss is not None and val_loss < self.prev_loss
         if air_dist.rank() == 0:
             ck = os.path.join(self.out_fold, "checkpoint")

@@ -9,7 +9,9 @@
  *   - no allocation inside: callers pass workspaces (see *_ws_bytes queries)
  *   - every launch goes to the caller's stream (air_stream_t == hipStream_t)
  *   - return 0 (AIR_OK) or a negative AIR_E* code; never throws
- *   - no global state; re-entrant across streams
+ *   - no per-call global state; re-entrant across streams.  The only process-wide
+ *     state is the dispatch-option table below (air_set_option): which of several
+ *     equivalent kernels serves a call
  *   - tensors are contiguous fp32, NCHW / (B,C,T) / (B,T,D) as stated per call
  */
 #ifndef AIR_HIP_H
@@ -33,6 +35,31 @@ typedef void* air_stream_t; /* hipStream_t */
 /* Library identification: returns "air_hip gfx950 <abi-version>". */
 const char* air_version(void);
 int air_abi_version(void);
+
+/* ------------------------------------------------------- dispatch options --
+ * Process-wide switches between equivalent kernels (A/B measurement, and the
+ * strict-parity configuration of the tests).  Each option NAME is seeded once
+ * from the environment variable AIR_<NAME>; air_set_option changes it at run
+ * time (takes effect at the next call; not meant to be flipped while another
+ * thread is launching).  Unknown names return AIR_EINVAL.
+ *   NO_WINO4 (0)          1: 3x3/stride-1 forward+dgrad skip Winograd F(4x4,3x3)
+ *   NO_WINOGRAD (0)       bit 1: 3x3/stride-1 forward+dgrad on the direct f32-MFMA
+ *                         kernels; bit 2: weight gradients too.  3 = every
+ *                         convolution is an fmaf chain (round-1 tolerances hold)
+ *   WINO4_SPLIT (1)       0 never / 1 when the last round is > 13 % empty / 2 always:
+ *                         cut the Winograd k-step stream evenly over the workgroups
+ *   WINO4_TH3 (1)         F(3x4,3x3) tiles where F(4x4,3x3) would waste rows (H = 9, 5, 3)
+ *   WINO4_XCD (1)         deal work items round-robin inside an XCD
+ *   CONV_MT (0)           force the direct kernels' pixel-tile count (1 | 2)
+ *   WGRAD_WGS (256), WINO_WGRAD_WGS (256)   workgroups of the split-K weight gradients
+ *   DIRECT_WGRAD_ROWS (1) row-staged conv1 weight gradient
+ *   C1B_PS (7)            bit mask of the persistent bf16 pointwise kernels
+ *   C1B_GEMM_PS (1)       256x256 persistent bf16 GEMM
+ */
+int air_set_option(const char* name, int value);
+int air_get_option(const char* name, int* value_out);
+int air_option_count(void);
+const char* air_option_name(int index); /* NULL when out of range */
 
 /* ------------------------------------------------------------------ LFCC --
  * Replaces LFCC.forward (feature_extraction.py:93-138) incl. delta (:41-58),

@@ -39,6 +39,24 @@ def test_version_and_sizes(lib):
     assert lib.air_preemph_ws_bytes(ctypes.c_int(0), ctypes.c_int(64000)) == 0
 
 
+def test_dispatch_options(lib):
+    """One setter for every dispatch switch (include/air_hip.h): names listed, defaults, round trip, and every
+    option the header documents exists."""
+    from asvspoof2021_air_amd import _hip
+    names = [lib.air_option_name(ctypes.c_int(i)).decode() for i in range(lib.air_option_count())]
+    assert lib.air_option_name(ctypes.c_int(len(names))) is None
+    text = open(os.path.join(ROOT, "include", "air_hip.h")).read()
+    for n in names:
+        assert re.search(r"\b%s\b" % n, text), "option %s is not documented in air_hip.h" % n
+    assert "NO_WINO4" in names and "NO_WINOGRAD" in names
+    assert _hip.get_option("WGRAD_WGS") == int(os.environ.get("AIR_WGRAD_WGS", 256))
+    with _hip.options(NO_WINOGRAD=3, AIR_NO_WINO4=1):  # the AIR_ prefix is accepted too
+        assert _hip.get_option("NO_WINOGRAD") == 3 and _hip.get_option("NO_WINO4") == 1
+    assert _hip.get_option("NO_WINOGRAD") == int(os.environ.get("AIR_NO_WINOGRAD", 0))
+    assert lib.air_set_option(b"NOT_AN_OPTION", ctypes.c_int(1)) == -1
+    assert lib.air_get_option(b"NO_WINO4", None) == -1
+
+
 def test_lfcc_plan_build_host(lib, golden):
     from asvspoof2021_air_amd import _hip
     g = golden("lfcc.npz")

@@ -77,9 +77,18 @@ def test_dropout_mask_statistics_and_determinism():
 
 
 @pytest.mark.gpu
-def test_adversarial_step_gradients_and_two_phase_update():
+@pytest.mark.parametrize("path", ["strict", "default"])
+def test_adversarial_step_gradients_and_two_phase_update(path):
     """Phase 1: encoder gradients of (OC-Softmax + CE(classifier(GRL(feats)))) vs the oracle;
-    phase 2: the classifier moves, encoder BN statistics are updated twice with recompute=True."""
+    phase 2: the classifier moves, encoder BN statistics are updated twice with recompute=True.
+    ``strict``: direct convolutions, round-1 bound 2e-3; ``default``: Winograd, 2e-3 x the emulated rounding ratio."""
+    from _budget import conv_path
+    with conv_path(path):
+        _adversarial_step(path)
+
+
+def _adversarial_step(path):
+    from _budget import record, tol
     from asvspoof2021_air_amd.adversarial import AdversarialTrainer
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     from asvspoof2021_air_amd.resnet import ResNet
@@ -123,9 +132,10 @@ def test_adversarial_step_gradients_and_two_phase_update():
         ref = sd[k].grad.numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         gap = np.abs(plain.numpy() - ref).max() / np.abs(ref).max()  # what dropping the adversarial term would cost
-        # 6e-3: the Winograd F(4x4,3x3) convolutions round at up to 1e-5 of a layer's output scale (F(2x2): 1e-6),
-        # which this filler-initialised net amplifies to 4.3e-3 of max on conv1.weight (measured; F(2x2): 8e-4)
-        assert err <= 6e-3 and gap > 20 * err, (k, err, gap)
+        # the Winograd convolutions round at a larger multiple of a layer's output scale than the direct ones,
+        # which this filler-initialised net amplifies to 4.3e-3 of max on conv1.weight (measured; direct: 8e-4)
+        record("adv_%s_rel_max[%s]" % (k, path), float(err))
+        assert err <= tol("adv_rel_max", path) and gap > 20 * err, (path, k, err, gap)
     np.testing.assert_allclose(float(tr.last["adv_loss"]), l_adv.item(), rtol=1e-4)
     # epoch 0: no adversarial term (main_train.py:377), classifiers still train in phase 2
     tr0 = make(False)

@@ -101,3 +101,82 @@ def test_allreduce_grads_gloo_world2():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+class Toy8(nn.Module):
+    """Several tensors of awkward sizes so that small buckets cut through the middle of them."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(13, 11)
+        self.b = nn.Linear(11, 9)
+        self.c = nn.Linear(9, 7)
+        self.tail = nn.Linear(7, 3)
+        self._arena = None
+
+    def arena(self):
+        if self._arena is None:
+            self._arena = ParamArena(list(self.named_parameters()), tail_names=("tail.weight", "tail.bias"))
+        if not self._arena.bound():
+            self._arena.bind(self.a.weight.device)
+        return self._arena
+
+
+def _worker8(rank, world, port, out, tail_has_grad):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    air_dist.init_from_env("gloo")
+    torch.manual_seed(0)
+    m = Toy8()
+    ar = m.arena()
+    n, h = ar.total, ar.head_total
+    base = torch.arange(n, dtype=torch.float32)
+    ar.grad.copy_((rank + 1) * base + rank)          # exact in fp32: the sums below are integers < 2^24
+    ar.tail_has_grad = tail_has_grad
+    centre = nn.Parameter(torch.zeros(1, 8))
+    centre.grad = torch.full((1, 8), float(rank + 1))
+    holder = nn.Module()
+    holder.center = centre
+    # 100-byte buckets = 25 floats: every tensor boundary (143, 11, 99, 9, 63, 7 floats, 16-byte padded) falls
+    # inside some bucket, and the first bucket sent is shorter than the rest of the head
+    air_dist.BUCKET_BYTES = 100
+    slices = air_dist.bucket_slices(h, 100)
+    offs = sorted(o for _, _, o, _ in ar.entries if 0 < o < h)
+    assert any(s < o < e for o in offs for s, e in slices), "no bucket cuts through a tensor"
+    # a GradBucketer that already sent the last 30 floats of the head from "inside backward"
+    bk = air_dist.GradBucketer(bucket_bytes=100)
+    m._bucketer = bk
+    bk.reset(ar.grad, h)
+    # CPU stand-in for flush(): same bookkeeping, no HIP stream
+    lo = h - 30
+    bk.lo = lo
+    bk.works.append(td.all_reduce(ar.grad[lo:h], op=td.ReduceOp.SUM, async_op=True))
+    bk.launched += 1
+    bk.hi = lo
+    air_dist.allreduce_grads(m, holder)
+    ws = sum(r + 1 for r in range(world))
+    wr = sum(range(world))
+    want = ws * base + wr
+    ok = torch.equal(ar.grad[:h], want[:h])
+    if tail_has_grad:
+        ok &= torch.equal(ar.grad[h:], want[h:])
+    else:
+        ok &= torch.equal(ar.grad[h:], ((rank + 1) * base + rank)[h:])  # untouched
+    ok &= bool((centre.grad == ws).all())
+    ok &= bk.grad is None  # reset for the next step
+    mean = air_dist.all_mean(float(rank))
+    ok &= abs(mean - (world - 1) / 2.0) < 1e-12
+    out[rank] = bool(ok)
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("tail_has_grad", [False, True])
+def test_allreduce_grads_gloo_world8_mid_tensor_buckets(tail_has_grad):
+    """World 8 (BASELINE configs[3]/[4] run 8 ranks): buckets that split tensors, a region already sent from
+    inside backward, and the tail both with and without gradients (fc_mu.* gets one under the CE head)."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), out, tail_has_grad), nprocs=world, join=True)
+    assert dict(out) == {r: True for r in range(world)}

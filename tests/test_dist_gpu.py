@@ -46,6 +46,20 @@ def _make(kind="resnet"):
     return Trainer(m, loss_module=lossm, feat_len=96, ecapa=(kind == "ecapa"))
 
 
+def _pcm_shard(rank):
+    """BASELINE configs[4]: raw PCM per rank; each rank draws its own impulse responses (seed 688 + rank)."""
+    from oracle.filler import synth_pcm
+    labels = torch.tensor([0, 1, 1, 0]) if rank == 0 else torch.tensor([1, 1, 0, 1])
+    return synth_pcm(4, 16000, seed=70 + rank), labels
+
+
+def _make_aug(rank):
+    from asvspoof2021_air_amd.augment import ChannelAugment
+    tr = _make("ecapa")
+    tr.augment = ChannelAugment(seed=688 + rank)
+    return tr
+
+
 def _shard(rank, kind="resnet"):
     x = synth_feat((4, 1, 60, 96) if kind == "resnet" else (4, 60, 96), seed=50 + rank)
     labels = torch.tensor([0, 1, 1, 0]) if rank == 0 else torch.tensor([1, 1, 0, 1])
@@ -58,10 +72,15 @@ def _worker(rank, world, port, out, kind="resnet"):
     from asvspoof2021_air_amd import dist as air_dist
     torch.cuda.set_device(0)
     air_dist.init_from_env("gloo")
-    tr = _make(kind)
+    if kind == "ecapa_aug":  # configs[4]: ECAPA bf16 + on-the-fly IR convolution + LFCC, from raw PCM
+        tr = _make_aug(rank)
+        pcm, labels = _pcm_shard(rank)
+        loss, _ = tr.step(pcm.cuda(), labels.cuda())
+    else:
+        tr = _make(kind)
+        x, labels = _shard(rank, kind)
+        loss, _ = tr.step_features(x.cuda(), labels.cuda())
     assert tr.world == world
-    x, labels = _shard(rank, kind)
-    loss, _ = tr.step_features(x.cuda(), labels.cuda())
     torch.cuda.synchronize()
     out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy(),
                  tr.model._bucketer.total_launched if tr.model._bucketer is not None else -1)
@@ -69,7 +88,7 @@ def _worker(rank, world, port, out, kind="resnet"):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["resnet", "ecapa"])
+@pytest.mark.parametrize("kind", ["resnet", "ecapa", "ecapa_aug"])
 def test_two_rank_step_equals_averaged_gradients(kind):
     world = 2
     mgr = mp.Manager()
@@ -82,8 +101,13 @@ def test_two_rank_step_equals_averaged_gradients(kind):
     # single process: per-shard gradients, averaged by hand, one optimiser step
     grads, cgrads, losses = [], [], []
     for r in range(world):
-        tr = _make(kind)
-        x, labels = _shard(r, kind)
+        if kind == "ecapa_aug":
+            tr = _make_aug(r)
+            pcm, labels = _pcm_shard(r)
+            x = tr.features(tr.augment(pcm.cuda()))
+        else:
+            tr = _make(kind)
+            x, labels = _shard(r, kind)
         tr.model.train()
         feats, _ = tr.model(x.cuda())
         loss, _ = tr.loss(feats, labels.cuda())
@@ -92,7 +116,7 @@ def test_two_rank_step_equals_averaged_gradients(kind):
         cgrads.append(tr.loss.center.grad.clone())
         losses.append(loss.item())
     np.testing.assert_allclose([l0, l1], losses, rtol=1e-6)
-    tr = _make(kind)
+    tr = _make("ecapa" if kind == "ecapa_aug" else kind)
     arena = tr.model.arena()
     for n_, p, _, _ in arena.entries:  # gradients = views of the arena, as backward leaves them
         p.grad = None if n_ in ("fc_mu.weight", "fc_mu.bias", "fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias") else arena.grad_view(n_)
@@ -104,6 +128,43 @@ def test_two_rank_step_equals_averaged_gradients(kind):
     n = arena.head_total
     np.testing.assert_array_equal(arena.flat[:n].cpu().numpy(), w0[:n])
     np.testing.assert_array_equal(tr.loss.center.detach().cpu().numpy(), c0)
+
+
+def _worker_nccl(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from asvspoof2021_air_amd import dist as air_dist
+    air_dist.init_from_env("nccl")  # one GPU per rank: RCCL
+    assert torch.cuda.current_device() == rank
+    tr = _make("resnet")
+    x, labels = _shard(rank, "resnet")
+    loss, _ = tr.step_features(x.cuda(), labels.cuda())
+    torch.cuda.synchronize()
+    out[rank] = (loss.item(), tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy(),
+                 tr.model._bucketer.total_launched)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_over_rccl():
+    """The same two-rank step with backend "nccl" (= RCCL over xGMI), one GPU per rank: GradBucketer's buckets
+    go out on its launch stream under RCCL's stream semantics.  Needs two GPUs: skipped on the 1-GPU box."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("RCCL refuses two ranks on one device; this box has %d GPU(s)" % n)
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_nccl, args=(world, _free_port(), out), nprocs=world, join=True)
+    (l0, w0, c0, nb0), (l1, w1, c1, nb1) = out[0], out[1]
+    assert np.array_equal(w0, w1) and np.array_equal(c0, c1)
+    assert nb0 == nb1 and nb0 >= 2
+    # against the gloo transport on cuda:0 (test above): the sums of two addends are order-independent, so the
+    # parameters after the step are bit-identical whatever carried the bytes
+    out2 = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out2, "resnet"), nprocs=world, join=True)
+    np.testing.assert_array_equal(out2[0][1], w0)
+    np.testing.assert_array_equal(out2[0][2], c0)
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -10,6 +10,8 @@ from oracle import ecapa as o_ecapa
 from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
 from oracle.filler import fill_module_, fill_state, fill_value, synth_feat, synth_pcm
 
+from _budget import conv_path, record, tol  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -25,47 +27,66 @@ def _resnet_trainer(feat_len=750):
     return Trainer(m, loss_module=lossm, feat_len=feat_len)
 
 
-def test_resnet_full_size_step_vs_oracle():
+_FULL = {}
+
+
+def _full_size_oracle():
+    """The CPU side of the full-size step (fp32 oracle step + fp64 gradients), computed once for both paths."""
+    if not _FULL:
+        B, L, FL = 64, 64000, 750
+        pcm = synth_pcm(B, L, seed=688)
+        g = torch.Generator().manual_seed(1)
+        labels = (torch.rand(B, generator=g) < 0.9).long()
+        labels[0], labels[1] = 0, 1
+        feat = torch.from_numpy(o_lfcc.lfcc_forward(pcm.numpy().copy()))
+        assert feat.shape == (B, 401, 60)
+        xin = torch.stack([o_pad.repeat_pad(feat[b:b + 1], FL) for b in range(B)])
+        xo = o_pad.to_model_input(xin).contiguous()
+        otr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
+        lo, no, _, go, _ = otr.step(xo, labels, None)
+        p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
+        o64 = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
+        _, _, _, g64, _, _ = o64.loss_and_grads(xo.double(), labels, None)
+        _FULL.update(pcm=pcm, labels=labels, lo=lo, no=no, go=go, g64=g64, otr=otr)
+    return _FULL
+
+
+@pytest.mark.parametrize("path", ["strict", "default"])
+def test_resnet_full_size_step_vs_oracle(path):
     """BASELINE configs[1] exactly: 64 x 64000 PCM -> LFCC (401 frames) -> repeat-pad 750 -> ResNet-18 ->
-    OC-Softmax -> backward -> Adam + SGD, against the oracle on the same inputs."""
+    OC-Softmax -> backward -> Adam + SGD, against the oracle on the same inputs.  ``strict`` = every convolution
+    on the direct f32-MFMA kernels with the round-1 slack (1e-3); ``default`` = the Winograd kernels with that
+    slack times the emulated per-convolution rounding ratio (tests/_budget.py)."""
     B, L, FL = 64, 64000, 750
-    tr = _resnet_trainer(FL)
-    pcm = synth_pcm(B, L, seed=688)
-    g = torch.Generator().manual_seed(1)
-    labels = (torch.rand(B, generator=g) < 0.9).long()
-    labels[0], labels[1] = 0, 1
-    loss, neg = tr.step(pcm.cuda(), labels.cuda())
+    o = _full_size_oracle()
+    pcm, labels, lo, no, go, g64, otr = (o[k] for k in ("pcm", "labels", "lo", "no", "go", "g64", "otr"))
+    with conv_path(path):
+        tr = _resnet_trainer(FL)
+        loss, neg = tr.step(pcm.cuda(), labels.cuda())
+        torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu().numpy() for k, p in tr.model.named_parameters() if p.grad is not None}
-    feat = torch.from_numpy(o_lfcc.lfcc_forward(pcm.numpy().copy()))
-    assert feat.shape == (B, 401, 60)
-    xin = torch.stack([o_pad.repeat_pad(feat[b:b + 1], FL) for b in range(B)])
-    xo = o_pad.to_model_input(xin).contiguous()
-    otr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
-    lo, no, _, go, _ = otr.step(xo, labels, None)
     np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
     np.testing.assert_allclose(neg.cpu().numpy(), no.numpy(), atol=2e-4)
     # Gradients.  At this size (55 M activations per layer) some pre-activations sit within fp32 rounding
     # of a ReLU threshold, and a flipped unit moves whole gradient elements: the fp32 CPU oracle ITSELF is
     # up to 5e-2 of max away from its fp64 evaluation on single elements (layer4.1.conv1.weight), and so is
     # the HIP path.  So: relative L2 per tensor against the fp64 oracle, bounded by what the fp32 oracle
-    # shows against the same fp64 truth (x3) plus 5e-3: the Winograd F(4x4,3x3) convolutions (conv_wino4.hip)
-    # round at up to 1e-5 of a layer's output scale where the direct fp32 convolution rounds at 1e-6 .. 3e-6,
-    # and this filler-initialised net amplifies that to 3.6e-3 on the worst tensor (layer4.1.bn2.weight;
-    # measured 1.0e-3 with F(2x2,3x3); the better-conditioned point set (0,1,-1,2,-1/2) halves the
-    # per-convolution error but measured 5.0e-3 here: the figure is set by flipped ReLUs, not by rounding).
-    p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
-    o64 = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
-    _, _, _, g64, _, _ = o64.loss_and_grads(xo.double(), labels, None)
+    # shows against the same fp64 truth (x3) plus a slack: 1e-3 for the direct kernels (round 1's constant);
+    # the Winograd convolutions round at a larger multiple of a layer's output scale and their slack is 1e-3
+    # times the emulated rounding ratio of the two kernels (tests/_budget.py: about 5e-3; measured 3.6e-3 on
+    # the worst tensor, layer4.1.bn2.weight).
+    slack = tol("full_size_slack", path)
     worst = ("", 0.0, 0.0)
     for k, gh in grads.items():
         ref = g64[k].numpy().ravel()
         nrm = np.linalg.norm(ref) + 1e-30
         e_hip = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / nrm
         e_cpu = np.linalg.norm(go[k].numpy().ravel().astype(np.float64) - ref) / nrm
-        assert e_hip <= 3.0 * e_cpu + 5e-3, (k, e_hip, e_cpu)
+        assert e_hip <= 3.0 * e_cpu + slack, (path, k, e_hip, e_cpu, slack)
         if e_hip > worst[1]:
             worst = (k, e_hip, e_cpu)
     print("worst relative L2 gradient error vs fp64: %s hip %.2e (fp32 CPU oracle: %.2e)" % worst)
+    record("resnet_full_size_worst_grad[%s]" % path, list(worst))
     # the updated weights (Adam, lr 5e-4: every element moves by ~lr in step 1) agree to a fraction of a step
     w = tr.model.state_dict()["layer4.1.conv2.weight"].cpu().numpy()
     assert np.abs(w - otr.params["layer4.1.conv2.weight"].numpy()).max() <= 2 * 5e-4 + 1e-6

@@ -8,6 +8,8 @@ from oracle import resnet as o_resnet
 from oracle import train as o_train
 from oracle.filler import fill_module_, fill_state, fill_value, synth_feat
 
+from _budget import conv_path, record, tol  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -66,7 +68,15 @@ def test_transposed_view_input():
     assert torch.equal(a, b)
 
 
-def test_grads_vs_oracle_small(golden):
+@pytest.mark.parametrize("path", ["strict", "default"])
+def test_grads_vs_oracle_small(golden, path):
+    """``strict``: every convolution on the direct f32-MFMA kernels, round-1 constants.  ``default``: Winograd
+    kernels, the centre-gradient floor scaled by the emulated rounding ratio (tests/_budget.py)."""
+    with conv_path(path):
+        _grads_vs_oracle_small(golden, path)
+
+
+def _grads_vs_oracle_small(golden, path):
     g = golden("resnet.npz")
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     m = make_model().train()
@@ -102,20 +112,29 @@ def test_grads_vs_oracle_small(golden):
         assert err < 5e-3, "%s: relative L2 grad err %.3g" % (k, err)
         assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max(), k
         np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=5e-3)
-    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=1e-5)
+    record("resnet_small_g_center_abs[%s]" % path, float(np.abs(lossm.center.grad.cpu().numpy() - g["g_center"]).max()))
+    record("resnet_small_worst_grad_relL2[%s]" % path, float(worst))
+    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=tol("g_center_atol", path))
     # gradients live in the flat arena (zero-copy views)
     arena = m.arena()
     assert m.conv1.weight.grad.data_ptr() == arena.grad_view("conv1.weight").data_ptr()
     print("worst relative L2 grad err", worst)
 
 
-def test_trajectory_vs_golden(golden):
+@pytest.mark.parametrize("path", ["strict", "default"])
+def test_trajectory_vs_golden(golden, path):
+    with conv_path(path):
+        _trajectory_vs_golden(golden, path)
+
+
+def _trajectory_vs_golden(golden, path):
     """3 optimisation steps (Adam on the arena + SGD on the centre) against the reference's
     losses.  Step 1 is pre-update (tight); later steps sit on Adam's sign-SGD noise floor
     (see tests/golden/make_golden.py): the first Adam updates are lr * sign(g), so rounding-level
     gradient differences flip whole updates of near-zero-gradient weights.  There the fp32 and
-    fp64 oracles differ by 1e-4, the direct-conv kernels by 1e-4, and the Winograd convs (F(4x4,3x3):
-    up to 1e-5 of scale per conv instead of 1e-6) by 3e-4 at step 2 and 2e-3 at step 3."""
+    fp64 oracles differ by 1e-4 and so do the direct-conv kernels (``strict``: rtol 1e-4 at step 2, the round-1
+    constant); the Winograd convolutions round at a larger multiple of a layer's output scale, and step 2's
+    allowance is 1e-4 times the emulated rounding ratio of the two kernels (tests/_budget.py; measured 3e-4)."""
     g = golden("trajectory.npz")
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     from asvspoof2021_air_amd.train import Trainer
@@ -132,7 +151,8 @@ def test_trajectory_vs_golden(golden):
         loss, _ = tr.step_features(xb, labels)
         losses.append(loss.item())
     np.testing.assert_allclose(losses[0], g["losses"][0], rtol=2e-5)
-    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=5e-4)
+    record("resnet_traj_rel[%s]" % path, [abs(a / b - 1.0) for a, b in zip(losses, g["losses"].tolist())])
+    np.testing.assert_allclose(losses[1], g["losses"][1], rtol=tol("step2_rtol", path))
     np.testing.assert_allclose(losses, g["losses"], rtol=5e-3)
     sd = m.state_dict()
     assert np.abs(sd["conv1.weight"].cpu().numpy() - g["conv1_w"]).max() <= 3 * 2 * 5e-4 + 1e-6
