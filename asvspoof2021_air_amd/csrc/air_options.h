@@ -10,8 +10,8 @@ enum AirOption {
   AIR_OPT_NO_WINOGRAD,         // bit 1: forward/dgrad on the direct f32 MFMA kernels; bit 2: weight gradients too
                                // (3 = the strict-parity configuration: every convolution an fmaf chain)
   AIR_OPT_WINO4_SPLIT,         // 0: never cut the k-step stream; 1: when the last round is > 13 % empty; 2: always
-  AIR_OPT_WINO4_TH3,           // 1: F(3x4,3x3) tiles where they waste fewer rows than F(4x4,3x3) (H = 9, 5, 3)
-  AIR_OPT_WINO4_XCD,           // 1: items dealt round-robin inside an XCD (shared x / U lines hit its L2)
+  AIR_OPT_WINO4_TH3,           // 1: F(3x4,3x3) tiles where they issue fewer positions than F(4x4,3x3); 2: on ties too
+  AIR_OPT_WINO4_XCD,           // 0: items dealt over the whole chip; 1 / 2: inside an XCD (contiguous / strided quads)
   AIR_OPT_CONV_MT,             // force the direct kernels' pixel-tile count (0 = heuristic)
   AIR_OPT_WGRAD_WGS,           // workgroups of the split-K direct weight gradient
   AIR_OPT_WINO_WGRAD_WGS,      // workgroups of the Winograd weight gradient

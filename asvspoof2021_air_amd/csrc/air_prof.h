@@ -26,14 +26,16 @@ enum AirKernelId {
 };
 
 bool air_prof_on();
-void air_prof_begin(int kid, double work, hipStream_t st);
+// work = algorithmic FLOPs (or bytes); issued = FLOPs the kernel really sends to the matrix pipe (Winograd kernels:
+// fewer than the algorithmic count, padded tiles included); < 0 = same as work
+void air_prof_begin(int kid, double work, hipStream_t st, double issued = -1.0);
 void air_prof_end(hipStream_t st);
 
 struct AirProfScope {
   hipStream_t st;
   bool on;
-  AirProfScope(int kid, double work, hipStream_t s) : st(s), on(air_prof_on()) {
-    if (on) air_prof_begin(kid, work, st);
+  AirProfScope(int kid, double work, hipStream_t s, double issued = -1.0) : st(s), on(air_prof_on()) {
+    if (on) air_prof_begin(kid, work, st, issued);
   }
   ~AirProfScope() {
     if (on) air_prof_end(st);

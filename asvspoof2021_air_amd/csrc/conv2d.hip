@@ -1116,7 +1116,7 @@ int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, 
   if (out_bytes < need) return AIR_EWORKSPACE;
   const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
   float* up = reinterpret_cast<float*>(out);
-  return wino_kind(p, pass) == 4 ? air_wino4_weights(w, up, M, Kc, pass, air_stream(stream))
+  return wino_kind(p, pass) == 4 ? air_wino4_weights(w, up, M, Kc, p->H, pass, air_stream(stream))
                                  : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
 }
 

@@ -32,4 +32,5 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M);
 size_t air_wino4_packed_elems(int M, int Kc);
 int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
                    int W, int M, int dgrad, float* up, double flops, hipStream_t st);
-int air_wino4_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st);
+// H: image height of the launch the weights are for (it picks the 4- or 3-row tile layout)
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st);

@@ -27,9 +27,23 @@
 // contiguous work items (32 channels x 4 groups) and the k-step stream runs on across item boundaries.
 // Tile groups are 1 x 16 or 2 x 8 tiles of the image rows STACKED over the batch (tile row = b * TH + th),
 // so short images (layer4: 3 x 94) fill the 16-tile MFMA width with tiles of two images.
+//
+// Round 3.  (a) Output tiles are MH x 4 with MH = 4 or 3 (template): F(3x4,3x3) has 5 x 6 = 30 positions for
+// 12 outputs (2.5 multiplies per output against 2.25), but the ResNet's feature maps are 18 / 9 / 5 / 3 rows
+// high: 4-row tiles compute 20 / 12 / 8 / 4 rows for them, 3-row tiles 18 / 9 / 6 / 3, so layers 2-4 issue
+// 60 MFMAs per k-step instead of 72 for the same tile count (and all 60 accumulators fit the AGPR half).
+// (b) Work items are dealt to the workgroups XCD by XCD: an XCD owns a contiguous range of the item list,
+// numbered so that 32 consecutive items are (up to) 8 channel slabs x 4 tile quads, and its workgroups take
+// items round-robin - at any time the workgroups of one XCD read the same patches (the slabs of a quad) and the
+// same transformed weights (the quads of a slab), which then hit that XCD's L2 instead of each workgroup
+// fetching its own copy through the fabric (round 2: 3.8x the algorithmic bytes).  (c) When the last round of
+// an XCD is at most half full its items are cut in two k-halves: the workgroups that take the upper halves do
+// so FIRST, store partial sums into y and raise a flag; the owners of the lower halves meet them LAST, add the
+// stored sums and the residual.  A workgroup publishes before it ever waits.
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "air_common.h"
@@ -47,24 +61,47 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W4_CO = 32;                       // output channels per workgroup
 constexpr int W4_CK = 4;                        // input channels per k-step (MFMA K)
-constexpr int W4_NP = 36;                       // Winograd positions
-constexpr int W4_USLAB = W4_CK * W4_CO * W4_NP;  // floats of transformed weights per k-step: [ci][co][36]
-constexpr int W4_ULDS = 5120;                   // LDS pitch of a slab: 5 x 16-byte DMAs per thread
-constexpr int W4_NU = 5;
 constexpr int W4_NI = 8;                        // patch DMAs per thread: 4 groups x 4 planes x 128 chunks
-constexpr int W4_ND = W4_NU + W4_NI;
 constexpr int W4_PLF = 512;                     // floats per (group, ci) plane (multiple of 64: bank-aligned)
 constexpr int W4_GRPF = W4_CK * W4_PLF;         // floats per tile group
 constexpr int W4_PATCHF = 4 * W4_GRPF;          // floats per patch buffer
 constexpr int W4_NBUF = 3;
+// Partial sums of a cut item travel between two workgroups that may sit on different XCDs, whose L2s are not
+// coherent with each other: stored and loaded with the sc1 (agent-scope) cache policy they go through to the
+// memory side, and the flag (an agent-scope atomic, sc1 too) follows the stores' acknowledgement.  Round 2
+// used an agent-scope RELEASE fence instead, which writes back the publishing XCD's whole L2: affordable for the
+// one layer that cut items then, a 7 % loss on layer1 when every layer's last round is cut.
+constexpr int W4_SC1 = 16;
 constexpr unsigned W4_OOB = 0x80000000u;        // byte offset beyond any tensor we accept: reads as zero
 
-template <int TRG>
+// Positions and the layout of the transformed weights for MH x 4 output tiles.
+//   MH = 4: 36 positions, slab [ci 4][co 32][36] (a lane's 36 floats are contiguous: 144-byte lane stride,
+//           conflict-free 16-byte reads), 4608 floats = 4.5 DMAs of 1024 floats, LDS pitch 5120;
+//   MH = 3: 30 positions in 8 quads (the last one half used), slab [ci 4][quad 8][co 32][4] (the 16 lanes of
+//           an MFMA row block read consecutive 16-byte words), 4096 floats = exactly 4 DMAs.
+template <int MH>
+struct W4Pos {
+  static constexpr int NPR = MH + 2;            // patch rows = positions along H
+  static constexpr int NP = NPR * 6;            // Winograd positions
+  static constexpr int NQ = (NP + 3) / 4;       // position quads per MFMA row block (A operands are read 4 at a time)
+  static constexpr int USLAB = MH == 4 ? W4_CK * W4_CO * NP : W4_CK * NQ * W4_CO * 4;  // floats per k-step
+  static constexpr int NU = (USLAB + 1023) / 1024;  // DMAs (256 threads x 16 bytes) per slab
+  static constexpr int ULDS = NU * 1024;        // LDS pitch of a slab
+  static constexpr int ND = NU + W4_NI;         // DMAs per thread and k-step
+  static constexpr int NACC = 2 * NP;           // accumulators per wave: 2 row blocks x positions
+  // float offset of (ci k, channel col, position p) inside a slab
+  __host__ __device__ static constexpr int uoff(int k, int col, int p) {
+    return MH == 4 ? (k * W4_CO + col) * NP + p : ((k * NQ + (p >> 2)) * W4_CO + col) * 4 + (p & 3);
+  }
+};
+
+template <int TRG, int MH>
 struct W4Cfg {
   static constexpr int TCG = 16 / TRG;          // tile columns of a group
   static constexpr int RC = TCG + 2;            // 16-byte chunks per staged row: columns 4 TCG twg - 4 ...
   static constexpr int ROWF = 4 * RC;           // floats per staged row
-  static constexpr int BANDC = 6 * RC;          // chunks per band (6 input rows of one tile row)
+  static constexpr int NPR = MH + 2;            // input rows of one tile row
+  static constexpr int BANDC = NPR * RC;        // chunks per band
   static constexpr int BANDF = 4 * BANDC;
   static_assert(TRG * BANDC <= 128, "a plane holds 128 chunks");
 };
@@ -89,9 +126,25 @@ __device__ __forceinline__ void w4_g6(double g0, double g1, double g2, double& u
   u5 = g2;
 }
 
-// U = G g G^T in double, rounded once.  Packed [cot][chunk][ci 4][co 32][36].
+// F(3,3), points (0, 1, -1, 2, inf):
+//   G   = [[1/2,0,0],[-1/2,-1/2,-1/2],[-1/6,1/6,-1/6],[1/6,1/3,2/3],[0,0,1]]
+//   B^T = [[2,-1,-2,1,0],[0,-2,-1,1,0],[0,2,-3,1,0],[0,-1,0,1,0],[0,2,-1,-2,1]]
+//   A^T = [[1,1,1,1,0],[0,1,-1,2,0],[0,1,1,4,1]]
+__device__ __forceinline__ void w4_g5(double g0, double g1, double g2, double& u0, double& u1, double& u2,
+                                      double& u3, double& u4) {
+  u0 = g0 / 2.0;
+  u1 = -(g0 + g1 + g2) / 2.0;
+  u2 = -(g0 - g1 + g2) / 6.0;
+  u3 = g0 / 6.0 + g1 / 3.0 + g2 * (2.0 / 3.0);
+  u4 = g2;
+}
+
+// U = G_h g G_w^T in double, rounded once (G_h: 6 or 5 points along H, G_w: 6 points along W).
+// Packed [cot][chunk][slab of W4Pos<MH>].
+template <int MH>
 __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int Kc,
                                      int dgrad) {
+  using P = W4Pos<MH>;
   const int nchunk = Kc / W4_CK;
   const size_t total = (size_t)M * Kc;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -107,18 +160,21 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
       g[t] = dgrad ? w[((size_t)k * M + m) * 9 + (8 - t)] : w[((size_t)m * Kc + k) * 9 + t];
     double tmp[6][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) w4_g6(g[c], g[3 + c], g[6 + c], tmp[0][c], tmp[1][c], tmp[2][c], tmp[3][c], tmp[4][c], tmp[5][c]);
-    float* o = up + ((((size_t)cot * nchunk + k / W4_CK) * W4_CK + k % W4_CK) * W4_CO + col) * W4_NP;
+    for (int c = 0; c < 3; ++c) {
+      if (MH == 4) w4_g6(g[c], g[3 + c], g[6 + c], tmp[0][c], tmp[1][c], tmp[2][c], tmp[3][c], tmp[4][c], tmp[5][c]);
+      else w4_g5(g[c], g[3 + c], g[6 + c], tmp[0][c], tmp[1][c], tmp[2][c], tmp[3][c], tmp[4][c]);
+    }
+    float* o = up + ((size_t)cot * nchunk + k / W4_CK) * P::USLAB;
+    const int kk = k % W4_CK;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      double u0, u1, u2, u3, u4, u5;
-      w4_g6(tmp[i][0], tmp[i][1], tmp[i][2], u0, u1, u2, u3, u4, u5);
-      o[6 * i + 0] = (float)u0;
-      o[6 * i + 1] = (float)u1;
-      o[6 * i + 2] = (float)u2;
-      o[6 * i + 3] = (float)u3;
-      o[6 * i + 4] = (float)u4;
-      o[6 * i + 5] = (float)u5;
+    for (int i = 0; i < P::NPR; ++i) {
+      double u[6];
+      w4_g6(tmp[i][0], tmp[i][1], tmp[i][2], u[0], u[1], u[2], u[3], u[4], u[5]);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) o[P::uoff(kk, col, 6 * i + j)] = (float)u[j];
+    }
+    if (P::NP % 4 != 0) {  // the unused half of the last position quad: multiplied into nothing, kept finite
+      for (int p = P::NP; p < 4 * P::NQ; ++p) o[P::uoff(kk, col, p)] = 0.0f;
     }
   }
 }
@@ -129,14 +185,18 @@ struct W4Args {
   float* y;               // (B, Cout, H, W)
   const float* residual;  // same shape as y (may be null)
   int B, Cin, H, W, Cout;
-  int TH, TW;             // 4x4 output tiles per image
+  int TH, TW;             // MH x 4 output tiles per image
   int SR;                 // stacked tile rows: B * TH
   int GRR, TWG;           // group rows (of TRG stacked tile rows), group columns
   int ngroups;            // GRR * TWG
   int ncot;               // Cout / 32
-  int nitems;             // work items: ceil(ngroups / 4) * ncot, numbered cot-fastest
-  int split;              // cut the k-step stream evenly over the workgroups (see the kernel)
-  unsigned* flags;        // split: one word per workgroup, raised to `epoch` when its tail sums are in y
+  int nquad;              // ceil(ngroups / 4)
+  int cotb;               // channel slabs per numbering block: min(ncot, 8)
+  int nitems;             // work items: nquad * ncot; id = ((cot / cotb) * nquad + quad) * cotb + cot % cotb
+  int nxg;                // item dealing groups (XCDs): workgroup b belongs to group b % nxg
+  int xmode;              // 1: a group owns a contiguous range of the item list; 2: the tile quads = group mod nxg
+  int split;              // cut the items of a half-empty last round in two k-halves (see the kernel)
+  unsigned* flags;        // split: one word per cut item, raised to `epoch` when its upper-half sums are in y
   unsigned epoch;
   long long* trace;       // debug: cycle totals of workgroup 0 (null in production)
 };
@@ -164,11 +224,16 @@ __device__ __forceinline__ void w4_wait() {
 // accumulate / start (C = 0) forms, accumulator pinned to the AGPR ("a") or VGPR ("v") half
 #define W4_MFMA_A(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W4_MFMA_V(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
-#define W4_MFMA_A0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
+// The start forms open with two wait states: V[] is live across the epilogue in front of an item's first k-step,
+// and when the allocator parks it there (MH = 3 leaves 16 AGPRs free: it uses them as spill space) it brings each
+// value back with a v_accvgpr_read right in front of the MFMA that reads it - a VALU write -> MFMA operand read,
+// which needs the states and which hipcc does not pad for an asm statement (round 3: NaNs in row block 0).
+// tools/audit_asm_hazards.py checks the build's ISA for the same pattern in front of the accumulate forms.
+#define W4_MFMA_A0(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
 // (early clobber: a fresh VGPR destination must not share registers with the A / B operands)
-#define W4_MFMA_V0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
+#define W4_MFMA_V0(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
 
-// one row / column of B^T d: 12 operations
+// one row / column of B^T d, 6 points: 12 operations
 __device__ __forceinline__ void w4_bt6(float d0, float d1, float d2, float d3, float d4, float d5, float& t0,
                                        float& t1, float& t2, float& t3, float& t4, float& t5) {
   t0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
@@ -180,7 +245,17 @@ __device__ __forceinline__ void w4_bt6(float d0, float d1, float d2, float d3, f
   t4 = __builtin_fmaf(-2.0f, e, c);
   t5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
 }
-// one row / column of A^T m: 10 operations
+// one column of B^T d, 5 points (F(3,3)): 9 operations
+__device__ __forceinline__ void w4_bt5(float d0, float d1, float d2, float d3, float d4, float& t0, float& t1,
+                                       float& t2, float& t3, float& t4) {
+  const float e = d3 - d1;
+  t0 = __builtin_fmaf(2.0f, d0 - d2, e);
+  t1 = __builtin_fmaf(-2.0f, d1, d3 - d2);
+  t2 = __builtin_fmaf(2.0f, d1, __builtin_fmaf(-3.0f, d2, d3));
+  t3 = e;
+  t4 = __builtin_fmaf(-2.0f, e, d4 - d2);
+}
+// one row / column of A^T m, 6 points -> 4 outputs: 10 operations
 __device__ __forceinline__ void w4_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0,
                                        float& y1, float& y2, float& y3) {
   const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
@@ -189,12 +264,23 @@ __device__ __forceinline__ void w4_at6(float m0, float m1, float m2, float m3, f
   y2 = __builtin_fmaf(4.0f, s2, s1);
   y3 = __builtin_fmaf(8.0f, d2, d1) + m5;
 }
+// one column of A^T m, 5 points -> 3 outputs: 7 operations
+__device__ __forceinline__ void w4_at5(float m0, float m1, float m2, float m3, float m4, float& y0, float& y1,
+                                       float& y2) {
+  const float s1 = m1 + m2, d1 = m1 - m2;
+  y0 = m0 + s1 + m3;
+  y1 = __builtin_fmaf(2.0f, m3, d1);
+  y2 = __builtin_fmaf(4.0f, m3, s1) + m4;
+}
 
-template <int TRG, bool TRACE = false>
+template <int TRG, int MH, bool TRACE = false>
 __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
-  using C = W4Cfg<TRG>;
+  using C = W4Cfg<TRG, MH>;
+  using P = W4Pos<MH>;
+  constexpr int NPR = P::NPR, NP = P::NP, NQ = P::NQ, ND = P::ND, NU = P::NU;
+  constexpr int ULDS = P::ULDS, USLAB = P::USLAB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  static_assert(2 * W4_ND <= 63, "vmcnt is a 6-bit counter");
+  static_assert(2 * ND <= 63, "vmcnt is a 6-bit counter");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = tile group of the item's 4
@@ -202,47 +288,57 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   const int nchunk = a.Cin / W4_CK;
   const int wrem = a.W & 3;  // pixels of the chunk that straddles the right edge
 
-  const int lw = xcd_remap(blockIdx.x, gridDim.x);
-  // Work = the global stream of nitems * nchunk k-steps.  Unsplit (a.split == 0), workgroup lw takes whole
-  // items [lw nitems / n, (lw + 1) nitems / n).  Split, it takes k-steps [lw G / n, (lw + 1) G / n) wherever
-  // they fall: 384 items over 256 workgroups (layer4) are 1.5 each instead of two rounds of one, and the
-  // workgroups reach their epilogues at different times instead of bursting 128 KB per CU into HBM together.
-  // An item cut in two is summed through y: the workgroup that owns its TAIL chunks [c, nchunk) meets it as
-  // its FIRST segment, stores the partial sums and raises its flag; the owner of the HEAD chunks [0, c)
-  // meets it as its LAST segment, waits for the successor's flag (set long before), adds the stored sums
-  // and the residual and stores the result.  Needs >= nchunk k-steps per workgroup (an item is cut at most
-  // once); no dependency cycle whatever the dispatch order (a workgroup publishes before it ever waits).
-  int fi, fc, nseg, last_end, S;
-  if (a.split) {
-    const long long G = (long long)a.nitems * nchunk;
-    const long long g0 = (long long)lw * G / (int)gridDim.x, g1 = (long long)(lw + 1) * G / (int)gridDim.x;
-    if (g0 >= g1) return;
-    fi = (int)(g0 / nchunk);
-    fc = (int)(g0 - (long long)fi * nchunk);
-    const int li = (int)((g1 - 1) / nchunk);
-    last_end = (int)((g1 - 1) - (long long)li * nchunk) + 1;
-    nseg = li - fi + 1;
-    S = (int)(g1 - g0);
-  } else {
-    const int i0 = (int)((long long)lw * a.nitems / (int)gridDim.x);
-    const int i1 = (int)((long long)(lw + 1) * a.nitems / (int)gridDim.x);
-    if (i0 >= i1) return;
-    fi = i0; fc = 0; nseg = i1 - i0; last_end = nchunk;
-    S = nseg * nchunk;
+  // ---- which items.  Dealing group xg = blockIdx % nxg (the XCD of this workgroup when nxg == 8: speed only,
+  // nothing below depends on where a workgroup really runs); it owns items [R0, R1) of the list and its Wx
+  // workgroups take them round-robin: `nfull` whole rounds, then `rem` items for the last one.  rem <= Wx / 2
+  // and a.split: each is cut in two k-halves; workgroups j < rem take the LOWER halves as their last segment,
+  // workgroups rem <= j < 2 rem the UPPER halves as their FIRST segment (stored as partial sums into y, flag
+  // raised), so a flag is up long before its reader arrives and no workgroup waits on one that waits.
+  const int xg = (int)blockIdx.x % a.nxg, j = (int)blockIdx.x / a.nxg;
+  const int Wx = ((int)gridDim.x - xg + a.nxg - 1) / a.nxg;
+  // xmode 1: group xg owns the contiguous id range [R0, R0 + nx); xmode 2: the quads congruent to xg mod nxg
+  // (nqx of them, every channel slab), numbered locally the same way.  Items below are LOCAL ids 0 .. nx - 1.
+  const int nqx = (a.nquad - xg + a.nxg - 1) / a.nxg;
+  const int R0 = a.xmode == 2 ? 0 : (int)((long long)xg * a.nitems / a.nxg);
+  const int nx = a.xmode == 2 ? nqx * a.ncot : (int)((long long)(xg + 1) * a.nitems / a.nxg) - R0;
+  const int nround = nx / Wx, rem = nx - nround * Wx;
+  const bool cut = a.split && rem > 0 && 2 * rem <= Wx && nchunk >= 2;
+  const int half = nchunk >> 1;
+  // segments of this workgroup: [upper half of a cut item]? whole items* [lower half | whole tail item]?
+  int tail_seg = -1, tail_item = 0, fc = 0, last_end = nchunk, nseg = nround;
+  const int full_base = j;
+  if (cut) {
+    if (j < rem) { tail_seg = nround; tail_item = nround * Wx + j; last_end = half; ++nseg; }
+    else if (j < 2 * rem) { tail_seg = 0; tail_item = nround * Wx + (j - rem); fc = half; ++nseg; }
+  } else if (j < rem) {
+    tail_seg = nround; tail_item = nround * Wx + j; ++nseg;
   }
+  if (nseg == 0) return;
+  const int S = nround * nchunk + (tail_seg < 0 ? 0 : (cut ? (tail_seg == 0 ? nchunk - half : half) : nchunk));
+  const int flag_idx = xg * 32 + (tail_item - nround * Wx);  // cut items of this launch: < 8 * 32
   long long tk0 = 0, tw0 = 0;
   if (TRACE) { tk0 = clock64(); tw0 = wall_clock64(); }
-  const int i0 = fi, c0 = fc;
-  auto seg_item = [&](int seg) { return fi + seg; };
+  const int c0 = fc;
+  auto seg_item = [&](int seg) {
+    return seg == tail_seg ? tail_item : full_base + (seg - (tail_seg == 0 ? 1 : 0)) * Wx;
+  };
   auto seg_end = [&](int seg) { return seg == nseg - 1 ? last_end : nchunk; };
+  // item id -> (tile quad, channel slab): 32 consecutive ids = cotb slabs x (32 / cotb) quads
+  const int per_block = (a.xmode == 2 ? nqx : a.nquad) * a.cotb;
+  auto item_quad = [&](int item) {
+    const int q = ((R0 + item) % per_block) / a.cotb;
+    return a.xmode == 2 ? xg + a.nxg * q : q;
+  };
+  auto item_cot = [&](int item) { return ((R0 + item) / per_block) * a.cotb + (R0 + item) % a.cotb; };
+  const int i0 = seg_item(0);
 
   float* const ldsU = lds;
-  float* const ldsP = lds + W4_NBUF * W4_ULDS;
+  float* const ldsP = lds + W4_NBUF * ULDS;
   const i32x4 xrs = w4_rsrc(a.x, (unsigned)a.B * a.Cin * HWi * 4u);
-  const i32x4 urs = w4_rsrc(a.up, (unsigned)a.Cout * a.Cin * (W4_NP * 4u));
+  const i32x4 urs = w4_rsrc(a.up, (unsigned)a.ncot * (unsigned)nchunk * (USLAB * 4u));
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
   const unsigned mU0 = lds0 + wave * 1024u;
-  const unsigned mP0 = lds0 + W4_NBUF * W4_ULDS * 4u + wave * 1024u;
+  const unsigned mP0 = lds0 + W4_NBUF * ULDS * 4u + wave * 1024u;
 
   // ---- staging cursors.  Behind the end of the stream they stay on the last k-step (restaged into free
   // buffers), so issue counts - and with them the vmcnt waits - never vary.
@@ -256,7 +352,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     const int band = rem2 / C::BANDC, rem3 = rem2 - band * C::BANDC;
     const int row = rem3 / C::RC, cc = rem3 - row * C::RC;
     const bool slot_ok = rem2 < TRG * C::BANDC;
-    const int quad = item / a.ncot;
+    const int quad = item_quad(item);
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
       const int g = 4 * quad + grp;
@@ -274,7 +370,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         th = band ? sr1 - b1 * a.TH : sr0 - b0 * a.TH;
         ok = ok && (band ? sr1 : sr0) < a.SR;
       }
-      const int hi = 4 * th - 1 + row, col0 = 4 * C::TCG * twg - 4 + 4 * cc;
+      const int hi = MH * th - 1 + row, col0 = 4 * C::TCG * twg - 4 + 4 * cc;
       ok = ok && hi >= 0 && hi < a.H && col0 >= 0 && col0 < a.W;
       const unsigned off = (unsigned)((((b * a.Cin + cilo) * a.H + hi) * a.W + col0) * 4);
       voff[2 * grp] = ok ? off : W4_OOB;
@@ -285,19 +381,19 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   int uSeg = 0, uChunk = c0, uBuf = 0, uLeft = S;
   unsigned xso = __builtin_amdgcn_readfirstlane((unsigned)c0 * (unsigned)(W4_CK * HWi * 4)), mP = mP0, mU = mU0;
   auto u_item_base = [&](int item) {
-    return (unsigned)(item % a.ncot) * (unsigned)nchunk * (W4_USLAB * 4u);
+    return (unsigned)item_cot(item) * (unsigned)nchunk * (USLAB * 4u);
   };
-  unsigned ubase = u_item_base(i0), uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)c0 * (W4_USLAB * 4u));
+  unsigned ubase = u_item_base(i0), uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)c0 * (USLAB * 4u));
   const unsigned uvoff = (unsigned)tid * 16u;
   set_voff(i0);
 
-  // DMA unit u of the restaging of one k-step: 0 .. 4 = the weight slab (4608 floats; the fifth DMA's upper
-  // half lands in the pad behind it - LDS pitch 5120 - and reads the next slab's head or, behind the last
-  // one, out of range), 5 .. 12 = the patches.
+  // DMA unit u of the restaging of one k-step: 0 .. NU - 1 = the weight slab (MH = 4: 4608 floats, the fifth
+  // DMA's upper half lands in the pad behind it - LDS pitch 5120 - and reads the next slab's head or, behind
+  // the last one, out of range; MH = 3: exactly four), NU .. NU + 7 = the patches.
   auto dma_unit = [&](auto unit_tag) {
     constexpr int u = decltype(unit_tag)::value;
-    if constexpr (u < W4_NU) w4_dma16<u * 4096>(urs, uso + (unsigned)u * 4096u, mU, uvoff);
-    else w4_dma16<(u - W4_NU) * 4096>(xrs, xso, mP, voff[u - W4_NU]);
+    if constexpr (u < NU) w4_dma16<u * 4096>(urs, uso + (unsigned)u * 4096u, mU, uvoff);
+    else if constexpr (u < ND) w4_dma16<(u - NU) * 4096>(xrs, xso, mP, voff[u - NU]);
   };
   auto adv_patch = [&]() {
     pBuf = pBuf + 1 == W4_NBUF ? 0 : pBuf + 1;
@@ -322,36 +418,39 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         ubase = u_item_base(seg_item(uSeg));
       }
     }
-    uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)uChunk * (W4_USLAB * 4u));
-    mU = __builtin_amdgcn_readfirstlane(mU0 + (unsigned)uBuf * (W4_ULDS * 4u));
+    uso = __builtin_amdgcn_readfirstlane(ubase + (unsigned)uChunk * (USLAB * 4u));
+    mU = __builtin_amdgcn_readfirstlane(mU0 + (unsigned)uBuf * (ULDS * 4u));
   };
 #define W4_UNIT(U_) dma_unit(std::integral_constant<int, U_>{})
   auto dma_u = [&]() {
-    W4_UNIT(0); W4_UNIT(1); W4_UNIT(2); W4_UNIT(3); W4_UNIT(4);
+    W4_UNIT(0); W4_UNIT(1); W4_UNIT(2); W4_UNIT(3);
+    if constexpr (NU > 4) W4_UNIT(4);
     adv_u();
   };
   auto dma_patch = [&]() {
-    W4_UNIT(5); W4_UNIT(6); W4_UNIT(7); W4_UNIT(8); W4_UNIT(9); W4_UNIT(10); W4_UNIT(11); W4_UNIT(12);
+    W4_UNIT(NU + 0); W4_UNIT(NU + 1); W4_UNIT(NU + 2); W4_UNIT(NU + 3);
+    W4_UNIT(NU + 4); W4_UNIT(NU + 5); W4_UNIT(NU + 6); W4_UNIT(NU + 7);
     adv_patch();
   };
 
   // ---- compute state
-  f32x4 accA[64], accV[8];  // accumulator cb * 36 + p: the first 64 in AGPRs, the last 8 in VGPRs
-  float V[36];              // B^T d B of the step about to be multiplied
-  float raw[36];            // patch of the next step
+  // accumulator cb * NP + p: the first 64 in AGPRs, the rest (MH = 4: 8) in VGPRs
+  f32x4 accA[P::NACC < 64 ? P::NACC : 64], accV[P::NACC > 64 ? P::NACC - 64 : 1];
+  float V[NP];         // B^T d B of the step about to be multiplied
+  float raw[NPR * 6];  // patch of the next step
   int pb_lane = 0, ub_lane = 0;
   auto lane_consts = [&]() {
     int t = tid;
     asm volatile("" : "+v"(t));
-    const int j = t & 15, k = (t >> 4) & 3;
-    const int tr = j / C::TCG, tc = j - tr * C::TCG;
+    const int jl = t & 15, k = (t >> 4) & 3;
+    const int tr = jl / C::TCG, tc = jl - tr * C::TCG;
     pb_lane = wave * W4_GRPF + k * W4_PLF + tr * C::BANDF + 4 * tc;
-    ub_lane = j * W4_NP + k * (W4_CO * W4_NP);
+    ub_lane = P::uoff(k, jl, 0);
   };
   // staged-row float offset of image column W - W % 4 for this wave's group of `item`, or -1
   auto edge_of = [&](int item) {
     if (wrem == 0) return -1;
-    const int g = 4 * (item / a.ncot) + wave;
+    const int g = 4 * item_quad(item) + wave;
     const int twg = g / a.GRR;
     const int cc = (a.W - wrem - (4 * C::TCG * twg - 4)) >> 2;
     return (g < a.ngroups && cc >= 0 && cc < C::RC) ? 4 * cc + wrem : -1;
@@ -360,8 +459,8 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     int t = tid;
     asm volatile("" : "+v"(t));
     const int l = t & 63;
-    if (l < 24 * TRG) {
-      const int ci = l / (6 * TRG), rb = l - ci * (6 * TRG);
+    if (l < 4 * NPR * TRG) {
+      const int ci = l / (NPR * TRG), rb = l - ci * (NPR * TRG);
       float* p = pbuf + wave * W4_GRPF + ci * W4_PLF + rb * C::ROWF + eoff;  // bands are contiguous rows
       p[0] = 0.0f;
       if (wrem < 3) p[1] = 0.0f;
@@ -371,7 +470,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   auto read_patch = [&](const float* pbuf) {
     const float* p = pbuf + pb_lane;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
+    for (int r = 0; r < NPR; ++r) {
       raw[6 * r] = p[r * C::ROWF + 3];
       const f32x4 m = *reinterpret_cast<const f32x4*>(p + r * C::ROWF + 4);
       raw[6 * r + 1] = m[0];
@@ -382,37 +481,38 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     }
   };
   auto transform = [&]() {
-    float t[36];
+    float t[NPR * 6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
+    for (int r = 0; r < NPR; ++r)  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
       w4_bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5],
              t[6 * r], t[6 * r + 1], t[6 * r + 2], t[6 * r + 3], t[6 * r + 4], t[6 * r + 5]);
 #pragma unroll
-    for (int c = 0; c < 6; ++c)  // down the column: V[i][j] = sum_r BT[i][r] t[r][j]
-      w4_bt6(t[c], t[6 + c], t[12 + c], t[18 + c], t[24 + c], t[30 + c],
-             V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c], V[30 + c]);
+    for (int c = 0; c < 6; ++c) {  // down the column: V[i][j] = sum_r BT_h[i][r] t[r][j]
+      if constexpr (MH == 4)
+        w4_bt6(t[c], t[6 + c], t[12 + c], t[18 + c], t[24 + c], t[30 + c],
+               V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c], V[30 + c]);
+      else
+        w4_bt5(t[c], t[6 + c], t[12 + c], t[18 + c], t[24 + c], V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c]);
+    }
   };
 
-  // Y = A^T M A per lane; D row (l >> 4) * 4 + r -> channel, D column l & 15 -> tile.
+  // Y = A_h^T M A_w per lane; D row (l >> 4) * 4 + r -> channel, D column l & 15 -> tile.
   // Output rows go out as 16-byte buffer stores whose offset is pushed out of range for lanes / rows that
   // do not exist (the store is dropped, the residual load returns zero): no branches in the common path.
   // Tiles that straddle the right image edge (W % 4 != 0) store element by element instead.
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-      a.y, (short)0, (int)((unsigned)a.B * a.Cout * HWi * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.residual != nullptr ? a.residual : a.y), (short)0,
-      (int)((unsigned)a.B * a.Cout * HWi * 4u), 0x00020000);
+  const unsigned ybytes = (unsigned)a.B * a.Cout * HWi * 4u;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, (short)0, (int)ybytes, 0x00020000);
   const bool has_res = a.residual != nullptr;
   const bool tracing = TRACE && a.trace != nullptr && blockIdx.x == 0;
   long long tS = 0, tDr = 0, tL = 0;
-  // partial: store the sums as they are (segment 0 of a rotated stream); accum: add what segment 0 stored
+  // partial: store the sums as they are (upper k-half of a cut item); accum: add what the upper half stored
   auto epilogue = [&](int item, bool partial, bool accum) {
     int t = tid;
     asm volatile("" : "+v"(t));
-    const int j = t & 15, q = (t >> 4) & 3;
-    const int tr = j / C::TCG, tc = j - tr * C::TCG;
-    const int cot = item % a.ncot;
-    const int g = 4 * (item / a.ncot) + wave;
+    const int jl = t & 15, q = (t >> 4) & 3;
+    const int tr = jl / C::TCG, tc = jl - tr * C::TCG;
+    const int cot = item_cot(item);
+    const int g = 4 * item_quad(item) + wave;
     const int gr = g % a.GRR, twg = g / a.GRR;
     int b, th, sr;
     if (TRG == 1) {
@@ -428,28 +528,32 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     }
     const int tw = twg * C::TCG + tc;
     const bool valid = g < a.ngroups && sr < a.SR && tw < a.TW;
-    const int ho = 4 * th, wo = 4 * tw;
+    const int ho = MH * th, wo = 4 * tw;
     const bool wide = valid && wo + 4 <= a.W;
     const bool part = valid && !wide;
     const int co0 = cot * W4_CO + 4 * q;
     const unsigned obase = (unsigned)(((b * a.Cout + co0) * a.H + ho) * a.W + wo) * 4u;  // bytes
-    unsigned orow[4];
+    unsigned orow[MH];
 #pragma unroll
-    for (int yy = 0; yy < 4; ++yy)
+    for (int yy = 0; yy < MH; ++yy)
       orow[yy] = (wide && ho + yy < a.H) ? obase + (unsigned)(yy * a.W) * 4u : W4_OOB;
     const unsigned chan = (unsigned)a.H * (unsigned)a.W * 4u;
     asm volatile("s_nop 15");  // the last MFMAs' results (inline asm: no compiler-inserted wait states)
+    // The residual and the partner's partial sums are ALWAYS loaded, through descriptors that are empty (every
+    // offset out of range: zeros, no memory access) when there is nothing to add: no branches around the loads, so
+    // the compiler issues a channel pair's loads together and waits for them once (with `if (use_res)` around
+    // each it waited for every single load with vmcnt(0)).
     const bool use_res = has_res && !partial;
-    f32x4 res[8][4];
+    const __amdgpu_buffer_rsrc_t rrs_e = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(has_res ? a.residual : a.y), (short)0, use_res ? (int)ybytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars_e = __builtin_amdgcn_make_buffer_rsrc(a.y, (short)0, accum ? (int)ybytes : 0, 0x00020000);
+    f32x4 res[8][MH];
     auto load_res = [&](int cr) {  // residual (and the stored partial sums) of channel pair cr, one step ahead
       const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
 #pragma unroll
-      for (int yy = 0; yy < 4; ++yy) {
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (use_res) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, orow[yy] + coff, 0, 0));
-        if (accum) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, orow[yy] + coff, 0, 0));
-        res[cr][yy] = v;
-      }
+      for (int yy = 0; yy < MH; ++yy)
+        res[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, orow[yy] + coff, 0, 0)) +
+                      __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars_e, orow[yy] + coff, 0, W4_SC1));
     };
     load_res(0);
 #pragma unroll
@@ -459,20 +563,21 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // gave wrong second dwords in lanes 12-15 of every row of 16 on gfx950 - not understood, avoided)
       const unsigned coff = (unsigned)(cb * 16 + r) * chan;
       if (cr + 1 < 8) load_res(cr + 1);
-      float T[4][6];
+      float T[MH][6];
 #pragma unroll
       for (int jj = 0; jj < 6; ++jj) {
-        float m[6];
+        float m[NPR];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int acc = cb * 36 + 6 * i + jj;
+        for (int i = 0; i < NPR; ++i) {
+          const int acc = cb * NP + 6 * i + jj;
           m[i] = acc < 64 ? accA[acc < 64 ? acc : 0][r] : accV[acc >= 64 ? acc - 64 : 0][r];
         }
-        w4_at6(m[0], m[1], m[2], m[3], m[4], m[5], T[0][jj], T[1][jj], T[2][jj], T[3][jj]);
+        if constexpr (MH == 4) w4_at6(m[0], m[1], m[2], m[3], m[4], m[5], T[0][jj], T[1][jj], T[2][jj], T[3][jj]);
+        else w4_at5(m[0], m[1], m[2], m[3], m[4], T[0][jj], T[1][jj], T[2][jj]);
       }
-      f32x4 Y[4];
+      f32x4 Y[MH];
 #pragma unroll
-      for (int yy = 0; yy < 4; ++yy) {
+      for (int yy = 0; yy < MH; ++yy) {
         float v0, v1, v2, v3;
         w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
         Y[yy] = (f32x4){v0, v1, v2, v3};
@@ -480,21 +585,23 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       long long cs = 0;
       if (tracing) { __builtin_amdgcn_sched_barrier(0); cs = clock64(); }
 #pragma unroll
-      for (int yy = 0; yy < 4; ++yy) {
+      for (int yy = 0; yy < MH; ++yy) {
         const f32x4 v = Y[yy] + res[cr][yy];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, 0);
+        if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, W4_SC1);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, 0);
       }
       if (tracing) { __builtin_amdgcn_sched_barrier(0); tS += clock64() - cs; }
       if (part) {  // lanes of the tile column that straddles the right edge
 #pragma unroll
-        for (int yy = 0; yy < 4; ++yy)
+        for (int yy = 0; yy < MH; ++yy)
 #pragma unroll
           for (int xx = 0; xx < 3; ++xx) {
             const unsigned o = (ho + yy < a.H && wo + xx < a.W) ? obase + (unsigned)(yy * a.W + xx) * 4u : W4_OOB;
             float v = Y[yy][xx];
-            if (use_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, o + coff, 0, 0));
-            if (accum) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, o + coff, 0, 0));
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, 0);
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs_e, o + coff, 0, 0));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars_e, o + coff, 0, W4_SC1));
+            if (partial) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, W4_SC1);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, 0);
           }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -505,7 +612,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   dma_patch();
   dma_u(); dma_patch();
   dma_u(); dma_patch();
-  w4_wait<2 * W4_ND>();
+  w4_wait<2 * ND>();
   __syncthreads();
   lane_consts();
   int e_cur = edge_of(i0), e_nxt = -1;
@@ -515,41 +622,53 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
 
   int cur = 0;
   long long tW = 0, tB = 0, tD = 0, tM = 0, tT = 0, tE = 0;
-  auto kstep = [&](auto first_tag, int e_next) {
+  // FIRST: the item's first k-step (accumulators start from zero).  LAST: its last one - the patch of the NEXT
+  // item's first step is not read and transformed here but behind the epilogue (next_patch below): V[] and
+  // raw[] are then dead across the epilogue, which otherwise spills them to scratch and brings them back inside
+  // the next k-step behind `s_waitcnt vmcnt(0)` - draining the DMA queue once per item (round 3: 10 % on layer1,
+  // whose items are 16 k-steps long).
+  auto kstep = [&](auto first_tag, auto last_tag, int e_next) {
     constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
     const int nxt = cur + 1 == W4_NBUF ? 0 : cur + 1;
-    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-    if (tracing) c0 = clock64();
+    long long c0_ = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    if (tracing) c0_ = clock64();
     // U(s) and patch(s+1) have landed (loads retire in order; the group issued last step may still fly)
-    w4_wait<W4_ND>();
+    w4_wait<ND>();
     if (tracing) c1 = clock64();
     __syncthreads();
     if (tracing) c2 = clock64();
     if (tracing) c3 = clock64();
     float* pn = ldsP + nxt * W4_PATCHF;
     if (e_next >= 0) fix_edge(pn, e_next);
-    read_patch(pn);
-    const float* ub = ldsU + cur * W4_ULDS + ub_lane;
-    f32x4 u[18];
+    if constexpr (!LAST) read_patch(pn);
+    const float* ub = ldsU + cur * ULDS + ub_lane;
+    constexpr int NG = 2 * NQ;  // operand groups: row block g / NQ, position quad g % NQ
+    f32x4 u[NG];
     constexpr int AHEAD = 3;
-    auto ldu = [&](int g) { u[g] = *reinterpret_cast<const f32x4*>(ub + (g / 9) * (16 * W4_NP) + (g % 9) * 4); };
+    auto ldu = [&](int g) {
+      const int rb = g / NQ, q = g % NQ;
+      u[g] = *reinterpret_cast<const f32x4*>(ub + P::uoff(0, 16 * rb, 4 * q));
+    };
 #pragma unroll
     for (int g = 0; g < AHEAD; ++g) ldu(g);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1");
 #pragma unroll
-    for (int g = 0; g < 18; ++g) {  // group g: row block g / 9, positions 4 (g % 9) .. + 3
-      if (g + AHEAD < 18) ldu(g + AHEAD);
+    for (int g = 0; g < NG; ++g) {
+      if (g + AHEAD < NG) ldu(g + AHEAD);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int p = 4 * (g % 9) + q, acc = (g / 9) * 36 + p;
-        if (acc < 64) {
-          if (FIRST) W4_MFMA_A0(accA[acc < 64 ? acc : 0], u[g][q], V[p]);
-          else W4_MFMA_A(accA[acc < 64 ? acc : 0], u[g][q], V[p]);
-        } else {
-          if (FIRST) W4_MFMA_V0(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p]);
-          else W4_MFMA_V(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p]);
+        const int p = 4 * (g % NQ) + q, acc = (g / NQ) * NP + p;
+        if (p < NP) {
+          if (acc < 64) {
+            if (FIRST) W4_MFMA_A0(accA[acc < 64 ? acc : 0], u[g][q], V[p < NP ? p : 0]);
+            else W4_MFMA_A(accA[acc < 64 ? acc : 0], u[g][q], V[p < NP ? p : 0]);
+          } else {
+            if (FIRST) W4_MFMA_V0(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p < NP ? p : 0]);
+            else W4_MFMA_V(accV[acc >= 64 ? acc - 64 : 0], u[g][q], V[p < NP ? p : 0]);
+          }
         }
       }
       // restaging, one DMA per group boundary so the memory pipeline takes them one at a time (issued back
@@ -573,50 +692,51 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the last MFMAs write the VGPR-resident accumulators: inline asm gets no compiler-inserted wait states,
-    // and a register copy the allocator places right behind them would read half-written results
+    // the last MFMAs write (MH = 4) the VGPR-resident accumulators: inline asm gets no compiler-inserted wait
+    // states, and a register copy the allocator places right behind them would read half-written results
     asm volatile("s_nop 15");
     adv_u();
     adv_patch();
     if (tracing) c4 = clock64();
-    transform();
+    if constexpr (!LAST) transform();
     __builtin_amdgcn_sched_barrier(0);
     if (tracing) {
       c5 = clock64();
-      tW += c1 - c0; tB += c2 - c1; tD += c3 - c2; tM += c4 - c3; tT += c5 - c4;
+      tW += c1 - c0_; tB += c2 - c1; tD += c3 - c2; tM += c4 - c3; tT += c5 - c4;
     }
     cur = nxt;
   };
   for (int seg = 0; seg < nseg; ++seg) {
     const int item = seg_item(seg);
     const int len = seg_end(seg) - (seg == 0 ? c0 : 0);
-    if (seg != 0) lane_consts();
     e_nxt = seg + 1 < nseg ? edge_of(seg_item(seg + 1)) : -1;
     long long cl = 0;
     if (tracing) cl = clock64();
     if (len == 1) {
-      kstep(std::true_type{}, e_nxt);
+      kstep(std::true_type{}, std::true_type{}, e_nxt);
     } else {
-      kstep(std::true_type{}, e_cur);
-      for (int chunk = 1; chunk < len - 1; ++chunk) kstep(std::false_type{}, e_cur);
-      kstep(std::false_type{}, e_nxt);
+      kstep(std::true_type{}, std::false_type{}, e_cur);
+      for (int chunk = 1; chunk < len - 1; ++chunk) kstep(std::false_type{}, std::false_type{}, e_cur);
+      kstep(std::false_type{}, std::true_type{}, e_nxt);
     }
     e_cur = e_nxt;
     long long ce = 0;
     if (tracing) { ce = clock64(); tL += ce - cl; }
-    const bool tail_part = seg == 0 && fc > 0;                        // -> partial sums into y
-    const bool head_part = seg == nseg - 1 && last_end < nchunk;      // <- the successor's partial sums
-    if (head_part) {
+    const bool upper_part = cut && seg == tail_seg && tail_seg == 0;        // -> partial sums into y
+    const bool lower_part = cut && seg == tail_seg && tail_seg != 0;        // <- the partner's partial sums
+    if (lower_part) {
       if (tid == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(a.flags + lw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch &&
-               ++spins < (1u << 24))
+        while (__hip_atomic_load(a.flags + flag_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
           __builtin_amdgcn_s_sleep(8);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          // the partner never ran (it publishes before anything else): fail the launch loudly instead of adding
+          // sums that are not there
+          if (++spins == (1u << 26)) __builtin_trap();
+        }
       }
       __syncthreads();
     }
-    epilogue(item, tail_part, head_part);
+    epilogue(item, upper_part, lower_part);
     if (tracing) tE += clock64() - ce;
     // Compiler-visible vmcnt(0): whatever it spilled around the epilogue has come back, so it puts no
     // vmcnt waits (which would also drain the DMAs in flight) into the k-step loop; the tail sums are out.
@@ -624,14 +744,15 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     if (tracing) cd = clock64();
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (tracing) tDr += clock64() - cd;
-    if (tail_part) {  // publish: every wave's stores are done (above); one agent-scope release, then the flag
+    if (seg + 1 < nseg) {  // the next item's first patch (buffer `cur` after the last k-step's swap; its right edge
+      lane_consts();       // was fixed there): the reads and the transform the LAST k-step left out
+      read_patch(ldsP + cur * W4_PATCHF);
+      transform();
+    }
+    if (upper_part) {  // publish: every wave's sc1 stores have been acknowledged (vmcnt(0) above), then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.flags + lw, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (tid == 0) __hip_atomic_store(a.flags + flag_idx, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (tracing && (tid & 63) == 0) {
@@ -644,6 +765,40 @@ int w4_grid_for(size_t n) {
   size_t g = (n + 255) / 256;
   if (g > 4096) g = 4096;
   return (int)(g < 1 ? 1 : g);
+}
+
+// output-tile height for an H-row image: the one that issues fewer positions (ties: 4)
+int w4_tile_rows(int H) {
+  const int opt = air_opt(AIR_OPT_WINO4_TH3);  // 0: always 4; 1: fewer positions, ties -> 4; 2: ties -> 3
+  if (!opt) return 4;
+  const int c4 = (H + 3) / 4 * 36, c3 = (H + 2) / 3 * 30;
+  return (c3 < c4 || (c3 == c4 && opt == 2)) ? 3 : 4;
+}
+
+template <int MH>
+int w4_launch(W4Args& a, int trg, int nblk, hipStream_t st) {
+  const size_t ldsb = (size_t)W4_NBUF * (W4Pos<MH>::ULDS + W4_PATCHF) * sizeof(float);
+  static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
+    const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, false>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, false>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, true>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, true>)};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i)
+      ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess;
+    return ok;
+  }();
+  if (!attr_ok) return AIR_ELAUNCH;
+  if (a.trace != nullptr) {
+    if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, MH, true>), dim3(nblk), dim3(256), ldsb, st, a);
+    else hipLaunchKernelGGL((wino4_conv_kernel<1, MH, true>), dim3(nblk), dim3(256), ldsb, st, a);
+  } else if (trg == 2) {
+    hipLaunchKernelGGL((wino4_conv_kernel<2, MH, false>), dim3(nblk), dim3(256), ldsb, st, a);
+  } else {
+    hipLaunchKernelGGL((wino4_conv_kernel<1, MH, false>), dim3(nblk), dim3(256), ldsb, st, a);
+  }
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
 }
 
 }  // namespace
@@ -660,25 +815,45 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
          (double)air_wino4_packed_elems(M, Kc) * 4.0 < 4294967296.0 && H >= 1 && W >= 4;
 }
 
-size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)M * Kc * W4_NP + 1024; }
+// (either tile height: 36 floats per (co, ci) cover the 32 of the 3-row layout)
+size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)M * Kc * 36 + 1024; }
 
-int air_wino4_weights(const float* w, float* up, int M, int Kc, int dgrad, hipStream_t st) {
-  hipLaunchKernelGGL(wino4_weights_kernel, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc,
-                     dgrad);
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st) {
+  if (w4_tile_rows(H) == 3)
+    hipLaunchKernelGGL(wino4_weights_kernel<3>, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc, dgrad);
+  else
+    hipLaunchKernelGGL(wino4_weights_kernel<4>, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc, dgrad);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
+}
+
+// cut-item flags: per device, 64 launches' worth of 256 words, zeroed once; epochs never repeat
+static unsigned* w4_flag_ring() {
+  static std::mutex mu;
+  static unsigned* rings[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (rings[dev] == nullptr) {
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, 64 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 64 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    rings[dev] = p;
+  }
+  return rings[dev];
 }
 
 int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
                    int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
   if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino4_weights)
-    const int rc = air_wino4_weights(w, up, M, Kc, dgrad, st);
+    const int rc = air_wino4_weights(w, up, M, Kc, H, dgrad, st);
     if (rc != AIR_OK) return rc;
   }
+  const int mh = w4_tile_rows(H);
   W4Args a;
   a.x = x; a.up = up; a.y = y; a.residual = residual;
   a.B = B; a.Cin = Kc; a.H = H; a.W = W; a.Cout = M;
-  a.TH = (H + 3) / 4; a.TW = (W + 3) / 4;
+  a.TH = (H + mh - 1) / mh; a.TW = (W + 3) / 4;
   a.SR = B * a.TH;
   // 1 x 16 or 2 x 8 tiles per group: fewer groups = less padding waste
   const long g1 = (long)a.SR * ((a.TW + 15) / 16), g2 = (long)((a.SR + 1) / 2) * ((a.TW + 7) / 8);
@@ -687,55 +862,33 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   a.TWG = (a.TW + 16 / trg - 1) / (16 / trg);
   a.ngroups = a.GRR * a.TWG;
   a.ncot = M / W4_CO;
-  a.nitems = (a.ngroups + 3) / 4 * a.ncot;
+  a.nquad = (a.ngroups + 3) / 4;
+  a.cotb = a.ncot < 8 ? a.ncot : 8;
+  while (a.ncot % a.cotb != 0) --a.cotb;  // (channel counts here are powers of two times 32: a no-op)
+  a.nitems = a.nquad * a.ncot;
   a.trace = g_wino4_trace;
-  int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
-  // split streams: only when every workgroup gets at least one item's worth of k-steps, not under stream
-  // capture (the per-launch epoch would be frozen into the graph), and when it changes the balance
-  const int split_on = air_opt(AIR_OPT_WINO4_SPLIT);
+  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  // dealing groups = XCDs (workgroup b runs on XCD b % 8); WINO4_XCD = 0: one group, i.e. round-robin over
+  // the whole chip (for A/B measurements of the locality)
+  a.xmode = air_opt(AIR_OPT_WINO4_XCD) == 2 ? 2 : 1;
+  a.nxg = air_opt(AIR_OPT_WINO4_XCD) ? (nblk < 8 ? nblk : 8) : 1;
+  if (a.nquad < a.nxg) a.xmode = 1;  // (xmode 2 wants at least one quad per group)
+  // cut items: not under stream capture (the per-launch epoch would be frozen into the graph)
   a.split = 0; a.flags = nullptr; a.epoch = 0;
-  // (an item cut in two costs an extra round trip of its 128 KB of sums: measured a gain only when whole
-  // items leave the last round more than 15 % empty - layer4: 384 items, 0.49 -> 0.41 ms; layer1: 1920
-  // items, 0.33 -> 0.35 ms)
-  const double fill = (double)a.nitems / (256.0 * ((a.nitems + 255) / 256));
-  if (split_on && a.nitems >= 256 && (fill < 0.87 || split_on > 1)) {
+  if (air_opt(AIR_OPT_WINO4_SPLIT)) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
-    static unsigned* flag_ring = [] {  // 64 launches' worth of 257 words, zeroed once; epochs never repeat
-      unsigned* p = nullptr;
-      if (hipMalloc(&p, 64 * 320 * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
-      if (hipMemset(p, 0, 64 * 320 * sizeof(unsigned)) != hipSuccess) return (unsigned*)nullptr;
-      return p;
-    }();
+    unsigned* flag_ring = cap == hipStreamCaptureStatusNone ? w4_flag_ring() : nullptr;
     static std::atomic<unsigned> next_epoch{1};
-    if (cap == hipStreamCaptureStatusNone && flag_ring != nullptr) {
+    if (flag_ring != nullptr) {
       a.epoch = next_epoch.fetch_add(1);
       if (a.epoch == 0) a.epoch = next_epoch.fetch_add(1);
-      a.flags = flag_ring + (a.epoch % 64) * 320;
+      a.flags = flag_ring + (a.epoch % 64) * 256;
       a.split = 1;
     }
   }
-  const size_t ldsb = (size_t)W4_NBUF * (W4_ULDS + W4_PATCHF) * sizeof(float);
-  static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
-    const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, false>),
-                         reinterpret_cast<const void*>(wino4_conv_kernel<2, false>),
-                         reinterpret_cast<const void*>(wino4_conv_kernel<1, true>),
-                         reinterpret_cast<const void*>(wino4_conv_kernel<2, true>)};
-    bool ok = true;
-    for (int i = 0; i < 4; ++i)
-      ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess;
-    return ok;
-  }();
-  if (!attr_ok) return AIR_ELAUNCH;
-  AirProfScope ps(AIR_K_CONV_WINO4, flops, st);
-  if (a.trace != nullptr) {
-    if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, true>), dim3(nblk), dim3(256), ldsb, st, a);
-    else hipLaunchKernelGGL((wino4_conv_kernel<1, true>), dim3(nblk), dim3(256), ldsb, st, a);
-  } else if (trg == 2) {
-    hipLaunchKernelGGL((wino4_conv_kernel<2, false>), dim3(nblk), dim3(256), ldsb, st, a);
-  } else {
-    hipLaunchKernelGGL((wino4_conv_kernel<1, false>), dim3(nblk), dim3(256), ldsb, st, a);
-  }
-  AIR_CHECK_LAUNCH();
-  return AIR_OK;
+  // MFMA FLOPs the launch issues: every item runs Cin / 4 k-steps of NACC MFMAs (16 x 16 x 4) in 4 waves
+  const double issued = (double)a.nitems * (Kc / W4_CK) * 4.0 * (mh == 3 ? W4Pos<3>::NACC : W4Pos<4>::NACC) * 2048.0;
+  AirProfScope ps(AIR_K_CONV_WINO4, flops, st, issued);
+  return mh == 3 ? w4_launch<3>(a, trg, nblk, st) : w4_launch<4>(a, trg, nblk, st);
 }

@@ -48,8 +48,11 @@ int air_abi_version(void);
  *                         convolution is an fmaf chain (round-1 tolerances hold)
  *   WINO4_SPLIT (1)       0 never / 1 when the last round is > 13 % empty / 2 always:
  *                         cut the Winograd k-step stream evenly over the workgroups
- *   WINO4_TH3 (1)         F(3x4,3x3) tiles where F(4x4,3x3) would waste rows (H = 9, 5, 3)
- *   WINO4_XCD (1)         deal work items round-robin inside an XCD
+ *   WINO4_TH3 (2)         0: F(4x4,3x3) tiles always; 1: F(3x4,3x3) where it issues fewer
+ *                         positions for the image height (H = 9, 5, 3); 2: also on ties (H = 18)
+ *   WINO4_XCD (2)         0: work items dealt round-robin over the whole chip; 1: an XCD owns a
+ *                         contiguous range of the item list; 2: an XCD owns the tile quads
+ *                         congruent to its index (same L2 sharing as 1, measured faster)
  *   CONV_MT (0)           force the direct kernels' pixel-tile count (1 | 2)
  *   WGRAD_WGS (256), WINO_WGRAD_WGS (256)   workgroups of the split-K weight gradients
  *   DIRECT_WGRAD_ROWS (1) row-staged conv1 weight gradient
@@ -483,6 +486,11 @@ int air_prof_enable(int on);
 int air_prof_kernel_count(void);
 const char* air_prof_kernel_name(int kid);
 int air_prof_collect(int kid, int* launches, double* total_ms, double* total_work);
+/* The same plus total_issued: the FLOPs those launches sent to the matrix pipe - equal to
+ * total_work for the direct kernels, fewer for the Winograd kernels (36 or 30 multiplies per
+ * 4x4 / 3x4 output tile, padded tiles included). */
+int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work,
+                      double* total_issued);
 
 /* ------------------------------------------------------------- utility ---- */
 int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream); /* y += x */

@@ -2,8 +2,10 @@
 
 The library has two configurations of the fp32 ResNet convolutions:
 
-* ``strict``: dispatch option NO_WINOGRAD = 3 - every convolution is a direct f32-MFMA kernel, i.e. an fmaf chain
-  that differs from the CPU oracle by summation order only.  It has to pass the ROUND-1 constants (``STRICT``).
+* ``strict``: dispatch option NO_WINO4 = 1 - round 1's configuration: 3x3 stride-1 layers on Winograd F(2x2,3x3)
+  (rounds BELOW the direct kernel: 3e-7 .. 7e-7 of the output scale), everything else on the direct f32-MFMA
+  kernels (fmaf chains: summation order only).  It has to pass the ROUND-1 constants (``STRICT``).
+  ``direct`` (NO_WINOGRAD = 3, no Winograd kernel at all) is exercised at kernel level.
 * ``default``: Winograd F(4x4,3x3) / F(3x4,3x3) forward + dgrad and F(3x3,2x2) weight gradients.  Their transforms
   round at a larger multiple of the output scale.  The allowance is not a hand-set constant: it is the strict
   constant times the ratio of the two kernels' per-convolution rounding errors, computed here by a numpy
@@ -156,6 +158,9 @@ def conv_path(path):
     """Run a block under the strict (all-direct) or the default (Winograd) convolution configuration."""
     from asvspoof2021_air_amd import _hip
     if path == "strict":
+        with _hip.options(NO_WINO4=1):
+            yield
+    elif path == "direct":
         with _hip.options(NO_WINOGRAD=3):
             yield
     else:

@@ -81,7 +81,7 @@ def test_dropout_mask_statistics_and_determinism():
 def test_adversarial_step_gradients_and_two_phase_update(path):
     """Phase 1: encoder gradients of (OC-Softmax + CE(classifier(GRL(feats)))) vs the oracle;
     phase 2: the classifier moves, encoder BN statistics are updated twice with recompute=True.
-    ``strict``: direct convolutions, round-1 bound 2e-3; ``default``: Winograd, 2e-3 x the emulated rounding ratio."""
+    ``strict``: round 1's kernels (NO_WINO4 = 1), round-1 bound 2e-3; ``default``: Winograd, 2e-3 x the emulated rounding ratio."""
     from _budget import conv_path
     with conv_path(path):
         _adversarial_step(path)

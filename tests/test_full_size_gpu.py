@@ -54,8 +54,8 @@ def _full_size_oracle():
 @pytest.mark.parametrize("path", ["strict", "default"])
 def test_resnet_full_size_step_vs_oracle(path):
     """BASELINE configs[1] exactly: 64 x 64000 PCM -> LFCC (401 frames) -> repeat-pad 750 -> ResNet-18 ->
-    OC-Softmax -> backward -> Adam + SGD, against the oracle on the same inputs.  ``strict`` = every convolution
-    on the direct f32-MFMA kernels with the round-1 slack (1e-3); ``default`` = the Winograd kernels with that
+    OC-Softmax -> backward -> Adam + SGD, against the oracle on the same inputs.  ``strict`` = round 1's kernels
+    (NO_WINO4 = 1: F(2x2,3x3) + direct) with the round-1 slack (1e-3); ``default`` = the Winograd kernels with that
     slack times the emulated per-convolution rounding ratio (tests/_budget.py)."""
     B, L, FL = 64, 64000, 750
     o = _full_size_oracle()

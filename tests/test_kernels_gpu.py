@@ -291,13 +291,13 @@ def test_conv2d_winograd(ops, cfg):
     acc = synth_feat((B, Cin, H, W), 15)
     got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda())
     close(got, xd.grad + acc.double(), rtol=wb, name="winograd dgrad + accumulate")
-    # strict configuration: the same calls on the direct f32-MFMA kernels hold round 1's 1e-5
-    with conv_path("strict"):
-        if Cin % 8 == 0 and Cout % 64 == 0:
+    # the same calls in round 1's configuration (F(2x2,3x3)) and on the direct f32-MFMA kernels hold round 1's 1e-5
+    for path in ("strict", "direct"):
+        with conv_path(path):
             close(ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1, residual=res.cuda()), y + res.double(),
-                  rtol=STRICT["conv_rtol"], name="direct fwd + residual")
+                  rtol=STRICT["conv_rtol"], name=path + " fwd + residual")
             close(ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda()),
-                  xd.grad + acc.double(), rtol=STRICT["conv_rtol"], name="direct dgrad + accumulate")
+                  xd.grad + acc.double(), rtol=STRICT["conv_rtol"], name=path + " dgrad + accumulate")
     # weight gradient: Winograd F(3x3,2x2) when both channel counts are multiples of 64
     wd = w.double().requires_grad_(True)
     F.conv2d(x.double(), wd, None, 1, 1).backward(dy.double())

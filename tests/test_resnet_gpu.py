@@ -70,7 +70,7 @@ def test_transposed_view_input():
 
 @pytest.mark.parametrize("path", ["strict", "default"])
 def test_grads_vs_oracle_small(golden, path):
-    """``strict``: every convolution on the direct f32-MFMA kernels, round-1 constants.  ``default``: Winograd
+    """``strict``: round 1's kernels (NO_WINO4 = 1: F(2x2,3x3) + direct), round-1 constants.  ``default``: Winograd
     kernels, the centre-gradient floor scaled by the emulated rounding ratio (tests/_budget.py)."""
     with conv_path(path):
         _grads_vs_oracle_small(golden, path)

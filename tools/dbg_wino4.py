@@ -7,7 +7,8 @@ want = F.conv2d(x.double(), w.double(), None, 1, 1)
 got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1).cpu().double()
 err = (got - want).abs()
 print("max err", err.max().item(), "scale", want.abs().max().item())
-bad = err > 1e-3
+bad = (err > 1e-3) | torch.isnan(got)
+print("nan count", torch.isnan(got).sum().item())
 print("bad count", bad.sum().item(), "of", bad.numel())
 idx = bad.nonzero()
 if len(idx):
