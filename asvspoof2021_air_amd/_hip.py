@@ -9,7 +9,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libair_hip.so")
+# AIR_HIP_LIB: another build of the same library (A/B variants from ``build.py --variant``); never a fallback
+_LIB_PATH = os.environ.get("AIR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libair_hip.so")
 _lib = None
 
 ERRORS = {-1: "AIR_EINVAL", -2: "AIR_EUNSUPPORTED", -3: "AIR_ELAUNCH", -4: "AIR_EWORKSPACE"}

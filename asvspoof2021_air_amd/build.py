@@ -69,5 +69,27 @@ def build(verbose=True, force=False):
     return LIB
 
 
+def build_variant(tag, src, defines):
+    """A/B tooling: libair_hip.<tag>.so = the current objects with `src` recompiled under extra -D flags
+    (``python -m asvspoof2021_air_amd.build --variant v1 conv_wino4.hip -DW4_X=1``); load it with
+    AIR_HIP_LIB=<path> (see _hip.py).  The default library is untouched."""
+    build(verbose=False)
+    s = os.path.join(CSRC, src)
+    o = os.path.join(OBJ, "%s.%s.o" % (src[:-4], tag))
+    r = subprocess.run([HIPCC] + CFLAGS + EXTRA.get(src, []) + list(defines) + ["-c", s, "-o", o], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in _sources() if f != src] + [o]
+    lib = os.path.join(LIBDIR, "libair_hip.%s.so" % tag)
+    r = subprocess.run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2], sys.argv[i + 3:]))
+    else:
+        print(build(force="--force" in sys.argv))

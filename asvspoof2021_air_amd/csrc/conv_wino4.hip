@@ -72,6 +72,12 @@ constexpr int W4_NBUF = 3;
 // used an agent-scope RELEASE fence instead, which writes back the publishing XCD's whole L2: affordable for the
 // one layer that cut items then, a 7 % loss on layer1 when every layer's last round is cut.
 constexpr int W4_SC1 = 16;
+#ifndef W4_DMA_PLACE
+#define W4_DMA_PLACE 0  // A/B: 0 = one DMA per MFMA group boundary; 1 = inside the transform; 2 = two per boundary
+#endif
+#ifndef W4_PATCH_FIRST
+#define W4_PATCH_FIRST 0  // A/B: 1 = round 2's order (patch reads, then the first operand reads)
+#endif
 constexpr unsigned W4_OOB = 0x80000000u;        // byte offset beyond any tensor we accept: reads as zero
 
 // Positions and the layout of the transformed weights for MH x 4 output tiles.
@@ -307,20 +313,18 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // segments of this workgroup: [upper half of a cut item]? whole items* [lower half | whole tail item]?
   int tail_seg = -1, tail_item = 0, fc = 0, last_end = nchunk, nseg = nround;
   const int full_base = j;
-  if (cut) {
-    if (j < rem) { tail_seg = nround; tail_item = nround * Wx + j; last_end = half; ++nseg; }
-    else if (j < 2 * rem) { tail_seg = 0; tail_item = nround * Wx + (j - rem); fc = half; ++nseg; }
-  } else if (j < rem) {
-    tail_seg = nround; tail_item = nround * Wx + j; ++nseg;
-  }
+  const bool is_lower = cut && j < rem, is_upper = cut && j >= rem && j < 2 * rem;
+  if (is_lower) { tail_seg = nround; tail_item = nround * Wx + j; last_end = half; ++nseg; }
+  else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + (j - rem); fc = half; ++nseg; }
+  else if (!cut && j < rem) { tail_seg = nround; tail_item = nround * Wx + j; ++nseg; }
   if (nseg == 0) return;
-  const int S = nround * nchunk + (tail_seg < 0 ? 0 : (cut ? (tail_seg == 0 ? nchunk - half : half) : nchunk));
+  const int S = nround * nchunk + (tail_seg < 0 ? 0 : (is_upper ? nchunk - half : (is_lower ? half : nchunk)));
   const int flag_idx = xg * 32 + (tail_item - nround * Wx);  // cut items of this launch: < 8 * 32
   long long tk0 = 0, tw0 = 0;
   if (TRACE) { tk0 = clock64(); tw0 = wall_clock64(); }
   const int c0 = fc;
   auto seg_item = [&](int seg) {
-    return seg == tail_seg ? tail_item : full_base + (seg - (tail_seg == 0 ? 1 : 0)) * Wx;
+    return seg == tail_seg ? tail_item : full_base + (seg - (is_upper ? 1 : 0)) * Wx;
   };
   auto seg_end = [&](int seg) { return seg == nseg - 1 ? last_end : nchunk; };
   // item id -> (tile quad, channel slab): 32 consecutive ids = cotb slabs x (32 / cotb) quads
@@ -480,12 +484,22 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       raw[6 * r + 5] = p[r * C::ROWF + 8];
     }
   };
-  auto transform = [&]() {
+  // with_dma (W4_DMA_PLACE == 1): the k-step's restaging DMAs go out between the transform's sub-steps
+  auto transform = [&](auto dma_tag) {
+    constexpr bool WITH_DMA = decltype(dma_tag)::value;
     float t[NPR * 6];
+    auto unit = [&](auto u_tag) {
+      if constexpr (WITH_DMA) { __builtin_amdgcn_sched_barrier(0); dma_unit(u_tag); __builtin_amdgcn_sched_barrier(0); }
+    };
+#define W4_TU(U_) unit(std::integral_constant<int, U_>{})
+    W4_TU(0);
 #pragma unroll
-    for (int r = 0; r < NPR; ++r)  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
+    for (int r = 0; r < NPR; ++r) {  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
       w4_bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5],
              t[6 * r], t[6 * r + 1], t[6 * r + 2], t[6 * r + 3], t[6 * r + 4], t[6 * r + 5]);
+      switch (r) { case 0: W4_TU(1); break; case 1: W4_TU(2); break; case 2: W4_TU(3); break; case 3: W4_TU(4); break;
+                   case 4: W4_TU(5); break; default: W4_TU(6); break; }
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {  // down the column: V[i][j] = sum_r BT_h[i][r] t[r][j]
       if constexpr (MH == 4)
@@ -493,6 +507,8 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
                V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c], V[30 + c]);
       else
         w4_bt5(t[c], t[6 + c], t[12 + c], t[18 + c], t[24 + c], V[c], V[6 + c], V[12 + c], V[18 + c], V[24 + c]);
+      switch (c) { case 0: W4_TU(NPR + 1); break; case 1: W4_TU(NPR + 2); break; case 2: W4_TU(NPR + 3); break;
+                   case 3: W4_TU(NPR + 4); break; case 4: W4_TU(NPR + 5); break; default: W4_TU(NPR + 6); break; }
     }
   };
 
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   int e_cur = edge_of(i0), e_nxt = -1;
   if (e_cur >= 0) fix_edge(ldsP, e_cur);
   read_patch(ldsP);
-  transform();
+  transform(std::false_type{});
 
   int cur = 0;
   long long tW = 0, tB = 0, tD = 0, tM = 0, tT = 0, tE = 0;
@@ -640,8 +656,6 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     if (tracing) c2 = clock64();
     if (tracing) c3 = clock64();
     float* pn = ldsP + nxt * W4_PATCHF;
-    if (e_next >= 0) fix_edge(pn, e_next);
-    if constexpr (!LAST) read_patch(pn);
     const float* ub = ldsU + cur * ULDS + ub_lane;
     constexpr int NG = 2 * NQ;  // operand groups: row block g / NQ, position quad g % NQ
     f32x4 u[NG];
@@ -650,8 +664,20 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       const int rb = g / NQ, q = g % NQ;
       u[g] = *reinterpret_cast<const f32x4*>(ub + P::uoff(0, 16 * rb, 4 * q));
     };
+#if W4_PATCH_FIRST
+    if (e_next >= 0) fix_edge(pn, e_next);
+    if constexpr (!LAST) read_patch(pn);
 #pragma unroll
     for (int g = 0; g < AHEAD; ++g) ldu(g);
+#else
+    // the first operand reads go out BEFORE the 3 NPR patch reads: LDS returns in order, and the first MFMA then
+    // waits for its own operand only while the patch (needed by the transform at the end) lands under the MFMAs
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) ldu(g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (e_next >= 0) fix_edge(pn, e_next);
+    if constexpr (!LAST) read_patch(pn);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1");
 #pragma unroll
@@ -674,6 +700,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // restaging, one DMA per group boundary so the memory pipeline takes them one at a time (issued back
       // to back by all four waves, 52 KB queue up in front of it and every issue stalls): U(s+2) into the
       // buffer U(s-1) left, patch(s+3) into the buffer patch(s) left
+#if W4_DMA_PLACE == 0
       switch (g) {
         case 0: W4_UNIT(0); break;
         case 1: W4_UNIT(1); break;
@@ -690,15 +717,43 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         case 12: W4_UNIT(12); break;
         default: break;
       }
+#elif W4_DMA_PLACE == 2
+      switch (g) {
+        case 0: W4_UNIT(0); W4_UNIT(1); break;
+        case 1: W4_UNIT(2); W4_UNIT(3); break;
+        case 2: W4_UNIT(4); W4_UNIT(5); break;
+        case 3: W4_UNIT(6); W4_UNIT(7); break;
+        case 4: W4_UNIT(8); W4_UNIT(9); break;
+        case 5: W4_UNIT(10); W4_UNIT(11); break;
+        case 6: W4_UNIT(12); break;
+        default: break;
+      }
+#else
+      if (LAST) {  // no transform in this k-step: restage here
+        switch (g) {
+          case 0: W4_UNIT(0); break; case 1: W4_UNIT(1); break; case 2: W4_UNIT(2); break; case 3: W4_UNIT(3); break;
+          case 4: W4_UNIT(4); break; case 5: W4_UNIT(5); break; case 6: W4_UNIT(6); break; case 7: W4_UNIT(7); break;
+          case 8: W4_UNIT(8); break; case 9: W4_UNIT(9); break; case 10: W4_UNIT(10); break; case 11: W4_UNIT(11); break;
+          case 12: W4_UNIT(12); break; default: break;
+        }
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     // the last MFMAs write (MH = 4) the VGPR-resident accumulators: inline asm gets no compiler-inserted wait
     // states, and a register copy the allocator places right behind them would read half-written results
     asm volatile("s_nop 15");
+#if W4_DMA_PLACE == 1
+    if (tracing) c4 = clock64();
+    if constexpr (!LAST) transform(std::true_type{});
+    adv_u();
+    adv_patch();
+#else
     adv_u();
     adv_patch();
     if (tracing) c4 = clock64();
-    if constexpr (!LAST) transform();
+    if constexpr (!LAST) transform(std::false_type{});
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (tracing) {
       c5 = clock64();
@@ -722,8 +777,8 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     e_cur = e_nxt;
     long long ce = 0;
     if (tracing) { ce = clock64(); tL += ce - cl; }
-    const bool upper_part = cut && seg == tail_seg && tail_seg == 0;        // -> partial sums into y
-    const bool lower_part = cut && seg == tail_seg && tail_seg != 0;        // <- the partner's partial sums
+    const bool upper_part = is_upper && seg == tail_seg;        // -> partial sums into y
+    const bool lower_part = is_lower && seg == tail_seg;        // <- the partner's partial sums
     if (lower_part) {
       if (tid == 0) {
         unsigned spins = 0;
@@ -747,7 +802,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     if (seg + 1 < nseg) {  // the next item's first patch (buffer `cur` after the last k-step's swap; its right edge
       lane_consts();       // was fixed there): the reads and the transform the LAST k-step left out
       read_patch(ldsP + cur * W4_PATCHF);
-      transform();
+      transform(std::false_type{});
     }
     if (upper_part) {  // publish: every wave's sc1 stores have been acknowledged (vmcnt(0) above), then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

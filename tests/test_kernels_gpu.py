@@ -267,6 +267,24 @@ WINO = [
 ]
 
 
+@pytest.mark.parametrize("opts", [dict(WINO4_XCD=x, WINO4_SPLIT=sp, WINO4_TH3=th)
+                                  for x in (0, 1, 2) for sp in (0, 1) for th in (0, 1, 2)])
+@pytest.mark.parametrize("cfg", [(2, 64, 18, 75, 64), (6, 32, 9, 100, 128), (9, 16, 7, 130, 64), (24, 8, 6, 40, 256)])
+def test_wino4_item_dealing_options(ops, cfg, opts):
+    """Every way the F(4x4 | 3x4, 3x3) kernel deals its work items (whole chip / XCD-contiguous / XCD-strided),
+    with and without half-cut tail items, 4- and 3-row tiles: the same result (cfg0 has a dealing group with one
+    item for two workgroups - a cut item and nothing else; the others leave 1 .. 3 whole rounds plus a tail)."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 21)
+    w = synth_feat((Cout, Cin, 3, 3), 22, scale=0.1)
+    res = synth_feat((B, Cout, H, W), 23)
+    want = F.conv2d(x.double(), w.double(), None, 1, 1) + res.double()
+    with _hip.options(**opts):
+        got = ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1, residual=res.cuda())
+    close(got, want, rtol=wino_conv_bound(), name="wino4 %s" % (opts,))
+
+
 @pytest.mark.parametrize("cfg", WINO)
 def test_conv2d_winograd(ops, cfg):
     B, Cin, H, W, Cout = cfg
