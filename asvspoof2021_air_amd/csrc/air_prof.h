@@ -27,15 +27,16 @@ enum AirKernelId {
 
 bool air_prof_on();
 // work = algorithmic FLOPs (or bytes); issued = FLOPs the kernel really sends to the matrix pipe (Winograd kernels:
-// fewer than the algorithmic count, padded tiles included); < 0 = same as work
-void air_prof_begin(int kid, double work, hipStream_t st, double issued = -1.0);
+// fewer than the algorithmic count, padded tiles included); < 0 = same as work.  bytes = algorithmic HBM bytes of
+// the launch (operands read once + results written once), 0 = not stated
+void air_prof_begin(int kid, double work, hipStream_t st, double issued = -1.0, double bytes = 0.0);
 void air_prof_end(hipStream_t st);
 
 struct AirProfScope {
   hipStream_t st;
   bool on;
-  AirProfScope(int kid, double work, hipStream_t s, double issued = -1.0) : st(s), on(air_prof_on()) {
-    if (on) air_prof_begin(kid, work, st, issued);
+  AirProfScope(int kid, double work, hipStream_t s, double issued = -1.0, double bytes = 0.0) : st(s), on(air_prof_on()) {
+    if (on) air_prof_begin(kid, work, st, issued, bytes);
   }
   ~AirProfScope() {
     if (on) air_prof_end(st);

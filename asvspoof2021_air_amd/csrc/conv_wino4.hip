@@ -944,6 +944,9 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   }
   // MFMA FLOPs the launch issues: every item runs Cin / 4 k-steps of NACC MFMAs (16 x 16 x 4) in 4 waves
   const double issued = (double)a.nitems * (Kc / W4_CK) * 4.0 * (mh == 3 ? W4Pos<3>::NACC : W4Pos<4>::NACC) * 2048.0;
-  AirProfScope ps(AIR_K_CONV_WINO4, flops, st, issued);
+  // algorithmic bytes: x and the transformed weights read once, y written once, the residual read once
+  const double abytes = 4.0 * ((double)B * Kc * H * W + (double)B * M * H * W * (residual ? 2.0 : 1.0) +
+                               (double)M * Kc * (mh == 3 ? 32.0 : 36.0));
+  AirProfScope ps(AIR_K_CONV_WINO4, flops, st, issued, abytes);
   return mh == 3 ? w4_launch<3>(a, trg, nblk, st) : w4_launch<4>(a, trg, nblk, st);
 }

@@ -10,7 +10,7 @@ namespace {
 struct Rec {
   hipEvent_t a, b;
   int kid;
-  double work, issued;
+  double work, issued, bytes;
 };
 std::mutex g_mu;
 std::vector<Rec> g_recs;
@@ -27,7 +27,8 @@ const char* const kNames[AIR_K_COUNT] = {
 
 bool air_prof_on() { return g_on; }
 
-void air_prof_begin(int kid, double work, hipStream_t st, double issued) {
+void air_prof_begin(int kid, double work, hipStream_t st, double issued, double bytes) {
+  g_cur.bytes = bytes;
   g_cur.kid = kid;
   g_cur.work = work;
   g_cur.issued = issued < 0.0 ? work : issued;
@@ -62,18 +63,20 @@ const char* air_prof_kernel_name(int kid) {
 
 /* Totals for kernel id `kid` since air_prof_enable(1): launches, summed event
  * time (ms) and summed algorithmic work (FLOPs or bytes).  Synchronises. */
-int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work, double* total_issued);
+int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work, double* total_issued,
+                      double* total_bytes);
 int air_prof_collect(int kid, int* launches, double* total_ms, double* total_work) {
-  double issued = 0.0;
-  return air_prof_collect2(kid, launches, total_ms, total_work, &issued);
+  double issued = 0.0, bytes = 0.0;
+  return air_prof_collect2(kid, launches, total_ms, total_work, &issued, &bytes);
 }
 
 /* The same plus the FLOPs the launches issued to the matrix pipe (== total_work for direct kernels). */
-int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work, double* total_issued) {
-  if (!launches || !total_ms || !total_work || !total_issued) return AIR_EINVAL;
+int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work, double* total_issued,
+                      double* total_bytes) {
+  if (!launches || !total_ms || !total_work || !total_issued || !total_bytes) return AIR_EINVAL;
   std::lock_guard<std::mutex> lk(g_mu);
   int n = 0;
-  double ms = 0.0, work = 0.0, issued = 0.0;
+  double ms = 0.0, work = 0.0, issued = 0.0, bytes = 0.0;
   for (auto& r : g_recs) {
     if (r.kid != kid) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) return AIR_ELAUNCH;
@@ -83,11 +86,13 @@ int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_wo
     ms += t;
     work += r.work;
     issued += r.issued;
+    bytes += r.bytes;
   }
   *launches = n;
   *total_ms = ms;
   *total_work = work;
   *total_issued = issued;
+  *total_bytes = bytes;
   return AIR_OK;
 }
 

@@ -34,8 +34,14 @@ FEAT_LEN = 750      # reference default --feat_len (main_train.py:43), padding='
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_HBM_GBS = 8000.0
-WINO_ISSUE = {"wino_conv_kernel": 16.0 / 36.0, "wino_wgrad_kernel": 16.0 / 36.0, "wino4_conv_kernel": 36.0 / 144.0}
-PMC_FILE = "r02_pmc_traffic.json"
+# Winograd kernels that do not report their issued MFMA FLOPs themselves (air_prof_collect2): F(2x2,3x3) and
+# F(3x3,2x2) multiply 16 transformed values per 2x2 tile where the direct algorithm multiplies 36.  wino4_conv_kernel
+# reports the exact count (30 or 36 positions per 3x4 / 4x4 tile, padded tiles included).
+WINO_ISSUE = {"wino_conv_kernel": 16.0 / 36.0, "wino_wgrad_kernel": 16.0 / 36.0}
+# kernel-name prefix (rocprofv3) of every template instance of a profiling family (csrc/air_prof.h)
+PMC_FAMILY = {"wino4_conv_kernel": "wino4_conv_kernel", "wino_conv_kernel": "wino_conv_kernel",
+              "wino_wgrad_kernel": "wino_wgrad_kernel", "c1b_gemm_kernel": "c1b_gemm", "c1b_fwd_kernel": "c1b_fwd",
+              "c1b_tap_kernel": "c1b_tap"}
 
 
 def synth_batch(step, rank, device):
@@ -65,12 +71,14 @@ def roofline_leg(trainer, batches):
     trainer.model.overlap_wgrad = overlap
     rows = []
     for kid in range(lib.air_prof_kernel_count()):
-        n, ms, work = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
-        _hip.check(lib.air_prof_collect(kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)),
-                   "air_prof_collect")
+        n, ms, work, issued, nbytes = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _hip.check(lib.air_prof_collect2(kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work),
+                                         ctypes.byref(issued), ctypes.byref(nbytes)), "air_prof_collect2")
         if n.value:
-            rows.append({"kernel": lib.air_prof_kernel_name(kid).decode(), "launches": n.value,
-                         "total_ms": ms.value, "work": work.value})
+            name = lib.air_prof_kernel_name(kid).decode()
+            rows.append({"kernel": name, "launches": n.value, "total_ms": ms.value, "work": work.value,
+                         "issued": issued.value if issued.value != work.value else WINO_ISSUE.get(name, 1.0) * work.value,
+                         "bytes": nbytes.value})
     lib.air_prof_enable(0)
     convs = [r for r in rows if r["kernel"].startswith(("conv", "wino", "c1b"))]
     dom = max(convs, key=lambda r: r["total_ms"])
@@ -84,7 +92,7 @@ def roofline_leg(trainer, batches):
     # 2x2 / 4x4 output tile where the direct algorithm multiplies 36 / 144.  "achieved" and "frac" are the
     # ISSUED rate against the MFMA peak - a fraction of the roofline, never above 1 - and the
     # algorithmic-equivalent rate (what a direct kernel would have to sustain) is reported beside it.
-    issue = WINO_ISSUE.get(dom["kernel"], 1.0)
+    issue = dom["issued"] / dom["work"]
     achieved = algorithmic * issue
     out = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -93,18 +101,10 @@ def roofline_leg(trainer, batches):
            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches_per_step": dom["launches"] // 2,
            "all_conv_kernels": {"algorithmic_equivalent": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                 "ms_per_step": round(all_ms / 2, 3)}}
-    # HBM-side bytes per launch of the dominant kernel from this round's committed PMC passes (separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, tools/profile_round.sh +
-    # tools/pmc_traffic.py); null when the file does not cover this kernel / configuration
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
-            pmc = json.load(fh)
-        model_key = "ecapa" if dom["kernel"].startswith("c1b") else "resnet"
-        if BATCH == (128 if model_key == "ecapa" else 64) and FEAT_LEN == 750:  # the measured configuration only
-            out["traffic"] = round(pmc[model_key + "_family"][dom["kernel"]]["traffic_bytes_per_launch"])
-            out["traffic_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)" % PMC_FILE
-    except (OSError, KeyError, ValueError):
-        pass
+    # algorithmic HBM bytes per launch where the kernel states them (operands read once, results written once);
+    # "traffic" (measured HBM-side bytes per launch) is filled in by pmc_traffic_leg() from PMC passes of THIS run
+    if dom["bytes"] > 0:
+        out["algorithmic_bytes"] = round(dom["bytes"] / dom["launches"])
     if dom["kernel"] == "c1b_fwd_kernel":
         # ECAPA: the fused 512-channel pointwise kernel is HBM-bound on the fp32 tensors (127 FLOP per
         # algorithmic byte < 312 FLOP/B machine balance): price it on bytes as well.  4*(Cin+Cout) bytes
@@ -121,9 +121,65 @@ def roofline_leg(trainer, batches):
     out["per_kernel"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // 2,
                           "ms_per_step": round(r["total_ms"] / 2, 3),
                           "algorithmic_rate": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2),
-                          "issued_rate": round(WINO_ISSUE.get(r["kernel"], 1.0) * r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2)}
+                          "issued_rate": round(r["issued"] / (r["total_ms"] * 1e-3) / 1e12, 2)}
                          for r in rows]
     return out
+
+
+def pmc_traffic_leg(model_name, family, argv_extra, timeout_s=170):
+    """HBM-side bytes per launch of the dominant kernel, measured in THIS run: two child runs of this script (2 timed
+    steps, no roofline / CPU legs) under ``rocprofv3 --kernel-trace --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` -
+    separate passes and the unit / gfx950 corrections as MI355X_MICROARCH.md prescribes (counters are KB;
+    FETCH_SIZE tallies 128-byte requests at 64 B on gfx950: doubled; WRITE_SIZE as reported).  Returns a dict for
+    the roofline object, with traffic = None and the reason when rocprofv3 is missing or a pass fails."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return {"traffic": None, "traffic_source": "rocprofv3 not on PATH: not measured in this run"}
+    prefix = PMC_FAMILY.get(family, family)
+    per, launches, whole = {}, 0, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--model", model_name, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-pmc"] + argv_extra
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s pass timed out after %d s" % (counter, timeout_s)}
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)}
+            try:
+                cur = sqlite3.connect(dbs[0]).cursor()
+                rows = cur.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+            except sqlite3.Error as e:
+                return {"traffic": None, "traffic_source": "rocpd database of the %s pass unreadable: %s" % (counter, e)}
+        tot, n, everything = 0.0, 0, 0.0
+        for k, c, v in rows:
+            k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+            if c != counter:
+                continue
+            everything += v
+            if k.startswith(prefix):
+                tot += v
+                n += 1
+        whole[counter] = everything / 3.0  # the child ran 1 warm-up + 2 timed steps
+        if n == 0:
+            return {"traffic": None, "traffic_source": "no %s launch in the %s pass" % (prefix, counter)}
+        per[counter] = tot / n
+        launches = n
+    return {"traffic": round((2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0),
+            "traffic_detail": {"fetch_kb_per_launch": round(per["FETCH_SIZE"], 1), "write_kb_per_launch": round(per["WRITE_SIZE"], 1),
+                               "launches_sampled": launches,
+                               "whole_step_bytes_all_kernels": round((2.0 * whole["FETCH_SIZE"] + whole["WRITE_SIZE"]) * 1024.0)},
+            "traffic_source": "measured in this run: child passes of this command under rocprofv3 --kernel-trace --pmc "
+                              "FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB per "
+                              "launch, launch average over every %s* instance" % prefix}
 
 
 def cpu_baseline_leg():
@@ -133,10 +189,10 @@ def cpu_baseline_leg():
     import numpy as np
     from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
     from oracle.filler import fill_state, fill_value, synth_pcm
-    # PyTorch-CPU's conv backward collapses when oversubscribed (256 threads on a batch-8
-    # problem ran 100x slower than 8 threads): use at most 16 threads and say so in "cores"
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    # PyTorch-CPU's conv backward collapses when oversubscribed (256 threads on a batch-8 problem ran 100x
+    # slower than 8 threads), so "all cores" is not its best: sweep {8, 16, 32, 64} threads with two steps
+    # each, then run BASELINE.md 5's 3 warm-up + 10 timed steps at the fastest count and report the sweep
+    ncpu = os.cpu_count() or 1
     pcm = synth_pcm(64, LENGTH, seed=688)
     fb, dct = o_lfcc.linear_filterbank(), o_lfcc.dct2_ortho_matrix()
     t0 = time.perf_counter()
@@ -146,6 +202,17 @@ def cpu_baseline_leg():
     x = o_pad.to_model_input(x).contiguous()
     labels = torch.tensor([0, 1, 1, 1, 0, 1, 1, 1])
     tr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
+    sweep = {}
+    for nt in (8, 16, 32, 64):
+        if nt > ncpu and sweep:
+            break
+        torch.set_num_threads(min(nt, ncpu))
+        tr.step(x, labels, None)
+        t0 = time.perf_counter()
+        tr.step(x, labels, None)
+        sweep[min(nt, ncpu)] = round(8.0 / (time.perf_counter() - t0), 2)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     times = []
     t_start = time.perf_counter()
     for it in range(13):  # 3 warm-up + 10 timed, median
@@ -161,8 +228,10 @@ def cpu_baseline_leg():
             "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
                       "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, 3 warm-up + "
-                      "%d timed, median %.3f s/step; threads capped at 16 of %d (PyTorch-CPU conv backward "
-                      "collapses when oversubscribed)" % (1e3 * t_lfcc / 64, len(times) - warm, step, os.cpu_count() or 1),
+                      "%d timed, median %.3f s/step at the fastest of the swept thread counts (%d of %d host threads; "
+                      "PyTorch-CPU conv backward collapses when oversubscribed)" % (
+                          1e3 * t_lfcc / 64, len(times) - warm, step, cores, ncpu),
+            "sweep": {"unit": "train-step utt/s after one warm-up step", "threads": sweep},
             "lfcc_utt_per_s": round(64 / t_lfcc, 1), "train_step_utt_per_s": round(8 / step, 2)}
 
 
@@ -186,6 +255,8 @@ def main():
                          "(BASELINE configs[4]; 30 synthetic 1024-tap IRs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1, rank 0 only)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="default run only: skip the ECAPA-TDNN-512 bf16 leg (BASELINE configs[2]) reported under 'configs'")
     args = ap.parse_args()
@@ -253,6 +324,28 @@ def main():
         res = {"value": round(world * BATCH * steps / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(1e3 * dt / steps, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
                "final_loss": round(float(last.item()), 5)}
+        comm = None
+        if world > 1:
+            # exposed communication: the same steps without the gradient exchange (no buckets from inside
+            # backward, no all-reduce; replicas drift apart, which no later figure depends on), MAX over ranks
+            arena = model.arena()
+            ar_bytes = 4 * (arena.head_total + sum(p.numel() for p in trainer.loss.parameters()))
+            saved = (trainer.world, getattr(model, "_bucketer", None))
+            trainer.world, model._bucketer = 1, None
+            k2 = max(2, min(steps, 5))
+            trainer.step(*batches[0])
+            fence()
+            t1 = time.perf_counter()
+            for i in range(k2):
+                trainer.step(*batches[i % nb])
+            fence()
+            d2 = torch.tensor([(time.perf_counter() - t1) / k2], device=device, dtype=torch.float64)
+            td.all_reduce(d2, op=td.ReduceOp.MAX)
+            trainer.world, model._bucketer = saved
+            trainer.sync_from_rank0()
+            comm = {"allreduce_bytes_per_step": ar_bytes, "step_ms_without_exchange": round(1e3 * float(d2.item()), 3),
+                    "exposed_ms": round(1e3 * (dt / steps - float(d2.item())), 3),
+                    "overlap": os.environ.get("AIR_DDP_OVERLAP", "1") == "1"}
         # The instrumented roofline steps are ordinary train steps: with world > 1 they contain the gradient
         # all-reduce, so EVERY rank runs them (rank 0 alone would wait for its peers forever); only rank 0 reports.
         if want_roofline:
@@ -260,6 +353,8 @@ def main():
         bucketer = getattr(model, "_bucketer", None)
         res["ddp"] = {"device": "cuda:%d" % local, "world": world,
                       "buckets_in_backward": (bucketer.total_launched if bucketer is not None else 0)}
+        if comm is not None:
+            res["ddp"]["communication"] = comm
         return model, res
 
     model, main_res = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup, args.augment,
@@ -284,6 +379,19 @@ def main():
             from asvspoof2021_air_amd.resnet import ResNet  # noqa: F401  (model for the line below)
         model = None
     BATCH = main_batch
+    # roofline.traffic: measured now, by PMC child passes of this same command (N = 1 only: rocprofv3 around one
+    # rank of a multi-process job would profile that rank alone)
+    if rank == 0 and world == 1 and roofline is not None and not args.no_pmc:
+        passthru = ["--feat-len", str(args.feat_len)] + (["--batch", str(args.batch)] if args.batch else [])
+        if args.model == "ecapa" and args.dtype:
+            passthru += ["--dtype", args.dtype]
+        if args.augment:
+            passthru += ["--augment"]
+        torch.cuda.empty_cache()
+        roofline.update(pmc_traffic_leg(args.model, roofline["kernel"], passthru))
+        e = extra.get("ecapa_bf16_b128")
+        if e is not None and "roofline" in e:
+            e["roofline"].update(pmc_traffic_leg("ecapa", e["roofline"]["kernel"], ["--feat-len", str(args.feat_len)]))
 
     if rank == 0:
         line = {

@@ -488,9 +488,10 @@ const char* air_prof_kernel_name(int kid);
 int air_prof_collect(int kid, int* launches, double* total_ms, double* total_work);
 /* The same plus total_issued: the FLOPs those launches sent to the matrix pipe - equal to
  * total_work for the direct kernels, fewer for the Winograd kernels (36 or 30 multiplies per
- * 4x4 / 3x4 output tile, padded tiles included). */
+ * 4x4 / 3x4 output tile, padded tiles included) - and total_bytes: their algorithmic HBM bytes
+ * (every operand read once, every result written once; 0 for kernels that do not state it). */
 int air_prof_collect2(int kid, int* launches, double* total_ms, double* total_work,
-                      double* total_issued);
+                      double* total_issued, double* total_bytes);
 
 /* ------------------------------------------------------------- utility ---- */
 int air_add_inplace(float* y, const float* x, size_t n, air_stream_t stream); /* y += x */
