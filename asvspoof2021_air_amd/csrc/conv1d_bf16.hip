@@ -41,6 +41,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDK = BK + 8;  // bf16 elements per LDS row: 80 bytes
 constexpr int NXCD = 8;
 
+typedef unsigned short u16;
 __device__ __forceinline__ unsigned pack2(float a, float b) {
   f32x2 v = {a, b};
   bf16x2 r = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32: round to nearest even
@@ -793,6 +794,14 @@ struct NtGemm {
   size_t acc_bs, acc2_bs;
   unsigned short* out_bf;   // optional bf16 copy of out: out_bf + (batch * M + m) * out_bf_rs + n (c1b_gemm_ps_kernel only)
   int out_bf_rs;
+  // bf16-RESIDENT output (c1b_gemm_ps_kernel<BKM, true>: `out` unused): out_bf + batch * out_bf_bs + m * out_bf_rs + n,
+  // frames n >= n_valid written as zeros; accumulate operands are bf16 rows of the same row pitch with their own
+  // batch strides; rows m >= m_valid (an M below the 256-row tile: the A operand reads zeros there) are not written
+  size_t out_bf_bs;
+  const unsigned short* acc_h;
+  const unsigned short* acc2_h;
+  size_t acc_h_bs, acc2_h_bs;
+  int m_valid;
   size_t a_rs, a_ss, a_bs, b_rs, b_ss, b_bs, o_rs, o_bs;
   int M, n_valid, kseg, nseg_per_batch, nseg_total, relu, tiles_m, tiles_n, total, per_xcd;
 };
@@ -931,7 +940,7 @@ __device__ __forceinline__ G2Tile g2_tile(const NtGemm& p, int work) {
 // lanes of a group point at a [4 k][16 n] block, 4 contiguous n each, and receive one column of it
 // (tools/ubench/tr_read.hip prints the mapping).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <bool BKM>
+template <bool BKM, bool HOUT = false>
 __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsigned a_bytes, unsigned b_bytes) {
   extern __shared__ __attribute__((aligned(1024))) char g2_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1038,6 +1047,65 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
       }
       slot ^= 1;
     }
+    if constexpr (HOUT) {
+      // bf16-resident epilogue: 8 rows x 64 columns at a time through this wave's own 2 KB of LDS; a lane owns 8
+      // consecutive frames of one row = one 16-byte store (a wave: eight 128-byte row pieces)
+      float* tile = reinterpret_cast<float*>(g2_lds + 2 * G2_SB) + wave * (G2_RP * 64);
+      const int c8 = (lane & 7) * 8, lrow = lane >> 3;
+      const int n = tl.n0 + wn * 64 + c8;
+      u16* __restrict__ ob = p.out_bf + (size_t)tl.batch * p.out_bf_bs;
+      const u16* __restrict__ ab = p.acc_h ? p.acc_h + (size_t)tl.batch * p.acc_h_bs : nullptr;
+      const u16* __restrict__ ab2 = p.acc2_h ? p.acc2_h + (size_t)tl.batch * p.acc2_h_bs : nullptr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int rr = hp * 4 + e;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tile[(e + 4 * kg) * 64 + j * 32 + r] = acc[i][j][rr];
+          }
+          const int m = tl.m0 + wm * 128 + i * 32 + hp * 8 + lrow;
+          const float4 v0 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8]);
+          const float4 v1 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8 + 4]);
+          if (m < p.m_valid) {
+            float add = 0.0f;
+            if (p.bias) add += p.bias[m];
+            if (p.bias_bc) add += p.bias_bc[(size_t)tl.batch * p.M + m];
+            float vv[8] = {v0.x + add, v0.y + add, v0.z + add, v0.w + add, v1.x + add, v1.y + add, v1.z + add, v1.w + add};
+            const size_t o = (size_t)m * p.out_bf_rs + n;
+            if (ab) {
+              const uint4 u = *reinterpret_cast<const uint4*>(ab + o);
+              const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                vv[2 * q] += __builtin_bit_cast(float, w[q] << 16);
+                vv[2 * q + 1] += __builtin_bit_cast(float, w[q] & 0xffff0000u);
+              }
+            }
+            if (ab2) {
+              const uint4 u = *reinterpret_cast<const uint4*>(ab2 + o);
+              const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                vv[2 * q] += __builtin_bit_cast(float, w[q] << 16);
+                vv[2 * q + 1] += __builtin_bit_cast(float, w[q] & 0xffff0000u);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              if (p.relu) vv[q] = fmaxf(vv[q], 0.0f);
+              if (n + q >= p.n_valid) vv[q] = 0.0f;
+            }
+            *reinterpret_cast<uint4*>(ob + o) =
+                make_uint4(pack2(vv[0], vv[1]), pack2(vv[2], vv[3]), pack2(vv[4], vv[5]), pack2(vv[6], vv[7]));
+          }
+        }
+      }
+      zero();
+      continue;
+    }
     // epilogue: RP rows x 64 columns at a time through this wave's own 2 KB of LDS, 16-byte stores
     float* __restrict__ ob = p.out + (size_t)tl.batch * p.o_bs;
     const float* __restrict__ ab = p.acc ? p.acc + (size_t)tl.batch * p.acc_bs : nullptr;
@@ -1121,6 +1189,7 @@ struct C1bTap {
   const float* acc;
   size_t x_bs, y_bs;
   int B, M, K, T, dil, relu, tiles_m, tiles_t, total, per_xcd;
+  int Tp;  // c1b_tap_kernel<true>: x and y are bf16 rows of Tp frames (x / y point at unsigned short)
 };
 
 // fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
@@ -1143,6 +1212,9 @@ __global__ __launch_bounds__(256) void c1b_pack3_kernel(const float* __restrict_
   }
 }
 
+// HIO: bf16-resident tensors (ecapa_bf16.hip) - x and y are bf16 rows [b][c][Tp]: staging copies the bits, the epilogue
+// rounds once and writes zeros for the frames T .. Tp - 1 (tiles cover the whole row).
+template <bool HIO>
 __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
   __shared__ __attribute__((aligned(16))) unsigned short sA[2][3 * 64 * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short sB[2][TAP_ROWS * LDK];
@@ -1158,11 +1230,14 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
 
   // A: 3 taps x 64 rows x 4 chunks = 768 chunks, 3 per thread
   // B: nrows frames x 4 channel groups of 8: slot s = tid + 256 i -> frame s % TAP_ROWS, group s / TAP_ROWS
-  const float* __restrict__ xb = p.x + (size_t)b * p.x_bs;
+  const int XP = HIO ? p.Tp : p.T;  // row pitch of x and y
+  const float* __restrict__ xb = HIO ? nullptr : p.x + (size_t)b * p.x_bs;
+  const u16* __restrict__ xh = HIO ? reinterpret_cast<const u16*>(p.x) + (size_t)b * p.x_bs : nullptr;
   // per-thread staging roles (3 slots each), fixed for the whole K loop
   const unsigned short* ga[3];
   int la[3], lb_[3];
   const float* gb[3];
+  const u16* gh[3];
   bool okb[3], stb[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1173,19 +1248,23 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
     const int t = t0 - d + fr;
     stb[i] = kg < 4;
     okb[i] = kg < 4 && fr < nrows && t >= 0 && t < p.T;
-    gb[i] = xb + (size_t)(kg * 8) * p.T + (okb[i] ? t : 0);
+    gb[i] = HIO ? nullptr : xb + (size_t)(kg * 8) * p.T + (okb[i] ? t : 0);
+    gh[i] = HIO ? xh + (size_t)(kg * 8) * XP + (okb[i] ? t : 0) : nullptr;
     lb_[i] = fr * LDK + kg * 8;
   }
   uint4 ra0, ra1, ra2;
   float rb[3][8];
+  unsigned rh[3][8];
 #define TAP_FETCH(k0)                                                                        \
   do {                                                                                       \
     ra0 = *reinterpret_cast<const uint4*>(ga[0] + (k0));                                     \
     ra1 = *reinterpret_cast<const uint4*>(ga[1] + (k0));                                     \
     ra2 = *reinterpret_cast<const uint4*>(ga[2] + (k0));                                     \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                     \
-            rb[i_][j_] = okb[i_] ? gb[i_][(size_t)((k0) + j_) * p.T] : 0.0f;                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                   \
+          if (HIO) rh[i_][j_] = okb[i_] ? (unsigned)gh[i_][(size_t)((k0) + j_) * XP] : 0u;   \
+          else rb[i_][j_] = okb[i_] ? gb[i_][(size_t)((k0) + j_) * p.T] : 0.0f;              \
+        }                                                                                    \
   } while (0)
 #define TAP_STASH(buf)                                                                       \
   do {                                                                                       \
@@ -1194,10 +1273,17 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
     *reinterpret_cast<uint4*>(&sA[buf][la[2]]) = ra2;                                        \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) if (stb[i_]) {                          \
       uint4 v_;                                                                              \
-      v_.x = pack2(rb[i_][0], rb[i_][1]);                                                    \
-      v_.y = pack2(rb[i_][2], rb[i_][3]);                                                    \
-      v_.z = pack2(rb[i_][4], rb[i_][5]);                                                    \
-      v_.w = pack2(rb[i_][6], rb[i_][7]);                                                    \
+      if (HIO) {                                                                             \
+        v_.x = rh[i_][0] | (rh[i_][1] << 16);                                                \
+        v_.y = rh[i_][2] | (rh[i_][3] << 16);                                                \
+        v_.z = rh[i_][4] | (rh[i_][5] << 16);                                                \
+        v_.w = rh[i_][6] | (rh[i_][7] << 16);                                                \
+      } else {                                                                               \
+        v_.x = pack2(rb[i_][0], rb[i_][1]);                                                  \
+        v_.y = pack2(rb[i_][2], rb[i_][3]);                                                  \
+        v_.z = pack2(rb[i_][4], rb[i_][5]);                                                  \
+        v_.w = pack2(rb[i_][6], rb[i_][7]);                                                  \
+      }                                                                                      \
       *reinterpret_cast<uint4*>(&sB[buf][lb_[i_]]) = v_;                                     \
     }                                                                                        \
   } while (0)
@@ -1235,6 +1321,21 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
 #undef TAP_STASH
 
   const int t = t0 + wave * 32 + r31;
+  if (HIO) {
+    if (t >= p.Tp) return;
+    u16* __restrict__ yh = reinterpret_cast<u16*>(p.y) + (size_t)b * p.y_bs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kgl;
+        float v = acc[i][q] + (p.bias ? p.bias[m] : 0.0f);
+        if (p.relu) v = fmaxf(v, 0.0f);
+        if (t >= p.T) v = 0.0f;
+        yh[(size_t)m * p.Tp + t] = (u16)(pack2(v, 0.0f) & 0xffffu);
+      }
+    return;
+  }
   if (t >= p.T) return;
   float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
   const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
@@ -1275,7 +1376,8 @@ int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.total = B * p.tiles_t * p.tiles_m;
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
   AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
-  hipLaunchKernelGGL(c1b_tap_kernel, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  p.Tp = 0;
+  hipLaunchKernelGGL(c1b_tap_kernel<false>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -1486,6 +1588,77 @@ int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* x
                      2.0 * B * T * (double)p->Cout * p->Cin, st, nullptr, true);
 }
 
+/* Dilated K = 3 conv of a Res2 branch on bf16-resident rows: forward (dgrad = 0: y = relu?(W * x + bias)) or data
+ * gradient (dgrad = 1, w_packed from air_conv1d_tap_pack_bf16(transpose = 1): dx = W^T * dy).  w_packed required. */
+int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                     const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y, size_t y_bs,
+                     air_stream_t stream) {
+  if (!x || !w_packed || !y || B <= 0 || T <= 0 || Tp < T || Tp % BN != 0) return AIR_EINVAL;
+  const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  if (dil < 1 || dil > TAP_MAXD || M % 64 != 0 || K % BK != 0) return AIR_EUNSUPPORTED;
+  C1bTap p;
+  p.x = reinterpret_cast<const float*>(x); p.a = w_packed; p.y = reinterpret_cast<float*>(y); p.bias = bias; p.acc = nullptr;
+  p.x_bs = x_bs ? x_bs : (size_t)K * Tp; p.y_bs = y_bs ? y_bs : (size_t)M * Tp;
+  p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu; p.Tp = Tp;
+  p.tiles_m = M / 64;
+  p.tiles_t = Tp / BN;
+  p.total = B * p.tiles_t * p.tiles_m;
+  p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  hipStream_t st = air_stream(stream);
+  AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
+  hipLaunchKernelGGL(c1b_tap_kernel<true>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_h_tp(int T) { return T > 0 ? round_up(T, G2_BN) : 0; }
+
+size_t air_h_conv1d_ws_bytes(int Cout, int Cin) { return align256((size_t)round_up(Cout, G2_BM) * Cin * 2) + 256; }
+
+int air_h_conv1d_pointwise(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs, const float* w,
+                           int dgrad, const float* bias, const float* bias_bc, int relu, const unsigned short* acc,
+                           size_t acc_bs, const unsigned short* acc2, size_t acc2_bs, unsigned short* y, size_t y_bs,
+                           void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || Tp < T) return AIR_EINVAL;
+  const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
+  if (Tp % G2_BN != 0 || K % GK != 0 || M % 8 != 0 || !air_opt(AIR_OPT_C1B_GEMM_PS)) return AIR_EUNSUPPORTED;
+  if (!ws || ws_bytes < air_h_conv1d_ws_bytes(dgrad ? Cin : Cout, dgrad ? Cout : Cin)) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  unsigned short* a = reinterpret_cast<unsigned short*>(ws);
+  const size_t n2 = (size_t)M * K / 2;
+  hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, dgrad ? 1 : 0);
+  AIR_CHECK_LAUNCH();
+  NtGemm g = {};
+  g.a = a; g.b = x; g.out = nullptr; g.bias = bias; g.bias_bc = bias_bc; g.acc = nullptr; g.acc2 = nullptr;
+  g.acc_bs = 0; g.acc2_bs = 0;
+  g.out_bf = y; g.out_bf_rs = Tp; g.out_bf_bs = y_bs ? y_bs : (size_t)M * Tp;
+  g.acc_h = acc; g.acc2_h = acc2;
+  g.acc_h_bs = acc_bs ? acc_bs : g.out_bf_bs; g.acc2_h_bs = acc2_bs ? acc2_bs : g.out_bf_bs;
+  g.m_valid = M;
+  g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
+  g.b_rs = Tp; g.b_ss = 0; g.b_bs = x_bs ? x_bs : (size_t)K * Tp;
+  g.o_rs = Tp; g.o_bs = g.out_bf_bs;
+  g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
+  const size_t a_bytes = (size_t)M * K * 2, b_bytes = ((size_t)(B - 1) * g.b_bs + (size_t)K * Tp) * 2;
+  // 16-byte rows everywhere: row pitch Tp % 8 == 0 (above), bases and batch strides multiples of 8 elements
+  if (((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(acc) |
+        reinterpret_cast<size_t>(acc2)) & 15) || g.b_bs % 8 || g.out_bf_bs % 8 || g.acc_h_bs % 8 || g.acc2_h_bs % 8 ||
+      a_bytes >= ((size_t)1 << 32) || b_bytes >= ((size_t)1 << 32))
+    return AIR_EUNSUPPORTED;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c1b_gemm_ps_kernel<true, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) == hipSuccess;
+  if (!attr_ok) return AIR_ELAUNCH;
+  g.tiles_m = (M + G2_BM - 1) / G2_BM;
+  g.tiles_n = Tp / G2_BN;
+  g.total = g.tiles_m * g.tiles_n * B;
+  g.per_xcd = (g.total + NXCD - 1) / NXCD;
+  AirProfScope prof(AIR_K_C1B_GEMM, 2.0 * B * T * (double)Cout * Cin, st);
+  hipLaunchKernelGGL((c1b_gemm_ps_kernel<true, true>), dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes,
+                     (unsigned)b_bytes);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 int air_conv1d_fwd_bf16_ex(const AirConv1d* p, const float* x, const float* w, const unsigned short* w_packed,
                            const float* bias, const float* bias_bc, int relu, float* y, unsigned short* y_bf16, void* ws,
                            size_t ws_bytes, air_stream_t stream) {
@@ -1611,6 +1784,39 @@ int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* d
   g.a = dys; g.b = xs; g.out = nsplit > 1 ? partial : dw; g.bias = nullptr; g.bias_bc = nullptr; g.acc = nullptr;
   g.acc2 = nullptr; g.acc_bs = 0; g.acc2_bs = 0;
   g.out_bf = nullptr; g.out_bf_rs = 0;
+  g.a_rs = Tp; g.a_ss = a_ss; g.a_bs = (size_t)per * g.a_ss;
+  g.b_rs = Tp; g.b_ss = b_ss; g.b_bs = (size_t)per * g.b_ss;
+  g.o_rs = N; g.o_bs = (size_t)M * N;
+  g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
+  int rc = launch_gemm(g, nsplit, N, ((size_t)(B - 1) * a_ss + (size_t)M * Tp) * 2, ((size_t)(B - 1) * b_ss + (size_t)N * Tp) * 2,
+                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
+  if (rc != AIR_OK) return rc;
+  if (nsplit > 1) {
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(c1b_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, partial, dw, n,
+                       nsplit);
+    AIR_CHECK_LAUNCH();
+  }
+  return AIR_OK;
+}
+
+/* Weight gradient of a K = 1 layer from bf16-resident operands: dw[co][ci] = sum_{b,t} dy[b][co][t] x[b][ci][t], both
+ * operands bf16 rows of Tp frames (zeros behind T), batch strides in elements (0 = dense).  Same split-K GEMM and
+ * fixed-order reduction as air_conv1d_wgrad_bf16_pre; ws of air_conv1d_bf16_ws_bytes for the layer. */
+int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs,
+                       const unsigned short* dy, size_t dy_bs, float* dw, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!x || !dy || !dw || B <= 0 || T <= 0 || Tp < T || Tp % TP_ALIGN != 0) return AIR_EINVAL;
+  AirConv1d q = {B, Cin, T, Cout, 1, 1, 0, 0, 0};
+  if (!air_conv1d_bf16_supported(&q, 2)) return AIR_EUNSUPPORTED;
+  int per;
+  const int nsplit = wgrad_nsplit(&q, &per);
+  const int M = Cout, N = Cin;
+  if (!ws || ws_bytes < align256((size_t)nsplit * M * N * sizeof(float))) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  float* partial = reinterpret_cast<float*>(ws);
+  const size_t a_ss = dy_bs ? dy_bs : (size_t)M * Tp, b_ss = x_bs ? x_bs : (size_t)N * Tp;
+  NtGemm g = {};
+  g.a = dy; g.b = x; g.out = nsplit > 1 ? partial : dw;
   g.a_rs = Tp; g.a_ss = a_ss; g.a_bs = (size_t)per * g.a_ss;
   g.b_rs = Tp; g.b_ss = b_ss; g.b_bs = (size_t)per * g.b_ss;
   g.o_rs = N; g.o_bs = (size_t)M * N;

@@ -1,0 +1,234 @@
+"""Tensor-level wrappers over the bf16-RESIDENT entry points of the C-ABI (include/air_hip.h, ``air_h_*``).
+
+A resident activation is a ``torch.int16`` tensor of shape (B, C, Tp) holding bf16 bits, Tp = ``tp(T)`` frames per
+row with the frames T .. Tp - 1 zero, or a channel-slice view of one (batch stride = the wide tensor's).  ``T`` (the
+logical frame count) travels as an argument.  Nothing here computes on the CPU or through ATen.
+"""
+import ctypes
+
+import torch
+
+from . import _hip, ops
+from ._hip import ci, cf, csz, dptr, stream
+
+
+def tp(T):
+    return int(_hip.lib().air_h_tp(ci(T)))
+
+
+def rows(B, C, T, device, zero=False):
+    """Fresh (B, C, Tp) buffer.  Writers fill every frame of every row they touch (zeros behind T)."""
+    f = torch.zeros if zero else torch.empty
+    return f((B, C, tp(T)), device=device, dtype=torch.int16)
+
+
+def hv(t, allow_none=False):
+    """(pointer, batch stride in elements) of a resident tensor or channel-slice view."""
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0), 0
+        raise _hip.AirError("null resident tensor")
+    if t.dtype != torch.int16 or not t.is_cuda or t.dim() != 3 or t.stride(2) != 1 or (t.shape[1] > 1 and t.stride(1) != t.shape[2]):
+        raise _hip.AirError("resident activation must be a (B, C, Tp) int16 GPU tensor or a channel slice of one")
+    return ctypes.c_void_p(t.data_ptr()), (t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2])
+
+
+def from_f32(x, out=None):
+    """(B, C, T) fp32 (or channel-slice view) -> resident rows, rounded to nearest even."""
+    B, C, T = x.shape
+    if out is None:
+        out = rows(B, C, T, x.device)
+    Tp = out.shape[2]
+    if Tp == int(_hip.lib().air_conv1d_bf16_tp(ci(T))) and out.is_contiguous():
+        return ops.conv1d_cvt_bf16(x, out)
+    tmp = x.contiguous().to(torch.bfloat16).view(torch.int16)  # test-size shapes only (Tp of the two layouts differ)
+    out.zero_()
+    out[:, :, :T] = tmp
+    return out
+
+
+def to_f32(x, T):
+    B, C, Tp = x.shape
+    y = torch.empty((B, C, T), device=x.device, dtype=torch.float32)
+    p, bs = hv(x)
+    _hip.check(_hip.lib().air_h_to_f32(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp), dptr(y), stream()), "air_h_to_f32")
+    return y
+
+
+def copy(x, out):
+    B, C, Tp = x.shape
+    p, bs = hv(x)
+    q, qs = hv(out)
+    _hip.check(_hip.lib().air_h_copy(p, csz(bs), ci(B), ci(C), ci(Tp), q, csz(qs), stream()), "air_h_copy")
+    return out
+
+
+def conv_pointwise(x, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, acc=None, acc2=None, out=None):
+    """K = 1 conv on resident rows.  w: the layer's (Cout, Cin, 1) fp32 weight.  Forward: x (B, Cin, Tp) ->
+    (B, Cout, Tp); dgrad: x = dy (B, Cout, Tp) -> (B, Cin, Tp) (+ acc + acc2, resident rows / slices)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    B, K, Tp = x.shape
+    M = Cin if dgrad else Cout
+    if K != (Cout if dgrad else Cin):
+        raise _hip.AirError("conv_pointwise: operand has %d channels" % K)
+    if out is None:
+        out = torch.empty((B, M, Tp), device=x.device, dtype=torch.int16)
+    lib = _hip.lib()
+    n = int(lib.air_h_conv1d_ws_bytes(ci(Cout), ci(Cin)))
+    n = max(n, int(lib.air_h_conv1d_ws_bytes(ci(Cin), ci(Cout))))
+    ws = ops.workspace(n, x.device)
+    xp, xb = hv(x)
+    ap, ab = hv(acc, True)
+    a2p, a2b = hv(acc2, True)
+    yp, yb = hv(out)
+    _hip.check(lib.air_h_conv1d_pointwise(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), xp, csz(xb), dptr(w), ci(1 if dgrad else 0),
+                                          dptr(bias, allow_none=True), dptr(bias_bc, allow_none=True), ci(1 if relu else 0),
+                                          ap, csz(ab), a2p, csz(a2b), yp, csz(yb), dptr(ws, torch.uint8), csz(n), stream()),
+               "air_h_conv1d_pointwise")
+    return out
+
+
+def conv_wgrad(x, dy, T, out):
+    """out (Cout, Cin, 1) fp32 = sum_{b,t} dy x over resident operands."""
+    B, Cin, Tp = x.shape
+    Cout = dy.shape[1]
+    d = _hip.AirConv1d(B, Cin, T, Cout, 1, 1, 0, 0, 0)
+    lib = _hip.lib()
+    n = int(lib.air_conv1d_bf16_ws_bytes(ctypes.byref(d)))
+    ws = ops.workspace(n, x.device)
+    xp, xb = hv(x)
+    yp, yb = hv(dy)
+    _hip.check(lib.air_h_conv1d_wgrad(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), xp, csz(xb), yp, csz(yb), dptr(out),
+                                      dptr(ws, torch.uint8), csz(n), stream()), "air_h_conv1d_wgrad")
+    return out
+
+
+def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None):
+    B, K, Tp = x.shape
+    M = Cin if dgrad else Cout
+    if out is None:
+        out = torch.empty((B, M, Tp), device=x.device, dtype=torch.int16)
+    xp, xb = hv(x)
+    yp, yb = hv(out)
+    _hip.check(_hip.lib().air_h_conv1d_tap(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
+                                           dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+                                           ci(1 if relu else 0), yp, csz(yb), stream()), "air_h_conv1d_tap")
+    return out
+
+
+def _bn_ws(B, C, device):
+    n = int(_hip.lib().air_h_bn_ws_bytes(ci(B), ci(C)))
+    return ops.workspace(n, device), n
+
+
+def bn_stats(x, T, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """(mean, invstd, scale, shift) of a resident tensor; updates the running statistics in place."""
+    B, C, Tp = x.shape
+    dev = x.device
+    mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    ws, n = _bn_ws(B, C, dev)
+    p, bs = hv(x)
+    _hip.check(_hip.lib().air_h_bn_stats(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp), dptr(gamma), dptr(beta), cf(eps),
+                                         cf(momentum), dptr(running_mean, allow_none=True),
+                                         dptr(running_var, allow_none=True), dptr(mean), dptr(invstd), dptr(scale),
+                                         dptr(shift), dptr(ws, torch.uint8), csz(n), stream()), "air_h_bn_stats")
+    return mean, invstd, scale, shift
+
+
+def bn_apply(x, T, scale, shift, out=None, rowmean=None):
+    B, C, Tp = x.shape
+    if out is None:
+        out = torch.empty((B, C, Tp), device=x.device, dtype=torch.int16)
+    p, bs = hv(x)
+    q, qs = hv(out)
+    _hip.check(_hip.lib().air_h_bn_apply(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp), dptr(scale), dptr(shift), q, csz(qs),
+                                         dptr(rowmean, allow_none=True), stream()), "air_h_bn_apply")
+    return out
+
+
+def bn_bwd(x, dy, T, mean, invstd, gamma, dgamma, dbeta, dx=None, dy2=None, rowbias=None, rowbias_scale=1.0,
+           dbias=None, relu_in=True):
+    B, C, Tp = x.shape
+    if dx is None:
+        dx = torch.empty((B, C, Tp), device=x.device, dtype=torch.int16)
+    ws, n = _bn_ws(B, C, x.device)
+    xp, xb = hv(x)
+    gp, gb = hv(dy)
+    g2p, g2b = hv(dy2, True)
+    dp, db = hv(dx)
+    _hip.check(_hip.lib().air_h_bn_bwd(xp, csz(xb), gp, csz(gb), g2p, csz(g2b), dptr(rowbias, allow_none=True),
+                                       cf(rowbias_scale), ci(B), ci(C), ci(T), ci(Tp), dptr(mean), dptr(invstd),
+                                       dptr(gamma), ci(1 if relu_in else 0), dp, csz(db), dptr(dgamma), dptr(dbeta),
+                                       dptr(dbias, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()),
+               "air_h_bn_bwd")
+    return dx
+
+
+def res2_bn_apply(x, T, scale, shift, y1, add=None, y2=None):
+    B, C, Tp = x.shape
+    xp, xb = hv(x)
+    y1p, y1b = hv(y1)
+    ap, ab = hv(add, True)
+    y2p, y2b = hv(y2, True)
+    _hip.check(_hip.lib().air_h_res2_bn_apply(xp, csz(xb), ci(B), ci(C), ci(T), ci(Tp), dptr(scale), dptr(shift), y1p,
+                                              csz(y1b), ap, csz(ab), y2p, csz(y2b), stream()), "air_h_res2_bn_apply")
+    return y2
+
+
+def se_scale_fwd(x, z, res, T, out):
+    B, C, Tp = x.shape
+    xp, xb = hv(x)
+    rp, rb = hv(res)
+    op, ob = hv(out)
+    _hip.check(_hip.lib().air_h_se_scale_fwd(xp, csz(xb), dptr(z), rp, csz(rb), ci(B), ci(C), ci(T), ci(Tp), op, csz(ob),
+                                             stream()), "air_h_se_scale_fwd")
+    return out
+
+
+def se_scale_bwd(x, z, dout, T):
+    B, C, Tp = x.shape
+    dx = torch.empty((B, C, Tp), device=x.device, dtype=torch.int16)
+    dz = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    xp, xb = hv(x)
+    dp, db = hv(dout)
+    qp, qb = hv(dx)
+    _hip.check(_hip.lib().air_h_se_scale_bwd(xp, csz(xb), dptr(z), dp, csz(db), ci(B), ci(C), ci(T), ci(Tp), qp, csz(qb),
+                                             dptr(dz), stream()), "air_h_se_scale_bwd")
+    return dx, dz
+
+
+def row_stats(x, T, want_std=True, clamp_min=1e-4):
+    B, C, Tp = x.shape
+    mean = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    std = torch.empty((B, C), device=x.device, dtype=torch.float32) if want_std else None
+    _hip.check(_hip.lib().air_h_row_stats(dptr(x, torch.int16), ci(B), ci(C), ci(T), ci(Tp), dptr(mean),
+                                          dptr(std, allow_none=True), cf(clamp_min), stream()), "air_h_row_stats")
+    return mean, std
+
+
+def row_stats_bwd(x, T, mean, std, dmean, dstd, dx, accumulate=True, clamp_min=1e-4, relu_mask=False, rowsum=None):
+    B, C, Tp = x.shape
+    _hip.check(_hip.lib().air_h_row_stats_bwd(dptr(x, torch.int16), ci(B), ci(C), ci(T), ci(Tp), dptr(mean),
+                                              dptr(std, allow_none=True), dptr(dmean, allow_none=True),
+                                              dptr(dstd, allow_none=True), cf(clamp_min), dptr(dx, torch.int16),
+                                              ci(1 if accumulate else 0), ci(1 if relu_mask else 0),
+                                              dptr(rowsum, allow_none=True), stream()), "air_h_row_stats_bwd")
+    return dx
+
+
+def asp_fwd(x, logits, T):
+    """logits (resident) is overwritten with the softmax weights.  Returns (B, 2C) [mu | sg] fp32."""
+    B, C, Tp = x.shape
+    out = torch.empty((B, 2 * C), device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_h_asp_fwd(dptr(x, torch.int16), dptr(logits, torch.int16), ci(B), ci(C), ci(T), ci(Tp),
+                                        dptr(out), stream()), "air_h_asp_fwd")
+    return out
+
+
+def asp_bwd(x, w, T, out, dout, dx, rowsum=None):
+    """w (resident) is overwritten with d(logits); dx (resident) is written."""
+    B, C, Tp = x.shape
+    _hip.check(_hip.lib().air_h_asp_bwd(dptr(x, torch.int16), dptr(w, torch.int16), ci(B), ci(C), ci(T), ci(Tp), dptr(out),
+                                        dptr(dout), dptr(dx, torch.int16), dptr(rowsum, allow_none=True), stream()),
+               "air_h_asp_bwd")
+    return dx

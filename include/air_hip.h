@@ -454,6 +454,78 @@ int air_asp_bwd_ex(const float* x, float* w_to_dlogits, int B, int C, int T, con
                    const float* dout, float* dx, int accumulate, float* rowsum_or_null,
                    unsigned short* dlogits_bf16, int dlogits_bf16_tp, air_stream_t stream);
 
+/* ------------------------------------------- bf16-resident activations ---
+ * BASELINE.json configs[2] ("ECAPA-TDNN-512 bf16 train"), round 3: every (B, C, T) activation between the layers
+ * of ecapa_tdnn.py:64-95,152-187 lives in HBM as bf16 rows - element (b, c, t) at p[b * bs + c * Tp + t] with
+ * Tp = air_h_tp(T) frames per row (a multiple of 256) and the frames T .. Tp - 1 ZERO; bs = batch stride in
+ * ELEMENTS (0 = C * Tp), so channel slices of wider tensors (the Res2 split, the concats) are addressed in place.
+ * Every entry point reads bf16, computes in fp32 and rounds each stored value once (nearest even) - the tensors
+ * torch.autocast(bfloat16) would hold in bf16; what is rounded where is stated by oracle/ecapa.py
+ * (bf16 = "resident").  Statistics, per-channel / per-row vectors, parameters and their gradients stay fp32.
+ * Every writer keeps the padding zero; the GEMMs read the rows as operands without masks. */
+int air_h_tp(int T);
+/* K = 1 Conv1d (ecapa_tdnn.py:39,55,118,140,143) on bf16 rows, 256 x 256 bf16-MFMA GEMM reading x K-major:
+ * dgrad = 0: y = relu?(W x + bias[co] + bias_bc[b][co]) (+ acc + acc2); dgrad = 1: dx = W^T dy + acc + acc2
+ * (w is always the layer's (Cout, Cin, 1) fp32 weight; packed to bf16 into ws).  acc / acc2: bf16 rows of the
+ * OUTPUT's channel count with their own batch strides, or NULL.  K (= Cin, or Cout for dgrad) % 64 == 0. */
+size_t air_h_conv1d_ws_bytes(int Cout, int Cin);
+int air_h_conv1d_pointwise(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs, const float* w,
+                           int dgrad, const float* bias, const float* bias_bc, int relu, const unsigned short* acc,
+                           size_t acc_bs, const unsigned short* acc2, size_t acc2_bs, unsigned short* y, size_t y_bs,
+                           void* ws, size_t ws_bytes, air_stream_t stream);
+/* dw[co][ci] = sum_{b,t} dy x (fp32 out, split-K in fixed order); ws >= air_conv1d_bf16_ws_bytes of the layer. */
+int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs,
+                       const unsigned short* dy, size_t dy_bs, float* dw, void* ws, size_t ws_bytes, air_stream_t stream);
+/* Dilated K = 3 conv of a Res2 branch (ecapa_tdnn.py:46), forward (relu?(W * x + bias)) or data gradient
+ * (dgrad = 1: w_packed from air_conv1d_tap_pack_bf16(transpose = 1)). */
+int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                     const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y, size_t y_bs,
+                     air_stream_t stream);
+/* BatchNorm1d, training mode: statistics of the bf16 tensor (fp64 two-stage sums, running-stat update) ... */
+size_t air_h_bn_ws_bytes(int B, int C);
+int air_h_bn_stats(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                   float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
+                   air_stream_t stream);
+/* ... y = bf16(x * scale[c] + shift[c]); rowmean (B*C, may be NULL) = mean over t of the STORED y (the SE squeeze) */
+int air_h_bn_apply(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* scale,
+                   const float* shift, unsigned short* y, size_t y_bs, float* rowmean, air_stream_t stream);
+/* ... and its backward for conv -> ReLU -> BN (x = the BN input, a ReLU output; relu_in masks dx where x == 0):
+ * incoming gradient dy + dy2 + rowbias_scale * dy_rowbias[b][c] as in air_bn_bwd_ex; dx bf16 (may alias dy);
+ * dgamma / dbeta / dbias (C) fp32. */
+int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy, size_t dy_bs, const unsigned short* dy2,
+                 size_t dy2_bs, const float* dy_rowbias, float rowbias_scale, int B, int C, int T, int Tp,
+                 const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
+                 size_t dx_bs, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                 air_stream_t stream);
+/* Res2 chain step (ecapa_tdnn.py:78-83): y1 = bf16(x * scale + shift); y2 = bf16(y1 + add) (add, y2 both or neither) */
+int air_h_res2_bn_apply(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* scale,
+                        const float* shift, unsigned short* y1, size_t y1_bs, const unsigned short* add, size_t add_bs,
+                        unsigned short* y2, size_t y2_bs, air_stream_t stream);
+/* SE gate + block residual (ecapa_tdnn.py:27-29,:93): out = bf16(x * sigmoid(z[b][c]) + res), and its backward
+ * dx = bf16(dout * sigmoid(z)), dz = s (1 - s) sum_t dout x. */
+int air_h_se_scale_fwd(const unsigned short* x, size_t x_bs, const float* z, const unsigned short* res, size_t res_bs,
+                       int B, int C, int T, int Tp, unsigned short* out, size_t out_bs, air_stream_t stream);
+int air_h_se_scale_bwd(const unsigned short* x, size_t x_bs, const float* z, const unsigned short* dout, size_t dout_bs,
+                       int B, int C, int T, int Tp, unsigned short* dx, size_t dx_bs, float* dz, air_stream_t stream);
+/* Context statistics (ecapa_tdnn.py:178) of a dense bf16 tensor and their backward folded into dx
+ * (dx = bf16(dx + ...), ReLU mask of layer4's output, rowsum of the stored values): air_row_stats[_bwd]. */
+int air_h_row_stats(const unsigned short* x, int B, int C, int T, int Tp, float* mean, float* std_or_null,
+                    float clamp_min, air_stream_t stream);
+int air_h_row_stats_bwd(const unsigned short* x, int B, int C, int T, int Tp, const float* mean, const float* std_,
+                        const float* dmean, const float* dstd, float clamp_min, unsigned short* dx, int accumulate,
+                        int relu_mask, float* rowsum_or_null, air_stream_t stream);
+/* Attentive statistics pooling (ecapa_tdnn.py:143-185): logits (bf16) -> w = bf16(softmax_T) in place; [mu | sg]
+ * from the STORED w.  bwd: dx written (bf16), w overwritten with bf16(d logits), rowsum of the stored d logits. */
+int air_h_asp_fwd(const unsigned short* x, unsigned short* logits_to_w, int B, int C, int T, int Tp, float* out,
+                  air_stream_t stream);
+int air_h_asp_bwd(const unsigned short* x, unsigned short* w_to_dlogits, int B, int C, int T, int Tp, const float* out,
+                  const float* dout, unsigned short* dx, float* rowsum_or_null, air_stream_t stream);
+/* Edges of the bf16 region: rows -> dense (B, C, T) fp32; rows -> rows (channel-slice copies). */
+int air_h_to_f32(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, float* y, air_stream_t stream);
+int air_h_copy(const unsigned short* x, size_t x_bs, int B, int C, int Tp, unsigned short* y, size_t y_bs,
+               air_stream_t stream);
+
 /* ----------------------------------------------------------- OC-Softmax ---
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
  * x (B,D), center (1,D), labels (B,) int64.  loss: scalar; neg_scores (B,).

@@ -1,0 +1,241 @@
+"""GPU parity of the bf16-RESIDENT ECAPA kernels (csrc/ecapa_bf16.hip, the ``air_h_*`` entry points of
+conv1d_bf16.hip) through the C-ABI wrappers of asvspoof2021_air_amd/ops_h.py.
+
+Every kernel reads bf16, computes in fp32 and stores each value rounded once to bf16.  The reference is an fp64
+evaluation of the same formula ON THE bf16 INPUT VALUES; a stored value is right when it lies within half a bf16
+ulp of that exact value (plus the fp32 evaluation's own noise: 2 % of an ulp) - i.e. it is one of the two bf16
+neighbours a correctly rounded result can be.  fp32 outputs (statistics, parameter gradients) hold 2e-5 of scale,
+the bound of every fp32 kernel test.  Padding frames T .. Tp - 1 must come out zero."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.filler import synth_feat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oh():
+    from asvspoof2021_air_amd import ops_h
+    return ops_h
+
+
+def res(oh, x):
+    """fp32 (B, C, T) CPU -> (resident GPU tensor, the bf16 values as fp64 CPU)."""
+    B, C, T = x.shape
+    xb = x.to(torch.bfloat16)
+    r = oh.rows(B, C, T, "cuda", zero=True)
+    r[:, :, :T] = xb.view(torch.int16).cuda()
+    return r, xb.double()
+
+
+def val(r, T):
+    assert int(r[:, :, T:].abs().max()) == 0 if r.shape[2] > T else True, "padding frames must stay zero"
+    return r[:, :, :T].contiguous().view(torch.bfloat16).cpu().double()
+
+
+def ulp_ok(got, exact, name, slack=0.52, floor=None):
+    got, exact = got.numpy(), exact.numpy()
+    # bf16: 8 significant bits -> ulp(x) = 2^(floor(log2|x|) - 7).  Results far below the tensor's scale come from
+    # cancelling fp32 terms, whose rounding is relative to the TERMS: the ulp is floored at 1e-5 of the scale.
+    if floor is None:
+        floor = max(float(np.abs(exact).max()) * 1e-5, 1e-30)
+    mag = np.maximum(np.abs(exact), floor)
+    ulp = 2.0 ** (np.floor(np.log2(mag)) - 7)
+    err = np.abs(got - exact) / ulp
+    bad = err > slack
+    assert not bad.any(), "%s: %d of %d values off by more than %.2f ulp (worst %.3f ulp at exact %.6g got %.6g)" % (
+        name, bad.sum(), bad.size, slack, err.max(), exact.flat[err.argmax()], got.flat[err.argmax()])
+
+
+def close32(got, want, name, rtol=2e-5):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    s = max(np.abs(want).max(), 1e-30)
+    assert np.abs(got - want).max() <= rtol * s, "%s: %.3g of scale %.3g" % (name, np.abs(got - want).max(), s)
+
+
+SHAPES = [(3, 64, 96), (2, 128, 750), (5, 64, 401)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bn_stats_apply_bwd(oh, shape):
+    B, C, T = shape
+    x, xd = res(oh, F.relu(synth_feat(shape, 1) * 1.5 + 0.3))
+    gamma = 1.0 + 0.3 * synth_feat((C,), 2)
+    beta = 0.2 * synth_feat((C,), 3)
+    rm, rv = 0.1 * synth_feat((C,), 4), 1.0 + 0.1 * synth_feat((C,), 5).abs()
+    rmg, rvg = rm.cuda(), rv.cuda()
+    mean, invstd, scale, shift = oh.bn_stats(x, T, gamma.cuda(), beta.cuda(), rmg, rvg)
+    xg = xd.clone().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(xg, rm64, rv64, gd, bd, True, 0.1, 1e-5)
+    close32(mean, xd.mean((0, 2)), "mean")
+    close32(invstd, 1.0 / torch.sqrt(xd.var((0, 2), unbiased=False) + 1e-5), "invstd")
+    close32(rmg, rm64, "running_mean")
+    close32(rvg, rv64, "running_var")
+    rowmean = torch.empty((B, C), device="cuda")
+    yh = oh.bn_apply(x, T, scale, shift, rowmean=rowmean)
+    ulp_ok(val(yh, T), y.detach(), "bn_apply")
+    close32(rowmean, val(yh, T).mean(2), "rowmean of the stored values")
+    # backward of conv -> ReLU -> BN with the joins: dy + dy2 + rowbias / T, ReLU mask, bias gradient
+    dy, dyd = res(oh, synth_feat(shape, 6))
+    dy2, dy2d = res(oh, 0.5 * synth_feat(shape, 7))
+    rb = synth_feat((B, C), 8)
+    g_in = dyd + dy2d + rb.double()[:, :, None] / T
+    y.backward(g_in)
+    mask = (xd > 0).double()
+    want_dx = xg.grad * mask
+    dgamma, dbeta, dbias = (torch.empty(C, device="cuda") for _ in range(3))
+    dx = oh.bn_bwd(x, dy, T, mean, invstd, gamma.cuda(), dgamma, dbeta, dy2=dy2, rowbias=rb.cuda(), rowbias_scale=1.0 / T,
+                   dbias=dbias, relu_in=True)
+    # the kernel forms xhat from the fp32 mean / invstd: allow their rounding on top of the half ulp
+    ulp_ok(val(dx, T), want_dx, "bn_bwd dx", slack=0.56, floor=float(want_dx.abs().max()) * 2e-3)
+    close32(dgamma, gd.grad, "dgamma", 1e-4)
+    close32(dbeta, bd.grad, "dbeta", 1e-4)
+    close32(dbias, want_dx.sum((0, 2)), "dbias", 1e-4)
+    # in place (dx aliases dy), slices of a wider tensor
+    wide = oh.rows(B, 2 * C, T, "cuda", zero=True)
+    wide[:, C:] = dy
+    oh.bn_bwd(x, wide[:, C:], T, mean, invstd, gamma.cuda(), dgamma, dbeta, dx=wide[:, C:], dy2=dy2, rowbias=rb.cuda(),
+              rowbias_scale=1.0 / T, relu_in=True)
+    assert torch.equal(wide[:, C:], dx)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_res2_se_copy(oh, shape):
+    B, C, T = shape
+    x, xd = res(oh, synth_feat(shape, 11))
+    add, addd = res(oh, synth_feat(shape, 12))
+    scale, shift = 1.0 + 0.2 * synth_feat((C,), 13), 0.3 * synth_feat((C,), 14)
+    wide = oh.rows(B, 3 * C, T, "cuda", zero=True)
+    y2 = oh.rows(B, C, T, "cuda")
+    oh.res2_bn_apply(x, T, scale.cuda(), shift.cuda(), wide[:, C:2 * C], add=add, y2=y2)
+    want1 = xd * scale.double()[None, :, None] + shift.double()[None, :, None]
+    ulp_ok(val(wide[:, C:2 * C].contiguous(), T), want1, "res2 y1")
+    y1 = val(wide[:, C:2 * C].contiguous(), T)
+    ulp_ok(val(y2, T), y1 + addd, "res2 y2 = bf16(stored y1 + add)")
+    assert int(wide[:, :C].abs().max()) == 0 and int(wide[:, 2 * C:].abs().max()) == 0
+    # SE gate + residual and its backward
+    z = synth_feat((B, C), 15)
+    out = oh.rows(B, C, T, "cuda")
+    oh.se_scale_fwd(x, z.cuda(), add, T, out)
+    g = torch.sigmoid(z.double())[:, :, None]
+    ulp_ok(val(out, T), xd * g + addd, "se_scale_fwd")
+    dout, doutd = res(oh, synth_feat(shape, 16))
+    dx, dz = oh.se_scale_bwd(x, z.cuda(), dout, T)
+    ulp_ok(val(dx, T), doutd * g, "se_scale_bwd dx")
+    close32(dz, (doutd * xd).sum(2) * (g * (1 - g))[:, :, 0], "se_scale_bwd dz", 1e-4)
+    # layout edges
+    close32(oh.to_f32(x, T), xd, "to_f32", 0.0)
+    cp = oh.rows(B, C, T, "cuda")
+    oh.copy(wide[:, C:2 * C], cp)
+    assert torch.equal(cp, wide[:, C:2 * C])
+    back = oh.from_f32(xd.float().cuda())
+    assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 96), (2, 64, 750)])
+def test_row_stats_asp(oh, shape):
+    B, C, T = shape
+    x, xd = res(oh, F.relu(synth_feat(shape, 21)))
+    mean, std = oh.row_stats(x, T)
+    close32(mean, xd.mean(2), "row mean")
+    close32(std, torch.sqrt(xd.var(2).clamp(min=1e-4)), "row std")
+    dmean, dstd = synth_feat((B, C), 22), synth_feat((B, C), 23)
+    dx, dxd = res(oh, synth_feat(shape, 24))
+    xg = xd.clone().requires_grad_(True)
+    (xg.mean(2) * dmean.double()).sum().backward()
+    g1 = xg.grad.clone()
+    xg.grad = None
+    (torch.sqrt(xg.var(2).clamp(min=1e-4)) * dstd.double()).sum().backward()
+    want = (dxd + g1 + xg.grad) * (xd > 0).double()
+    rowsum = torch.empty((B, C), device="cuda")
+    oh.row_stats_bwd(x, T, mean, std, dmean.cuda(), dstd.cuda(), dx, accumulate=True, relu_mask=True, rowsum=rowsum)
+    ulp_ok(val(dx, T), want, "row_stats_bwd", slack=0.56, floor=float(want.abs().max()) * 2e-3)
+    close32(rowsum, val(dx, T).sum(2), "rowsum of the stored values", 1e-5)
+    # attentive statistics pooling
+    lg, lgd = res(oh, 2.0 * synth_feat(shape, 25))
+    w = lg.clone()
+    out = oh.asp_fwd(x, w, T)
+    wd = torch.softmax(lgd, 2)
+    ulp_ok(val(w, T), wd, "asp softmax", slack=0.56)
+    ws = val(w, T)  # the stored weights define the pooled statistics
+    mu = (xd * ws).sum(2)
+    sg = torch.sqrt(((xd ** 2) * ws).sum(2) - mu ** 2).clamp(min=1e-2)
+    sg = torch.sqrt((((xd ** 2) * ws).sum(2) - mu ** 2).clamp(min=1e-4))
+    close32(out[:, :C], mu, "asp mu")
+    close32(out[:, C:], sg, "asp sg", 1e-4)
+    # backward: stored w as a leaf
+    dout = synth_feat((B, 2 * C), 26)
+    xl = xd.clone().requires_grad_(True)
+    al = lgd.clone().requires_grad_(True)
+    wl = torch.softmax(al, 2)
+    # the kernel differentiates through softmax at the STORED weights: evaluate the analytic formula there
+    dm_, ds_ = dout.double()[:, :C], dout.double()[:, C:]
+    dq = torch.where(sg * sg > 1e-4, ds_ / (2 * sg), torch.zeros_like(sg))
+    dmm = dm_ - 2 * mu * dq
+    dwv = dmm[:, :, None] * xd + dq[:, :, None] * xd ** 2
+    want_dx = dmm[:, :, None] * ws + 2 * dq[:, :, None] * xd * ws
+    dot = (ws * dwv).sum(2, keepdim=True)
+    want_da = ws * (dwv - dot)
+    dxo = oh.rows(B, C, T, "cuda")
+    rs = torch.empty((B, C), device="cuda")
+    oh.asp_bwd(x, w, T, out, dout.cuda(), dxo, rowsum=rs)
+    ulp_ok(val(dxo, T), want_dx, "asp_bwd dx", slack=0.6, floor=float(want_dx.abs().max()) * 2e-3)
+    ulp_ok(val(w, T), want_da, "asp_bwd dlogits", slack=0.6, floor=float(want_da.abs().max()) * 2e-3)
+    # (analytically zero - softmax over T is shift-invariant: compare on the scale of the summed magnitudes)
+    assert float((rs.cpu().double() - val(w, T).sum(2)).abs().max()) <= 1e-5 * float(val(w, T).abs().sum(2).max())
+
+
+POINTWISE = [(2, 512, 512, 750), (3, 1536, 1536, 96), (2, 1536, 128, 401), (2, 128, 1536, 401), (4, 512, 512, 96)]
+
+
+@pytest.mark.parametrize("cfg", POINTWISE)
+def test_pointwise_conv_fwd_dgrad_wgrad(oh, cfg):
+    B, Cin, Cout, T = cfg
+    x, xd = res(oh, synth_feat((B, Cin, T), 31))
+    w = synth_feat((Cout, Cin, 1), 32, scale=0.05)
+    wb = w.to(torch.bfloat16).double()
+    bias, bbc = 0.1 * synth_feat((Cout,), 33), 0.1 * synth_feat((B, Cout), 34)
+    y = oh.conv_pointwise(x, w.cuda(), T, bias=bias.cuda(), bias_bc=bbc.cuda(), relu=True)
+    want = F.relu(F.conv1d(xd, wb) + bias.double()[None, :, None] + bbc.double()[:, :, None])
+    # K-long fp32 sums of exact products: their order noise (1e-6 of scale) on top of the half ulp
+    ulp_ok(val(y, T), want, "pointwise fwd", slack=0.56, floor=float(want.abs().max()) * 4e-3)
+    dy, dyd = res(oh, synth_feat((B, Cout, T), 35))
+    a1, a1d = res(oh, synth_feat((B, Cin, T), 36))
+    wide = oh.rows(B, 2 * Cin, T, "cuda", zero=True)
+    a2v, a2d = res(oh, synth_feat((B, Cin, T), 37))
+    wide[:, Cin:] = a2v
+    dx = oh.conv_pointwise(dy, w.cuda(), T, dgrad=True, acc=a1, acc2=wide[:, Cin:])
+    want = F.conv_transpose1d(dyd, wb) + a1d + a2d
+    ulp_ok(val(dx, T), want, "pointwise dgrad + acc + acc2", slack=0.56, floor=float(want.abs().max()) * 4e-3)
+    if Cin % 128 == 0 and Cout % 128 == 0:
+        dw = torch.empty((Cout, Cin, 1), device="cuda")
+        oh.conv_wgrad(x, dy, T, dw)
+        close32(dw, torch.einsum("bot,bit->oi", dyd, xd).unsqueeze(2), "pointwise wgrad")
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (2, 64, 401, 4)])
+def test_tap_conv(oh, cfg):
+    from asvspoof2021_air_amd import ops
+    B, C, T, d = cfg
+    wide = oh.rows(B, 4 * C, T, "cuda", zero=True)
+    xv, xd = res(oh, synth_feat((B, C, T), 41))
+    wide[:, C:2 * C] = xv
+    w = synth_feat((C, C, 3), 42, scale=0.1)
+    wb = w.to(torch.bfloat16).double()
+    bias = 0.1 * synth_feat((C,), 43)
+    wp = ops.conv1d_tap_pack([w.cuda()], transpose=False)
+    y = oh.conv_tap(wide[:, C:2 * C], wp[0], T, d, C, C, bias=bias.cuda(), relu=True)
+    want = F.relu(F.conv1d(xd, wb, bias.double(), 1, d, d))
+    ulp_ok(val(y, T), want, "tap fwd", slack=0.56, floor=float(want.abs().max()) * 4e-3)
+    dy, dyd = res(oh, synth_feat((B, C, T), 44))
+    wpt = ops.conv1d_tap_pack([w.cuda()], transpose=True)
+    oh.conv_tap(dy, wpt[0], T, d, C, C, dgrad=True, out=wide[:, 3 * C:])
+    want = F.conv_transpose1d(dyd, wb, None, 1, d, 0, 1, d)
+    ulp_ok(val(wide[:, 3 * C:].contiguous(), T), want, "tap dgrad", slack=0.56, floor=float(want.abs().max()) * 4e-3)
+    assert int(wide[:, :C].abs().max()) == 0 and int(wide[:, 2 * C:3 * C].abs().max()) == 0
