@@ -12,11 +12,17 @@ Layout choices that remove the reference's copies:
   * the (B,4608,T) context tensor (ecapa_tdnn.py:178) is never built: the tiled mean/std
     part of ``attention.0`` is constant over T, so it is applied as a per-utterance bias
     W[:,1536:] @ [mean; std] in the conv epilogue (same arithmetic, re-associated).
-``compute_dtype``: "fp32" (the reference's arithmetic) or "bf16" (BASELINE.json configs[2]):
-the pointwise layers that hold 97 % of the FLOPs (Bottle2neck conv1/conv3, layer4, attention.0's
-layer4 part, attention.3) run forward, dgrad and wgrad on the bf16 matrix cores with fp32
-accumulation (csrc/conv1d_bf16.hip), and so do the forward / input-gradient passes of the dilated
-K=3 Res2 convs; tensors in HBM, BatchNorm, pooling and the K=3 weight gradients stay fp32.  Set it with ``model.set_compute_dtype("bf16")``.
+``compute_dtype`` (``model.set_compute_dtype``):
+  * "fp32": the reference's arithmetic;
+  * "bf16" (BASELINE.json configs[2], round 3): bf16-RESIDENT activations - every (B, C, T) tensor from the first
+    BatchNorm's output to the pooling lives in HBM as bf16 rows (csrc/ecapa_bf16.hip), the K = 1 and the dilated
+    K = 3 convolutions run forward, dgrad and (K = 1) wgrad on the bf16 matrix cores with fp32 accumulation and
+    write bf16; BatchNorm / SE / pooling read bf16, compute in fp32 and round each stored value once.  The tensors a
+    torch.autocast(bfloat16) run of the reference holds in bf16 are the same; conv1 (K = 5, fp32 input), the
+    statistics, the SE and pooled vectors, fc6 and every parameter / gradient stay fp32 (oracle/ecapa.py,
+    bf16="resident", states each rounding);
+  * "bf16c" (rounds 1-2): bf16 COMPUTE only - the same contractions on the bf16 matrix cores, operands rounded as
+    they are staged, but every tensor fp32 in HBM (plus bf16 operand copies for the weight gradients).
 """
 import math
 
@@ -26,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip, ops
+from . import ops_h as oh
 from .arena import ParamArena
 
 
@@ -161,8 +168,8 @@ class Res2Net2(nn.Module):
         return st
 
     def set_compute_dtype(self, dtype):
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+        if dtype not in ("fp32", "bf16", "bf16c"):
+            raise ValueError("compute_dtype must be 'fp32', 'bf16' or 'bf16c', got %r" % (dtype,))
         self.compute_dtype = dtype
         return self
 
@@ -194,7 +201,7 @@ class Res2Net2(nn.Module):
         B, C, T = inp.shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16"
+        bf = self.compute_dtype == "bf16c"
         r1 = ops.conv1d_fwd(inp, det(blk.conv1.weight), det(blk.conv1.bias), relu=True, bf16=bf)
         st1 = _bn(r1, blk.bn1, training)
         o1 = ops.bn_apply(r1, st1[2], st1[3])
@@ -243,9 +250,11 @@ class Res2Net2(nn.Module):
         return None
 
     def _forward_impl(self, x, save):
+        if self.compute_dtype == "bf16":
+            return self._forward_h(x, save)
         training = self.training
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16"
+        bf = self.compute_dtype == "bf16c"
         B, _, T = x.shape
         C = self.C
         r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
@@ -321,7 +330,7 @@ class Res2Net2(nn.Module):
             on_side = lambda fn, *reads: fn()
         blk = S["blk"]
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16"
+        bf = self.compute_dtype == "bf16c"
         B, C, T = S["o3"].shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         se = blk.se.se
@@ -379,6 +388,8 @@ class Res2Net2(nn.Module):
         return ops.conv1d_dgrad(dc1, det(blk.conv1.weight), accumulate=dout, bf16=bf, accumulate2=add2)
 
     def _backward_impl(self, S, dfeat, dout):
+        if S.get("resident"):
+            return self._backward_h(S, dfeat, dout)
         arena = self.arena()
         G = arena.grad_views()
         # gradient accumulation (a second backward without zero_grad): p.grad already IS the arena view, so
@@ -389,7 +400,7 @@ class Res2Net2(nn.Module):
                            for n, p, _, _ in arena.entries)
         old = arena.grad.clone() if accumulating else None
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16"
+        bf = self.compute_dtype == "bf16c"
         B, _, T = S["x"].shape
         C = self.C
         tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")
@@ -536,6 +547,267 @@ class Res2Net2(nn.Module):
                 arena.grad[arena.head_total:].zero_()
             ops.add_(arena.grad, old)
             arena.tail_has_grad = True  # old tail sums may be live; the optimiser covers the whole arena
+            return [None if (p.grad is not None and p.grad.data_ptr() == G[n].data_ptr())
+                    else (G[n] if (have_tail or n not in tail) else None) for n, p, _, _ in arena.entries]
+        return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]
+
+    # =================================================================== bf16-resident path (compute_dtype "bf16")
+    def _bn_h(self, x, T, bn, training):
+        """BatchNorm1d on resident rows: (mean, invstd, scale, shift)."""
+        if training:
+            st = oh.bn_stats(x, T, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            ops.bn_tick(bn.num_batches_tracked)
+            return st
+        scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        return None, None, scale, shift
+
+    def _block_fwd_h(self, blk, inp, out, T, training, save):
+        """Bottle2neck (ecapa_tdnn.py:64-95) on resident rows.  ``inp`` / ``out`` may be channel-slice views.
+        o1 = bn1(relu(conv1(inp))) is written into the buffer that becomes the concat: branch i's BatchNorm output
+        replaces o1's slice i after that slice has been consumed, the pass-through group (:85) never moves."""
+        B, C, Tp = inp.shape
+        w, d, nums = blk.width, blk.dilation, blk.nums
+        det = lambda p: p.detach()
+        dev = inp.device
+        r1 = oh.conv_pointwise(inp, det(blk.conv1.weight), T, bias=det(blk.conv1.bias), relu=True)
+        st1 = self._bn_h(r1, T, blk.bn1, training)
+        cat = oh.bn_apply(r1, T, st1[2], st1[3])
+        t_i = oh.copy(cat[:, :w], oh.rows(B, w, T, dev))  # branch 0's input outlives its slice (weight gradient)
+        wp = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=False)
+        t_list, r_list, st_list = [], [], []
+        for i in range(nums):
+            r_i = oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True)
+            st_i = self._bn_h(r_i, T, blk.bns[i], training)
+            if i + 1 < nums:
+                t_next = oh.rows(B, w, T, dev)
+                oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w],
+                                 add=cat[:, (i + 1) * w:(i + 2) * w], y2=t_next)
+            else:
+                t_next = None
+                oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
+            t_list.append(t_i)
+            r_list.append(r_i)
+            st_list.append(st_i)
+            t_i = t_next
+        r3 = oh.conv_pointwise(cat, det(blk.conv3.weight), T, bias=det(blk.conv3.bias), relu=True)
+        st3 = self._bn_h(r3, T, blk.bn3, training)
+        m = torch.empty((B, C), device=dev, dtype=torch.float32)
+        o3 = oh.bn_apply(r3, T, st3[2], st3[3], rowmean=m)  # + the SE squeeze of the stored tensor
+        se = blk.se.se
+        z1 = ops.linear_fwd(m, det(se[1].weight).view(se[1].out_channels, -1), det(se[1].bias), relu=True)
+        stS = _bn(z1.view(B, -1, 1), se[3], training)
+        z1n = ops.bn_apply(z1.view(B, -1, 1), stS[2], stS[3]).view(B, -1)
+        z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
+        oh.se_scale_fwd(o3, z2, inp, T, out)
+        if save:
+            return dict(blk=blk, inp=inp, r1=r1, st1=st1, t=t_list, r=r_list, st=st_list, cat=cat, r3=r3, st3=st3,
+                        o3=o3, m=m, z1=z1, stS=stS, z1n=z1n, z2=z2)
+        return None
+
+    def _forward_h(self, x, save):
+        training = self.training
+        det = lambda p: p.detach()
+        B, _, T = x.shape
+        C = self.C
+        dev = x.device
+        # conv1 (K = 5 on the fp32 features) and its BatchNorm statistics stay fp32; the BatchNorm output is the
+        # first resident tensor
+        r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
+        st0 = _bn(r0, self.bn1, training)
+        h = oh.from_f32(ops.bn_apply(r0, st0[2], st0[3]))  # :161
+        cat123 = oh.rows(B, 3 * C, T, dev)
+        blocks = []
+        inp = h
+        for k, blk in enumerate((self.layer1, self.layer2, self.layer3)):
+            out = cat123[:, k * C:(k + 1) * C]
+            blocks.append(self._block_fwd_h(blk, inp, out, T, training, save))
+            inp = out
+        x4 = oh.conv_pointwise(cat123, det(self.layer4.weight), T, bias=det(self.layer4.bias), relu=True)  # :172-173
+        mean, std = oh.row_stats(x4, T, True, 1e-4)  # context statistics (:178)
+        ctx = torch.cat((mean, std), 1)
+        a0, a3 = self.attention[0], self.attention[3]
+        w0 = det(a0.weight).view(128, -1)
+        w_x = ops.add_strided(torch.empty((128, 1, 1536), device=dev), w0[:, :1536].unsqueeze(1)).view(128, 1536, 1)
+        w_c = ops.add_strided(torch.empty((128, 1, 3072), device=dev), w0[:, 1536:].unsqueeze(1)).view(128, 3072)
+        ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std], a per-utterance bias
+        a1 = oh.conv_pointwise(x4, w_x, T, bias=det(a0.bias), bias_bc=ctxb, relu=True)  # attention.0 + ReLU
+        stA = self._bn_h(a1, T, self.attention[2], training)
+        a1n = oh.bn_apply(a1, T, stA[2], stA[3])
+        wts = oh.conv_pointwise(a1n, det(a3.weight), T, bias=det(a3.bias))  # logits -> softmax weights below
+        pooled = oh.asp_fwd(x4, wts, T)  # :184-187 (mu | sg)
+        st5 = _bn(pooled.view(B, -1, 1), self.bn5, training)
+        p5 = ops.bn_apply(pooled.view(B, -1, 1), st5[2], st5[3]).view(B, -1)
+        feat = ops.linear_fwd(p5, det(self.fc6.weight), det(self.fc6.bias))  # :191
+        o7 = ops.linear_fwd(feat, det(self.fc7.weight), det(self.fc7.bias))  # :193
+        st7 = None
+        out = o7
+        if self.out_bn:
+            st7 = _bn(o7.view(B, -1, 1), self.bn7, training)
+            out = ops.bn_apply(o7.view(B, -1, 1), st7[2], st7[3]).view(B, -1)
+        S = None
+        if save:
+            if not training:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
+            S = dict(resident=True, T=T, x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
+                     ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5, p5=p5,
+                     feat=feat, o7=o7, st7=st7)
+        ops.bn_flush()
+        return feat, out, S
+
+    def _block_bwd_h(self, S, dout, T, G, pre, add2, on_side):
+        """dout: gradient w.r.t. the block output (resident rows or a channel slice).  Returns d(inp) + dout + add2."""
+        blk = S["blk"]
+        det = lambda p: p.detach()
+        B, C, Tp = S["o3"].shape
+        w, d, nums = blk.width, blk.dilation, blk.nums
+        se = blk.se.se
+        gv = lambda n: G[pre + n]
+        do3, dz2 = oh.se_scale_bwd(S["o3"], S["z2"], dout, T)
+        dz1n, _, _ = ops.linear_bwd(S["z1n"], det(se[4].weight).view(se[4].out_channels, -1), dz2, True,
+                                    dw=gv("se.se.4.weight").view(se[4].out_channels, -1), db=gv("se.se.4.bias"))
+        stS = S["stS"]
+        dz1, _, _ = ops.bn_bwd(S["z1"].view(B, -1, 1), dz1n.view(B, -1, 1), stS[0], stS[1], det(se[3].weight),
+                               det(se[3].bias), relu_in=True, dgamma=gv("se.se.3.weight"), dbeta=gv("se.se.3.bias"))
+        dm, _, _ = ops.linear_bwd(S["m"], det(se[1].weight).view(se[1].out_channels, -1), dz1.view(B, -1), True,
+                                  dw=gv("se.se.1.weight").view(se[1].out_channels, -1), db=gv("se.se.1.bias"))
+        st3 = S["st3"]
+        dc3 = oh.bn_bwd(S["r3"], do3, T, st3[0], st3[1], det(blk.bn3.weight), gv("bn3.weight"), gv("bn3.bias"), dx=do3,
+                        rowbias=dm, rowbias_scale=1.0 / T, dbias=gv("conv3.bias"))
+        on_side(lambda: oh.conv_wgrad(S["cat"], dc3, T, gv("conv3.weight")), dc3)
+        dcat = oh.conv_pointwise(dc3, det(blk.conv3.weight), T, dgrad=True)  # becomes d(o1) slice by slice
+        wpt = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=True)
+        din_next = None
+        for i in reversed(range(nums)):
+            st_i = S["st"][i]
+            dc_i = oh.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], T, st_i[0], st_i[1], det(blk.bns[i].weight),
+                             gv("bns.%d.weight" % i), gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i))
+
+            def tap_wgrad(dc_i=dc_i, i=i):
+                # the K = 3 weight gradient (0.6 % of the FLOPs) stays an fp32 contraction: operands widened here
+                ops.conv1d_wgrad(oh.to_f32(S["t"][i], T), oh.to_f32(dc_i, T), blk.convs[i].weight.shape, d, d,
+                                 out=gv("convs.%d.weight" % i))
+
+            on_side(tap_wgrad, dc_i)
+            din = oh.conv_tap(dc_i, wpt[i], T, d, w, w, dgrad=True, out=dcat[:, i * w:(i + 1) * w])
+            din_next = din if i > 0 else None
+        st1 = S["st1"]
+        dc1 = oh.bn_bwd(S["r1"], dcat, T, st1[0], st1[1], det(blk.bn1.weight), gv("bn1.weight"), gv("bn1.bias"), dx=dcat,
+                        dbias=gv("conv1.bias"))
+        on_side(lambda: oh.conv_wgrad(S["inp"], dc1, T, gv("conv1.weight")), dc1)
+        # + dout: the residual branch (ecapa_tdnn.py:93), + add2: the concat gradient's slice of the previous block
+        return oh.conv_pointwise(dc1, det(blk.conv1.weight), T, dgrad=True, acc=dout, acc2=add2)
+
+    def _backward_h(self, S, dfeat, dout):
+        arena = self.arena()
+        G = arena.grad_views()
+        accumulating = any(p.grad is not None and p.grad.data_ptr() == G[n].data_ptr() for n, p, _, _ in arena.entries)
+        old = arena.grad.clone() if accumulating else None
+        det = lambda p: p.detach()
+        B, _, T = S["x"].shape
+        C = self.C
+        tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")
+        have_tail = dout is not None
+        main = torch.cuda.current_stream()
+        use_side = self.overlap_wgrad and not accumulating
+        if use_side and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=main.device)
+        side = self._side_stream if use_side else main
+        keep = []
+
+        def on_side(fn, *reads):
+            if not use_side:
+                fn()
+                return
+            keep.extend(reads)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                fn()
+
+        if dfeat is None:
+            dfeat = torch.zeros_like(S["feat"])
+        dfeat = dfeat.contiguous()
+        if have_tail:  # CE branch through fc7/bn7 (dead under ang_iso, main_train.py:355 -> 376)
+            do7 = dout.contiguous()
+            if self.out_bn:
+                st7 = S["st7"]
+                do7, _, _ = ops.bn_bwd(S["o7"].view(B, -1, 1), do7.view(B, -1, 1), st7[0], st7[1], det(self.bn7.weight),
+                                       det(self.bn7.bias), dgamma=G["bn7.weight"], dbeta=G["bn7.bias"])
+                do7 = do7.view(B, -1)
+            dx7, _, _ = ops.linear_bwd(S["feat"], det(self.fc7.weight), do7, True, dw=G["fc7.weight"], db=G["fc7.bias"])
+            dfeat = ops.add_(dx7, dfeat)
+        dp5, _, _ = ops.linear_bwd(S["p5"], det(self.fc6.weight), dfeat, True, dw=G["fc6.weight"], db=G["fc6.bias"])
+        st5 = S["st5"]
+        dpooled, _, _ = ops.bn_bwd(S["pooled"].view(B, -1, 1), dp5.view(B, -1, 1), st5[0], st5[1], det(self.bn5.weight),
+                                   det(self.bn5.bias), dgamma=G["bn5.weight"], dbeta=G["bn5.bias"])
+        x4, wts = S["x4"], S["wts"]
+        dev = x4.device
+        dx4 = torch.empty_like(x4)
+        rows3 = torch.empty((B, x4.shape[1]), device=dev, dtype=torch.float32)
+        oh.asp_bwd(x4, wts, T, S["pooled"], dpooled.view(B, -1).contiguous(), dx4, rowsum=rows3)  # wts -> d(logits)
+        a0, a3 = self.attention[0], self.attention[3]
+        ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
+        on_side(lambda: oh.conv_wgrad(S["a1n"], wts, T, G["attention.3.weight"]), wts)
+        da1n = oh.conv_pointwise(wts, det(a3.weight), T, dgrad=True)
+        stA = S["stA"]
+        da1 = oh.bn_bwd(S["a1"], da1n, T, stA[0], stA[1], det(self.attention[2].weight), G["attention.2.weight"],
+                        G["attention.2.bias"], dx=da1n, dbias=G["attention.0.bias"])
+        gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
+
+        def att0_wgrad():
+            dwx = oh.conv_wgrad(x4, da1, T, torch.empty((128, 1536, 1), device=dev, dtype=torch.float32))
+            ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
+
+        on_side(att0_wgrad, da1)
+        oh.conv_pointwise(da1, S["w_x"], T, dgrad=True, acc=dx4, out=dx4)
+        dctxb = oh.row_stats(da1, T, want_std=False)[0] * float(T)  # (B,128): sum over time of d(a1)
+        dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb.contiguous(), True, need_db=False)
+        ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
+        dmean = dctx[:, :1536].contiguous()
+        dstd = dctx[:, 1536:].contiguous()
+        rows = torch.empty((B, x4.shape[1]), device=dev, dtype=torch.float32)
+        oh.row_stats_bwd(x4, T, S["mean"], S["std"], dmean, dstd, dx4, accumulate=True, relu_mask=True, rowsum=rows)
+        ops.sum_rows(rows, out=G["layer4.bias"])
+        on_side(lambda: oh.conv_wgrad(S["cat123"], dx4, T, G["layer4.weight"]), dx4)
+        bucketer = None if accumulating else getattr(self, "_bucketer", None)
+        offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
+
+        def grads_final_from(first_param):
+            if bucketer is not None:
+                evs = [torch.cuda.Event()]
+                evs[0].record(main)
+                if use_side:
+                    evs.append(torch.cuda.Event())
+                    evs[1].record(side)
+                bucketer.ready(offsets[first_param], evs)
+
+        if bucketer is not None:
+            bucketer.reset(arena.grad, arena.head_total)
+        grads_final_from("layer4.weight")
+        dcat123 = oh.conv_pointwise(dx4, det(self.layer4.weight), T, dgrad=True)
+        dnext = None
+        for k in (2, 1, 0):
+            # d(block k output) = its slice of the concat gradient + d(block k + 1 input): block k + 1's last dgrad
+            # already added this block's slice (add2); block 3 reads its slice in place
+            dblk = dcat123[:, k * C:(k + 1) * C] if dnext is None else dnext
+            add2 = dcat123[:, (k - 1) * C:k * C] if k > 0 else None
+            dnext = self._block_bwd_h(S["blocks"][k], dblk, T, G, "layer%d." % (k + 1), add2, on_side)
+            grads_final_from("layer%d.conv1.weight" % (k + 1))
+        st0 = S["st0"]
+        dn32 = oh.to_f32(dnext, T)  # back to the fp32 first layer
+        dc0, _, _ = ops.bn_bwd(S["r0"], dn32, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias), relu_in=True,
+                               dx=dn32, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"], dbias=G["conv1.bias"])
+        ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
+        if use_side:
+            main.wait_stream(side)
+        del keep[:]
+        arena.tail_has_grad = have_tail
+        if accumulating:
+            if not have_tail:
+                arena.grad[arena.head_total:].zero_()
+            ops.add_(arena.grad, old)
+            arena.tail_has_grad = True
             return [None if (p.grad is not None and p.grad.data_ptr() == G[n].data_ptr())
                     else (G[n] if (have_tail or n not in tail) else None) for n, p, _, _ in arena.entries]
         return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]

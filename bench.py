@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--model", default="resnet", choices=["resnet", "ecapa"],
                     help="resnet = the headline config (BASELINE configs[1]); ecapa = ECAPA-TDNN-512 "
                          "(BASELINE configs[2], see --dtype)")
-    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16", "bf16c"],
                     help="ecapa only: bf16 = BASELINE configs[2] (pointwise convs on the bf16 matrix cores, "
                          "fp32 accumulate; default for --model ecapa), fp32 = the reference's arithmetic")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 resnet / 128 ecapa)")
