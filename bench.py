@@ -371,8 +371,8 @@ def main():
         _, e = run_config("ecapa", "bf16", 0, max(2, min(args.steps, 8)), min(args.warmup, 2), False, not args.no_roofline)
         e["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
         e["dtype"] = "bf16"
-        e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16 compute "
-                         "(pointwise and dilated convs on v_mfma_f32_32x32x16_bf16, fp32 accumulate), T=401 "
+        e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16-resident "
+                         "activations (pointwise and dilated convs on v_mfma_f32_32x32x16_bf16, fp32 accumulate), T=401 "
                          "repeat-padded to %d" % FEAT_LEN)
         extra["ecapa_bf16_b128"] = e
         if args.model == "resnet":
@@ -411,11 +411,13 @@ def main():
         if args.model == "ecapa":
             line["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
             dt = args.dtype or "bf16"
-            line["dtype"] = "bf16" if dt == "bf16" else "f32"
+            line["dtype"] = "bf16" if dt in ("bf16", "bf16c") else "f32"
             line["config"]["workload"] = (
                 "BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, T=401 repeat-padded to "
-                "%d, " % FEAT_LEN + ("bf16 compute (pointwise convs = 97 % of FLOPs on v_mfma_f32_32x32x16_bf16, fp32 "
-                           "accumulate; tensors, BatchNorm and K=3 convs fp32)" if dt == "bf16" else
+                "%d, " % FEAT_LEN + ("bf16-resident activations (every (B,C,T) tensor bf16 in HBM; K=1 and dilated K=3 convs on "
+                           "v_mfma_f32_32x32x16_bf16 with fp32 accumulate; statistics, parameters and gradients fp32)"
+                           if dt == "bf16" else
+                           "bf16 compute on fp32 tensors (rounds 1-2 arithmetic)" if dt == "bf16c" else
                            "fp32 compute (the reference's arithmetic; configs[2] itself is the bf16 variant)"))
         if args.augment:
             line["config"]["workload"] += "; + on-the-fly IR convolution (1024 taps) of every utterance ahead of LFCC"

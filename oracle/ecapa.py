@@ -19,6 +19,21 @@ to bf16 (nearest even), products accumulate in fp32; the dilated K=3 convs of th
 do the same in their forward and input-gradient contractions (their weight gradient stays fp32);
 everything else (conv1, SE, BatchNorm, pooling, biases) stays fp32.  The bf16 oracle is pinned against the reference
 through the fp32 goldens at bf16 tolerance (tests/test_oracle_golden.py).
+
+``bf16="resident"`` (round 3, the HIP path's ``compute_dtype="bf16"``) states the bf16-RESIDENT arithmetic: every
+(B, C, T) activation from the first BatchNorm's output to the pooling is a bf16 tensor - the tensors
+``torch.autocast(bfloat16)`` holds in bf16 for this graph - and so is every (B, C, T) gradient.  Each op reads bf16
+values, computes in fp32 and rounds what it stores ONCE (nearest even).  Rounded in the forward pass: the output of
+every K = 1 / dilated K = 3 conv after bias + ReLU, every BatchNorm output, the Res2 sums ``sp + spx[i]``, the SE
+result ``x * gate + residual`` (one rounding; autocast rounds the product and the sum), layer4's ReLU output, the
+attention logits and the softmax weights (the pooled statistics use the STORED weights).  Rounded in the backward
+pass: every data gradient where a kernel stores it - conv dgrad outputs (with the residual / concat slices folded
+into the same rounding), BatchNorm backward outputs, the SE gate's d(x), the three partial sums that build d(x4).
+NOT rounded (wider than autocast): conv1 (K = 5 on the fp32 features) with its ReLU and BatchNorm statistics, all
+statistics / per-channel and per-utterance vectors (SE squeeze and MLP, context mean / std, pooled mu / sg, bn5,
+fc6), the softmax and the pooling sums (fp32 on the stored bf16 values), parameters and parameter gradients (fp32
+accumulation of bf16 operands; the K = 3 weight gradient an fp32 contraction).  tests/golden/make_golden_bf16.py
+measures the distance of both modes to the reference run under torch.autocast on the CPU.
 """
 from collections import OrderedDict
 
@@ -27,6 +42,64 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+BF16_MODES = (True, "resident")
+
+
+def _rnd(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Round(torch.autograd.Function):
+    """Identity up to bf16 rounding of the value (fwd) and / or of the gradient flowing back through it (bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return _rnd(x) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_rnd(g) if ctx.bwd else g), None, None
+
+
+def RF(x):  # the stored tensor is bf16
+    return _Round.apply(x, True, False)
+
+
+def RG(x):  # the gradient stored at this point is bf16
+    return _Round.apply(x, False, True)
+
+
+def RB(x):
+    return _Round.apply(x, True, True)
+
+
+class _X4Fan(torch.autograd.Function):
+    """layer4's output feeds the pooling, attention.0 and the context statistics; the HIP backward builds d(x4) in
+    three stored steps: bf16(pooling) -> bf16(. + attention.0's dgrad) -> bf16(. + statistics) [ReLU mask upstream]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone(), x.clone(), x.clone()
+
+    @staticmethod
+    def backward(ctx, g_pool, g_att, g_stat):
+        return _rnd(_rnd(_rnd(g_pool) + g_att) + g_stat)
+
+
+class _SoftmaxStored(torch.autograd.Function):
+    """w = bf16(softmax_T(a)); the backward differentiates at the STORED weights (asp_bwd reads them back)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        w = _rnd(torch.softmax(a, dim=2))
+        ctx.save_for_backward(w)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        (w,) = ctx.saved_tensors
+        return w * (dw - (w * dw).sum(2, keepdim=True))
 
 
 def _bn_shapes(prefix, c, out):
@@ -143,6 +216,29 @@ def se_module(x, p, prefix, training, updates):
     return x * s
 
 
+def bottle2neck_resident(x, p, prefix, dilation, scale, training, updates):
+    """ecapa_tdnn.py:64-95 on bf16-resident tensors (module docstring): x is a bf16-valued tensor."""
+    out = RF(_bn(RB(F.relu(_conv(x, p, prefix + ".conv1", bf16=True))), p, prefix + ".bn1", training, updates))
+    width = out.shape[1] // scale
+    spx = torch.split(out, width, 1)
+    outs = []
+    sp = None
+    for i in range(scale - 1):
+        sp = RG(spx[i]) if i == 0 else RB(sp + spx[i])
+        sp = RB(F.relu(_conv(sp, p, prefix + ".convs.%d" % i, dilation, dilation, bf16=True)))
+        sp = RF(_bn(sp, p, prefix + ".bns.%d" % i, training, updates))
+        outs.append(sp)
+    outs.append(spx[scale - 1])
+    cat = RG(torch.cat(outs, 1))
+    o3 = RF(_bn(RB(F.relu(_conv(cat, p, prefix + ".conv3", bf16=True))), p, prefix + ".bn3", training, updates))
+    # SEModule (:18-29) in fp32 on the stored tensor; gate * x + residual stored with one rounding
+    s = o3.mean(dim=2, keepdim=True)
+    s = F.relu(_conv(s, p, prefix + ".se.se.1"))
+    s = _bn(s, p, prefix + ".se.se.3", training, updates)
+    s = torch.sigmoid(_conv(s, p, prefix + ".se.se.4"))
+    return RB(RG(o3) * s + x)
+
+
 def bottle2neck(x, p, prefix, dilation, scale, training, updates, bf16=False):
     """ecapa_tdnn.py:64-95."""
     out = _bn(F.relu(_conv(x, p, prefix + ".conv1", bf16=bf16)), p, prefix + ".bn1", training, updates)
@@ -171,6 +267,8 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
             taps[name] = t
         return t
 
+    if bf16 == "resident":
+        return _ecapa_forward_resident(p, x, scale, training, updates, tap, context, out_bn)
     x = _bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates)  # :159-161
     x1 = tap("x1", bottle2neck(x, p, "layer1", 2, scale, training, updates, bf16))
     x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates, bf16))
@@ -200,6 +298,37 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
     tap("sg", sg)
     x = _bn(torch.cat((mu, sg), 1), p, "bn5", training, updates)  # :187-189
     feat = F.linear(x, p["fc6.weight"], p["fc6.bias"])  # :191
+    out = F.linear(feat, p["fc7.weight"], p["fc7.bias"])  # :193
+    if out_bn:
+        out = _bn(out, p, "bn7", training, updates)  # :195-196
+    return feat, out
+
+
+def _ecapa_forward_resident(p, x, scale, training, updates, tap, context, out_bn):
+    """Res2Net2.forward (ecapa_tdnn.py:152-198) with bf16-resident activations (module docstring)."""
+    assert context, "resident arithmetic is stated for context=True (main_train.py:167)"
+    h = RB(_bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates))  # fp32 up to the BatchNorm's output
+    x1 = tap("x1", bottle2neck_resident(h, p, "layer1", 2, scale, training, updates))
+    x2 = tap("x2", bottle2neck_resident(x1, p, "layer2", 3, scale, training, updates))
+    x3 = tap("x3", bottle2neck_resident(x2, p, "layer3", 4, scale, training, updates))
+    x4 = RF(F.relu(_conv(RG(torch.cat((x1, x2, x3), 1)), p, "layer4", bf16=True)))  # :172-173
+    tap("layer4", x4)
+    x_pool, x_att, x_stat = _X4Fan.apply(x4)
+    mean = x_stat.mean(2, keepdim=True)
+    std = torch.sqrt(x_stat.var(2, keepdim=True).clamp(min=1e-4))
+    w0, c = p["attention.0.weight"], x4.shape[1]
+    a0 = (_Bf16Pointwise.apply(x_att, w0[:, :c]) + F.conv1d(torch.cat((mean, std), 1), w0[:, c:])
+          + p["attention.0.bias"][None, :, None])
+    a = RF(_bn(RB(F.relu(a0)), p, "attention.2", training, updates))
+    logits = RB(_conv(RG(a), p, "attention.3", bf16=True))
+    w = _SoftmaxStored.apply(logits)  # :139-145
+    tap("w", w)
+    mu = torch.sum(x_pool * w, dim=2)  # :184
+    sg = torch.sqrt((torch.sum((x_pool ** 2) * w, dim=2) - mu ** 2).clamp(min=1e-4))  # :185
+    tap("mu", mu)
+    tap("sg", sg)
+    y = _bn(torch.cat((mu, sg), 1), p, "bn5", training, updates)  # :187-189
+    feat = F.linear(y, p["fc6.weight"], p["fc6.bias"])  # :191
     out = F.linear(feat, p["fc7.weight"], p["fc7.bias"])  # :193
     if out_bn:
         out = _bn(out, p, "bn7", training, updates)  # :195-196

@@ -97,8 +97,8 @@ class OracleTrainer:
         return loss, neg_scores, feat, grads, gcenter
 
 
-def bf16_gradient_band(x, labels, got):
-    """Test helper for ECAPA in bf16 compute (oracle/ecapa.py, ``bf16=True``).  bf16 rounding is
+def bf16_gradient_band(x, labels, got, mode=True):
+    """Test helper for ECAPA in bf16 (oracle/ecapa.py, ``bf16=mode``: True = compute only, "resident").  bf16 rounding is
     discontinuous, so two correct evaluations of the same graph that differ in fp32 summation order
     disagree on gradients far more than in fp32.  Returns (band, errs): ``band`` = the oracle's own
     fp32-vs-fp64 relative-L2 gradient spread on this input (max / median over tensors) and the fp64 loss;
@@ -107,17 +107,21 @@ def bf16_gradient_band(x, labels, got):
     shapes = ecapa_oracle.ecapa_shapes()
     p32 = fill_state(shapes)
     p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in p32.items()}
-    t64 = OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), bf16=True)
+    t64 = OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), bf16=mode)
     l64, _, _, g64, _, _ = t64.loss_and_grads(x.double(), labels)
-    t32 = OracleTrainer("ecapa", p32, fill_value("center", (1, 256)), bf16=True)
+    t32 = OracleTrainer("ecapa", p32, fill_value("center", (1, 256)), bf16=mode)
     _, _, _, g32, _, _ = t32.loss_and_grads(x, labels)
-    own, errs = [], {}
+    own, own_cos, errs = [], [], {}
     for k, ref in g64.items():
         if ref is None or k in ("attention.2.bias", "attention.3.bias"):  # analytically zero gradients
             continue
         r = ref.numpy().ravel()
         nr = np.linalg.norm(r) + 1e-30
-        own.append(np.linalg.norm(g32[k].double().numpy().ravel() - r) / nr)
+        o32 = g32[k].double().numpy().ravel()
+        own.append(np.linalg.norm(o32 - r) / nr)
+        own_cos.append(float(o32 @ r) / (np.linalg.norm(o32) * nr + 1e-30))
         g = got[k]
         errs[k] = (np.linalg.norm(g - r) / nr, float(g @ r) / (np.linalg.norm(g) * nr + 1e-30))
-    return {"max": float(max(own)), "median": float(np.median(own)), "loss64": l64.item()}, errs
+    # "min_cos": the smallest cosine the oracle's own fp32 evaluation reaches against its fp64 one
+    return {"max": float(max(own)), "median": float(np.median(own)), "loss64": l64.item(),
+            "min_cos": float(min(own_cos))}, errs

@@ -115,7 +115,11 @@ def test_ce_branch_gradients():
 
 
 # ------------------------------------------------------------------ bf16 compute (BASELINE configs[2])
-def test_bf16_forward_vs_bf16_oracle_and_fp32_golden(golden):
+BF16_MODES = [("bf16c", True), ("bf16", "resident")]  # (HIP compute_dtype, oracle bf16 mode)
+
+
+@pytest.mark.parametrize("hip_dt,omode", BF16_MODES)
+def test_bf16_forward_vs_bf16_oracle_and_fp32_golden(golden, hip_dt, omode):
     """Eval-mode forward in bf16 compute vs (a) the bf16 oracle (same arithmetic: bf16-rounded
     operands, fp32 accumulation) and (b) the reference's fp32 goldens at bf16 tolerance.
     A value within fp32 noise of a bf16 rounding boundary can round the other way on the GPU
@@ -123,19 +127,23 @@ def test_bf16_forward_vs_bf16_oracle_and_fp32_golden(golden):
     stack 21 bf16 convs in sequence, so (a) is bounded at 3e-3 of |feat|max (measured 1.4e-3) instead of
     the fp32 path's 1e-4.  The arithmetic itself is pinned at 2e-5 per kernel (test_conv1d_bf16_gpu.py)."""
     g = golden("ecapa.npz")
-    m = make_model().eval().set_compute_dtype("bf16")
+    m = make_model().eval().set_compute_dtype(hip_dt)
     params = fill_state(o_ecapa.ecapa_shapes())
+    # resident: every activation is ALSO rounded when stored (a flip there moves a value by 2^-8 relative), and
+    # twice as many tensors are rounded: 6e-3 of |feat|max; the embedding stays within 2e-2 of the fp32 golden
+    tol_o, tol_g = (3e-3, 1e-2) if omode is True else (6e-3, 2e-2)
     for tag, B, T in (("small", 2, 96), ("full", 2, 750)):
         x = synth_feat((B, 60, T), seed=400 + T)
         with torch.no_grad():
             feat, out = m(x.cuda())
-        fo, oo = o_ecapa.ecapa_forward(params, x, training=False, bf16=True)
+        fo, oo = o_ecapa.ecapa_forward(params, x, training=False, bf16=omode)
         scale = float(fo.abs().max())
-        assert float((feat.cpu() - fo).abs().max()) <= 3e-3 * scale
-        assert float((out.cpu() - oo).abs().max()) <= 3e-3 * max(float(oo.abs().max()), 1.0)
+        print(hip_dt, tag, "feat vs oracle", float((feat.cpu() - fo).abs().max()) / scale)
+        assert float((feat.cpu() - fo).abs().max()) <= tol_o * scale
+        assert float((out.cpu() - oo).abs().max()) <= tol_o * max(float(oo.abs().max()), 1.0)
         ref = g["feat_%s_eval" % tag]
         rel = np.linalg.norm(feat.cpu().numpy() - ref) / np.linalg.norm(ref)
-        assert rel <= 1e-2, rel  # measured 2.6e-3: the 2^-9 operand rounding through ~20 layers
+        assert rel <= tol_g, rel  # measured 2.6e-3 (compute only): the 2^-9 operand rounding through ~20 layers
         # and the fp32 mode of the same module is still the reference's arithmetic
     m.set_compute_dtype("fp32")
     with torch.no_grad():
@@ -143,7 +151,8 @@ def test_bf16_forward_vs_bf16_oracle_and_fp32_golden(golden):
     np.testing.assert_allclose(feat.cpu().numpy(), g["feat_small_eval"], atol=2e-4)
 
 
-def test_bf16_grads_vs_bf16_oracle():
+@pytest.mark.parametrize("hip_dt,omode", BF16_MODES)
+def test_bf16_grads_vs_bf16_oracle(hip_dt, omode):
     """All gradients of one bf16-compute train step vs the fp64 evaluation of the bf16 oracle.
     Tolerance: this filler-initialised net amplifies perturbations ~100x and bf16 rounding is
     discontinuous (a value within fp32 noise of a rounding boundary rounds the other way), so the ORACLE
@@ -153,7 +162,7 @@ def test_bf16_grads_vs_bf16_oracle():
     loss rtol 2e-3.  The tight check of the bf16 arithmetic is tests/test_conv1d_bf16_gpu.py (2e-5)."""
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     B, T = 32, 96
-    m = make_model().train().set_compute_dtype("bf16")
+    m = make_model().train().set_compute_dtype(hip_dt)
     lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
     fill_module_(lossm)
     lossm = lossm.cuda()
@@ -163,11 +172,12 @@ def test_bf16_grads_vs_bf16_oracle():
     loss, _ = lossm(feat, labels.cuda())
     loss.backward()
     got = {k: p.grad.cpu().double().numpy().ravel() for k, p in m.named_parameters() if p.grad is not None}
-    band, errs = o_train.bf16_gradient_band(x, labels, got)
+    band, errs = o_train.bf16_gradient_band(x, labels, got, omode)
     lo = band["loss64"]
     np.testing.assert_allclose(loss.item(), lo, rtol=2e-3)
     for k, (err, cos) in errs.items():
-        assert err <= 2.5 * band["max"] and cos >= 0.85, (k, err, cos, band["max"])
+        # cosine floor: 0.85, or what the oracle's own fp32 evaluation reaches against its fp64 one less 0.1
+        assert err <= 2.5 * band["max"] and cos >= min(0.85, band["min_cos"] - 0.1), (k, err, cos, band)
     print("bf16 grads vs bf16 oracle (fp64): median rel L2 %.3g, max %.3g; oracle fp32-vs-fp64 band: median %.3g max %.3g"
           % (np.median([e for e, _ in errs.values()]), max(e for e, _ in errs.values()), band["median"], band["max"]))
 
@@ -181,7 +191,7 @@ def test_bf16_training_tracks_fp32():
     x = synth_feat((16, 60, 128), seed=77).cuda()
     labels = (torch.arange(16) % 3 != 0).long().cuda()
     curves = {}
-    for dt in ("fp32", "bf16"):
+    for dt in ("fp32", "bf16", "bf16c"):
         m = make_model().set_compute_dtype(dt)
         lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
         fill_module_(lossm)
@@ -190,6 +200,7 @@ def test_bf16_training_tracks_fp32():
     print(curves)
     assert curves["bf16"][2] < curves["bf16"][0]
     np.testing.assert_allclose(curves["bf16"], curves["fp32"], rtol=5e-2)
+    np.testing.assert_allclose(curves["bf16c"], curves["fp32"], rtol=5e-2)
 
 
 def test_whole_module_pickle_roundtrip(tmp_path):
@@ -206,7 +217,7 @@ def test_whole_module_pickle_roundtrip(tmp_path):
         assert torch.equal(m(x)[0], m2(x)[0])
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16c"])
 def test_gradient_accumulation_two_backwards(dtype):
     """backward twice without zero_grad: p.grad (a view of the gradient arena) must end as the SUM of both
     gradients, like torch's AccumulateGrad - not twice the second one (ECAPA had no guard)."""

@@ -142,8 +142,8 @@ def test_synthetic_corpus_eer_matches_reference(golden):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_synthetic_corpus_eer_ecapa(golden, dtype):
-    """ECAPA-TDNN-512 in the reference's fp32 arithmetic and in bf16 compute (BASELINE configs[2]) against the
-    same fp32 reference run."""
+    """ECAPA-TDNN-512 in the reference's fp32 arithmetic and with bf16-resident activations (BASELINE configs[2],
+    compute_dtype "bf16") against the same fp32 reference run."""
     g = golden("synth_eer2_ecapa.npz")
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, "ecapa", dtype)
     _check(g, epoch_loss, scores, eer, lab_ho, "ecapa " + dtype, (0.15, 3.5))
@@ -156,7 +156,7 @@ def test_synthetic_corpus_eer_ecapa(golden, dtype):
     o_scores = []
     with torch.no_grad():
         for i in range(0, len(lab_ho), B):
-            ft, _ = o_ecapa.ecapa_forward(sd, xo[i:i + B], training=False, bf16=(dtype == "bf16"))
+            ft, _ = o_ecapa.ecapa_forward(sd, xo[i:i + B], training=False, bf16=("resident" if dtype == "bf16" else False))
             o_scores.append(-ocsoftmax_forward(ft, centre, torch.zeros(B, dtype=torch.long), 0.9, 0.2, 20.0)[1])
     o_scores = torch.cat(o_scores).numpy()
     np.testing.assert_allclose(scores, o_scores, atol=1e-3 if dtype == "fp32" else 1e-2)

@@ -123,7 +123,7 @@ def test_resnet_full_size_properties():
     assert float((f_all - f_parts).abs().max()) <= 2e-5 * float(f_all.abs().max())
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16c"])
 def test_ecapa_full_length_step_vs_oracle(dtype):
     """ECAPA-TDNN-512 at the reference frame count T = 750 (B = 16 keeps the CPU oracle to seconds):
     loss and every gradient as relative L2 per tensor; fp32 within 5e-3 of the fp64 oracle, bf16 against
@@ -144,12 +144,13 @@ def test_ecapa_full_length_step_vs_oracle(dtype):
     loss, _ = lossm(feat, labels.cuda())
     loss.backward()
     got = {k: p.grad.cpu().double().numpy().ravel() for k, p in m.named_parameters() if p.grad is not None}
-    if dtype == "bf16":
-        band, errs = o_train.bf16_gradient_band(x, labels, got)
+    if dtype != "fp32":  # "bf16" = resident activations, "bf16c" = bf16 compute on fp32 tensors (oracle/ecapa.py)
+        band, errs = o_train.bf16_gradient_band(x, labels, got, "resident" if dtype == "bf16" else True)
         np.testing.assert_allclose(loss.item(), band["loss64"], rtol=2e-3)
         for k, (err, cos) in errs.items():
-            assert err <= 2.5 * band["max"] and cos >= 0.85, (k, err, cos, band["max"])
-        print("bf16 worst relative L2 %.3g (oracle's own fp32-vs-fp64 worst %.3g)" % (max(e for e, _ in errs.values()), band["max"]))
+            # cosine floor: 0.85, or what the oracle's own fp32 evaluation reaches against its fp64 one less 0.1
+            assert err <= 2.5 * band["max"] and cos >= min(0.85, band["min_cos"] - 0.1), (k, err, cos, band)
+        print("%s worst relative L2 %.3g (oracle's own fp32-vs-fp64 worst %.3g)" % (dtype, max(e for e, _ in errs.values()), band["max"]))
         return
     p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_ecapa.ecapa_shapes()).items()}
     tr = o_train.OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double())
@@ -167,7 +168,7 @@ def test_ecapa_full_length_step_vs_oracle(dtype):
     print("fp32 worst relative L2 gradient error", worst)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16", "bf16c", "fp32"])
 def test_ecapa_configs2_size_properties(dtype):
     """BASELINE configs[2] at size under pytest: ECAPA-TDNN-512, batch 128, T = 750 (bf16 compute = configs[2]
     itself, fp32 = the reference's arithmetic).  The CPU oracle needs minutes at this size, so the checks are

@@ -239,3 +239,41 @@ def test_ecapa_bf16_oracle_pinned_to_fp32_goldens(golden):
     torch.nn.functional.conv1d(xb, wb).backward(rnd(dy))
     np.testing.assert_allclose(xa.grad.numpy(), xb.grad.numpy(), atol=1e-12)
     np.testing.assert_allclose(wa.grad.numpy(), wb.grad.numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", [True, "resident"])
+def test_ecapa_bf16_oracle_vs_reference_under_autocast(golden, mode):
+    """X2 pin (round 3): tests/golden/ecapa_bf16.npz holds the REAL reference ``Res2Net2`` run under
+    ``torch.autocast('cpu', bfloat16)`` on the filler weights (make_golden_bf16.py).  On this filler-initialised net
+    bf16 rounding is amplified ~100x, so two bf16 arithmetics agree only statistically - autocast itself sits 0.14
+    (B = 2, T = 96) / 0.056 (B = 8, T = 750) relative L2 from the fp32 reference on the embedding and 0.45 - 0.94
+    (median over tensors) on the gradients.  What can be pinned, and is asserted here: this repo's arithmetic is no
+    farther from the autocast run than the autocast run is from fp32 (x 1.25), its loss is inside the same band, and
+    the eval-mode embedding (no batch statistics, no amplification) is within bf16 tolerance of the fp32 golden."""
+    g = golden("ecapa_bf16.npz")
+    seed, B, T = [int(v) for v in g["x_seed_small"]]
+    x = synth_feat((B, 60, T), seed=seed)
+    labels = (torch.arange(B) % 3 != 0).long()
+    tr = o_train.OracleTrainer("ecapa", fill_state(o_ecapa.ecapa_shapes()), fill_value("center", (1, 256)), bf16=mode)
+    loss, _, feat, grads, _, _ = tr.loss_and_grads(x, labels)
+    fa, f32 = g["feat_autocast_small"].astype(np.float64), g["feat_fp32_small"].astype(np.float64)
+    d_auto = np.linalg.norm(fa - f32) / np.linalg.norm(f32)
+    d_mine = np.linalg.norm(feat.double().numpy() - fa) / np.linalg.norm(fa)
+    assert d_mine <= 1.25 * d_auto, (d_mine, d_auto)
+    la, l32 = float(g["loss_autocast_small"]), float(g["loss_fp32_small"])
+    assert abs(loss.item() - la) <= 3.0 * abs(la - l32) + 1e-3 * l32, (loss.item(), la, l32)
+    tag = "%s_" % str(mode).lower()
+    # the recorded figures of the generator run reproduce (same code, same seeds)
+    np.testing.assert_allclose(d_mine, float(g["oracle_feat_rel_autocast_" + tag + "small"]), rtol=0.05)
+    for sz in ("small", "full"):
+        da = g["oracle_grad_rel_autocast_" + tag + sz]
+        ref = g["grad_rel_autocast_vs_fp32_" + sz]
+        assert np.median(da) <= 1.4 * np.median(ref), (sz, np.median(da), np.median(ref))
+        assert float(g["oracle_feat_rel_autocast_" + tag + sz]) <= 1.25 * np.linalg.norm(
+            g["feat_autocast_" + sz].astype(np.float64) - g["feat_fp32_" + sz]) / np.linalg.norm(g["feat_fp32_" + sz])
+    # eval mode (running statistics): bf16 tolerance of the reference's fp32 golden
+    e = golden("ecapa.npz")
+    xe = synth_feat((2, 60, 96), seed=496)
+    fe, _ = o_ecapa.ecapa_forward(fill_state(o_ecapa.ecapa_shapes()), xe, training=False, bf16=mode)
+    rel = np.linalg.norm(fe.numpy() - e["feat_small_eval"]) / np.linalg.norm(e["feat_small_eval"])
+    assert 1e-4 < rel < 2e-2, rel
