@@ -51,7 +51,21 @@ class SEModule(nn.Module):
         )
 
     def forward(self, input):
-        raise NotImplementedError("SEModule runs inside Res2Net2.forward (fused HIP path)")
+        """Stand-alone forward of ecapa_tdnn.py:27-29 (fp32, forward only): x * sigmoid(se(x))."""
+        _forward_only(self, input, "SEModule")
+        x = input.float().contiguous()
+        B, C, T = x.shape
+        se = self.se
+        det = lambda p: p.detach()
+        m, _ = ops.row_stats(x, want_std=False)
+        z1 = ops.linear_fwd(m, det(se[1].weight).view(se[1].out_channels, -1), det(se[1].bias), relu=True)
+        st = _bn(z1.view(B, -1, 1), se[3], self.training)
+        z1n = ops.bn_apply(z1.view(B, -1, 1), st[2], st[3]).view(B, -1)
+        z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
+        out = torch.empty_like(x)
+        ops.se_scale_fwd(x, z2, torch.zeros_like(x), out)
+        ops.bn_flush()
+        return out
 
 
 class Bottle2neck(nn.Module):
@@ -78,7 +92,52 @@ class Bottle2neck(nn.Module):
         self.se = SEModule(planes)
 
     def forward(self, x):
-        raise NotImplementedError("Bottle2neck runs inside Res2Net2.forward (fused HIP path)")
+        """Stand-alone forward of ecapa_tdnn.py:64-95 (fp32, forward only), composed from the kernels
+        ``Res2Net2.forward`` sequences: conv1 -> ReLU -> BN, the Res2 chain of dilated convs, conv3 -> ReLU -> BN,
+        SE gate, + x."""
+        _forward_only(self, x, "Bottle2neck")
+        x = x.float().contiguous()
+        B, C, T = x.shape
+        w, d, nums = self.width, self.dilation, self.nums
+        det = lambda p: p.detach()
+        training = self.training
+        r1 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True)
+        st1 = _bn(r1, self.bn1, training)
+        o1 = ops.bn_apply(r1, st1[2], st1[3])
+        cat = torch.empty_like(o1)
+        t_i = o1[:, :w]
+        for i in range(nums):
+            r_i = ops.conv1d_fwd(t_i, det(self.convs[i].weight), det(self.convs[i].bias), relu=True, dil=d, pad=d)
+            st_i = _bn(r_i, self.bns[i], training)
+            if i + 1 < nums:
+                t_next = torch.empty((B, w, T), device=x.device, dtype=torch.float32)
+                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w], o1[:, (i + 1) * w:(i + 2) * w], t_next)
+            else:
+                t_next = None
+                ops.res2_bn_apply(r_i, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
+            t_i = t_next
+        ops.add_strided(cat[:, nums * w:], o1[:, nums * w:])
+        r3 = ops.conv1d_fwd(cat, det(self.conv3.weight), det(self.conv3.bias), relu=True)
+        st3 = _bn(r3, self.bn3, training)
+        o3 = ops.bn_apply(r3, st3[2], st3[3])
+        se = self.se.se
+        m, _ = ops.row_stats(o3, want_std=False)
+        z1 = ops.linear_fwd(m, det(se[1].weight).view(se[1].out_channels, -1), det(se[1].bias), relu=True)
+        stS = _bn(z1.view(B, -1, 1), se[3], training)
+        z1n = ops.bn_apply(z1.view(B, -1, 1), stS[2], stS[3]).view(B, -1)
+        z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
+        out = torch.empty_like(x)
+        ops.se_scale_fwd(o3, z2, x, out)
+        ops.bn_flush()
+        return out
+
+
+def _forward_only(mod, x, name):
+    if not x.is_cuda:
+        raise _hip.AirError("%s HIP path needs a GPU tensor; there is no CPU fallback" % name)
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        raise NotImplementedError("%s.forward is forward-only (use torch.no_grad()); gradients flow through "
+                                  "Res2Net2.forward" % name)
 
 
 def _bn(x3, bn, training):

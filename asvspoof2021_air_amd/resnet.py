@@ -64,7 +64,25 @@ class PreActBlock(nn.Module):
                 nn.Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=stride, bias=False))
 
     def forward(self, x):
-        raise NotImplementedError("PreActBlock runs inside ResNet.forward (fused HIP path)")
+        """Stand-alone forward of resnet.py:63-69 composed from the same kernels ``ResNet.forward`` sequences
+        (BatchNorm statistics -> apply + ReLU -> 1x1 shortcut on the activated tensor -> conv1 -> BatchNorm + ReLU
+        -> conv2 + shortcut in the epilogue).  Forward only: training through a lone block is not on the hot path
+        (nobody in the reference calls a block directly), so a graph-recording call raises."""
+        if not x.is_cuda:
+            raise _hip.AirError("PreActBlock HIP path needs a GPU tensor; there is no CPU fallback")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("PreActBlock.forward is forward-only (use torch.no_grad()); gradients flow "
+                                      "through ResNet.forward")
+        x = x.float().contiguous()
+        w = lambda conv: conv.weight.detach()
+        st1 = _bn_train_coeffs(x, self.bn1, self.training)
+        a1 = ops.bn_apply(x, st1[2], st1[3], relu=True)
+        sc = ops.conv2d_fwd(a1, w(self.shortcut[0]), self.stride, 0) if hasattr(self, "shortcut") else x
+        h = ops.conv2d_fwd(a1, w(self.conv1), self.stride, 1)
+        st2 = _bn_train_coeffs(h, self.bn2, self.training)
+        out = ops.conv2d_fwd(ops.bn_apply(h, st2[2], st2[3], relu=True), w(self.conv2), 1, 1, residual=sc)
+        ops.bn_flush()
+        return out
 
 
 RESNET_CONFIGS = {"18": [[2, 2, 2, 2], PreActBlock],

@@ -24,12 +24,10 @@ def utterance(seed, idx, length=32000, sr=16000, mix_lo=0.0):
     fc, bw = rng.uniform(500.0, 2500.0), rng.uniform(80.0, 300.0)
     r = np.exp(-np.pi * bw / sr)
     a1, a2 = -2 * r * np.cos(2 * np.pi * fc / sr), r * r
-    y = np.zeros(length)
-    y1 = y2 = 0.0
-    for n in range(length):  # small: 32k samples
-        v = x[n] - a1 * y1 - a2 * y2
-        y[n] = v
-        y2, y1 = y1, v
+    # y[n] = x[n] - a1 y[n-1] - a2 y[n-2] (round 3: scipy's filter instead of a Python loop over the samples -
+    # the 4096-utterance held-out sets and the 4 s variant need ~20 M samples)
+    from scipy.signal import lfilter
+    y = lfilter([1.0], [1.0, a1, a2], x)
     y /= np.abs(y).max() + 1e-9
     if label == 1:
         # notch around 3.2 kHz (second-order zero pair) + 4 kHz buzz

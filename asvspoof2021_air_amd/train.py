@@ -57,6 +57,10 @@ class Trainer:
         # optional augment.ChannelAugment: on-the-fly IR convolution of the TRAINING batches ahead
         # of the LFCC kernel (BASELINE configs[4]; replaces channel_simulation/*.py's offline pass)
         self.augment = augment
+        # optional hipGraph replay of the fused front-end + forward + loss + backward (enable_graph)
+        self._graph = None
+        self._graph_warm = 0
+        self.use_graph = False
 
     # ------------------------------------------------------------------ data parallel
     def sync_from_rank0(self):
@@ -173,7 +177,59 @@ class Trainer:
     def step(self, pcm, labels, start=None):
         if self.augment is not None:
             pcm = self.augment(pcm)
+        if self.use_graph and start is None and self.world == 1:
+            out = self._graphed_step(pcm, labels)
+            if out is not None:
+                return out
         return self.step_features(self.features(pcm, start), labels)
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def enable_graph(self, on=True):
+        """Capture front-end + forward + loss + backward of one fixed-shape batch in a hipGraph and replay it per
+        step (the optimiser launches stay outside: Adam's step count is a kernel argument).  ECAPA's step is
+        ~450 launches of 5 - 150 us each and the host cannot keep the queue full once the activations are bf16
+        (13 % GPU idle, tools/gpu_idle.py); replaying one graph removes the launch gaps.  Only models without
+        host-side randomness in their step qualify (Res2Net2; the ResNet draws its attention noise per call and
+        is GPU-bound anyway), single process only (the bucketed all-reduce is launched from inside backward)."""
+        from .ecapa_tdnn import Res2Net2
+        self.use_graph = bool(on) and isinstance(self.model, Res2Net2)
+        self._graph = None
+        self._graph_warm = 0
+        return self
+
+    def _graphed_step(self, pcm, labels):
+        key = (tuple(pcm.shape), pcm.dtype, tuple(labels.shape), self.model.compute_dtype, self.feat_len)
+        g = self._graph
+        if g is None or g["key"] != key:
+            if g is not None and g["key"] != key:
+                self._graph, self._graph_warm = None, 0
+            # two eager steps first: arenas, workspaces, lazy kernel attributes, optimiser state, the side stream
+            if self._graph_warm < 2:
+                self._graph_warm += 1
+                return None
+            g = self._capture(key, pcm, labels)
+        g["pcm"].copy_(pcm, non_blocking=True)
+        g["labels"].copy_(labels, non_blocking=True)
+        g["graph"].replay()
+        self.feat_optimizer.step(grad_scale=1.0)
+        self.loss_optimizer.step(grad_scale=1.0)
+        return g["loss"].detach().clone(), g["neg"]
+
+    def _capture(self, key, pcm, labels):
+        self.model.train()
+        s_pcm, s_labels = pcm.detach().clone(), labels.detach().clone()
+        self.feat_optimizer.zero_grad()
+        self.loss_optimizer.zero_grad()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            feats, _ = self.model(self.features(s_pcm, None))
+            loss, neg = self.loss(feats, s_labels)
+            (loss * self.weight_loss).backward()
+        # p.grad now ARE the views of the gradient arena the captured kernels write: they stay set (no zero_grad
+        # between replays - every gradient is overwritten, none accumulated)
+        self._graph = dict(key=key, graph=graph, pcm=s_pcm, labels=s_labels, loss=loss, neg=neg)
+        return self._graph
 
     @torch.no_grad()
     def score(self, pcm, start=None):

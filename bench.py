@@ -64,11 +64,13 @@ def roofline_leg(trainer, batches):
     # co-running kernels would include each other's time
     overlap = getattr(trainer.model, "overlap_wgrad", False)
     trainer.model.overlap_wgrad = False
+    graphed, trainer.use_graph = trainer.use_graph, False  # eager launches: a replayed hipGraph records no events
     lib.air_prof_enable(1)
     for pcm, labels in batches[:2]:
         trainer.step(pcm, labels)
     torch.cuda.synchronize()
     trainer.model.overlap_wgrad = overlap
+    trainer.use_graph = graphed
     rows = []
     for kid in range(lib.air_prof_kernel_count()):
         n, ms, work, issued, nbytes = ctypes.c_int(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -303,6 +305,11 @@ def main():
         # (Trainer broadcasts rank 0's weights, loss centre and BatchNorm buffers when world > 1)
         trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
                           feat_len=FEAT_LEN, device=device, ecapa=(model_name == "ecapa"))
+        # hipGraph replay of front-end + forward + backward (train.py): bit-identical to the eager launches
+        # (tests/test_ecapa_gpu.py) but measured no faster - 11983 vs 11930 utt/s: outside the profiler the step is
+        # GPU-bound, the gaps rocprofv3 shows are its own per-launch cost - so it stays opt-in (AIR_GRAPH=1)
+        if model_name == "ecapa" and world == 1 and not augment and os.environ.get("AIR_GRAPH", "0") == "1":
+            trainer.enable_graph()
         if augment:
             from asvspoof2021_air_amd.augment import ChannelAugment
             trainer.augment = ChannelAugment(p=1.0, seed=688 + rank, device=device)

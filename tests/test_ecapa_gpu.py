@@ -251,3 +251,59 @@ def test_gradient_accumulation_two_backwards(dtype):
         assert p.grad.data_ptr() == arena.grad_view(k).data_ptr()  # still the zero-copy arena view
         tol = 1e-6 * float(want.abs().max()) + 1e-12
         assert float((p.grad - want).abs().max()) <= tol, k
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bottle2neck_and_se_standalone_forward(training):
+    """Bottle2neck.forward / SEModule.forward on their own (ecapa_tdnn.py:64-95, :27-29) against the oracle."""
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, SEModule
+    blk = Bottle2neck(512, 512, kernel_size=3, dilation=3, scale=8)
+    fill_module_(blk)
+    sd = {"b." + k: v.clone() for k, v in blk.state_dict().items()}
+    blk = blk.cuda().train(training)
+    x = synth_feat((4, 512, 96), seed=62)
+    with torch.no_grad():
+        got = blk(x.cuda())
+    want = o_ecapa.bottle2neck(x, sd, "b", 3, 8, training, {})
+    assert float((got.cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    se = SEModule(512)
+    fill_module_(se)
+    sds = {"s." + k: v.clone() for k, v in se.state_dict().items()}
+    se = se.cuda().train(training)
+    with torch.no_grad():
+        got = se(x.cuda())
+    want = o_ecapa.se_module(x, sds, "s", training, {})
+    assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    if training:
+        with pytest.raises(NotImplementedError):
+            blk(x.cuda())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_graphed_train_step_equals_eager(dtype):
+    """Trainer.enable_graph(): the hipGraph replay of front-end + forward + loss + backward (optimisers outside) ends
+    on bit-identical weights, centre and BatchNorm statistics as the eager launches, over five steps with changing
+    batches and a learning-rate change in between."""
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.train import Trainer
+    from oracle.filler import synth_pcm
+    batches = [(synth_pcm(8, 16000, seed=300 + i).cuda(), ((torch.arange(8) + i) % 3 != 0).long().cuda()) for i in range(5)]
+    ends = []
+    for graph in (False, True):
+        m = make_model().set_compute_dtype(dtype)
+        lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+        fill_module_(lossm)
+        tr = Trainer(m, loss_module=lossm, feat_len=128, ecapa=True)
+        if graph:
+            tr.enable_graph()
+        losses = []
+        for i, (pcm, lab) in enumerate(batches):
+            if i == 3:
+                tr.set_epoch(4, lr_decay=0.5, interval=4)
+            losses.append(tr.step(pcm, lab)[0].item())
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        ends.append((losses, m.arena().flat.clone(), tr.loss.center.detach().clone(), m.bn1.running_var.clone(),
+                     int(m.bn1.num_batches_tracked)))
+    (l0, w0, c0, rv0, n0), (l1, w1, c1, rv1, n1) = ends
+    assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and n0 == n1 == 5

@@ -1,23 +1,19 @@
-"""GPU: EER parity in a regime where the reference separates the classes.
+"""GPU: EER parity in a regime where the reference separates the classes (round 3 fixtures).
 
-tests/golden/synth_eer2_{resnet,ecapa}.npz hold the REAL reference (its LFCC, ResNet-18 / ECAPA-TDNN-512,
+tests/golden/synth_eer3_{resnet,ecapa}.npz hold the REAL reference (its LFCC, ResNet-18 / ECAPA-TDNN-512,
 AngularIsoLoss, torch.optim Adam + SGD, its own step decay with --interval 4) trained from the seeded
 construction (torch.manual_seed(688)) for 16 epochs on the separable synthetic corpus
-(asvspoof2021_air_amd/synth.py, mix_lo = 0.4; 768 training / 512 held-out 1 s utterances, batch 32):
-it ends at EER 0.39 % with a final-epoch loss of 0.064.  The HIP path runs the same recipe from raw PCM
-(fused LFCC -> model -> OC-Softmax -> Adam + SGD) from the same seeded construction - bit-equal to the
-reference's (tests/test_train_io_cpu.py) - and must land on the same EER (|EER_hip - EER_ref| <= 0.02) and in
-the same converged regime.
+(asvspoof2021_air_amd/synth.py, mix_lo = 0.4; 768 training utterances of 1 s, batch 32) and scored on 4096
+HELD-OUT utterances: 13 wrong trials of 4096 (EER 0.34 % ResNet, 0.29 % ECAPA).  synth_eer4s_* is BASELINE's
+workload shape: 4 s utterances, 401 LFCC frames repeat-padded to feat_len 750, batch 64, 12 epochs, 1024 held-out.
+The HIP path runs the same recipe from raw PCM (fused LFCC -> model -> OC-Softmax -> Adam + SGD) from the same
+seeded construction - bit-equal to the reference's (tests/test_train_io_cpu.py) - and must land within THREE
+TRIALS of the reference's EER; both systems' error counts at their EER thresholds are printed.
 
 How tight the LOSS CURVE can be is set by the training run itself, not by the kernels: it is chaotic from the
-third optimisation step on.  From identical seeded weights and identical batches the first step agrees to every
-digit on all four convolution paths of this library (direct, Winograd F(2x2), F(4x4), F(4x4) with rotated
-k-streams), the second to 1.4e-4 and the third only to 0.4 % (tools/dbg_eer_epoch0.py) - Adam's first updates
-are lr * sign(g), so rounding-level gradient differences flip whole updates.  Measured over those paths and two
-Winograd point sets: epoch-1 mean loss 3.63 .. 4.01 (reference 4.005), final-epoch loss 0.0639 .. 0.0842
-(reference 0.0640; the floor is set by which two or three of the 768 training utterances stay on the wrong
-side of the margin), EER 0.0078 .. 0.0117 (reference 0.0039 = 2 of 512 trials).  The bands below are those
-spreads with margin; the EER band is the judge's."""
+third optimisation step on (Adam's first updates are lr * sign(g), so rounding-level gradient differences flip
+whole updates; tools/dbg_eer_epoch0.py).  The curve is therefore held by its envelope (below); the EER, which is
+a property of where the run converges, is held tightly."""
 import numpy as np
 import pytest
 import torch
@@ -29,7 +25,7 @@ _CORPUS = {}
 
 def _corpus(g):
     from asvspoof2021_air_amd.synth import corpus
-    L, B, NTR, NHO, EPOCHS, INTERVAL = [int(v) for v in g["cfg"]]
+    L, B, NTR, NHO, EPOCHS, INTERVAL, FL = [int(v) for v in g["cfg"]]
     key = (L, NTR, NHO, float(g["mix_lo"]))
     if key not in _CORPUS:  # ~25 s of host numpy: shared by the three tests of this module
         pcm_tr, lab_tr = corpus(688, NTR, L, mix_lo=float(g["mix_lo"]))
@@ -47,7 +43,7 @@ def _run(g, which, dtype):
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     from asvspoof2021_air_amd.resnet import ResNet
     from asvspoof2021_air_amd.train import Trainer
-    L, B, NTR, NHO, EPOCHS, INTERVAL = [int(v) for v in g["cfg"]]
+    L, B, NTR, NHO, EPOCHS, INTERVAL, FL = [int(v) for v in g["cfg"]]
     pcm_tr, lab_tr, pcm_ho, lab_ho = _corpus(g)
     torch.manual_seed(int(g["seed"]))  # the reference's construction order: model, then the loss centre
     if which == "resnet":
@@ -56,9 +52,8 @@ def _run(g, which, dtype):
         model = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
         model.set_compute_dtype(dtype)
     lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
-    T = 1 + L // 160
-    tr = Trainer(model, loss_module=lossm, feat_len=T, ecapa=(which == "ecapa"))
-    TA = T
+    tr = Trainer(model, loss_module=lossm, feat_len=FL, ecapa=(which == "ecapa"))  # T < FL: repeat-padded
+    TA = FL
     for _ in range(3):
         TA = (TA + 2 - 3) // 2 + 1
     xtr, ltr = torch.from_numpy(pcm_tr).cuda(), torch.from_numpy(lab_tr).cuda()
@@ -88,12 +83,29 @@ def _run(g, which, dtype):
     return tr, model, lossm, np.array(epoch_loss), scores, eer, lab_ho, pcm_ho
 
 
+def _eer_first(scores, labels):
+    from asvspoof2021_air_amd.eval_metrics import eer_both_polarities
+    return eer_both_polarities(scores, labels)
+
+
+def _error_counts(scores, labels):
+    from asvspoof2021_air_amd.eval_metrics import compute_eer
+    eer, thr = compute_eer(scores[labels == 0], scores[labels == 1])
+    return int((scores[labels == 0] < thr).sum()), int((scores[labels == 1] >= thr).sum())
+
+
 def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol):
+    from _budget import record
     ref_eer = float(g["eer"])
-    print("%s epoch losses %s\nreference        %s\nEER %.4f vs reference %.4f" % (
-        name, np.round(epoch_loss, 4).tolist(), np.round(g["epoch_loss"], 4).tolist(), eer, ref_eer))
+    n_side = int(min((lab_ho == 0).sum(), (lab_ho == 1).sum()))
+    mine, ref = _error_counts(scores, lab_ho), [int(v) for v in g["errors"]]
+    print("%s epoch losses %s\nreference        %s\nEER %.5f vs reference %.5f; wrong trials (bona fide, spoofed) %s vs "
+          "reference %s of %d per side" % (name, np.round(epoch_loss, 4).tolist(), np.round(g["epoch_loss"], 4).tolist(),
+                                           eer, ref_eer, mine, ref, n_side))
+    record("eer[%s]" % name, {"eer": float(eer), "ref_eer": ref_eer, "errors": list(mine), "ref_errors": ref,
+                               "final_loss": float(epoch_loss[-1]), "ref_final_loss": float(g["epoch_loss"][-1])})
     assert ref_eer < 0.05                       # the regime: the reference separates the classes
-    assert abs(eer - ref_eer) <= 0.02, (eer, ref_eer)
+    assert abs(eer - ref_eer) <= 3.0 / n_side + 1e-12, (eer, ref_eer, mine, ref)   # within three trials
     np.testing.assert_allclose(epoch_loss[-1], g["epoch_loss"][-1], rtol=0.40)    # final-epoch loss: converged floor
     assert epoch_loss[-1] < 0.15 and epoch_loss[-1] <= 1.05 * epoch_loss[-4:].min()  # ... and it IS a floor
     np.testing.assert_allclose(epoch_loss[0], g["epoch_loss"][0], rtol=curve_rtol[0])
@@ -114,9 +126,12 @@ def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol):
 
 
 def test_synthetic_corpus_eer_matches_reference(golden):
-    g = golden("synth_eer2_resnet.npz")
+    g = golden("synth_eer3_resnet.npz")
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, "resnet", "fp32")
     _check(g, epoch_loss, scores, eer, lab_ho, "resnet", (0.15, 3.5))
+    NO = 512  # the oracle re-scores the first 512 held-out utterances (CPU time)
+    scores, lab_ho, pcm_ho = scores[:NO], lab_ho[:NO], pcm_ho[:NO]
+    eer = _eer_first(scores, lab_ho)
     # score parity proper: the ORACLE scores the held-out set with the weights the HIP path trained.
     # Same weights -> same scores (1e-3) -> same EER (to one trial).
     from oracle import eer as o_eer, lfcc as o_lfcc, resnet as o_resnet
@@ -144,9 +159,12 @@ def test_synthetic_corpus_eer_matches_reference(golden):
 def test_synthetic_corpus_eer_ecapa(golden, dtype):
     """ECAPA-TDNN-512 in the reference's fp32 arithmetic and with bf16-resident activations (BASELINE configs[2],
     compute_dtype "bf16") against the same fp32 reference run."""
-    g = golden("synth_eer2_ecapa.npz")
+    g = golden("synth_eer3_ecapa.npz")
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, "ecapa", dtype)
     _check(g, epoch_loss, scores, eer, lab_ho, "ecapa " + dtype, (0.15, 3.5))
+    NO = 512
+    scores, lab_ho, pcm_ho = scores[:NO], lab_ho[:NO], pcm_ho[:NO]
+    eer = _eer_first(scores, lab_ho)
     from oracle import ecapa as o_ecapa, eer as o_eer, lfcc as o_lfcc
     from oracle.loss import ocsoftmax_forward
     B = int(g["cfg"][1])
@@ -161,3 +179,13 @@ def test_synthetic_corpus_eer_ecapa(golden, dtype):
     o_scores = torch.cat(o_scores).numpy()
     np.testing.assert_allclose(scores, o_scores, atol=1e-3 if dtype == "fp32" else 1e-2)
     assert abs(eer - o_eer.eer_both_polarities(o_scores, lab_ho)) <= (1.0 / 256 if dtype == "fp32" else 4.0 / 256)
+
+
+@pytest.mark.parametrize("which,dtype", [("resnet", "fp32"), ("ecapa", "bf16")])
+def test_synthetic_corpus_eer_at_baseline_shape(golden, which, dtype):
+    """BASELINE's workload shape: 4 s utterances, 401 LFCC frames repeat-padded to feat_len 750
+    inside the fused front-end, batch 64, 12 epochs with the reference's step decay, 1024 held-out utterances -
+    against the real reference trained the same way (synth_eer4s_*.npz)."""
+    g = golden("synth_eer4s_%s.npz" % which)
+    tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, which, dtype)
+    _check(g, epoch_loss, scores, eer, lab_ho, "%s %s 4 s" % (which, dtype), (0.15, 3.5))

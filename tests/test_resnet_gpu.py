@@ -244,3 +244,24 @@ def test_optimizer_skips_without_gradients_and_rejects_frozen():
     m.conv1.weight.requires_grad_(False)
     with pytest.raises(RuntimeError, match="frozen"):
         opt.step()
+
+
+@pytest.mark.parametrize("stride,cin,cout", [(1, 64, 64), (2, 64, 128)])
+@pytest.mark.parametrize("training", [True, False])
+def test_preact_block_standalone_forward(stride, cin, cout, training):
+    """PreActBlock.forward on its own (resnet.py:63-69) against the oracle's block, train and eval mode."""
+    from asvspoof2021_air_amd.resnet import PreActBlock
+    blk = PreActBlock(cin, cout, stride)
+    fill_module_(blk)
+    sd = {"b." + k: v.clone() for k, v in blk.state_dict().items()}
+    blk = blk.cuda().train(training)
+    x = synth_feat((3, cin, 18, 40), seed=61)
+    with torch.no_grad():
+        got = blk(x.cuda())
+    upd = {}
+    want = o_resnet.preact_block(x, sd, "b", stride, training, upd)
+    assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    if training:
+        np.testing.assert_allclose(blk.bn1.running_mean.cpu().numpy(), upd["b.bn1.running_mean"].numpy(), atol=1e-6)
+        with pytest.raises(NotImplementedError):
+            blk(x.cuda())  # recording a graph through a lone block is not on the hot path
