@@ -788,6 +788,9 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
           // sums that are not there
           if (++spins == (1u << 26)) __builtin_trap();
         }
+        // consumed: back to zero, so that a REPLAY of this launch from a captured hipGraph (same epoch, same
+        // flag word) waits for its own upper half again instead of finding last replay's flag
+        __hip_atomic_store(a.flags + flag_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
     }
@@ -883,13 +886,15 @@ int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad
 }
 
 // cut-item flags: per device, 64 launches' worth of 256 words, zeroed once; epochs never repeat
-static unsigned* w4_flag_ring() {
+static unsigned* w4_flag_ring(hipStream_t st) {
   static std::mutex mu;
   static unsigned* rings[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
   if (rings[dev] == nullptr) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
     unsigned* p = nullptr;
     if (hipMalloc(&p, 64 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, 64 * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
@@ -928,12 +933,11 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   a.xmode = air_opt(AIR_OPT_WINO4_XCD) == 2 ? 2 : 1;
   a.nxg = air_opt(AIR_OPT_WINO4_XCD) ? (nblk < 8 ? nblk : 8) : 1;
   if (a.nquad < a.nxg) a.xmode = 1;  // (xmode 2 wants at least one quad per group)
-  // cut items: not under stream capture (the per-launch epoch would be frozen into the graph)
+  // cut items.  Under stream capture the per-launch epoch and flag slot are frozen into the graph: the reader of
+  // a flag resets it, so every replay starts from zero; the ring must exist before the capture (hipMalloc)
   a.split = 0; a.flags = nullptr; a.epoch = 0;
   if (air_opt(AIR_OPT_WINO4_SPLIT)) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
-    unsigned* flag_ring = cap == hipStreamCaptureStatusNone ? w4_flag_ring() : nullptr;
+    unsigned* flag_ring = w4_flag_ring(st);
     static std::atomic<unsigned> next_epoch{1};
     if (flag_ring != nullptr) {
       a.epoch = next_epoch.fetch_add(1);

@@ -32,6 +32,10 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // x: (B, C, T) channel-major (conv5 output after bn5+ReLU, squeezed); the
 // reference works on its (B, T, C) permutation (resnet.py:185) - same numbers.
 // dynamic LDS: xs[C][T+1] + w[T] + alpha[T]
+// INLDS = false (round 3): maps longer than the LDS holds (T' > 148 at C = 256, i.e. more than ~1190 input
+// frames; the reference pools any length, resnet.py:23-46) are read from global memory / L2 in place - the same
+// arithmetic in the same order, only slower; the per-frame vectors stay in LDS.
+template <bool INLDS>
 __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict__ x, int C, int T,
                                                          const float* __restrict__ att,
                                                          const float* __restrict__ noise,
@@ -39,13 +43,13 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
                                                          float* __restrict__ alpha_save) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[NT / 64];
-  const int TP = T + 1;
-  float* xs = smem;
-  float* ws = xs + (size_t)C * TP;
+  const int TP = INLDS ? T + 1 : T;
   const int b = blockIdx.x;
   const float* __restrict__ xb = x + (size_t)b * C * T;
+  const float* xs = INLDS ? smem : xb;
+  float* ws = INLDS ? smem + (size_t)C * TP : smem;
   // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
-  for (int e0 = threadIdx.x; e0 < C * T; e0 += 8 * NT) {
+  for (int e0 = threadIdx.x; INLDS && e0 < C * T; e0 += 8 * NT) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = e0 + u * NT < C * T ? xb[e0 + u * NT] : 0.0f;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
       const int e = e0 + u * NT;
       if (e < C * T) {
         const int c = e / T, t = e - c * T;
-        xs[c * TP + t] = v[u];
+        smem[c * TP + t] = v[u];
       }
     }
   }
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
 //   z[t][c] = x[c][t] alpha_t + noise;  G[t][c] = d_avg[c] + d_std[c] (z - mean_z)/((T-1) std)
 //   dalpha_t = sum_c G x;  du = alpha (dalpha - <alpha, dalpha>);  dw = du (1 - tanh^2)
 //   dx[c][t] = G alpha_t + dw_t a_c;  datt[c] = sum_t dw_t x[c][t]
+template <bool INLDS>
 __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
     const float* __restrict__ x, int C, int T, const float* __restrict__ att,
     const float* __restrict__ noise, const float* __restrict__ alpha,
@@ -115,9 +120,8 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
     float* __restrict__ datt_partial) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[NT / 64];
-  const int TP = T + 1;
-  float* xs = smem;
-  float* al = xs + (size_t)C * TP;
+  const int TP = INLDS ? T + 1 : T;
+  float* al = INLDS ? smem + (size_t)C * TP : smem;
   float* dal = al + T;
   float* dw = dal + T;
   float* zm = dw + T;
@@ -125,9 +129,12 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   float* dav = coef + C;
   const int b = blockIdx.x;
   const float* __restrict__ xb = x + (size_t)b * C * T;
+  const float* xs = INLDS ? smem : xb;
+  float* __restrict__ dxb = dx + (size_t)b * C * T;
+  float* dst = INLDS ? smem : dxb;  // dx rows: staged over the x rows, or straight to memory
   const float* __restrict__ nb = noise ? noise + (size_t)b * T * C : nullptr;
   // staging with eight loads in flight per thread (a load-then-store loop pays one memory latency per element)
-  for (int e0 = threadIdx.x; e0 < C * T; e0 += 8 * NT) {
+  for (int e0 = threadIdx.x; INLDS && e0 < C * T; e0 += 8 * NT) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = e0 + u * NT < C * T ? xb[e0 + u * NT] : 0.0f;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
       const int e = e0 + u * NT;
       if (e < C * T) {
         const int c = e / T, t = e - c * T;
-        xs[c * TP + t] = v[u];
+        smem[c * TP + t] = v[u];
       }
     }
   }
@@ -193,17 +200,16 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
       float z = xv * al[t];
       if (nb) z += nb[(size_t)t * C + c];
       const float g = dv + cf * (z - zmc);
-      xs[c * TP + t] = g * al[t] + dw[t] * ac;  // dx, staged: this thread is the only reader of its x row
+      dst[c * TP + t] = g * al[t] + dw[t] * ac;  // dx (staged: this thread is the only reader of its x row)
       da = fmaf(dw[t], xv, da);
     }
     datt_partial[(size_t)b * C + c] = da;
   }
   __syncthreads();
   // dx leaves with consecutive lanes on consecutive frames (a thread per channel row wrote 64 rows per store)
-  float* __restrict__ dxb = dx + (size_t)b * C * T;
-  for (int e = threadIdx.x; e < C * T; e += NT) {
+  for (int e = threadIdx.x; INLDS && e < C * T; e += NT) {
     const int c = e / T, t = e - c * T;
-    dxb[e] = xs[c * TP + t];
+    dxb[e] = smem[c * TP + t];
   }
 }
 
@@ -419,13 +425,19 @@ int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
 int air_selfatt_pool_fwd(const float* x, int B, int C, int T, const float* att_w,
                          const float* noise, float* out, float* alpha_save, air_stream_t stream) {
   if (!x || !att_w || !out || !alpha_save || B <= 0 || C <= 0 || T <= 1) return AIR_EINVAL;
-  const size_t lds = ((size_t)C * (T + 1) + 2 * (size_t)T) * sizeof(float);
-  if (lds > 150 * 1024) return AIR_EUNSUPPORTED;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(selfatt_fwd_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return AIR_ELAUNCH;
-  hipLaunchKernelGGL(selfatt_fwd_kernel, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T,
-                     att_w, noise, out, alpha_save);
+  size_t lds = ((size_t)C * (T + 1) + 2 * (size_t)T) * sizeof(float);
+  const bool inlds = lds <= 150 * 1024;
+  if (!inlds) lds = 2 * (size_t)T * sizeof(float);
+  if (lds > 150 * 1024) return AIR_EUNSUPPORTED;  // (T' > 19200)
+  const void* k = inlds ? reinterpret_cast<const void*>(selfatt_fwd_kernel<true>)
+                        : reinterpret_cast<const void*>(selfatt_fwd_kernel<false>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AIR_ELAUNCH;
+  if (inlds)
+    hipLaunchKernelGGL(selfatt_fwd_kernel<true>, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T, att_w, noise, out,
+                       alpha_save);
+  else
+    hipLaunchKernelGGL(selfatt_fwd_kernel<false>, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T, att_w, noise, out,
+                       alpha_save);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -436,13 +448,19 @@ int air_selfatt_pool_bwd(const float* x, int B, int C, int T, const float* att_w
   if (!x || !att_w || !alpha || !out || !dout || !dx || !datt_partial || B <= 0 || C <= 0 ||
       T <= 1)
     return AIR_EINVAL;
-  const size_t lds = ((size_t)C * (T + 1) + 3 * (size_t)T + 3 * (size_t)C) * sizeof(float);
-  if (lds > 150 * 1024) return AIR_EUNSUPPORTED;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(selfatt_bwd_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return AIR_ELAUNCH;
-  hipLaunchKernelGGL(selfatt_bwd_kernel, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T,
-                     att_w, noise, alpha, out, dout, dx, datt_partial);
+  size_t lds = ((size_t)C * (T + 1) + 3 * (size_t)T + 3 * (size_t)C) * sizeof(float);
+  const bool inlds = lds <= 150 * 1024;
+  if (!inlds) lds = (3 * (size_t)T + 3 * (size_t)C) * sizeof(float);
+  if (lds > 150 * 1024 || (!inlds && x == dx)) return AIR_EUNSUPPORTED;
+  const void* k = inlds ? reinterpret_cast<const void*>(selfatt_bwd_kernel<true>)
+                        : reinterpret_cast<const void*>(selfatt_bwd_kernel<false>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AIR_ELAUNCH;
+  if (inlds)
+    hipLaunchKernelGGL(selfatt_bwd_kernel<true>, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T, att_w, noise, alpha,
+                       out, dout, dx, datt_partial);
+  else
+    hipLaunchKernelGGL(selfatt_bwd_kernel<false>, dim3(B), dim3(NT), lds, air_stream(stream), x, C, T, att_w, noise,
+                       alpha, out, dout, dx, datt_partial);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -121,7 +121,8 @@ class _ResNetFn(torch.autograd.Function):
 
 
 class ResNet(nn.Module):
-    MAX_POOL_FRAMES = 148  # csrc/pool_head.hip: (256 (T' + 1) + 2 T') floats <= 150 KB of LDS
+    MAX_POOL_FRAMES = 148  # csrc/pool_head.hip: (256 (T' + 1) + 2 T') floats <= 150 KB of LDS: the LDS-resident kernel
+    MAX_POOL_FRAMES_GLOBAL = 12000  # its in-place variant: (3 T' + 3 x 256) floats of per-frame vectors in LDS
 
     def __init__(self, num_nodes, enc_dim, resnet_type="18", nclasses=2):
         self.in_planes = 16
@@ -251,12 +252,12 @@ class ResNet(nn.Module):
         ta = x.shape[3]
         for _ in range(3):  # the three stride-2 stages (resnet.py:136-138)
             ta = (ta - 1) // 2 + 1
-        if ta > self.MAX_POOL_FRAMES:
-            # checked up front (not in the middle of a scoring run): the attention pooling kernel keeps one
-            # utterance's (256, T') map in LDS
+        if ta > self.MAX_POOL_FRAMES_GLOBAL:
+            # checked up front (not in the middle of a scoring run).  Up to MAX_POOL_FRAMES pooled frames the
+            # attention pooling kernel keeps an utterance's (256, T') map in LDS; longer ones (the reference pools
+            # any length, resnet.py:23-46) take its in-place variant, whose per-frame vectors still live in LDS
             raise ValueError("ResNet HIP path: %d input frames give %d pooled frames; the SelfAttention pooling "
-                             "kernel holds at most %d (about %d input frames, feat_len 750 = 94)" % (
-                                 x.shape[3], ta, self.MAX_POOL_FRAMES, 8 * self.MAX_POOL_FRAMES))
+                             "kernels hold at most %d" % (x.shape[3], ta, self.MAX_POOL_FRAMES_GLOBAL))
         x = x.float().contiguous()  # main_train.py:338 hands over a transposed view
         arena = self.arena()
         # eval-mode forward never records a graph (backward through running-stat BN is not

@@ -173,7 +173,8 @@ def test_batchnorm(ops, shape, relu):
     close(ops.bn_apply(xg, sc, sh, False), ye, name="bn eval")
 
 
-@pytest.mark.parametrize("B,C,T,with_noise", [(3, 256, 94, True), (2, 256, 12, False), (1, 64, 7, True)])
+@pytest.mark.parametrize("B,C,T,with_noise", [(3, 256, 94, True), (2, 256, 12, False), (1, 64, 7, True),
+                                              (2, 256, 149, True), (2, 256, 400, False)])  # > 148: the in-place variant
 def test_selfatt_pool(ops, B, C, T, with_noise):
     x = synth_feat((B, C, T), 1).abs()
     att = synth_feat((1, C), 2, scale=0.1)

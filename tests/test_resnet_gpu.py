@@ -265,3 +265,20 @@ def test_preact_block_standalone_forward(stride, cin, cout, training):
         np.testing.assert_allclose(blk.bn1.running_mean.cpu().numpy(), upd["b.bn1.running_mean"].numpy(), atol=1e-6)
         with pytest.raises(NotImplementedError):
             blk(x.cuda())  # recording a graph through a lone block is not on the hot path
+
+
+def test_long_utterance_beyond_lds_pooling():
+    """resnet.py:23-46 pools any length; beyond T' = 148 pooled frames (about 1190 input frames) the map no longer
+    fits the pooling kernel's LDS and its in-place variant takes over: forward against the oracle, and a train step
+    runs (12 s utterance = 1201 frames -> T' = 151)."""
+    m = make_model().eval()
+    m.set_attention_noise(None)
+    x = synth_feat((2, 1, 60, 1201), seed=77)
+    with torch.no_grad():
+        feat, _ = m(x.cuda())
+    fo, _ = o_resnet.resnet18_forward(fill_state(o_resnet.resnet18_shapes()), x, training=False, noise=None)
+    assert float((feat.cpu() - fo).abs().max()) <= 2e-5 * float(fo.abs().max()) + 2e-5
+    m.train()
+    feat, _ = m(x.cuda())
+    feat.square().mean().backward()
+    assert torch.isfinite(m.conv1.weight.grad).all() and float(m.conv1.weight.grad.abs().max()) > 0
