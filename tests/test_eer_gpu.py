@@ -94,7 +94,16 @@ def _error_counts(scores, labels):
     return int((scores[labels == 0] < thr).sum()), int((scores[labels == 1] >= thr).sum())
 
 
-def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol):
+def _spread(golden, fixture):
+    """The reference's OWN run-to-run spread (make_golden_eer3.py ``spread``: the same recipe from initial weights
+    moved by 1e-7 in one element - the trajectory is chaotic, so this is a second / third sample of it)."""
+    import os
+    from conftest import GOLDEN
+    path = fixture.replace(".npz", "_spread.npz")
+    return golden(path) if os.path.exists(os.path.join(GOLDEN, path)) else None
+
+
+def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol, spread=None):
     from _budget import record
     ref_eer = float(g["eer"])
     n_side = int(min((lab_ho == 0).sum(), (lab_ho == 1).sum()))
@@ -105,7 +114,15 @@ def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol):
     record("eer[%s]" % name, {"eer": float(eer), "ref_eer": ref_eer, "errors": list(mine), "ref_errors": ref,
                                "final_loss": float(epoch_loss[-1]), "ref_final_loss": float(g["epoch_loss"][-1])})
     assert ref_eer < 0.05                       # the regime: the reference separates the classes
-    assert abs(eer - ref_eer) <= 3.0 / n_side + 1e-12, (eer, ref_eer, mine, ref)   # within three trials
+    # within three trials of the reference - or, where the reference's own perturbed runs land farther from it than
+    # that, within 1.5 x its own spread (ResNet: 13 wrong trials unperturbed, 27 with one initial weight moved by 1e-7)
+    band = 3.0 / n_side
+    if spread is not None:
+        own = float(np.abs(spread["eer"] - ref_eer).max())
+        print("reference's own spread: EER %s (errors %s) around %.5f" % (np.round(spread["eer"], 5).tolist(),
+                                                                          spread["errors"].tolist(), ref_eer))
+        band = max(band, 1.5 * own)
+    assert abs(eer - ref_eer) <= band + 1e-12, (eer, ref_eer, mine, ref, band)
     np.testing.assert_allclose(epoch_loss[-1], g["epoch_loss"][-1], rtol=0.40)    # final-epoch loss: converged floor
     assert epoch_loss[-1] < 0.15 and epoch_loss[-1] <= 1.05 * epoch_loss[-4:].min()  # ... and it IS a floor
     np.testing.assert_allclose(epoch_loss[0], g["epoch_loss"][0], rtol=curve_rtol[0])
@@ -128,7 +145,7 @@ def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol):
 def test_synthetic_corpus_eer_matches_reference(golden):
     g = golden("synth_eer3_resnet.npz")
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, "resnet", "fp32")
-    _check(g, epoch_loss, scores, eer, lab_ho, "resnet", (0.15, 3.5))
+    _check(g, epoch_loss, scores, eer, lab_ho, "resnet", (0.15, 3.5), _spread(golden, "synth_eer3_resnet.npz"))
     NO = 512  # the oracle re-scores the first 512 held-out utterances (CPU time)
     scores, lab_ho, pcm_ho = scores[:NO], lab_ho[:NO], pcm_ho[:NO]
     eer = _eer_first(scores, lab_ho)
@@ -161,7 +178,7 @@ def test_synthetic_corpus_eer_ecapa(golden, dtype):
     compute_dtype "bf16") against the same fp32 reference run."""
     g = golden("synth_eer3_ecapa.npz")
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, "ecapa", dtype)
-    _check(g, epoch_loss, scores, eer, lab_ho, "ecapa " + dtype, (0.15, 3.5))
+    _check(g, epoch_loss, scores, eer, lab_ho, "ecapa " + dtype, (0.15, 3.5), _spread(golden, "synth_eer3_ecapa.npz"))
     NO = 512
     scores, lab_ho, pcm_ho = scores[:NO], lab_ho[:NO], pcm_ho[:NO]
     eer = _eer_first(scores, lab_ho)
@@ -188,4 +205,5 @@ def test_synthetic_corpus_eer_at_baseline_shape(golden, which, dtype):
     against the real reference trained the same way (synth_eer4s_*.npz)."""
     g = golden("synth_eer4s_%s.npz" % which)
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, which, dtype)
-    _check(g, epoch_loss, scores, eer, lab_ho, "%s %s 4 s" % (which, dtype), (0.15, 3.5))
+    _check(g, epoch_loss, scores, eer, lab_ho, "%s %s 4 s" % (which, dtype), (0.15, 3.5),
+           _spread(golden, "synth_eer4s_%s.npz" % which))
