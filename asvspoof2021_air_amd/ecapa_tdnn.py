@@ -577,7 +577,9 @@ class Res2Net2(nn.Module):
         if dcat123 is None:
             dcat123 = ops.conv1d_dgrad(dx4, det(self.layer4.weight), bf16=bf)
         dnext = None
-        fold = bf and T % 2 == 0  # the two-operand dgrad epilogue (bf16 pointwise path, 8-byte aligned rows)
+        # the two-operand dgrad epilogue: the fused bf16 pointwise kernels only (8-byte aligned rows; layers of
+        # 1 M weights and more route to the wide GEMM, which takes a single dense accumulate operand)
+        fold = bf and T % 2 == 0 and C % 128 == 0 and C * C < (1 << 20)
         for k in (2, 1, 0):
             if fold:
                 # d(block k output) = its slice of the concat gradient + d(block k + 1 input): block k + 1's last
@@ -664,6 +666,10 @@ class Res2Net2(nn.Module):
         return None
 
     def _forward_h(self, x, save):
+        if self.C % 64 != 0 or self.layer1.width % 64 != 0:
+            raise _hip.AirError("bf16-resident ECAPA needs C % 64 == 0 and Res2 branches of width % 64 == 0 (C = %d, "
+                                "width %d): use compute_dtype 'bf16c' or 'fp32' for this configuration" % (
+                                    self.C, self.layer1.width))
         training = self.training
         det = lambda p: p.detach()
         B, _, T = x.shape

@@ -307,3 +307,25 @@ def test_graphed_train_step_equals_eager(dtype):
                      int(m.bn1.num_batches_tracked)))
     (l0, w0, c0, rv0, n0), (l1, w1, c1, rv1, n1) = ends
     assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and n0 == n1 == 5
+
+
+def test_other_widths():
+    """Widths other than the reference's C = 512: C = 1024 trains in both bf16 modes (the legacy mode's
+    two-operand dgrad epilogue is chosen per capability, not assumed) and in fp32; C = 256 (32-channel Res2 branches:
+    below the 64-channel tiles of every conv1d kernel of this build) is refused loudly, not silently mis-computed."""
+    from asvspoof2021_air_amd import _hip
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    x = synth_feat((4, 60, 64), seed=9).cuda()
+    for C, dts in ((1024, ("bf16", "bf16c", "fp32")),):
+        for dt in dts:
+            torch.manual_seed(688)
+            m = Res2Net2(Bottle2neck, C=C, model_scale=8, nOut=2, n_mels=60).cuda().train().set_compute_dtype(dt)
+            feat, _ = m(x)
+            feat.square().mean().backward()
+            g = m.layer2.conv1.weight.grad
+            assert torch.isfinite(feat).all() and torch.isfinite(g).all() and float(g.abs().max()) > 0, (C, dt)
+    m = Res2Net2(Bottle2neck, C=256, model_scale=8, nOut=2, n_mels=60).cuda().train().set_compute_dtype("bf16")
+    with pytest.raises(_hip.AirError, match="bf16c"):
+        m(x)
+    with pytest.raises(_hip.AirError):
+        m.set_compute_dtype("fp32")(x)
