@@ -667,7 +667,7 @@ class Res2Net2(nn.Module):
 
     def _forward_h(self, x, save):
         if self.C % 64 != 0 or self.layer1.width % 64 != 0:
-            raise _hip.AirError("bf16-resident ECAPA needs C % 64 == 0 and Res2 branches of width % 64 == 0 (C = %d, "
+            raise _hip.AirError("bf16-resident ECAPA needs C %% 64 == 0 and Res2 branches of width %% 64 == 0 (C = %d, "
                                 "width %d): use compute_dtype 'bf16c' or 'fp32' for this configuration" % (
                                     self.C, self.layer1.width))
         training = self.training
