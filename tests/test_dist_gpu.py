@@ -181,4 +181,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
-    assert d["roofline"]["kernel"].startswith(("wino", "conv")) and d["roofline"]["achieved"] > 0
+    # two processes time-slice ONE GPU here: the event-bracketed kernel times include the other rank's slices (a 7 ms
+    # kernel reads 20 - 180 ms), so only the presence and sanity of the roofline object is asserted, not its rate
+    r = d["roofline"]
+    assert r["kernel"].startswith(("wino", "conv")) and r["avg_launch_ms"] > 0 and 0.0 <= r["frac"] <= 1.0

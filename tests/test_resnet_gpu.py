@@ -35,8 +35,14 @@ def test_state_dict_surface():
     assert sum(p.numel() for p in m.parameters()) == 12450290
 
 
+@pytest.mark.parametrize("path", ["strict", "default"])
 @pytest.mark.parametrize("tag,B,T", [("small", 2, 96), ("full", 2, 750)])
-def test_forward_vs_golden(golden, tag, B, T):
+def test_forward_vs_golden(golden, tag, B, T, path):
+    with conv_path(path):
+        _forward_vs_golden(golden, tag, B, T, path)
+
+
+def _forward_vs_golden(golden, tag, B, T, path):
     g = golden("resnet.npz")
     m = make_model()
     x = synth_feat((B, 1, 60, T), seed=200 + T)
@@ -53,7 +59,7 @@ def test_forward_vs_golden(golden, tag, B, T):
         if mode == "train":
             sd = m.state_dict()
             for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn2.running_mean", "bn5.running_var"):
-                np.testing.assert_allclose(sd[k].cpu().numpy(), g["%s_%s" % (k, tag)], atol=1e-5)
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g["%s_%s" % (k, tag)], atol=tol("running_stat_atol", path))
             assert int(sd["bn1.num_batches_tracked"]) == 1
 
 
@@ -109,9 +115,9 @@ def _grads_vs_oracle_small(golden, path):
         got = p.grad.cpu().double().numpy()
         err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
         worst = max(worst, err)
-        assert err < 5e-3, "%s: relative L2 grad err %.3g" % (k, err)
+        assert err < tol("grad_rel_l2", path), "%s: relative L2 grad err %.3g" % (k, err)
         assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max(), k
-        np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=5e-3)
+        np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=tol("grad_rel_l2", path))
     record("resnet_small_g_center_abs[%s]" % path, float(np.abs(lossm.center.grad.cpu().numpy() - g["g_center"]).max()))
     record("resnet_small_worst_grad_relL2[%s]" % path, float(worst))
     np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=tol("g_center_atol", path))
