@@ -933,6 +933,87 @@ __device__ __forceinline__ G2Tile g2_tile(const NtGemm& p, int work) {
   return t;
 }
 
+// bf16-resident epilogue of c1b_gemm_ps_kernel<BKM, true>: 8 rows x 64 columns at a time through the wave's own 2 KB
+// of LDS; a lane owns 8 consecutive frames of one row = one 16-byte store (a wave: eight 128-byte row pieces).  Per
+// 32-row group the bias values and the accumulate operands of its four 8-row pieces are requested up front (one
+// exposed round trip per group instead of one per operand per piece); the number of accumulate operands and the
+// ReLU are template parameters picked by a uniform branch (as runtime flags the compiler evaluates every variant
+// and selects: 130 VALU instructions per piece instead of 40 - the epilogue, not the k-loop, was the longer half).
+template <int NACC, bool RELU>
+__device__ __forceinline__ void g2_hout_epilogue(const NtGemm& p, const G2Tile& tl, f32x16 (&acc)[4][2], float* tile,
+                                                 int lane, int wm, int wn) {
+  const int r = lane & 31, kg = lane >> 5;
+  const int c8 = (lane & 7) * 8, lrow = lane >> 3;
+  const int n = tl.n0 + wn * 64 + c8;
+  u16* __restrict__ ob = p.out_bf + (size_t)tl.batch * p.out_bf_bs;
+  const u16* __restrict__ ab = p.acc_h ? p.acc_h + (size_t)tl.batch * p.acc_h_bs : p.acc2_h + (size_t)tl.batch * p.acc2_h_bs;
+  const u16* __restrict__ ab2 = p.acc2_h + (size_t)tl.batch * p.acc2_h_bs;
+  const bool mask_n = tl.n0 + G2_BN > p.n_valid;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mg = tl.m0 + wm * 128 + i * 32 + lrow;  // piece hp: row mg + 8 hp
+    float add[4];
+    uint4 ua[4], ub[4];
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+      const int m = mg + hp * 8;
+      const bool mv = m < p.m_valid;
+      add[hp] = 0.0f;
+      if (p.bias && mv) add[hp] = p.bias[m];
+      if (p.bias_bc && mv) add[hp] += p.bias_bc[(size_t)tl.batch * p.M + m];
+      if (NACC >= 1) {
+        ua[hp] = make_uint4(0u, 0u, 0u, 0u);
+        if (mv) ua[hp] = *reinterpret_cast<const uint4*>(ab + (size_t)m * p.out_bf_rs + n);
+      }
+      if (NACC >= 2) {
+        ub[hp] = make_uint4(0u, 0u, 0u, 0u);
+        if (mv) ub[hp] = *reinterpret_cast<const uint4*>(ab2 + (size_t)m * p.out_bf_rs + n);
+      }
+    }
+#pragma unroll
+    for (int hp = 0; hp < 4; ++hp) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int rr = hp * 4 + e;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tile[(e + 4 * kg) * 64 + j * 32 + r] = acc[i][j][rr];
+      }
+      const int m = mg + hp * 8;
+      const float4 v0 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8]);
+      const float4 v1 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8 + 4]);
+      f32x2 vv[4] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
+      const f32x2 a2 = {add[hp], add[hp]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        vv[q] += a2;
+        if (NACC >= 1) {
+          const unsigned w = q == 0 ? ua[hp].x : q == 1 ? ua[hp].y : q == 2 ? ua[hp].z : ua[hp].w;
+          vv[q] += f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+        }
+        if (NACC >= 2) {
+          const unsigned w = q == 0 ? ub[hp].x : q == 1 ? ub[hp].y : q == 2 ? ub[hp].z : ub[hp].w;
+          vv[q] += f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+        }
+        if (RELU) vv[q] = __builtin_elementwise_max(vv[q], f32x2{0.0f, 0.0f});
+      }
+      if (mask_n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (n + 2 * q >= p.n_valid) vv[q][0] = 0.0f;
+          if (n + 2 * q + 1 >= p.n_valid) vv[q][1] = 0.0f;
+        }
+      }
+#ifdef G2_X_NOSTORE
+      if (pack2(vv[0][0], vv[0][1]) == 0x12345678u)
+#endif
+      if (m < p.m_valid)
+        *reinterpret_cast<uint4*>(ob + (size_t)m * p.out_bf_rs + n) =
+            make_uint4(pack2(vv[0][0], vv[0][1]), pack2(vv[1][0], vv[1][1]), pack2(vv[2][0], vv[2][1]),
+                       pack2(vv[3][0], vv[3][1]));
+    }
+  }
+}
+
 // BKM: the B operand is K-MAJOR - element (k, n) at b + k * b_rs + n, n contiguous - i.e. an activation's bf16 copy
 // [b][channel][Tp] as the producers write it and the weight gradient reads it; no transposed copy (c1b_cvt_t) is
 // made for the forward / dgrad GEMM.  Its stage is [64 k][256 n] (512-byte rows, 16-byte chunk c of row k at
@@ -974,10 +1055,12 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
     const unsigned bo = BKM ? (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)iseg * p.b_ss +
                                           ((size_t)ik * GK + 8 * wave) * p.b_rs + ti.n0) * 2)
                             : (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + 32 * wave) * p.b_rs + koffb) * 2);
+#ifndef G2_X_NODMA
 #pragma unroll
     for (int q = 0; q < 4; ++q) fd_dma16(ars, ao + q * arow8, base + q * 1024, (q & 1) ? av1 : av0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) fd_dma16(brs, bo + q * brow8, base + G2_AB + q * 1024, (q & 1) ? bv1 : bv0);
+#endif
     islot ^= 1;
     if (++ik == kst) {
       ik = 0;
@@ -1002,6 +1085,13 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   };
   zero();
+#ifdef G2_X_STAGGER
+  {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long d = (unsigned long long)((blockIdx.x / NXCD) % 3) * G2_X_STAGGER;
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   issue();
   int slot = 0;
   for (int it = 0; it < nmy; ++it) {
@@ -1013,6 +1103,9 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
       if (g + 1 < ng || it + 1 < nmy) issue();
       const unsigned short* sA = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB);
       const unsigned short* sB = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB + G2_AB);
+#ifdef G2_X_NOMFMA
+      if (p.kseg < 0)
+#endif
 #pragma unroll
       for (int kk = 0; kk < GK / 16; ++kk) {
         const int cpos = ((kk * 2 + kg) ^ sw) * 8;
@@ -1047,61 +1140,22 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
       }
       slot ^= 1;
     }
+#ifdef G2_X_NOEPI
+    if (acc[0][0][0] + acc[3][1][15] + acc[1][0][7] + acc[2][1][3] == 12345.678f) p.out_bf[0] = 1;
+    zero();
+    continue;
+#endif
     if constexpr (HOUT) {
-      // bf16-resident epilogue: 8 rows x 64 columns at a time through this wave's own 2 KB of LDS; a lane owns 8
-      // consecutive frames of one row = one 16-byte store (a wave: eight 128-byte row pieces)
       float* tile = reinterpret_cast<float*>(g2_lds + 2 * G2_SB) + wave * (G2_RP * 64);
-      const int c8 = (lane & 7) * 8, lrow = lane >> 3;
-      const int n = tl.n0 + wn * 64 + c8;
-      u16* __restrict__ ob = p.out_bf + (size_t)tl.batch * p.out_bf_bs;
-      const u16* __restrict__ ab = p.acc_h ? p.acc_h + (size_t)tl.batch * p.acc_h_bs : nullptr;
-      const u16* __restrict__ ab2 = p.acc2_h ? p.acc2_h + (size_t)tl.batch * p.acc2_h_bs : nullptr;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int hp = 0; hp < 4; ++hp) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int rr = hp * 4 + e;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) tile[(e + 4 * kg) * 64 + j * 32 + r] = acc[i][j][rr];
-          }
-          const int m = tl.m0 + wm * 128 + i * 32 + hp * 8 + lrow;
-          const float4 v0 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8]);
-          const float4 v1 = *reinterpret_cast<const float4*>(&tile[lrow * 64 + c8 + 4]);
-          if (m < p.m_valid) {
-            float add = 0.0f;
-            if (p.bias) add += p.bias[m];
-            if (p.bias_bc) add += p.bias_bc[(size_t)tl.batch * p.M + m];
-            float vv[8] = {v0.x + add, v0.y + add, v0.z + add, v0.w + add, v1.x + add, v1.y + add, v1.z + add, v1.w + add};
-            const size_t o = (size_t)m * p.out_bf_rs + n;
-            if (ab) {
-              const uint4 u = *reinterpret_cast<const uint4*>(ab + o);
-              const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                vv[2 * q] += __builtin_bit_cast(float, w[q] << 16);
-                vv[2 * q + 1] += __builtin_bit_cast(float, w[q] & 0xffff0000u);
-              }
-            }
-            if (ab2) {
-              const uint4 u = *reinterpret_cast<const uint4*>(ab2 + o);
-              const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                vv[2 * q] += __builtin_bit_cast(float, w[q] << 16);
-                vv[2 * q + 1] += __builtin_bit_cast(float, w[q] & 0xffff0000u);
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              if (p.relu) vv[q] = fmaxf(vv[q], 0.0f);
-              if (n + q >= p.n_valid) vv[q] = 0.0f;
-            }
-            *reinterpret_cast<uint4*>(ob + o) =
-                make_uint4(pack2(vv[0], vv[1]), pack2(vv[2], vv[3]), pack2(vv[4], vv[5]), pack2(vv[6], vv[7]));
-          }
-        }
+      const int nacc = (p.acc_h != nullptr) + (p.acc2_h != nullptr);
+      if (p.relu) {
+        if (nacc == 0) g2_hout_epilogue<0, true>(p, tl, acc, tile, lane, wm, wn);
+        else if (nacc == 1) g2_hout_epilogue<1, true>(p, tl, acc, tile, lane, wm, wn);
+        else g2_hout_epilogue<2, true>(p, tl, acc, tile, lane, wm, wn);
+      } else {
+        if (nacc == 0) g2_hout_epilogue<0, false>(p, tl, acc, tile, lane, wm, wn);
+        else if (nacc == 1) g2_hout_epilogue<1, false>(p, tl, acc, tile, lane, wm, wn);
+        else g2_hout_epilogue<2, false>(p, tl, acc, tile, lane, wm, wn);
       }
       zero();
       continue;
