@@ -22,6 +22,7 @@ enum AirKernelId {
   AIR_K_C1B_GEMM,          // c1b_gemm_kernel / c1b_gemm_ps_kernel: LDS-DMA bf16 GEMM (ECAPA layer4 forward / dgrad, every pointwise wgrad)
   AIR_K_C1B_TAP,           // c1b_tap_kernel: bf16 dilated K=3 Res2 convs, forward / dgrad (ECAPA)
   AIR_K_CONV_WINO4,        // wino4_conv_kernel: 3x3 s1 forward and dgrad, Winograd F(4x4,3x3)
+  AIR_K_C1B_TAPW,          // c1b_tapw_kernel: bf16 weight gradient of the dilated K=3 Res2 convs, all branches of a block (ECAPA)
   AIR_K_COUNT
 };
 

@@ -1574,6 +1574,163 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   return launch_gemm(g, B, Tp, (size_t)M * K * 2, (size_t)B * Tp * K * 2, AIR_K_C1B_GEMM, flops, st, bf_done);
 }
 
+
+// ===================================================================================
+// Path 4: weight gradient of the dilated K = 3 Res2 convs on bf16-resident rows,
+//   dw[co][ci][k] = sum_{b,t} dy[b][co][t] x[b][ci][t + (k - 1) dil]        (ecapa_tdnn.py:46, padding = dil)
+// for ALL branches of a block in one launch.  A branch is two (B, 64 j, Tp) operands = 25 MB for 2.4 GFLOP: the
+// kernel is bound by reading them once.  Work item = (branch, 64 x 64 (co, ci) tile, part): the part's utterances
+// are walked in 64-frame stages; dy[64 co][64 t] and x[64 ci][8 + 64 + 8 t] (one 16-byte chunk of halo each side,
+// zeros outside [0, Tp)) go through registers into padded LDS rows (144 / 176 bytes: 8 consecutive rows cover all
+// banks for 16-byte reads).  t is the contraction index of v_mfma_f32_32x32x16_bf16, so a shifted tap is a shift
+// ALONG k: a lane reads the three chunks around its 8 frames and funnel-shifts the pair (v_alignbit for odd
+// dilations, plain register selection for even ones) - the two outer taps cost no extra staging.  Products of
+// bf16 values are exact in fp32 and the sums are fp32: the same arithmetic as the fp32 contraction of the widened
+// operands this replaces (conv_wgrad_kernel<1,3,1> on air_h_to_f32 copies), without the copies.
+// Wave w owns the 32 x 32 block (w & 1, w >> 1) of the tile for all three taps; per-part partial sums are
+// reduced in fixed order by c1b_tapw_reduce_kernel.
+constexpr int TW_MAXB = 16;
+constexpr int TW_KC = 64;                 // frames per stage
+constexpr int TW_AS = TW_KC + 8;          // A row pitch (elements): 144 bytes
+constexpr int TW_BS = TW_KC + 16 + 8;     // B row pitch: 8 + 64 + 8 frames + 8 pad = 176 bytes
+
+struct TapWgrad {
+  const u16* x[TW_MAXB];
+  const u16* dy[TW_MAXB];
+  size_t x_bs[TW_MAXB], dy_bs[TW_MAXB];
+  float* dw[TW_MAXB];
+  float* partial;  // [branch][tile][part][3][64][64]
+  int nb, B, W, Tp, nparts, tiles_c;
+};
+
+template <int SUB>
+__device__ __forceinline__ bf16x8 tw_shift(const uint4 lo, const uint4 hi) {
+  // elements SUB .. SUB + 7 of the 16 bf16 values lo ++ hi
+  const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  constexpr int q = SUB / 2;
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = (SUB & 1) ? __builtin_amdgcn_alignbit(w[q + j + 1], w[q + j], 16) : w[q + j];
+  const uint4 v = make_uint4(o[0], o[1], o[2], o[3]);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int DIL>
+__global__ __launch_bounds__(256) void c1b_tapw_kernel(const TapWgrad a) {
+  __shared__ __attribute__((aligned(16))) u16 sA[2][64 * TW_AS];
+  __shared__ __attribute__((aligned(16))) u16 sB[2][64 * TW_BS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int part = blockIdx.x % a.nparts;
+  const int rest = blockIdx.x / a.nparts;
+  const int tiles = a.tiles_c * a.tiles_c;
+  const int tile = rest % tiles, br = rest / tiles;
+  const int co0 = (tile / a.tiles_c) * 64, ci0 = (tile % a.tiles_c) * 64;
+  const int Tp = a.Tp, spu = Tp / TW_KC;  // stages per utterance
+  const int nutt = (a.B - part + a.nparts - 1) / a.nparts;
+  const int nst = nutt * spu;
+  const u16* __restrict__ xg = a.x[br];
+  const u16* __restrict__ yg = a.dy[br];
+  const size_t xbs = a.x_bs[br], ybs = a.dy_bs[br];
+
+  // staging roles: A slots tid, tid + 256 of [64 rows][8 chunks]; B slots tid, tid + 256, tid + 512 of [64][10]
+  uint4 ra0, ra1, rb0, rb1, rb2;
+  auto lda = [&](int s, int e) __attribute__((always_inline)) -> uint4 {
+    const int u = s / spu, k0 = (s - u * spu) * TW_KC;
+    const int b = part + u * a.nparts;
+    const int slot = tid + 256 * e, row = slot >> 3, ch = slot & 7;
+    return *reinterpret_cast<const uint4*>(yg + (size_t)b * ybs + (size_t)(co0 + row) * Tp + k0 + ch * 8);
+  };
+  auto ldb = [&](int s, int e) __attribute__((always_inline)) -> uint4 {
+    const int u = s / spu, k0 = (s - u * spu) * TW_KC;
+    const int b = part + u * a.nparts;
+    const int slot = tid + 256 * e, row = slot / 10, ch = slot - row * 10;
+    const int f = k0 - 8 + ch * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (slot < 640 && f >= 0 && f < Tp)
+      v = *reinterpret_cast<const uint4*>(xg + (size_t)b * xbs + (size_t)(ci0 + row) * Tp + f);
+    return v;
+  };
+  auto sta = [&](int buf, int e, const uint4 v) __attribute__((always_inline)) {
+    const int slot = tid + 256 * e, row = slot >> 3, ch = slot & 7;
+    *reinterpret_cast<uint4*>(&sA[buf][row * TW_AS + ch * 8]) = v;
+  };
+  auto stb = [&](int buf, int e, const uint4 v) __attribute__((always_inline)) {
+    const int slot = tid + 256 * e, row = slot / 10, ch = slot - row * 10;
+    if (slot < 640) *reinterpret_cast<uint4*>(&sB[buf][row * TW_BS + ch * 8]) = v;
+  };
+#define TW_LOAD(s) do { ra0 = lda(s, 0); ra1 = lda(s, 1); rb0 = ldb(s, 0); rb1 = ldb(s, 1); rb2 = ldb(s, 2); } while (0)
+#define TW_STORE(buf) do { sta(buf, 0, ra0); sta(buf, 1, ra1); stb(buf, 0, rb0); stb(buf, 1, rb1); stb(buf, 2, rb2); } while (0)
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r = lane & 31, kg = lane >> 5;
+
+  if (nst > 0) {
+    TW_LOAD(0);
+    TW_STORE(0);
+    if (nst > 1) TW_LOAD(1);
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+      const int buf = s & 1;
+      const u16* pa = &sA[buf][(wm * 32 + r) * TW_AS + kg * 8];
+      const u16* pb = &sB[buf][(wn * 32 + r) * TW_BS + kg * 8];
+#pragma unroll
+      for (int kk = 0; kk < TW_KC / 16; ++kk) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(pa + kk * 16);
+        const uint4 L = *reinterpret_cast<const uint4*>(pb + kk * 16);
+        const uint4 C = *reinterpret_cast<const uint4*>(pb + kk * 16 + 8);
+        const uint4 R = *reinterpret_cast<const uint4*>(pb + kk * 16 + 16);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, tw_shift<8 - DIL>(L, C), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, C), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, tw_shift<DIL>(C, R), acc[2], 0, 0, 0);
+      }
+      if (s + 1 < nst) {
+        TW_STORE(buf ^ 1);  // its previous readers passed the barrier that ended stage s - 1
+        if (s + 2 < nst) TW_LOAD(s + 2);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* __restrict__ po = a.partial + ((size_t)(br * tiles + tile) * a.nparts + part) * (3 * 64 * 64);
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+      po[(t * 64 + m) * 64 + wn * 32 + col] = acc[t][q];
+    }
+#undef TW_LOAD
+#undef TW_STORE
+}
+
+// dw[co0 + co][ci0 + ci][tap] = sum over parts, fixed order.  One thread per (branch, tile, tap, co, ci).
+__global__ __launch_bounds__(256) void c1b_tapw_reduce_kernel(const TapWgrad a) {
+  const int tiles = a.tiles_c * a.tiles_c;
+  const int per_br = tiles * 3 * 64 * 64;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.nb * per_br) return;
+  const int br = idx / per_br, e = idx - br * per_br;
+  const int tile = e / (3 * 64 * 64), w = e - tile * (3 * 64 * 64);
+  const int tap = w / 4096, co = (w >> 6) & 63, ci = w & 63;
+  const float* __restrict__ src = a.partial + (size_t)(br * tiles + tile) * a.nparts * (3 * 64 * 64) + w;
+  float s0 = 0.0f, s1 = 0.0f;
+  int p = 0;
+  for (; p + 1 < a.nparts; p += 2) {
+    s0 += src[(size_t)p * (3 * 64 * 64)];
+    s1 += src[(size_t)(p + 1) * (3 * 64 * 64)];
+  }
+  if (p < a.nparts) s0 += src[(size_t)p * (3 * 64 * 64)];
+  const int co_g = (tile / a.tiles_c) * 64 + co, ci_g = (tile % a.tiles_c) * 64 + ci;
+  a.dw[br][((size_t)co_g * a.W + ci_g) * 3 + tap] = s0 + s1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1661,6 +1818,53 @@ int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const uns
   hipStream_t st = air_stream(stream);
   AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
   hipLaunchKernelGGL(c1b_tap_kernel<true>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+static int tapw_parts(int nb, int B, int W) {
+  const int tiles = (W / 64) * (W / 64);
+  int parts = 1024 / (nb * tiles);
+  parts = parts < 1 ? 1 : parts;
+  return parts < B ? parts : B;
+}
+
+size_t air_h_conv1d_tap_wgrad_ws_bytes(int n_branches, int B, int W) {
+  if (n_branches <= 0 || B <= 0 || W <= 0 || W % 64 != 0) return 0;
+  const size_t tiles = (size_t)(W / 64) * (W / 64);
+  return (size_t)n_branches * tiles * tapw_parts(n_branches, B, W) * (3 * 64 * 64) * sizeof(float);
+}
+
+/* Weight gradients of the n_branches dilated K = 3 convs of one Res2 block (W -> W channels each) in one launch:
+ * dw[i] (W, W, 3) fp32 = sum_{b,t} dy[i][b][co][t] x[i][b][ci][t + (k - 1) dil] over bf16-resident operands. */
+int air_h_conv1d_tap_wgrad(int n_branches, int B, int W, int T, int Tp, int dil, const unsigned short* const* x,
+                           const size_t* x_bs, const unsigned short* const* dy, const size_t* dy_bs, float* const* dw,
+                           void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!x || !dy || !dw || !ws || n_branches <= 0 || B <= 0 || T <= 0 || Tp < T || Tp % TW_KC != 0) return AIR_EINVAL;
+  if (n_branches > TW_MAXB || W % 64 != 0 || dil < 2 || dil > 4) return AIR_EUNSUPPORTED;
+  if (ws_bytes < air_h_conv1d_tap_wgrad_ws_bytes(n_branches, B, W)) return AIR_EINVAL;
+  TapWgrad a = {};
+  for (int i = 0; i < n_branches; ++i) {
+    if (!x[i] || !dy[i] || !dw[i]) return AIR_EINVAL;
+    a.x[i] = x[i]; a.dy[i] = dy[i]; a.dw[i] = dw[i];
+    a.x_bs[i] = (x_bs && x_bs[i]) ? x_bs[i] : (size_t)W * Tp;
+    a.dy_bs[i] = (dy_bs && dy_bs[i]) ? dy_bs[i] : (size_t)W * Tp;
+  }
+  a.partial = reinterpret_cast<float*>(ws);
+  a.nb = n_branches; a.B = B; a.W = W; a.Tp = Tp; a.tiles_c = W / 64;
+  a.nparts = tapw_parts(n_branches, B, W);
+  const int tiles = a.tiles_c * a.tiles_c;
+  const int grid = n_branches * tiles * a.nparts;
+  hipStream_t st = air_stream(stream);
+  {
+    AirProfScope prof(AIR_K_C1B_TAPW, 2.0 * n_branches * B * T * (double)W * W * 3, st);
+    if (dil == 2) hipLaunchKernelGGL(c1b_tapw_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    else if (dil == 3) hipLaunchKernelGGL(c1b_tapw_kernel<3>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(c1b_tapw_kernel<4>, dim3(grid), dim3(256), 0, st, a);
+    AIR_CHECK_LAUNCH();
+  }
+  const int total = n_branches * tiles * 3 * 64 * 64;
+  hipLaunchKernelGGL(c1b_tapw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -742,19 +742,18 @@ class Res2Net2(nn.Module):
         dcat = oh.conv_pointwise(dc3, det(blk.conv3.weight), T, dgrad=True)  # becomes d(o1) slice by slice
         wpt = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=True)
         din_next = None
+        dcs = [None] * nums
         for i in reversed(range(nums)):
             st_i = S["st"][i]
             dc_i = oh.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], T, st_i[0], st_i[1], det(blk.bns[i].weight),
                              gv("bns.%d.weight" % i), gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i))
-
-            def tap_wgrad(dc_i=dc_i, i=i):
-                # the K = 3 weight gradient (0.6 % of the FLOPs) stays an fp32 contraction: operands widened here
-                ops.conv1d_wgrad(oh.to_f32(S["t"][i], T), oh.to_f32(dc_i, T), blk.convs[i].weight.shape, d, d,
-                                 out=gv("convs.%d.weight" % i))
-
-            on_side(tap_wgrad, dc_i)
+            dcs[i] = dc_i
             din = oh.conv_tap(dc_i, wpt[i], T, d, w, w, dgrad=True, out=dcat[:, i * w:(i + 1) * w])
             din_next = din if i > 0 else None
+        # the K = 3 weight gradients of all branches in one launch: bf16 MFMA on the resident operands (exact
+        # products, fp32 sums = the fp32 contraction of the widened operands, without widened copies)
+        on_side(lambda: oh.conv_tap_wgrad([S["t"][i] for i in range(nums)], dcs, T, d,
+                                          [gv("convs.%d.weight" % i) for i in range(nums)]), *dcs)
         st1 = S["st1"]
         dc1 = oh.bn_bwd(S["r1"], dcat, T, st1[0], st1[1], det(blk.bn1.weight), gv("bn1.weight"), gv("bn1.bias"), dx=dcat,
                         dbias=gv("conv1.bias"))

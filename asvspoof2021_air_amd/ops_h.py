@@ -116,6 +116,35 @@ def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False,
     return out
 
 
+def conv_tap_wgrad(xs, dys, T, dil, outs):
+    """outs[i] (W, W, 3) fp32 = sum_{b,t} dys[i][b, co, t] xs[i][b, ci, t + (k - 1) dil] for all branches of a Res2
+    block in one launch (bf16 MFMA on the resident operands: exact products, fp32 sums)."""
+    n = len(xs)
+    if n == 0 or len(dys) != n or len(outs) != n:
+        raise _hip.AirError("conv_tap_wgrad: %d inputs, %d gradients, %d outputs" % (n, len(dys), len(outs)))
+    B, W, Tp = xs[0].shape
+    xp, xb, yp, yb, op = [], [], [], [], []
+    for x, dy, o in zip(xs, dys, outs):
+        if tuple(x.shape) != (B, W, Tp) or tuple(dy.shape) != (B, W, Tp) or tuple(o.shape) != (W, W, 3):
+            raise _hip.AirError("conv_tap_wgrad: branch shapes differ")
+        if o.dtype != torch.float32 or not o.is_contiguous() or not o.is_cuda:
+            raise _hip.AirError("conv_tap_wgrad: outputs must be contiguous fp32 GPU tensors")
+        p, s = hv(x)
+        xp.append(p.value), xb.append(s)
+        p, s = hv(dy)
+        yp.append(p.value), yb.append(s)
+        op.append(o.data_ptr())
+    lib = _hip.lib()
+    nbytes = int(lib.air_h_conv1d_tap_wgrad_ws_bytes(ci(n), ci(B), ci(W)))
+    if nbytes == 0:
+        raise _hip.AirError("conv_tap_wgrad: unsupported width %d" % W)
+    ws = ops.workspace(nbytes, xs[0].device)
+    VP, SZ = ctypes.c_void_p * n, ctypes.c_size_t * n
+    _hip.check(lib.air_h_conv1d_tap_wgrad(ci(n), ci(B), ci(W), ci(T), ci(Tp), ci(dil), VP(*xp), SZ(*xb), VP(*yp), SZ(*yb),
+                                          VP(*op), dptr(ws, torch.uint8), csz(nbytes), stream()), "air_h_conv1d_tap_wgrad")
+    return outs
+
+
 def _bn_ws(B, C, device):
     n = int(_hip.lib().air_h_bn_ws_bytes(ci(B), ci(C)))
     return ops.workspace(n, device), n

@@ -481,6 +481,16 @@ int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned s
 int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
                      const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y, size_t y_bs,
                      air_stream_t stream);
+/* Weight gradients of the n_branches dilated K = 3 convs of one Res2 block (ecapa_tdnn.py:46, W -> W channels,
+ * padding = dilation) in ONE launch: dw[i] (W, W, 3) fp32 = sum_{b,t} dy[i][b][co][t] x[i][b][ci][t + (k - 1) dil],
+ * bf16 MFMA over the resident operands (products exact, fp32 sums, fixed-order split over the utterances) - the
+ * fp32 contraction of the widened operands without the widened copies.  x / dy / dw: HOST arrays of n_branches
+ * device pointers, x_bs / dy_bs their batch strides in elements (NULL or 0 = W * Tp).  W % 64 == 0, dil in 2..4,
+ * n_branches <= 16, Tp % 64 == 0; ws >= air_h_conv1d_tap_wgrad_ws_bytes(). */
+size_t air_h_conv1d_tap_wgrad_ws_bytes(int n_branches, int B, int W);
+int air_h_conv1d_tap_wgrad(int n_branches, int B, int W, int T, int Tp, int dil, const unsigned short* const* x,
+                           const size_t* x_bs, const unsigned short* const* dy, const size_t* dy_bs, float* const* dw,
+                           void* ws, size_t ws_bytes, air_stream_t stream);
 /* BatchNorm1d, training mode: statistics of the bf16 tensor (fp64 two-stage sums, running-stat update) ... */
 size_t air_h_bn_ws_bytes(int B, int C);
 int air_h_bn_stats(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* gamma,

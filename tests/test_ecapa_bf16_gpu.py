@@ -239,3 +239,28 @@ def test_tap_conv(oh, cfg):
     want = F.conv_transpose1d(dyd, wb, None, 1, d, 0, 1, d)
     ulp_ok(val(wide[:, 3 * C:].contiguous(), T), want, "tap dgrad", slack=0.56, floor=float(want.abs().max()) * 4e-3)
     assert int(wide[:, :C].abs().max()) == 0 and int(wide[:, 2 * C:3 * C].abs().max()) == 0
+
+
+@pytest.mark.parametrize("cfg", [(3, 64, 96, 2, 3), (2, 64, 750, 3, 7), (5, 128, 401, 4, 2), (130, 64, 200, 2, 7)])
+def test_tap_conv_wgrad_all_branches(oh, cfg):
+    """air_h_conv1d_tap_wgrad: every branch of a block in one launch, operands as channel slices of wider tensors
+    (batch strides), against the fp64 contraction of the same bf16 values."""
+    B, W, T, d, nb = cfg
+    widex = oh.rows(B, nb * W, T, "cuda", zero=True)
+    xs, dys, want = [], [], []
+    for i in range(nb):
+        xv, xd = res(oh, synth_feat((B, W, T), 51 + i))
+        widex[:, i * W:(i + 1) * W] = xv
+        dy, dyd = res(oh, synth_feat((B, W, T), 71 + i))
+        xs.append(widex[:, i * W:(i + 1) * W])
+        dys.append(dy)
+        xp = F.pad(xd, (d, d))
+        want.append(torch.stack([torch.einsum("bot,bit->oi", dyd, xp[:, :, k * d:k * d + T]) for k in range(3)], dim=2))
+    outs = [torch.full((W, W, 3), float("nan"), device="cuda") for _ in range(nb)]
+    oh.conv_tap_wgrad(xs, dys, T, d, outs)
+    for i in range(nb):
+        close32(outs[i], want[i], "tap wgrad branch %d" % i)
+    # run-to-run identical (fixed-order split over the utterances)
+    again = [torch.empty((W, W, 3), device="cuda") for _ in range(nb)]
+    oh.conv_tap_wgrad(xs, dys, T, d, again)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
