@@ -991,6 +991,93 @@ size_t packed_dgrad_elems(const AirConv2d* p) {  // dgrad packs with Cin padded 
 }
 
 
+// ---- 1x1 stride-1 weight gradient of a NARROW layer (the ResNet's 16 -> 64 shortcut, resnet.py:62): a
+// (Cout x Cin) = 64 x 16 output contracted over B H W = 864,000 pixels - 276 MB of operands for 1.8 GFLOP, i.e.
+// a streaming job (55 us at 5 TB/s) that the 64-channel-tile kernel above ran at 6 TFLOP/s.  Here the pixels are
+// the k index of v_mfma_f32_16x16x4_f32: a lane owns one channel row of a 16-row block and four consecutive
+// pixels (one 16-byte load per block), the four values feed four MFMAs (k = the lane's quarter, the same pixel on
+// the A and the B side), so a wave turns MB + NB loads into 4 MB NB MFMAs.  Workgroup = (utterance, pixel chunk),
+// its four waves split the chunk; their sums meet in LDS in wave order and go out as one partial per workgroup
+// (reduce_partials_kernel).  PRO: x' = relu(x scale[ci] + shift[ci]) applied as the values arrive (the BN + ReLU
+// in front of the shortcut conv).
+struct SkinnyWg {
+  const float* x;
+  const float* dy;
+  float* partial;
+  const float* scale;
+  const float* shift;
+  size_t x_bs, dy_bs;
+  int HW, chunk, nchunk;
+};
+
+template <int MB, int NB, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_1x1_skinny_kernel(const SkinnyWg a) {
+  __shared__ float red[4][MB * NB * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / a.nchunk, ch = blockIdx.x - b * a.nchunk;
+  const int r = lane & 15, kq = lane >> 4;
+  const int per_wave = a.chunk / 4;  // a multiple of 16
+  const int p_lo = ch * a.chunk + wave * per_wave;
+  const int p_hi = min(p_lo + per_wave, a.HW);
+  const float* __restrict__ xb = a.x + (size_t)b * a.x_bs;
+  const float* __restrict__ yb = a.dy + (size_t)b * a.dy_bs;
+  float sc[NB], sh[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    sc[nb] = PRO ? a.scale[nb * 16 + r] : 1.0f;
+    sh[nb] = PRO ? a.shift[nb * 16 + r] : 0.0f;
+  }
+  f32x4 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int p0 = p_lo; p0 < p_hi; p0 += 32) {  // two 16-pixel steps per trip: 2 (MB + NB) loads in flight
+    f32x4 av[2][MB], bv[2][NB];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = p0 + 16 * u + 4 * kq;
+      const bool ok = p < p_hi;  // HW % 4 == 0: a lane's four pixels are in or out together
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        av[u][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (ok) av[u][mb] = *reinterpret_cast<const f32x4*>(yb + (size_t)(mb * 16 + r) * a.HW + p);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bv[u][nb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (ok) bv[u][nb] = *reinterpret_cast<const f32x4*>(xb + (size_t)(nb * 16 + r) * a.HW + p);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (PRO) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[u][nb][e] = fmaxf(fmaf(bv[u][nb][e], sc[nb], sh[nb]), 0.0f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mb][e], bv[u][nb][e], acc[mb][nb], 0, 0, 0);
+    }
+  }
+  // D[i = 4 (lane / 16) + v][j = lane % 16]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave][((mb * 16 + 4 * kq + v) * NB + nb) * 16 + r] = acc[mb][nb][v];
+  __syncthreads();
+  float* __restrict__ out = a.partial + (size_t)blockIdx.x * (MB * NB * 256);
+  for (int e = tid; e < MB * NB * 256; e += 256) out[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+}
+
 struct WgradGeom {
   int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
   int dil;
@@ -1061,6 +1148,21 @@ static bool wino_pad_wgrad(const AirConv2d* p) {
          air_wino_wgrad_ok(p->B, 64, p->H, p->W, p->Cout);
 }
 
+// narrow 1x1 / stride 1 layers served by conv_wgrad_1x1_skinny_kernel: pixel chunks per utterance (0 = not served)
+static int skinny_wgrad_chunks(const AirConv2d* p) {
+  if (p->KH != 1 || p->KW != 1 || p->sh != 1 || p->sw != 1 || p->ph != 0 || p->pw != 0) return 0;
+  if (p->Cout != 64 || p->Cin != 16 || (p->H * p->W) % 4 != 0 || !air_opt(AIR_OPT_SKINNY_WGRAD)) return 0;
+  const int hw = p->H * p->W;
+  int n = 512 / p->B;  // ~2 workgroups per CU over the chip
+  if (n < 1) n = 1;
+  while (n > 1 && hw / n < 256) --n;
+  return n;
+}
+static int skinny_wgrad_chunk_px(const AirConv2d* p, int nchunk) {
+  const int hw = p->H * p->W;
+  return ((hw + nchunk - 1) / nchunk + 63) / 64 * 64;
+}
+
 size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   if (!p || !shape_ok(p)) return 0;
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
@@ -1085,6 +1187,10 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
     const size_t pad = (size_t)p->B * 64 * p->H * p->W + 64 +
                        (size_t)(air_wino_wgrad_nsplit(p->B, 64, p->H, p->W, p->Cout) + 1) * p->Cout * 64 * 9;
     if (pad > wgrad) wgrad = pad;
+  }
+  if (const int nch = skinny_wgrad_chunks(p)) {
+    const size_t sk = (size_t)p->B * nch * wsz;
+    if (sk > wgrad) wgrad = sk;
   }
   size_t m = fwd > dgrad ? fwd : dgrad;
   if (wgrad > m) m = wgrad;
@@ -1372,6 +1478,24 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     // dw[co][ci < Cin][tap] = dw64[co][ci][tap]: the first Cin * 9 floats of every 64 * 9 row
     hipLaunchKernelGGL(copy_rows_kernel, dim3(1, p->Cout), dim3(256), 0, st, dw, (size_t)p->Cin * 9, dw64,
                        (size_t)64 * 9, (size_t)p->Cin * 9);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (const int nch = skinny_wgrad_chunks(p)) {
+    const int nparts = p->B * nch;
+    if (!ws || ws_bytes < (size_t)nparts * wsz * sizeof(float)) return AIR_EWORKSPACE;
+    SkinnyWg a = {x, dy, reinterpret_cast<float*>(ws), in_scale, in_shift, (size_t)p->Cin * p->H * p->W,
+                  (size_t)p->Cout * p->H * p->W, p->H * p->W, skinny_wgrad_chunk_px(p, nch), nch};
+    {
+      AirProfScope ps(AIR_K_CONV_WG_111, conv_flops(p), st);
+      if (in_scale)
+        hipLaunchKernelGGL((conv_wgrad_1x1_skinny_kernel<4, 1, true>), dim3(nparts), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((conv_wgrad_1x1_skinny_kernel<4, 1, false>), dim3(nparts), dim3(256), 0, st, a);
+      AIR_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nparts)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), dw, wsz, nparts, 1);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
   }

@@ -58,6 +58,7 @@ int air_abi_version(void);
  *   DIRECT_WGRAD_ROWS (1) row-staged conv1 weight gradient
  *   C1B_PS (7)            bit mask of the persistent bf16 pointwise kernels
  *   C1B_GEMM_PS (1)       256x256 persistent bf16 GEMM
+ *   SKINNY_WGRAD (1)      streaming weight gradient of the 16 -> 64 1x1 layer (0: generic 64-channel tiles)
  */
 int air_set_option(const char* name, int value);
 int air_get_option(const char* name, int* value_out);

@@ -129,7 +129,7 @@ if __name__ == "__main__":
     for n in names:
         for m in models:
             if "spread" in sys.argv[1:]:
-                res = [run(n, m, perturb=k) for k in (1, 2)]
+                res = [run(n, m, perturb=k) for k in range(1, 1 + int(os.environ.get("EER_SPREAD", "6")))]
                 save("synth_%s_%s_spread.npz" % (n, m), eer=np.array([r[0] for r in res]),
                      errors=np.array([r[1] for r in res]), final_loss=np.array([r[2] for r in res]))
             else:

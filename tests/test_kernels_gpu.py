@@ -44,6 +44,8 @@ CONVS = [
     (2, 256, 5, 47, 256, (3, 3), 1, (1, 1)),
     (1, 512, 3, 94, 512, (3, 3), 1, (1, 1)),    # layer4 3x3
     (2, 16, 18, 75, 64, (1, 1), 1, (0, 0)),     # layer1.0.shortcut
+    (2, 16, 18, 76, 64, (1, 1), 1, (0, 0)),     # the same with H W % 4 == 0: the streaming weight-gradient kernel
+    (5, 16, 18, 750, 64, (1, 1), 1, (0, 0)),    # at the full width (ragged last pixel chunk)
     (2, 64, 18, 75, 128, (1, 1), 2, (0, 0)),    # layer2.0.shortcut
     (2, 256, 5, 47, 512, (1, 1), 2, (0, 0)),    # layer4.0.shortcut-like
     (2, 512, 3, 94, 256, (3, 3), 1, (0, 1)),    # conv5
