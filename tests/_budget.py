@@ -30,6 +30,7 @@ STRICT = {
     "adv_rel_max": 2e-3,       # tests/test_adversarial.py: conv1 / fc gradient, relative to max
     "conv_rtol": 1e-5,         # tests/test_kernels_gpu.py: one 3x3 convolution, of the output scale
     "running_stat_atol": 1e-5,  # tests/test_resnet_gpu.py::test_forward_vs_golden, BatchNorm running statistics (~1.5)
+    "grad_max_entry": 5e-2,    # ::test_grads_vs_oracle_small, worst entry of a gradient tensor relative to its largest
     "grad_rel_l2": 5e-3,       # ::test_grads_vs_oracle_small, per-tensor relative L2 of the gradients at B = 2 (ReLU
                                # sign flips of pre-activations within rounding of 0: their number grows with the rounding)
 }

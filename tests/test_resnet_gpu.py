@@ -116,7 +116,16 @@ def _grads_vs_oracle_small(golden, path):
         err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
         worst = max(worst, err)
         assert err < tol("grad_rel_l2", path), "%s: relative L2 grad err %.3g" % (k, err)
-        assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max(), k
+        # worst entry: 5 % of the tensor's largest under `strict`.  Under `default` a pre-activation that lands on
+        # the other side of a ReLU (see above) moves the entries of ONE input channel's weights by a whole
+        # product term: isolated outliers among errors of 1e-6 - at most 1 % of a tensor's entries may exceed the
+        # strict bound, none the derived one
+        e_abs, scale_k = np.abs(got - ref), np.abs(ref).max()
+        if path == "strict":
+            assert e_abs.max() <= 5e-2 * scale_k, k
+        else:
+            assert (e_abs > 5e-2 * scale_k).mean() <= 1e-2, (k, float((e_abs > 5e-2 * scale_k).mean()))
+            assert e_abs.max() <= tol("grad_max_entry", path) * scale_k, (k, float(e_abs.max() / scale_k))
         np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=tol("grad_rel_l2", path))
     record("resnet_small_g_center_abs[%s]" % path, float(np.abs(lossm.center.grad.cpu().numpy() - g["g_center"]).max()))
     record("resnet_small_worst_grad_relL2[%s]" % path, float(worst))
