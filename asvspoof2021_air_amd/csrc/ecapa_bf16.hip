@@ -584,6 +584,38 @@ __global__ __launch_bounds__(NT) void h_copy_kernel(const u16* __restrict__ x, s
   for (int i = lane; i < Tp / 4; i += 64) q[i] = p[i];
 }
 
+// ---- first layer (ecapa_tdnn.py:111, K = 5 Conv1d on the fp32 features) as a pointwise GEMM: the fp32 input is
+// unfolded once into bf16 rows, row ci K + k (the order of the weight's own (Cin, K) axes, so the (Cout, Cin, K)
+// weight IS the GEMM's (Cout, Cin K) matrix) holding x[ci][t + k dil - pad], zeros outside [0, T), in the frames
+// T .. Tp - 1 and in the rows Cin K .. R - 1 that pad the contraction to the GEMM's 64-row steps.  One thread =
+// 8 frames of one row = one 16-byte store.
+__global__ __launch_bounds__(NT) void h_unfold_kernel(const float* __restrict__ x, size_t xbs, int Cin, int T, int Tp,
+                                                      int K, int dil, int pad, int R, u16* __restrict__ y, size_t ybs,
+                                                      size_t total) {
+  const size_t idx = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (idx >= total) return;
+  const int nch = Tp >> 3;
+  const int chunk = (int)(idx % nch);
+  const size_t rowi = idx / nch;
+  const int row = (int)(rowi % R);
+  const size_t b = rowi / R;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+  if (row < Cin * K) {
+    const int ci = row / K, k = row - ci * K;
+    const float* __restrict__ src = x + b * xbs + (size_t)ci * T;
+    const int t0 = chunk * 8, sh = k * dil - pad;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = t0 + e, ts = t + sh;
+      if (t < T && ts >= 0 && ts < T) v[e] = src[ts];
+    }
+  }
+  *reinterpret_cast<uint4*>(y + b * ybs + (size_t)row * Tp + chunk * 8) =
+      make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+
 inline size_t bs_or(size_t bs, int C, int Tp) { return bs ? bs : (size_t)C * Tp; }
 
 }  // namespace
@@ -728,6 +760,19 @@ int air_h_to_f32(const unsigned short* x, size_t x_bs, int B, int C, int T, int 
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(h_to_f32_kernel, dim3(h_row_grid(rows)), dim3(NT), 0, air_stream(stream), x, bs_or(x_bs, C, Tp), C, T,
                      Tp, y, rows);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_h_unfold(const float* x, size_t x_bs, int B, int Cin, int T, int Tp, int K, int dil, int pad, int rows,
+                 unsigned short* y, size_t y_bs, air_stream_t stream) {
+  if (!x || !y || B <= 0 || Cin <= 0 || T <= 0 || Tp < T || Tp % 8 != 0 || K <= 0 || dil <= 0 || pad < 0 ||
+      rows < Cin * K)
+    return AIR_EINVAL;
+  const size_t total = (size_t)B * rows * (Tp / 8);
+  hipLaunchKernelGGL(h_unfold_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, air_stream(stream), x,
+                     x_bs ? x_bs : (size_t)Cin * T, Cin, T, Tp, K, dil, pad, rows, y, y_bs ? y_bs : (size_t)rows * Tp,
+                     total);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

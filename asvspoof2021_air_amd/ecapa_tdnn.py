@@ -613,6 +613,22 @@ class Res2Net2(nn.Module):
         return [G[n] if (have_tail or n not in tail) else None for n, _, _, _ in arena.entries]
 
     # =================================================================== bf16-resident path (compute_dtype "bf16")
+    def _conv1_rows(self):
+        """Rows of the unfolded first-layer input: Cin * K padded to the weight-gradient GEMM's 128-row tiles."""
+        n = self.conv1.in_channels * self.conv1.kernel_size[0]
+        return (n + 127) // 128 * 128
+
+    def _conv1_matrix(self):
+        """conv1.weight (C, Cin, K) as the (C, rows, 1) matrix of the unfolded GEMM (zero columns behind Cin * K)."""
+        R0, nk = self._conv1_rows(), self.conv1.in_channels * self.conv1.kernel_size[0]
+        w = self.conv1.weight.detach()
+        m = getattr(self, "_conv1_wm", None)
+        if m is None or m.device != w.device or m.shape[1] != R0:
+            m = torch.zeros((self.C, R0, 1), device=w.device, dtype=torch.float32)
+            self._conv1_wm = m
+        ops.add_strided(m.view(self.C, 1, R0)[:, :, :nk], w.view(self.C, 1, nk))
+        return m
+
     def _bn_h(self, x, T, bn, training):
         """BatchNorm1d on resident rows: (mean, invstd, scale, shift)."""
         if training:
@@ -675,11 +691,12 @@ class Res2Net2(nn.Module):
         B, _, T = x.shape
         C = self.C
         dev = x.device
-        # conv1 (K = 5 on the fp32 features) and its BatchNorm statistics stay fp32; the BatchNorm output is the
-        # first resident tensor
-        r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
-        st0 = _bn(r0, self.bn1, training)
-        h = oh.from_f32(ops.bn_apply(r0, st0[2], st0[3]))  # :161
+        # conv1 (K = 5 on the fp32 features, :159-161) as a pointwise GEMM on the input unfolded into bf16 rows (autocast
+        # runs this layer in bf16 as well): its ReLU output and its BatchNorm output are resident tensors like the rest
+        xcol = oh.unfold(x.contiguous(), self.conv1.kernel_size[0], 1, self.conv1.padding[0], self._conv1_rows())
+        r0 = oh.conv_pointwise(xcol, self._conv1_matrix(), T, bias=det(self.conv1.bias), relu=True)
+        st0 = self._bn_h(r0, T, self.bn1, training)
+        h = oh.bn_apply(r0, T, st0[2], st0[3])
         cat123 = oh.rows(B, 3 * C, T, dev)
         blocks = []
         inp = h
@@ -713,7 +730,7 @@ class Res2Net2(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S = dict(resident=True, T=T, x=x, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
+            S = dict(resident=True, T=T, x=x, xcol=xcol, r0=r0, st0=st0, h=h, cat123=cat123, blocks=blocks, x4=x4, mean=mean, std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5, p5=p5,
                      feat=feat, o7=o7, st7=st7)
         ops.bn_flush()
@@ -859,10 +876,15 @@ class Res2Net2(nn.Module):
             dnext = self._block_bwd_h(S["blocks"][k], dblk, T, G, "layer%d." % (k + 1), add2, on_side)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
-        dn32 = oh.to_f32(dnext, T)  # back to the fp32 first layer
-        dc0, _, _ = ops.bn_bwd(S["r0"], dn32, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias), relu_in=True,
-                               dx=dn32, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"], dbias=G["conv1.bias"])
-        ops.conv1d_wgrad(S["x"], dc0, self.conv1.weight.shape, 1, 2, out=G["conv1.weight"])
+        dc0 = oh.bn_bwd(S["r0"], dnext, T, st0[0], st0[1], det(self.bn1.weight), G["bn1.weight"], G["bn1.bias"], dx=dnext,
+                        dbias=G["conv1.bias"])
+
+        def conv1_wgrad():
+            R0, nk = self._conv1_rows(), self.conv1.in_channels * self.conv1.kernel_size[0]
+            dwm = oh.conv_wgrad(S["xcol"], dc0, T, torch.empty((C, R0, 1), device=dev, dtype=torch.float32))
+            ops.add_strided(G["conv1.weight"].view(C, 1, nk), dwm.view(C, 1, R0)[:, :, :nk])  # drop the zero columns
+
+        on_side(conv1_wgrad, dc0)
         if use_side:
             main.wait_stream(side)
         del keep[:]

@@ -55,6 +55,17 @@ def to_f32(x, T):
     return y
 
 
+def unfold(x, K, dil, pad, rows_out):
+    """Dense fp32 (B, Cin, T) -> resident (B, rows_out, Tp): row ci * K + k = x[ci][t + k * dil - pad] (zeros outside)."""
+    B, Cin, T = x.shape
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise _hip.AirError("unfold: dense fp32 input expected")
+    out = rows(B, rows_out, T, x.device)
+    _hip.check(_hip.lib().air_h_unfold(dptr(x), csz(0), ci(B), ci(Cin), ci(T), ci(out.shape[2]), ci(K), ci(dil), ci(pad),
+                                       ci(rows_out), dptr(out, torch.int16), csz(0), stream()), "air_h_unfold")
+    return out
+
+
 def copy(x, out):
     B, C, Tp = x.shape
     p, bs = hv(x)

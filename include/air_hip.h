@@ -536,6 +536,12 @@ int air_h_asp_bwd(const unsigned short* x, unsigned short* w_to_dlogits, int B, 
 int air_h_to_f32(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, float* y, air_stream_t stream);
 int air_h_copy(const unsigned short* x, size_t x_bs, int B, int C, int Tp, unsigned short* y, size_t y_bs,
                air_stream_t stream);
+/* The K = 5 first layer (ecapa_tdnn.py:111) as a pointwise GEMM: dense fp32 (B, Cin, T) -> bf16 rows (B, rows, Tp),
+ * row ci K + k = x[ci][t + k dil - pad] (zeros outside [0, T), behind T, and in rows >= Cin K), so that
+ * air_h_conv1d_pointwise / air_h_conv1d_wgrad with the (Cout, Cin, K) weight seen as (Cout, Cin K [+ zero columns])
+ * are the layer's forward and weight gradient. */
+int air_h_unfold(const float* x, size_t x_bs, int B, int Cin, int T, int Tp, int K, int dil, int pad, int rows,
+                 unsigned short* y, size_t y_bs, air_stream_t stream);
 
 /* ----------------------------------------------------------- OC-Softmax ---
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).

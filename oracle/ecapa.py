@@ -29,11 +29,14 @@ result ``x * gate + residual`` (one rounding; autocast rounds the product and th
 attention logits and the softmax weights (the pooled statistics use the STORED weights).  Rounded in the backward
 pass: every data gradient where a kernel stores it - conv dgrad outputs (with the residual / concat slices folded
 into the same rounding), BatchNorm backward outputs, the SE gate's d(x), the three partial sums that build d(x4).
-NOT rounded (wider than autocast): conv1 (K = 5 on the fp32 features) with its ReLU and BatchNorm statistics, all
-statistics / per-channel and per-utterance vectors (SE squeeze and MLP, context mean / std, pooled mu / sg, bn5,
-fc6), the softmax and the pooling sums (fp32 on the stored bf16 values), parameters and parameter gradients (fp32
-accumulation of bf16 operands; the K = 3 weight gradient an fp32 contraction).  tests/golden/make_golden_bf16.py
-measures the distance of both modes to the reference run under torch.autocast on the CPU.
+The first layer (conv1, K = 5 on the fp32 features, ecapa_tdnn.py:111) computes like the other convs, as autocast
+runs it: the features and the weight rounded to bf16 as operands, fp32 accumulation, its ReLU output and its BatchNorm
+output stored bf16, its weight gradient a contraction of the stored bf16 gradient with the rounded features.
+NOT rounded (wider than autocast): all statistics / per-channel and per-utterance vectors (BatchNorm statistics,
+SE squeeze and MLP, context mean / std, pooled mu / sg, bn5, fc6), the softmax and the pooling sums (fp32 on the
+stored bf16 values), parameters and parameter gradients (fp32 accumulation of bf16 operands; the K = 3 weight
+gradient an fp32 contraction of the stored bf16 values).  tests/golden/make_golden_bf16.py measures the distance of
+both modes to the reference run under torch.autocast on the CPU.
 """
 from collections import OrderedDict
 
@@ -198,6 +201,26 @@ class _Bf16Dilated(torch.autograd.Function):
         return dx, dw, None
 
 
+class _Bf16Conv(torch.autograd.Function):
+    """Conv1d of any kernel size with bf16-rounded operands in all three contractions, fp32 accumulation (the
+    resident mode's first layer: the HIP path unfolds the rounded input and runs a pointwise GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, w, dilation, padding):
+        xb, wb = _rnd(x), _rnd(w)
+        ctx.save_for_backward(xb, wb)
+        ctx.geom = (dilation, padding)
+        return F.conv1d(xb, wb, None, 1, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        d, pad = ctx.geom
+        dyb = _rnd(dy)
+        dx = torch.nn.grad.conv1d_input(xb.shape, wb, dyb, 1, pad, d) if ctx.needs_input_grad[0] else None
+        return dx, torch.nn.grad.conv1d_weight(xb, wb.shape, dyb, 1, pad, d), None, None
+
+
 def _conv(x, p, prefix, dilation=1, padding=0, bf16=False):
     w = p[prefix + ".weight"]
     if bf16 and w.shape[2] == 1:
@@ -307,7 +330,8 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
 def _ecapa_forward_resident(p, x, scale, training, updates, tap, context, out_bn):
     """Res2Net2.forward (ecapa_tdnn.py:152-198) with bf16-resident activations (module docstring)."""
     assert context, "resident arithmetic is stated for context=True (main_train.py:167)"
-    h = RB(_bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates))  # fp32 up to the BatchNorm's output
+    c1 = _Bf16Conv.apply(x, p["conv1.weight"], 1, 2) + p["conv1.bias"][None, :, None]  # :159
+    h = RF(_bn(RB(F.relu(c1)), p, "bn1", training, updates))  # :160-161, stored like every other conv -> ReLU -> BN
     x1 = tap("x1", bottle2neck_resident(h, p, "layer1", 2, scale, training, updates))
     x2 = tap("x2", bottle2neck_resident(x1, p, "layer2", 3, scale, training, updates))
     x3 = tap("x3", bottle2neck_resident(x2, p, "layer3", 4, scale, training, updates))

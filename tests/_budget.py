@@ -172,6 +172,21 @@ def conv_path(path):
         yield
 
 
+def check_bf16_band(errs, band):
+    """bf16 gradients of a HIP run against the fp64 evaluation of the bf16 oracle (oracle/train.py::bf16_gradient_band).
+    The band (the oracle's own fp32-vs-fp64 distances) is a SAMPLE of a chaotic process over ~150 tensors and so is
+    the run under test: every tensor within 2.5x the oracle's own worst, cosine >= 0.85 (or the oracle's own worst
+    cosine less 0.1) - except at most 2 % of the tensors, which may reach 4x with cosine >= 0.6; the median within
+    2.5x the oracle's median."""
+    cos_floor = min(0.85, band["min_cos"] - 0.1)
+    out = [k for k, (err, cos) in errs.items() if err > 2.5 * band["max"] or cos < cos_floor]
+    print("outside the band:", [(k, round(errs[k][0], 3), round(errs[k][1], 3)) for k in out])
+    assert len(out) <= max(1, len(errs) // 50), (out, band)
+    for k in out:
+        assert errs[k][0] <= 4.0 * band["max"] and errs[k][1] >= 0.6, (k, errs[k], band)
+    assert np.median([e for e, _ in errs.values()]) <= 2.5 * band["median"], (np.median([e for e, _ in errs.values()]), band)
+
+
 def record(name, value):
     """Append a measured parity figure to gpurun_out/parity_measured.jsonl (DESIGN.md quotes these)."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

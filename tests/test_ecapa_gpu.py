@@ -7,6 +7,8 @@ from oracle import ecapa as o_ecapa
 from oracle import train as o_train
 from oracle.filler import fill_module_, fill_state, fill_value, synth_feat
 
+from _budget import check_bf16_band  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -157,9 +159,8 @@ def test_bf16_grads_vs_bf16_oracle(hip_dt, omode):
     Tolerance: this filler-initialised net amplifies perturbations ~100x and bf16 rounding is
     discontinuous (a value within fp32 noise of a rounding boundary rounds the other way), so the ORACLE
     ITSELF - fp32 vs fp64 evaluation of the same bf16 graph - moves gradients by 0.13 median / 0.22 max
-    relative L2 per tensor at this size (fp32 graph: 6e-4 / 3e-3).  The band is measured in the test:
-    every tensor of the HIP path must sit within 2.5x the oracle's own worst tensor, with cosine >= 0.85;
-    loss rtol 2e-3.  The tight check of the bf16 arithmetic is tests/test_conv1d_bf16_gpu.py (2e-5)."""
+    relative L2 per tensor at this size (fp32 graph: 6e-4 / 3e-3).  The band is measured in the test
+    (see the assertions); loss rtol 2e-3.  The tight check of the bf16 arithmetic is tests/test_conv1d_bf16_gpu.py (2e-5)."""
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     B, T = 32, 96
     m = make_model().train().set_compute_dtype(hip_dt)
@@ -175,9 +176,7 @@ def test_bf16_grads_vs_bf16_oracle(hip_dt, omode):
     band, errs = o_train.bf16_gradient_band(x, labels, got, omode)
     lo = band["loss64"]
     np.testing.assert_allclose(loss.item(), lo, rtol=2e-3)
-    for k, (err, cos) in errs.items():
-        # cosine floor: 0.85, or what the oracle's own fp32 evaluation reaches against its fp64 one less 0.1
-        assert err <= 2.5 * band["max"] and cos >= min(0.85, band["min_cos"] - 0.1), (k, err, cos, band)
+    check_bf16_band(errs, band)
     print("bf16 grads vs bf16 oracle (fp64): median rel L2 %.3g, max %.3g; oracle fp32-vs-fp64 band: median %.3g max %.3g"
           % (np.median([e for e, _ in errs.values()]), max(e for e, _ in errs.values()), band["median"], band["max"]))
 
