@@ -55,6 +55,8 @@ def _run(g, which, dtype, perturb=0):
     if perturb:  # tools/dbg_eer_spread.py: the HIP path's own run-to-run spread (one weight moved by 1e-7)
         with torch.no_grad():
             model.conv1.weight.view(-1)[perturb] *= (1.0 + 1e-7)
+            if dtype == "bf16":  # conv1's weight is a bf16 operand there (1e-7 rounds away): move an fp32-read one too
+                model.bn1.weight.view(-1)[perturb] *= (1.0 + 1e-7)
     tr = Trainer(model, loss_module=lossm, feat_len=FL, ecapa=(which == "ecapa"))  # T < FL: repeat-padded
     TA = FL
     for _ in range(3):
