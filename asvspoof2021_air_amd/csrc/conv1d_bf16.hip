@@ -676,7 +676,17 @@ __global__ __launch_bounds__(256) void c1b_reduce_kernel(const float* __restrict
                                                          size_t n, int nsplit) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n / 4; e += (size_t)gridDim.x * 256) {
     float4 s = reinterpret_cast<const float4*>(partial)[e];
-    for (int k = 1; k < nsplit; ++k) {
+    int k = 1;
+    for (; k + 7 < nsplit; k += 8) {  // eight loads in flight, summed in index order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(partial + (size_t)(k + u) * n)[e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      }
+    }
+    for (; k < nsplit; ++k) {
       const float4 v = reinterpret_cast<const float4*>(partial + (size_t)k * n)[e];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -1710,25 +1720,37 @@ __global__ __launch_bounds__(256) void c1b_tapw_kernel(const TapWgrad a) {
 #undef TW_STORE
 }
 
-// dw[co0 + co][ci0 + ci][tap] = sum over parts, fixed order.  One thread per (branch, tile, tap, co, ci).
+// dw[co0 + co][ci0 + ci][tap] = sum over parts.  A workgroup owns 64 consecutive (tap, co, ci) outputs of one
+// (branch, tile); its four waves take the parts p = w, w + 4, ... (every load instruction one coalesced 256-byte
+// segment, 8 in flight per wave) and their sums meet in LDS in wave order: deterministic, whatever the part count.
 __global__ __launch_bounds__(256) void c1b_tapw_reduce_kernel(const TapWgrad a) {
+  __shared__ float s_part[4][64];
+  constexpr int PER = 3 * 64 * 64;
   const int tiles = a.tiles_c * a.tiles_c;
-  const int per_br = tiles * 3 * 64 * 64;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.nb * per_br) return;
-  const int br = idx / per_br, e = idx - br * per_br;
-  const int tile = e / (3 * 64 * 64), w = e - tile * (3 * 64 * 64);
-  const int tap = w / 4096, co = (w >> 6) & 63, ci = w & 63;
-  const float* __restrict__ src = a.partial + (size_t)(br * tiles + tile) * a.nparts * (3 * 64 * 64) + w;
-  float s0 = 0.0f, s1 = 0.0f;
-  int p = 0;
-  for (; p + 1 < a.nparts; p += 2) {
-    s0 += src[(size_t)p * (3 * 64 * 64)];
-    s1 += src[(size_t)(p + 1) * (3 * 64 * 64)];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int blocks_per = PER / 64;
+  const int bt = blockIdx.x / blocks_per;  // (branch, tile)
+  const int e = (blockIdx.x - bt * blocks_per) * 64 + lane;
+  const int br = bt / tiles, tile = bt - br * tiles;
+  const float* __restrict__ src = a.partial + (size_t)bt * a.nparts * PER + e;
+  float acc = 0.0f;
+  int p = w;
+  for (; p + 28 < a.nparts; p += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + 4 * u) * PER];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
-  if (p < a.nparts) s0 += src[(size_t)p * (3 * 64 * 64)];
-  const int co_g = (tile / a.tiles_c) * 64 + co, ci_g = (tile % a.tiles_c) * 64 + ci;
-  a.dw[br][((size_t)co_g * a.W + ci_g) * 3 + tap] = s0 + s1;
+  for (; p < a.nparts; p += 4) acc += src[(size_t)p * PER];
+  s_part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    const float r = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+    const int tap = e / 4096, co = (e >> 6) & 63, ci = e & 63;
+    const int co_g = (tile / a.tiles_c) * 64 + co, ci_g = (tile % a.tiles_c) * 64 + ci;
+    a.dw[br][((size_t)co_g * a.W + ci_g) * 3 + tap] = r;
+  }
 }
 
 }  // namespace
@@ -1863,8 +1885,7 @@ int air_h_conv1d_tap_wgrad(int n_branches, int B, int W, int T, int Tp, int dil,
     else hipLaunchKernelGGL(c1b_tapw_kernel<4>, dim3(grid), dim3(256), 0, st, a);
     AIR_CHECK_LAUNCH();
   }
-  const int total = n_branches * tiles * 3 * 64 * 64;
-  hipLaunchKernelGGL(c1b_tapw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(c1b_tapw_reduce_kernel, dim3(n_branches * tiles * (3 * 64 * 64 / 64)), dim3(256), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
