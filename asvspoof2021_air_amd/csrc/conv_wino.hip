@@ -577,6 +577,13 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a) {
 //   * zero padding = the buffer descriptor's out-of-range rule per 16-byte lane; a lane chunk that
 //     straddles the right image edge brings the next row's first pixels instead of zeros: the
 //     two cells a valid tile can see (columns W, W+1) are zeroed in LDS by the reading wave.
+#ifndef W2_DMA_KS
+#define W2_DMA_KS 4  // k-steps over which the next stage's 32 DMAs are issued
+#endif
+#ifndef W2_TX_AT
+#define W2_TX_AT 6   // MFMA slots after which the next k-step's patch / dy transforms are placed
+#define W2_TG_AT 10
+#endif
 constexpr int WG_SEG = 16;                    // tiles per stage
 constexpr int WG_XC = 40;                     // staged x columns per row: image cols 32 seg - 4 ...
 constexpr int WG_XP = 4 * WG_XC + 2;          // floats per channel (odd half: conflict-free b64 / b32x2)
@@ -685,7 +692,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
 
   f32x16 acc[16];
   f32x2 d[8], g[2];      // raw: patch rows (cols 0-1, 2-3), dy tile rows
-  f32x2 V[8], Q[4], Sd[4];  // operands: V[2i], V[2i+1]; Gd row i = Q[i].x, Sd[i].x, Sd[i].y, Q[i].y
+  // operands, two sets (k-step ks multiplies set ks & 1 while the transform of k-step ks + 1 fills the other between
+  // its MFMAs): V[2i], V[2i+1]; Gd row i = Q[i].x, Sd[i].x, Sd[i].y, Q[i].y
+  f32x2 V[2][8], Q[2][4], Sd[2][4];
   f32x2 tl[4], th2[4];
 
   auto ld = [&](const float* __restrict__ bufp, int ks) {
@@ -701,26 +710,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     g[0] = *reinterpret_cast<const f32x2*>(pd);
     g[1] = *reinterpret_cast<const f32x2*>(pd + 32);
   };
-  auto transform = [&]() {
+  auto transform_x = [&](int set) {  // patch -> V[set]
     tl[0] = pk_sub(d[0], d[4]); th2[0] = pk_sub(d[1], d[5]);
     tl[1] = pk_add(d[2], d[4]); th2[1] = pk_add(d[3], d[5]);
     tl[2] = pk_sub(d[4], d[2]); th2[2] = pk_sub(d[5], d[3]);
     tl[3] = pk_sub(d[2], d[6]); th2[3] = pk_sub(d[3], d[7]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      V[2 * i] = pk_col01(tl[i], th2[i]);
-      V[2 * i + 1] = pk_col23(tl[i], th2[i]);
+      V[set][2 * i] = pk_col01(tl[i], th2[i]);
+      V[set][2 * i + 1] = pk_col23(tl[i], th2[i]);
     }
-    // G' g G'^T without its 1/2 factors (they are applied in the output transform)
-    Q[0] = g[0];
-    Q[1] = pk_add(g[0], g[1]);
-    Q[2] = pk_sub(g[0], g[1]);
-    Q[3] = g[1];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Sd[i] = pk_sumdiff(Q[i]);
   };
-  auto opA = [&](int i, int j) -> float {
-    return j == 0 ? Q[i][0] : (j == 1 ? Sd[i][0] : (j == 2 ? Sd[i][1] : Q[i][1]));
+  auto transform_g = [&](int set) {  // dy tile -> Q[set], Sd[set]
+    // G' g G'^T without its 1/2 factors (they are applied in the output transform)
+    Q[set][0] = g[0];
+    Q[set][1] = pk_add(g[0], g[1]);
+    Q[set][2] = pk_sub(g[0], g[1]);
+    Q[set][3] = g[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Sd[set][i] = pk_sumdiff(Q[set][i]);
+  };
+  auto opA = [&](int set, int i, int j) -> float {
+    return j == 0 ? Q[set][i][0] : (j == 1 ? Sd[set][i][0] : (j == 2 ? Sd[set][i][1] : Q[set][i][1]));
   };
   // zero the cells (columns W, W+1 of the 4 patch rows of this lane's channel) that a chunk
   // straddling the right image edge filled with the next row's pixels
@@ -755,22 +766,31 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
       mDn = __builtin_amdgcn_readfirstlane(mD0 + nb);
     }
     ld(bcur, 0);
+    transform_x(0);  // the stage's first k-step: exposed; the other seven are transformed under the MFMAs before them
+    transform_g(0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      transform();
+      const int cs = ks & 1, ns = cs ^ 1;
       if (ks < 7) ld(bcur, ks + 1);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         // the next stage's 32 DMAs: one per second MFMA slot of the first four k-steps
+#if W2_DMA_KS == 2
+        if (ks < 2 && more) dma_unit(ks * 16 + j);
+#else
         if (ks < 4 && (j & 1) == 0 && more) dma_unit(ks * 8 + j / 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (FIRST && ks == 0)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(j >> 2, j & 3), V[j >> 1][j & 1],
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(cs, j >> 2, j & 3), V[cs][j >> 1][j & 1],
                                                        (f32x16){0}, 0, 0, 0);
         else
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(j >> 2, j & 3), V[j >> 1][j & 1],
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(cs, j >> 2, j & 3), V[cs][j >> 1][j & 1],
                                                        acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        // the next k-step's operands, in the shadow of this one's MFMAs (its LDS reads were issued 6 MFMAs ago)
+        if (ks < 7 && j == W2_TX_AT) transform_x(ns);
+        if (ks < 7 && j == W2_TG_AT) transform_g(ns);
       }
     }
     edge_col = n_edge;

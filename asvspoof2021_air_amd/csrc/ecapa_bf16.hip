@@ -73,26 +73,26 @@ __global__ __launch_bounds__(NT) void h_bn_partial_kernel(const u16* __restrict_
   const int b0 = split * per, b1 = min(B, b0 + per);
   const float K = lo_f((unsigned)x[(size_t)c * Tp]);
   const int nv = (T + 3) >> 2;
-  double d1 = 0.0, d2 = 0.0;
-  for (int b = b0; b < b1; ++b) {
-    const uint2* __restrict__ p = row_ld(x + (size_t)b * bs + (size_t)c * Tp);
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int i = threadIdx.x; i < nv; i += NT) {
-      float v[4];
-      unpack4(p[i], v);
+  // one flat loop over the split's (utterance, 4-frame vector) pairs, four loads in flight per thread: the Res2
+  // branches' tensors are 12 MB, a launch is a handful of vectors per thread and lives on its load latency
+  const int total = (b1 - b0) * nv;
+  float s1 = 0.0f, s2 = 0.0f;
+  const u16* __restrict__ xc = x + (size_t)c * Tp;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < total; idx += NT) {
+    const int bq = idx / nv, i = idx - bq * nv;
+    float v[4];
+    unpack4(row_ld(xc + (size_t)(b0 + bq) * bs)[i], v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (4 * i + e < T) {
-          const float d = v[e] - K;
-          s1 += d;
-          s2 = fmaf(d, d, s2);
-        }
-    }
-    d1 += (double)s1;
-    d2 += (double)s2;
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < T) {
+        const float d = v[e] - K;
+        s1 += d;
+        s2 = fmaf(d, d, s2);
+      }
   }
-  d1 = block_sum_d(d1, sh);
-  d2 = block_sum_d(d2, sh);
+  double d1 = block_sum_d((double)s1, sh);
+  double d2 = block_sum_d((double)s2, sh);
   if (threadIdx.x == 0) {
     partial[(size_t)blockIdx.x * 2] = d1;
     partial[(size_t)blockIdx.x * 2 + 1] = d2;
@@ -255,39 +255,38 @@ __global__ __launch_bounds__(NT) void h_bn_bwd_partial_kernel(
   const int b0 = split * per, b1 = min(B, b0 + per);
   const float mu = mean[c], is = invstd[c];
   const int nv = (T + 3) >> 2;
-  double d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
-  for (int b = b0; b < b1; ++b) {
-    const uint2* __restrict__ px = row_ld(x + (size_t)b * xbs + (size_t)c * Tp);
-    const uint2* __restrict__ pg = row_ld(dy + (size_t)b * dybs + (size_t)c * Tp);
-    const uint2* __restrict__ pg2 = dy2 ? row_ld(dy2 + (size_t)b * dy2bs + (size_t)c * Tp) : nullptr;
-    const float rb = rowbias ? rowbias[(size_t)b * C + c] * rb_scale : 0.0f;
-    float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
-    for (int i = threadIdx.x; i < nv; i += NT) {
-      float xv[4], g[4];
-      unpack4(px[i], xv);
-      unpack4(pg[i], g);
-      if (pg2) {
-        float g2[4];
-        unpack4(pg2[i], g2);
+  // flat loop over the split's (utterance, 4-frame vector) pairs, as in h_bn_partial_kernel
+  const int total = (b1 - b0) * nv;
+  float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
+#pragma unroll 2
+  for (int idx = threadIdx.x; idx < total; idx += NT) {
+    const int bq = idx / nv, i = idx - bq * nv;
+    const int b = b0 + bq;
+    float xv[4], g[4];
+    unpack4(row_ld(x + (size_t)b * xbs + (size_t)c * Tp)[i], xv);
+    unpack4(row_ld(dy + (size_t)b * dybs + (size_t)c * Tp)[i], g);
+    if (dy2) {
+      float g2[4];
+      unpack4(row_ld(dy2 + (size_t)b * dy2bs + (size_t)c * Tp)[i], g2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] += g2[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (4 * i + e < T) {
-          const float gg = g[e] + rb;
-          const float xh = (xv[e] - mu) * is;
-          s1 += gg;
-          s2 = fmaf(gg, xh, s2);
-          if (want_bias && xv[e] > 0.0f) {
-            s3 += gg;
-            s4 += 1.0f;
-            s5 += xh;
-          }
-        }
+      for (int e = 0; e < 4; ++e) g[e] += g2[e];
     }
-    d1 += (double)s1; d2 += (double)s2; d3 += (double)s3; d4 += (double)s4; d5 += (double)s5;
+    const float rb = rowbias ? rowbias[(size_t)b * C + c] * rb_scale : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < T) {
+        const float gg = g[e] + rb;
+        const float xh = (xv[e] - mu) * is;
+        s1 += gg;
+        s2 = fmaf(gg, xh, s2);
+        if (want_bias && xv[e] > 0.0f) {
+          s3 += gg;
+          s4 += 1.0f;
+          s5 += xh;
+        }
+      }
   }
+  double d1 = (double)s1, d2 = (double)s2, d3 = (double)s3, d4 = (double)s4, d5 = (double)s5;
   d1 = block_sum_d(d1, sh);
   d2 = block_sum_d(d2, sh);
   if (want_bias) {
