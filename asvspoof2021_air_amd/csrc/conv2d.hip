@@ -1078,6 +1078,150 @@ __global__ __launch_bounds__(256) void conv_wgrad_1x1_skinny_kernel(const Skinny
   for (int e = tid; e < MB * NB * 256; e += 256) out[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
+// ---- 3x3 / stride 1 / pad 1 weight gradient of the same narrow layer shape (16 -> 64: the ResNet's layer1.0.conv1,
+// resnet.py:58): nine (64 x 16) products over the pixels, tap (dh, dw) contracting dy[h][w] with
+// x[h + dh - 1][w + dw - 1].  Same pixels-as-k mapping as conv_wgrad_1x1_skinny_kernel: a lane owns one channel row
+// of a 16-row block and four consecutive pixels of ONE image row; per input row (h - 1, h, h + 1) it loads its four
+// pixels and the two neighbours and forms the three column shifts in registers (zeros outside the image - applied
+// AFTER the optional BN + ReLU prologue), so 4 dy loads + 9 x loads feed 9 x 16 MFMAs: the kernel runs at the
+// f32 MFMA rate of the direct algorithm (15.9 GFLOP, ~0.1 ms) where the Winograd weight-gradient kernel needed the
+// input zero-padded to 64 channels (a 221 MB copy and 4x the products).  The waves of one workgroup per CU deal the
+// (utterance, row, quarter-row) units among themselves; sums meet in LDS three taps at a time; one partial
+// [tap][co][ci] per workgroup.
+struct Skinny3Wg {
+  const float* x;
+  const float* dy;
+  float* partial;
+  const float* scale;
+  const float* shift;
+  size_t x_bs, dy_bs;
+  int B, H, W;
+};
+
+template <int MB, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_3x3_skinny_kernel(const Skinny3Wg a) {
+  __shared__ float red[4][3 * MB * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int W = a.W, H = a.H;
+  const float sc = PRO ? a.scale[r] : 1.0f, sh = PRO ? a.shift[r] : 0.0f;
+  f32x4 acc[9][MB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[t][mb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // one 16-pixel step: this lane's four dy pixels of MB channel rows and its 3 x 6 input neighbourhood
+  auto load_step = [&](int b, int h, int wb, f32x4 (&av)[MB], float (&xv)[3][6]) __attribute__((always_inline)) {
+    const int w0 = wb + 4 * kq;
+    const float* __restrict__ yb = a.dy + (size_t)b * a.dy_bs + (size_t)h * W + w0;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float* __restrict__ src = yb + (size_t)(mb * 16 + r) * H * W;
+      if (w0 + 3 < W) {
+        av[mb] = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[mb][e] = w0 + e < W ? src[e] : 0.0f;
+      }
+    }
+    const float* __restrict__ xr = a.x + (size_t)b * a.x_bs + (size_t)r * H * W + w0;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hh = h + dh - 1;
+      const bool rok = hh >= 0 && hh < H;
+      const float* __restrict__ src = xr + (size_t)(rok ? hh : 0) * W;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) xv[dh][e] = 0.0f;
+      if (rok) {
+        if (w0 + 3 < W) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+          xv[dh][1] = v[0]; xv[dh][2] = v[1]; xv[dh][3] = v[2]; xv[dh][4] = v[3];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (w0 + e < W) xv[dh][1 + e] = src[e];
+        }
+        if (w0 > 0 && w0 - 1 < W) xv[dh][0] = src[-1];
+        if (w0 + 4 < W) xv[dh][5] = src[4];
+      }
+    }
+  };
+  auto mfma_step = [&](int h, int wb, const f32x4 (&av)[MB], float (&xv)[3][6]) __attribute__((always_inline)) {
+    if (PRO) {  // BN + ReLU on the values that exist; the zero padding stays zero
+      const int w0 = wb + 4 * kq;
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+        const int hh = h + dh - 1;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const int wc = w0 - 1 + e;
+          xv[dh][e] = (hh >= 0 && hh < H && wc >= 0 && wc < W) ? fmaxf(fmaf(xv[dh][e], sc, sh), 0.0f) : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            acc[dh * 3 + dw][mb] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb][e], xv[dh][e + dw], acc[dh * 3 + dw][mb], 0, 0, 0);
+  };
+
+  // units = (utterance, image row, quarter of the row), dealt round-robin over all waves of the launch; the loads of
+  // a step are issued before the MFMAs of the step before it
+  const int spr = (W + 15) / 16, spq = (spr + 3) / 4;  // steps per row / per quarter
+  const int units = a.B * H * 4;
+  const int nwaves = gridDim.x * 4;
+  // two steps of loads in flight: slot 0 is multiplied while slots 1 and 2 are on their way
+  f32x4 av0[MB], av1[MB], av2[MB];
+  float xv0[3][6], xv1[3][6], xv2[3][6];
+  int have = 0, h0 = 0, wb0 = 0, h1 = 0, wb1 = 0;
+  auto shift = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { av0[mb] = av1[mb]; av1[mb] = av2[mb]; }
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { xv0[dh][e] = xv1[dh][e]; xv1[dh][e] = xv2[dh][e]; }
+    h0 = h1; wb0 = wb1;
+  };
+  for (int u = blockIdx.x * 4 + wave; u < units; u += nwaves) {
+    const int q = u & 3, bh = u >> 2;
+    const int b = bh / H, h = bh - b * H;
+    const int s_lo = q * spq, s_hi = min(spr, s_lo + spq);
+    for (int st = s_lo; st < s_hi; ++st) {
+      load_step(b, h, st * 16, av2, xv2);
+      if (have == 2) mfma_step(h0, wb0, av0, xv0);
+      shift();
+      h1 = h; wb1 = st * 16;
+      if (have < 2) ++have;
+    }
+  }
+  // drain: slot 1 holds the last step loaded, slot 0 the one before it (when there were two)
+  if (have == 2) mfma_step(h0, wb0, av0, xv0);
+  if (have >= 1) mfma_step(h1, wb1, av1, xv1);
+
+  float* __restrict__ out = a.partial + (size_t)blockIdx.x * (9 * MB * 256);
+#pragma unroll
+  for (int tg = 0; tg < 3; ++tg) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wave][(t * MB * 16 + mb * 16 + 4 * kq + v) * 16 + r] = acc[tg * 3 + t][mb][v];
+    __syncthreads();
+    for (int e = tid; e < 3 * MB * 256; e += 256)
+      out[tg * 3 * MB * 256 + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    __syncthreads();
+  }
+}
+
 struct WgradGeom {
   int B, Cin, H, W, Cout, KH, KW, S, ph, pw, Ho, Wo;
   int dil;
@@ -1158,6 +1302,14 @@ static int skinny_wgrad_chunks(const AirConv2d* p) {
   while (n > 1 && hw / n < 256) --n;
   return n;
 }
+static bool skinny3_wgrad_ok(const AirConv2d* p) {
+  return p->KH == 3 && p->KW == 3 && p->sh == 1 && p->sw == 1 && p->ph == 1 && p->pw == 1 && p->Cout == 64 &&
+         p->Cin == 16 && p->W >= 4 && air_opt(AIR_OPT_SKINNY_WGRAD);
+}
+static int skinny3_wgrad_parts(const AirConv2d* p) {
+  const int units = p->B * p->H;  // one workgroup (4 waves, a row's quarters each) per row, at most one per CU
+  return units < 256 ? units : 256;
+}
 static int skinny_wgrad_chunk_px(const AirConv2d* p, int nchunk) {
   const int hw = p->H * p->W;
   return ((hw + nchunk - 1) / nchunk + 63) / 64 * 64;
@@ -1190,6 +1342,10 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   }
   if (const int nch = skinny_wgrad_chunks(p)) {
     const size_t sk = (size_t)p->B * nch * wsz;
+    if (sk > wgrad) wgrad = sk;
+  }
+  if (skinny3_wgrad_ok(p)) {
+    const size_t sk = (size_t)skinny3_wgrad_parts(p) * wsz;
     if (sk > wgrad) wgrad = sk;
   }
   size_t m = fwd > dgrad ? fwd : dgrad;
@@ -1455,6 +1611,24 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     if (rc != AIR_OK) return rc;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nsplit)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, nsplit, 9);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (skinny3_wgrad_ok(p)) {
+    const int nparts = skinny3_wgrad_parts(p);
+    if (!ws || ws_bytes < (size_t)nparts * wsz * sizeof(float)) return AIR_EWORKSPACE;
+    Skinny3Wg a = {x, dy, reinterpret_cast<float*>(ws), in_scale, in_shift, (size_t)p->Cin * p->H * p->W,
+                   (size_t)p->Cout * p->H * p->W, p->B, p->H, p->W};
+    {
+      AirProfScope ps(AIR_K_CONV_WG_331, conv_flops(p), st);
+      if (in_scale)
+        hipLaunchKernelGGL((conv_wgrad_3x3_skinny_kernel<4, true>), dim3(nparts), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((conv_wgrad_3x3_skinny_kernel<4, false>), dim3(nparts), dim3(256), 0, st, a);
+      AIR_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nparts)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), dw, wsz, nparts, 9);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
   }

@@ -24,3 +24,7 @@ for opt in (1, 0):
         t0 = timeit(lambda: ops.conv2d_wgrad(x, dy, (64, 16, 1, 1), 1, 0))
         t1 = timeit(lambda: ops.conv2d_wgrad(x, dy, (64, 16, 1, 1), 1, 0, sc, sh, relu=True))
     print("SKINNY_WGRAD=%d: plain %.1f us, with BN+ReLU prologue %.1f us (276 MB of operands)" % (opt, t0, t1))
+for opt in (1, 0):
+    with _hip.options(SKINNY_WGRAD=opt):
+        t0 = timeit(lambda: ops.conv2d_wgrad(x, dy, (64, 16, 3, 3), 1, 1))
+    print("3x3 SKINNY_WGRAD=%d: %.1f us (15.9 GFLOP)" % (opt, t0))
