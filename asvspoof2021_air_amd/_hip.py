@@ -97,8 +97,20 @@ def check(rc, what):
         raise AirError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def raw_stream():
+    """The current HIP stream handle of the current device as an int.  torch.cuda.current_stream() builds a Stream
+    object per call (7 us; ~350 calls per ECAPA step made the eager step host-bound); the raw getters cost 0.3 us."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def dptr(t, dtype=torch.float32, allow_none=False):

@@ -249,7 +249,7 @@ class Res2Net2(nn.Module):
             raise ValueError("Res2Net2 expects (B, %d, T), got %s" % (self.n_mfcc, tuple(x.shape)))
         x = x.float().contiguous()
         arena = self.arena()
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for _, p, _, _ in arena.entries):
             return _EcapaFn.apply(self, x, *[p for _, p, _, _ in arena.entries])
         feat, out, _ = self._forward_impl(x, save=False)
         return feat, out

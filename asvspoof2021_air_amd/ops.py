@@ -17,7 +17,9 @@ _WS = {}
 def workspace(nbytes, device):
     """One growing scratch buffer per (device, stream): ops run back to back on a stream, and
     the weight-gradient side stream (resnet.py) must not share scratch with the main one."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    cur = _hip._RAW_DEVICE() if _hip._RAW_DEVICE is not None else torch.cuda.current_device()
+    key = (device.type, device.index,
+           _hip.raw_stream() if device.index in (None, cur) else torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

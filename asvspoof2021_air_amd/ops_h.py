@@ -5,6 +5,7 @@ row with the frames T .. Tp - 1 zero, or a channel-slice view of one (batch stri
 logical frame count) travels as an argument.  Nothing here computes on the CPU or through ATen.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -85,8 +86,7 @@ def conv_pointwise(x, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, ac
     if out is None:
         out = torch.empty((B, M, Tp), device=x.device, dtype=torch.int16)
     lib = _hip.lib()
-    n = int(lib.air_h_conv1d_ws_bytes(ci(Cout), ci(Cin)))
-    n = max(n, int(lib.air_h_conv1d_ws_bytes(ci(Cin), ci(Cout))))
+    n = _pointwise_ws_bytes(Cout, Cin)
     ws = ops.workspace(n, x.device)
     xp, xb = hv(x)
     ap, ab = hv(acc, True)
@@ -103,9 +103,8 @@ def conv_wgrad(x, dy, T, out):
     """out (Cout, Cin, 1) fp32 = sum_{b,t} dy x over resident operands."""
     B, Cin, Tp = x.shape
     Cout = dy.shape[1]
-    d = _hip.AirConv1d(B, Cin, T, Cout, 1, 1, 0, 0, 0)
     lib = _hip.lib()
-    n = int(lib.air_conv1d_bf16_ws_bytes(ctypes.byref(d)))
+    n = _wgrad_ws_bytes(B, Cin, T, Cout)
     ws = ops.workspace(n, x.device)
     xp, xb = hv(x)
     yp, yb = hv(dy)
@@ -156,8 +155,25 @@ def conv_tap_wgrad(xs, dys, T, dil, outs):
     return outs
 
 
+@functools.lru_cache(maxsize=None)
+def _bn_ws_bytes(B, C):
+    return int(_hip.lib().air_h_bn_ws_bytes(ci(B), ci(C)))
+
+
+@functools.lru_cache(maxsize=None)
+def _pointwise_ws_bytes(Cout, Cin):
+    lib = _hip.lib()
+    return max(int(lib.air_h_conv1d_ws_bytes(ci(Cout), ci(Cin))), int(lib.air_h_conv1d_ws_bytes(ci(Cin), ci(Cout))))
+
+
+@functools.lru_cache(maxsize=None)
+def _wgrad_ws_bytes(B, Cin, T, Cout):
+    d = _hip.AirConv1d(B, Cin, T, Cout, 1, 1, 0, 0, 0)
+    return int(_hip.lib().air_conv1d_bf16_ws_bytes(ctypes.byref(d)))
+
+
 def _bn_ws(B, C, device):
-    n = int(_hip.lib().air_h_bn_ws_bytes(ci(B), ci(C)))
+    n = _bn_ws_bytes(B, C)
     return ops.workspace(n, device), n
 
 
@@ -165,7 +181,7 @@ def bn_stats(x, T, gamma, beta, running_mean=None, running_var=None, eps=1e-5, m
     """(mean, invstd, scale, shift) of a resident tensor; updates the running statistics in place."""
     B, C, Tp = x.shape
     dev = x.device
-    mean, invstd, scale, shift = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    mean, invstd, scale, shift = torch.empty((4, C), device=dev, dtype=torch.float32).unbind(0)  # one allocation
     ws, n = _bn_ws(B, C, dev)
     p, bs = hv(x)
     _hip.check(_hip.lib().air_h_bn_stats(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp), dptr(gamma), dptr(beta), cf(eps),

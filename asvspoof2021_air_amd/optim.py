@@ -18,8 +18,13 @@ class FusedAdam:
         self.m = None
         self.v = None
 
+    def _params(self):
+        """The model's parameters, listed once (Module.parameters() walks the module tree on every call)."""
+        arena = self.model.arena()
+        return [p for _, p, _, _ in arena.entries]
+
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
+        for p in self._params():
             p.grad = None
 
     def step(self, grad_scale=1.0):
@@ -27,7 +32,7 @@ class FusedAdam:
         alone: a step() with no backward since zero_grad() is a no-op (the arena still holds the previous
         step's sums, which must not be applied twice)."""
         import torch
-        params = list(self.model.parameters())
+        params = self._params()
         if any(not p.requires_grad for p in params):
             raise RuntimeError("FusedAdam updates the whole parameter arena in one launch: frozen parameters "
                                "(requires_grad=False) are not supported")

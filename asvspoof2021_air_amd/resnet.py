@@ -262,7 +262,7 @@ class ResNet(nn.Module):
         arena = self.arena()
         # eval-mode forward never records a graph (backward through running-stat BN is not
         # on the hot path; generate_score.py only scores)
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for _, p, _, _ in arena.entries):
             params = [p for _, p, _, _ in arena.entries]
             return _ResNetFn.apply(self, x, None, *params)
         feat, mu, _ = self._forward_impl(x, None, save=False)

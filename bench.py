@@ -322,6 +322,7 @@ def main():
         last = None
         for i in range(steps):
             last, _ = trainer.step(*batches[i % nb])
+        t_host = time.perf_counter() - t0  # all launches issued (the host side of the step; the GPU is behind)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -330,7 +331,7 @@ def main():
             dt = float(t.item())
         res = {"value": round(world * BATCH * steps / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
                "ms_per_step": round(1e3 * dt / steps, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
-               "final_loss": round(float(last.item()), 5)}
+               "final_loss": round(float(last.item()), 5), "host_issue_ms_per_step": round(1e3 * t_host / steps, 3)}
         comm = None
         if world > 1:
             # exposed communication: the same steps without the gradient exchange (no buckets from inside
@@ -413,6 +414,7 @@ def main():
                        "global_batch": world * BATCH, "per_gpu_batch": BATCH, "feat_len": FEAT_LEN,
                        "parallelism": "dp%d" % world},
             "final_loss": main_res["final_loss"],
+            "host_issue_ms_per_step": main_res["host_issue_ms_per_step"],
             "ddp": main_res["ddp"],
         }
         if args.model == "ecapa":
