@@ -162,7 +162,7 @@ def conv_path(path):
     """Run a block under the strict (all-direct) or the default (Winograd) convolution configuration."""
     from asvspoof2021_air_amd import _hip
     if path == "strict":
-        with _hip.options(NO_WINO4=1):
+        with _hip.options(NO_WINO4=1, CONV_S2=0):  # (CONV_S2 = 0: round 1's chunking of the stride-2 layers too)
             yield
     elif path == "direct":
         with _hip.options(NO_WINOGRAD=3):

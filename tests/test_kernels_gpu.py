@@ -75,6 +75,40 @@ def test_conv2d_fwd(ops, cfg, fused):
     close(got, want, name="conv2d_fwd")
 
 
+S2 = [
+    # (B, Cin, H, W, Cout): stride-2 3x3 layers - layer2.0 / layer3.0 / layer4.0 conv1 geometries, odd sizes, ragged tiles
+    (3, 64, 18, 33, 128), (2, 64, 9, 75, 128), (2, 128, 9, 131, 256), (2, 256, 5, 47, 512), (1, 64, 18, 750, 128),
+    (2, 96, 6, 40, 128),  # three 32-channel weight-gradient tiles
+]
+
+
+@pytest.mark.parametrize("s2", [0, 1])
+@pytest.mark.parametrize("cfg", S2)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv2d_stride2_options(ops, cfg, fused, s2):
+    """Option CONV_S2: the stride-2 3x3 forward in 4- or 8-channel K chunks - either an fmaf chain held to the direct
+    kernels' constant (1e-5 of the output scale); the weight gradient of the same layers beside it."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 1)
+    w = synth_feat((Cout, Cin, 3, 3), 2, scale=0.1).double().requires_grad_(True)
+    scale = shift = None
+    xa = x.double()
+    if fused:
+        scale = 1.0 + 0.2 * synth_feat((Cin,), 3)
+        shift = 0.3 * synth_feat((Cin,), 4)
+        xa = F.relu(xa * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    y = F.conv2d(xa, w, None, 2, 1)
+    dy = synth_feat(tuple(y.shape), 6)
+    y.backward(dy.double())
+    sc, sh = (None, None) if scale is None else (scale.cuda(), shift.cuda())
+    with _hip.options(CONV_S2=s2):
+        got = ops.conv2d_fwd(x.cuda(), w.detach().float().cuda(), 2, 1, sc, sh, relu=fused)
+        gw = ops.conv2d_wgrad(x.cuda(), dy.cuda(), tuple(w.shape), 2, 1, sc, sh, relu=fused)
+    close(got, y.detach(), rtol=1e-5, name="conv2d_fwd stride 2")
+    close(gw, w.grad, rtol=1e-5, name="conv2d_wgrad stride 2")
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv2d_dgrad(ops, cfg):
     B, Cin, H, W, Cout, k, s, p = cfg
