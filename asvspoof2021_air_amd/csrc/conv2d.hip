@@ -451,6 +451,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < C::NI; ++i)
         dma4_auto(xt + eoff[i], pl + 256 * i + 64 * wave);
+    } else if (MODE == 0) {
+      // plain input: the cells outside the image are ZEROED in LDS once the tile has landed (zero_padding below),
+      // so any address inside the tensor will do for them - the interior offset clamped to the utterance, two
+      // instructions per element instead of the row / column clamps
+      const int tb = hi0 * a.W + wi0, lim = a.Cin * HWi - 1;
+#pragma unroll
+      for (int i = 0; i < C::NI; ++i)
+        dma4_auto(xb + min(max(tb + eoff[i], 0), lim), pl + 256 * i + 64 * wave);
     } else {
 #pragma unroll
       for (int i = 0; i < C::NI; ++i) {
@@ -481,13 +489,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   if (t_begin < t_end) dma(t_begin, 0);
   __syncthreads();
+  // MODE 0: padding as zeros IN LDS.  A tile that reaches over the image edge (the first and the last tile of every
+  // row, every tile of a padded row: 26 / 47 / 78 % of the tiles of the ResNet's three stride-2 layers) used to run
+  // a loop with two selects and a compare per MFMA behind 20 address instructions per staged element; now its
+  // out-of-image rows and columns and the dy columns behind the row's end are overwritten with zeros after the
+  // tile has landed - a few LDS stores per thread - and every tile runs the mask-free loop.  (What a zeroed dy
+  // column multiplies is staged from clamped addresses: real, finite values.)
+  auto zero_padding = [&](float* plw, int hi0, int wi0, int wo0) {
+    float* dlw = plw + C::PATCHP;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+      if (hi0 + kh < 0 || hi0 + kh >= a.H)  // wave-uniform
+        for (int e = tid; e < C::CT * C::PW; e += 256) {
+          const int cil = e / C::PW;
+          plw[cil * C::CHS + kh * C::PW + (e - cil * C::PW)] = 0.0f;
+        }
+    const int pxv = min(PXT, a.Wo - wo0);                  // real pixels of this tile
+    const int clast = (pxv - 1) * S + (KW - 1) * DIL;      // last patch column a real pixel reads
+    const int cell = (tid / KH) * C::CHS + (tid % KH) * C::PW;
+    if (tid < C::CT * KH) {
+      for (int c = 0; c < -wi0; ++c) plw[cell + c] = 0.0f;
+      for (int c = max(0, a.W - wi0); c <= clast; ++c) plw[cell + c] = 0.0f;
+    }
+    if (pxv < PXT)
+      for (int e = tid; e < C::BMW * PXT; e += 256) {
+        const int co = e / PXT, px = e % PXT;
+        if (px >= pxv) dlw[(co >> 1) * C::DPAIR + (co & 1) * 32 + px] = 0.0f;
+      }
+  };
   for (int nt = t_begin; nt < t_end; ++nt) {
     const int cur = (nt - t_begin) & 1;
-    if (nt + 1 < t_end) dma(nt + 1, cur ^ 1);
     const int wt = nt % a.WT;
     const int ho = (nt / a.WT) % a.Ho;
     const int wo0 = wt * PXT;
     const int hi0 = ho * S - a.ph, wi0 = wo0 * S - a.pw;
+    if (MODE == 0) {
+      // (before the next tile's DMA goes out: the compiler drains vmcnt in front of LDS stores it cannot tell apart
+      // from a DMA's destination, and here nothing is in flight)
+      const bool edge = !(hi0 >= 0 && hi0 + KH - 1 < a.H && wi0 >= 0 && wi0 + C::PW - 1 < a.W && wo0 + PXT <= a.Wo);
+      if (edge) {  // wave-uniform
+        zero_padding(lds + cur * C::BUF, hi0, wi0, wo0);
+        __syncthreads();
+      }
+    }
+    if (nt + 1 < t_end) dma(nt + 1, cur ^ 1);
     const float* __restrict__ pl = lds + cur * C::BUF;
     const float* __restrict__ dl = pl + C::PATCHP;
     const float* __restrict__ pbase = pl + (ch * 32 + l31) * C::CHS;
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
       }
     };
-    if (interior)
+    if (MODE == 0 || interior)
       steps(std::false_type{});
     else
       steps(std::true_type{});

@@ -5,7 +5,7 @@ from asvspoof2021_air_amd import ops, _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 CFG = {"l2s": (64, 18, 750, 128), "l3s": (128, 9, 375, 256), "l4s": (256, 5, 188, 512)}
-SETS = [("base", {"CONV_S2": 0}), ("fwd ck4", {"CONV_S2": 1}), ("wg px16", {"CONV_S2": 2}), ("wg px16 170", {"CONV_S2": 2, "WGRAD_WGS": 170}), ("wg px16 512", {"CONV_S2": 2, "WGRAD_WGS": 512}), ("both", {"CONV_S2": 3})]
+SETS = [("base", {"CONV_S2": 0}), ("fwd ck4", {"CONV_S2": 1}), ("fwd ck4 mt1", {"CONV_S2": 1, "CONV_MT": 1}), ("wg 512", {"WGRAD_WGS": 512})]
 def timeit(f, n=reps):
     for _ in range(3): f()
     torch.cuda.synchronize()
