@@ -317,35 +317,65 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   // epilogue: D row i = (r&3) + 8*(r>>2) + 4*half -> output channel, col = l31 -> pixel.
   // Output pixel (ho, wo) lands at y[(ho*oh_mul)*ow_row + wo*ow_mul + o_off] of its channel
   // plane (identity for a plain conv; a parity class of a stride-2 dgrad otherwise).
+  // One uniform branch per OPERAND around all 16 rows of an accumulator (not one per element: those kept every
+  // residual load behind its own s_waitcnt - 32 dependent round trips per workgroup - and made the epilogue
+  // 1500 instructions of a kernel whose 1-tap instances issue 128 - 512 MFMAs per wave).
   if (!tile_ok) return;
   const int wo = wo0 + l31;
   if (wo >= a.Wo) return;
   const size_t oplane = a.oplane;
   const size_t obase = (size_t)b * a.y_bstride + (size_t)cot * C::BMT * oplane +
                        (size_t)(ho * a.oh_mul) * a.ow_row + (size_t)wo * a.ow_mul + a.o_off;
+  const bool full = (cot + 1) * C::BMT <= a.Cout;  // every row of this channel tile is a real channel
+  auto emit = [&](const f32x16& acc, int cofs) {
+    const int cb = cot * C::BMT + cofs + 4 * half;
+    const size_t o0 = obase + (size_t)(cofs + 4 * half) * oplane;
+    float v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-    const size_t o0 = obase + (size_t)i * oplane;
-    const size_t o1 = o0 + 32 * oplane;
-    const int co = cot * C::BMT + i;
-    if (co < a.Cout) {
-      float v0 = acc0[r];
-      if (a.bias != nullptr) v0 += a.bias[co];
-      if (a.bias_bc != nullptr) v0 += a.bias_bc[(size_t)b * a.Cout + co];
-      if (a.residual != nullptr) v0 += a.residual[o0];
-      if (a.out_relu) v0 = fmaxf(v0, 0.0f);
-      a.y[o0] = v0;
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    float t[16];  // the residual's 16 loads go out together, ahead of the bias terms (added in the old order)
+    if (a.residual != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        t[r] = (full || cb + i < a.Cout) ? a.residual[o0 + (size_t)i * oplane] : 0.0f;
+      }
     }
-    if (MT == 2 && co + 32 < a.Cout) {
-      float v1 = acc1[r];
-      if (a.bias != nullptr) v1 += a.bias[co + 32];
-      if (a.bias_bc != nullptr) v1 += a.bias_bc[(size_t)b * a.Cout + co + 32];
-      if (a.residual != nullptr) v1 += a.residual[o1];
-      if (a.out_relu) v1 = fmaxf(v1, 0.0f);
-      a.y[o1] = v1;
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        v[r] += a.bias[min(cb + i, a.Cout - 1)];
+      }
     }
-  }
+    if (a.bias_bc != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        v[r] += a.bias_bc[(size_t)b * a.Cout + min(cb + i, a.Cout - 1)];
+      }
+    }
+    if (a.residual != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += t[r];
+    }
+    if (a.out_relu) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+    }
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a.y[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * oplane] = v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2);
+        if (cb + i < a.Cout) a.y[o0 + (size_t)i * oplane] = v[r];
+      }
+    }
+  };
+  emit(acc0, 0);
+  if (MT == 2) emit(acc1, 32);
 }
 
 // ------------------------------------------------------------------- wgrad
@@ -954,10 +984,33 @@ int pick_mt(int ntiles, int cout) {
   return (eff1 > eff2 + 0.08) ? 1 : 2;
 }
 
+// How pack() serves the direct kernels' weight slabs.  They depend on the weights only, so - like the Winograd
+// transforms - they can be produced off the critical path (air_conv2d_prepack) and handed back as w_packed:
+//   PK_RUN      transform `w` into the workspace slab in front of the launch (the default)
+//   PK_SIZE     air_conv2d_prepack_bytes: walk the same code path, add up the slab sizes, launch nothing
+//   PK_COLLECT  air_conv2d_prepack: transform into consecutive slabs of the caller's buffer, launch no convolution
+//   PK_USE      w_packed given: take the next slab of the caller's buffer instead of transforming
+// One walk of fwd_generic / dgrad_generic serves all four, so the slabs can never be laid out differently from how
+// they are consumed.
+enum { PK_RUN = 0, PK_SIZE, PK_COLLECT, PK_USE };
+struct PackCtx {
+  int mode;
+  float* cur;
+  size_t used;  // floats
+};
+thread_local PackCtx g_pk = {PK_RUN, nullptr, 0};
+struct PackScope {
+  PackCtx saved;
+  PackScope(int mode, float* buf) : saved(g_pk) { g_pk = PackCtx{mode, buf, 0}; }
+  ~PackScope() { g_pk = saved; }
+};
+inline bool pk_dry() { return g_pk.mode == PK_SIZE || g_pk.mode == PK_COLLECT; }  // no convolution launches
+
 // y = conv(act(x), packed w): shared by fwd and every dgrad
 int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
             int relu, const float* residual, const FwdGeom& g, int ck, int mt, double flops,
             hipStream_t st) {
+  if (pk_dry()) return AIR_OK;
   FwdArgs a;
   a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
   a.B = g.B; a.Cin = g.Cin; a.H = g.H; a.W = g.W; a.Cout = g.Cout; a.Ho = g.Ho; a.Wo = g.Wo;
@@ -1005,11 +1058,14 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   return AIR_EUNSUPPORTED;
 }
 
-int pack(const float* w, float* wp, int Cout, int Cin, int taps_full, int transpose, int ck,
+int pack(const float* w, float*& wp, int Cout, int Cin, int taps_full, int transpose, int ck,
          int mt, const TapSel& sel, hipStream_t st) {
   const int M = transpose ? Cin : Cout, Kc = transpose ? Cout : Cin;
   const int bm = 32 * mt;
-  const size_t n = (size_t)((M + bm - 1) / bm * bm) * ((Kc + ck - 1) / ck * ck) * sel.n;
+  const size_t n = (size_t)((M + bm - 1) / bm * bm) * ((Kc + ck - 1) / ck * ck) * sel.n;  // (a multiple of 32)
+  if (g_pk.mode == PK_SIZE) { g_pk.used += n; return AIR_OK; }
+  if (g_pk.mode == PK_USE) { wp = g_pk.cur + g_pk.used; g_pk.used += n; return AIR_OK; }
+  if (g_pk.mode == PK_COLLECT) { wp = g_pk.cur + g_pk.used; g_pk.used += n; }
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, wp, Cout, Cin,
                      taps_full, transpose, ck, bm, sel);
   AIR_CHECK_LAUNCH();
@@ -1412,65 +1468,9 @@ static int wino_kind(const AirConv2d* p, int pass) {
   return 0;
 }
 
-size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
-  if (!p || !shape_ok(p)) return 0;
-  const int kind = wino_kind(p, pass);
-  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
-  if (kind == 4) return air_wino4_packed_elems(M, Kc) * sizeof(float);
-  if (kind == 2) return air_wino_packed_elems(M, Kc) * sizeof(float);
-  return 0;
-}
-
-int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes, air_stream_t stream) {
-  if (!p || !w || !out || !shape_ok(p)) return AIR_EINVAL;
-  const size_t need = air_conv2d_prepack_bytes(p, pass);
-  if (need == 0) return AIR_EUNSUPPORTED;
-  if (out_bytes < need) return AIR_EWORKSPACE;
-  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
-  float* up = reinterpret_cast<float*>(out);
-  return wino_kind(p, pass) == 4 ? air_wino4_weights(w, up, M, Kc, p->H, pass, air_stream(stream))
-                                 : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
-}
-
-int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
-                       const float* in_scale, const float* in_shift, int relu, const float* residual,
-                       double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
-  if (!p || !x || !w || !y || !shape_ok(p)) return AIR_EINVAL;
-  if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
-  if (stats != nullptr) return AIR_EUNSUPPORTED;  // fused BN statistics: not in this build
-  hipStream_t st = air_stream(stream);
-  if (direct_ok(p)) {
-    if (in_scale || relu || residual) return AIR_EUNSUPPORTED;
-    DirectArgs a = {x, w, y, nullptr, nullptr, p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW,
-                    p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
-    hipLaunchKernelGGL(conv_direct_fwd_kernel, dim3(grid_for((size_t)p->B * p->Ho * p->Wo)),
-                       dim3(256), 0, st, a);
-    AIR_CHECK_LAUNCH();
-    return AIR_OK;
-  }
-  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
-  // fused prologue = BatchNorm-apply + ReLU together (the pre-activation block), or none
-  if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;
-  if (in_scale != nullptr && p->Cin > MAXC) return AIR_EUNSUPPORTED;
-  const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
-  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
-  float* wp = reinterpret_cast<float*>(ws);
-  if (in_scale == nullptr && wino_shape(p) && air_wino4_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
-    if (ws_bytes < air_wino4_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
-    if (w_packed)  // transformed earlier (air_conv2d_prepack): no weights kernel in front of the conv
-      return air_wino4_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
-                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
-    return air_wino4_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
-                          conv_flops(p), st);
-  }
-  if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
-    if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
-    if (w_packed)
-      return air_wino_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
-                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
-    return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
-                         conv_flops(p), st);
-  }
+// forward on the direct kernels (whatever pack mode is current: see PackCtx)
+static int fwd_generic(const AirConv2d* p, const float* x, const float* w, float* y, const float* in_scale,
+                       const float* in_shift, int relu, const float* residual, float* wp, hipStream_t st) {
   const int taps = p->KH * p->KW;
   // stride-2 3x3: the 65-column patches of 8 channels leave room for ONE workgroup per CU (88 KB of LDS);
   // 4-channel chunks fit three (option CONV_S2, bit 1)
@@ -1489,38 +1489,10 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
                  ck, mt, conv_flops(p), st);
 }
 
-int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
-                   const float* in_scale, const float* in_shift, int relu, const float* residual,
-                   double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
-  return air_conv2d_fwd_pre(p, x, w, nullptr, y, in_scale, in_shift, relu, residual, stats, ws, ws_bytes, stream);
-}
-
-int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
-                         const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
-  if (!p || !dy || !w || !dx || !shape_ok(p)) return AIR_EINVAL;
-  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
-  hipStream_t st = air_stream(stream);
-  const size_t wsz = packed_dgrad_elems(p);
-  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
-  float* wp = reinterpret_cast<float*>(ws);
+// data gradient on the direct kernels (whatever pack mode is current: see PackCtx)
+static int dgrad_generic(const AirConv2d* p, const float* dy, const float* w, float* dx, const float* accumulate,
+                         float* wp, hipStream_t st) {
   const int taps = p->KH * p->KW;
-  // roles swap: "input" channels = Cout, "output" channels = Cin
-  if (wino_shape(p) && air_wino4_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
-    if (ws_bytes < air_wino4_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
-    if (w_packed)
-      return air_wino4_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
-                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
-    return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
-                          conv_flops(p), st);
-  }
-  if (wino_shape(p) && air_wino_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
-    if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
-    if (w_packed)
-      return air_wino_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
-                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
-    return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
-                         conv_flops(p), st);
-  }
   if (p->sh == 1 && p->Ho == 1 && p->ph == 0 && p->KH == p->H && p->KH > 1 && p->KW == 3 && p->Cout % 16 == 0) {
     // The kernel spans the whole image height (resnet.py:140 conv5: (num_nodes, 3) taps, no vertical padding,
     // one output row): input row h only ever meets kernel row h.  As ONE KH x 3 convolution over the
@@ -1566,7 +1538,9 @@ int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, co
   const size_t dx_elems = (size_t)p->B * p->Cin * plane;
   if (p->KH == 1) {
     // 1x1 stride 2: only even/even pixels receive gradient
-    if (accumulate == nullptr) {
+    if (pk_dry()) {
+      // (weights only: nothing touches dx)
+    } else if (accumulate == nullptr) {
       if (hipMemsetAsync(dx, 0, dx_elems * sizeof(float), st) != hipSuccess) return AIR_ELAUNCH;
     } else if (accumulate != dx) {
       if (hipMemcpyAsync(dx, accumulate, dx_elems * sizeof(float), hipMemcpyDeviceToDevice, st) !=
@@ -1610,6 +1584,127 @@ int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, co
     }
   }
   return AIR_OK;
+}
+
+// (direct_ok: the ResNet's 1 -> 16 first layer reads its weights as they are)
+static bool generic_pack_ok(const AirConv2d* p, int pass) {
+  return generic_ok(p) && !direct_ok(p) && wino_kind(p, pass) == 0;
+}
+
+size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
+  if (!p || !shape_ok(p)) return 0;
+  const int kind = wino_kind(p, pass);
+  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
+  if (kind == 4) return air_wino4_packed_elems(M, Kc) * sizeof(float);
+  if (kind == 2) return air_wino_packed_elems(M, Kc) * sizeof(float);
+  if (!generic_pack_ok(p, pass)) return 0;
+  PackScope size(PK_SIZE, nullptr);
+  float* none = nullptr;
+  const int rc = pass ? dgrad_generic(p, nullptr, nullptr, nullptr, nullptr, none, nullptr)
+                      : fwd_generic(p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, none, nullptr);
+  return rc == AIR_OK ? g_pk.used * sizeof(float) : 0;
+}
+
+int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes, air_stream_t stream) {
+  if (!p || !w || !out || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_prepack_bytes(p, pass);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  if (out_bytes < need) return AIR_EWORKSPACE;
+  const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
+  float* up = reinterpret_cast<float*>(out);
+  const int kind = wino_kind(p, pass);
+  if (kind == 0) {  // the direct kernels' slabs, in the order fwd_generic / dgrad_generic consume them
+    PackScope collect(PK_COLLECT, up);
+    float* none = nullptr;
+    return pass ? dgrad_generic(p, nullptr, w, nullptr, nullptr, none, air_stream(stream))
+                : fwd_generic(p, nullptr, w, nullptr, nullptr, nullptr, 0, nullptr, none, air_stream(stream));
+  }
+  return kind == 4 ? air_wino4_weights(w, up, M, Kc, p->H, pass, air_stream(stream))
+                   : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
+}
+
+int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
+                       const float* in_scale, const float* in_shift, int relu, const float* residual,
+                       double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!p || !x || !w || !y || !shape_ok(p)) return AIR_EINVAL;
+  if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
+  if (stats != nullptr) return AIR_EUNSUPPORTED;  // fused BN statistics: not in this build
+  hipStream_t st = air_stream(stream);
+  if (direct_ok(p)) {
+    if (in_scale || relu || residual) return AIR_EUNSUPPORTED;
+    DirectArgs a = {x, w, y, nullptr, nullptr, p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW,
+                    p->sh, p->sw, p->ph, p->pw, p->Ho, p->Wo};
+    hipLaunchKernelGGL(conv_direct_fwd_kernel, dim3(grid_for((size_t)p->B * p->Ho * p->Wo)),
+                       dim3(256), 0, st, a);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  // fused prologue = BatchNorm-apply + ReLU together (the pre-activation block), or none
+  if ((in_scale != nullptr) != (relu != 0)) return AIR_EUNSUPPORTED;
+  if (in_scale != nullptr && p->Cin > MAXC) return AIR_EUNSUPPORTED;
+  const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
+  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
+  float* wp = reinterpret_cast<float*>(ws);
+  if (in_scale == nullptr && wino_shape(p) && air_wino4_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    if (ws_bytes < air_wino4_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)  // transformed earlier (air_conv2d_prepack): no weights kernel in front of the conv
+      return air_wino4_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
+                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
+    return air_wino4_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
+                          conv_flops(p), st);
+  }
+  if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
+    if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
+                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
+    return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
+                         conv_flops(p), st);
+  }
+  if (w_packed != nullptr && wino_kind(p, 0) == 0) {  // slabs from air_conv2d_prepack (a Winograd-shaped layer's
+    PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));  // buffer is not ours)
+    return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st);
+  }
+  return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st);
+}
+
+int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
+                   const float* in_scale, const float* in_shift, int relu, const float* residual,
+                   double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_conv2d_fwd_pre(p, x, w, nullptr, y, in_scale, in_shift, relu, residual, stats, ws, ws_bytes, stream);
+}
+
+int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
+                         const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!p || !dy || !w || !dx || !shape_ok(p)) return AIR_EINVAL;
+  if (!generic_ok(p)) return AIR_EUNSUPPORTED;
+  hipStream_t st = air_stream(stream);
+  const size_t wsz = packed_dgrad_elems(p);
+  if (!ws || ws_bytes < wsz * sizeof(float)) return AIR_EWORKSPACE;
+  float* wp = reinterpret_cast<float*>(ws);
+  // roles swap: "input" channels = Cout, "output" channels = Cin
+  if (wino_shape(p) && air_wino4_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
+    if (ws_bytes < air_wino4_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino4_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
+                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
+    return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
+                          conv_flops(p), st);
+  }
+  if (wino_shape(p) && air_wino_ok(p->B, p->Cout, p->H, p->W, p->Cin)) {
+    if (ws_bytes < air_wino_packed_elems(p->Cin, p->Cout) * sizeof(float)) return AIR_EWORKSPACE;
+    if (w_packed)
+      return air_wino_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
+                           const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
+    return air_wino_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, wp,
+                         conv_flops(p), st);
+  }
+  if (w_packed != nullptr && wino_kind(p, 1) == 0) {
+    PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));
+    return dgrad_generic(p, dy, w, dx, accumulate, wp, st);
+  }
+  return dgrad_generic(p, dy, w, dx, accumulate, wp, st);
 }
 
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,

@@ -269,9 +269,10 @@ class ResNet(nn.Module):
         return feat, mu
 
     def _launch_prepack(self, fuse):
-        """Enqueue the Winograd weight transforms of every 3x3 stride-1 layer (forward unless the BatchNorm is fused
-        into the conv's operand read, dgrad always) on the side stream, for the layer geometries the previous
-        training forward saw.  Returns {(layer key, pass): buffer}; events in self._pack_ev."""
+        """Enqueue the weight transforms of every conv behind conv1 - Winograd for the 3x3 stride-1 layers, the direct
+        kernels' slabs for the rest (forward unless the BatchNorm is fused into the conv's operand read, dgrad
+        always) - on the side stream, for the layer geometries the previous training forward saw.  Returns
+        {(layer key, pass): buffer}; events in self._pack_ev."""
         self._geo_live = {}
         if not self._geo:
             return {}
@@ -289,7 +290,9 @@ class ResNet(nn.Module):
                 if which == 0 and fuse:
                     continue
                 for (bi, ci), (shape, s, pad) in self._geo.items():
-                    conv = blocks[bi].conv1 if ci == 1 else blocks[bi].conv2
+                    # (bi, 1 | 2): a block's 3x3 convs; (bi, 0): its 1x1 shortcut; (-1, 5): conv5
+                    conv = self.conv5 if bi < 0 else (blocks[bi].shortcut[0] if ci == 0 else
+                                                      blocks[bi].conv1 if ci == 1 else blocks[bi].conv2)
                     buf = ops.conv2d_prepack(conv.weight.detach(), shape, s, pad, which, out=self._packs.get(((bi, ci), which)))
                     if buf is not None:
                         self._packs[((bi, ci), which)] = buf
@@ -330,14 +333,14 @@ class ResNet(nn.Module):
         self._geo_sp = {}
         for bi, blk in enumerate(self.blocks()):
             s = blk.stride
-            self._geo_sp[(bi, 1)], self._geo_sp[(bi, 2)] = (s, 1), (1, 1)
+            self._geo_sp[(bi, 1)], self._geo_sp[(bi, 2)], self._geo_sp[(bi, 0)] = (s, 1), (1, 1), (s, 0)
             stA = _bn_train_coeffs(cur, blk.bn1, training)
             if fuse:  # BN-apply + ReLU folded into the conv's operand read (no activated tensor)
                 actA, pA = cur, dict(in_scale=stA[2], in_shift=stA[3], relu=True)
             else:     # activated tensor written once (HBM-bound pass), convs run their plain loop
                 actA, pA = ops.bn_apply(cur, stA[2], stA[3], relu=True), {}
             if hasattr(blk, "shortcut"):
-                sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, **pA)
+                sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, w_packed=packed((bi, 0), 0, actA.shape), **pA)
             else:
                 sc = cur
             h = ops.conv2d_fwd(actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
@@ -350,7 +353,8 @@ class ResNet(nn.Module):
             if save:
                 S["blocks"].append((blk, cur, stA, h, stB, actA, actB))
             cur = out
-        c5 = ops.conv2d_fwd(cur, w(self.conv5), 1, (0, 1))  # resnet.py:182
+        self._geo_sp[(-1, 5)] = (1, (0, 1))
+        c5 = ops.conv2d_fwd(cur, w(self.conv5), 1, (0, 1), w_packed=packed((-1, 5), 0, cur.shape))  # resnet.py:182
         st5 = _bn_train_coeffs(c5, self.bn5, training)
         a5 = ops.bn_apply(c5, st5[2], st5[3], relu=True)  # resnet.py:183
         B, C5, H5, T5 = a5.shape
@@ -461,11 +465,11 @@ class ResNet(nn.Module):
         g5 = gv("conv5.weight")
         on_side(lambda: ops.conv2d_wgrad(l4, dc5, self.conv5.weight.shape, 1, (0, 1), out=g5), dc5)
         grads_final_from("conv5.weight")
-        dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1))
         fuse = self.fuse_bn_into_conv
         packs = S.get("packs") or {}
         if packs and S.get("pack_ev") is not None:
             main.wait_event(S["pack_ev"])  # the dgrad weight transforms enqueued on the side stream during forward
+        dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1), w_packed=packs.get(((-1, 5), 1)))
         nblk = len(S["blocks"])
         for ri, (blk, xin, stA, h, stB, actA, actB) in enumerate(reversed(S["blocks"])):
             bi = nblk - 1 - ri
@@ -495,7 +499,7 @@ class ResNet(nn.Module):
             d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
             if has_sc:
                 ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
-                                 out=d_actA)
+                                 out=d_actA, w_packed=packs.get(((bi, 0), 1)))
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
                                         blk.bn1.bias.detach(), relu=True, dx=d_actA,
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))

@@ -162,8 +162,11 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
  * launch (25 + 25 launches of ~9 us per ResNet-18 step, serialised with the convs).  They depend on the weights
  * only: air_conv2d_prepack writes them for `pass` (0 forward, 1 dgrad) into a caller-owned buffer of
  * air_conv2d_prepack_bytes(p, pass) bytes (0 = this layer / pass has no such form) - on any stream, e.g. a side
- * stream at the start of the step - and the _pre entry points take that buffer as w_packed (NULL = transform here;
- * layers that do not run as Winograd kernels ignore it). */
+ * stream at the start of the step - and the _pre entry points take that buffer as w_packed (NULL = transform here).
+ * Round 3: the direct kernels' weight slabs (stride-2 3x3, 1x1, conv5, the parity classes of a stride-2 data
+ * gradient: 28 more ~5 us launches per step) travel the same way: air_conv2d_prepack writes every slab the pass
+ * consumes, in consumption order (one code path walks them for sizing, packing and use).  A buffer must be consumed
+ * under the dispatch options it was produced under. */
 size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass);
 int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes,
                        air_stream_t stream);

@@ -110,6 +110,27 @@ def test_conv2d_stride2_options(ops, cfg, fused, s2):
 
 
 @pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_prepack(ops, cfg):
+    """air_conv2d_prepack for every layer kind (Winograd transforms or the direct kernels' slabs - one or several per
+    pass): forward and data gradient with the prepacked buffer are bit-identical to the calls that transform in place."""
+    B, Cin, H, W, Cout, k, s, p = cfg
+    x = synth_feat((B, Cin, H, W), 1).cuda()
+    w = synth_feat((Cout, Cin) + k, 2, scale=0.1).cuda()
+    y = ops.conv2d_fwd(x, w, s, p)
+    dy = synth_feat(tuple(y.shape), 6).cuda()
+    acc = synth_feat((B, Cin, H, W), 7).cuda()
+    dx = ops.conv2d_dgrad(dy, w, x.shape, s, p, accumulate=acc)
+    pf = ops.conv2d_prepack(w, x.shape, s, p, 0)
+    pd = ops.conv2d_prepack(w, x.shape, s, p, 1)
+    assert pf is not None and pd is not None
+    w_gone = torch.full_like(w, float("nan"))  # the packed buffers carry everything the kernels read
+    y2 = ops.conv2d_fwd(x, w_gone, s, p, w_packed=pf)
+    dx2 = ops.conv2d_dgrad(dy, w_gone, x.shape, s, p, accumulate=acc, w_packed=pd)
+    assert torch.equal(y, y2)
+    assert torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("cfg", CONVS)
 def test_conv2d_dgrad(ops, cfg):
     B, Cin, H, W, Cout, k, s, p = cfg
     x = synth_feat((B, Cin, H, W), 1).double().requires_grad_(True)
