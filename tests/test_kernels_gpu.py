@@ -79,6 +79,9 @@ S2 = [
     # (B, Cin, H, W, Cout): stride-2 3x3 layers - layer2.0 / layer3.0 / layer4.0 conv1 geometries, odd sizes, ragged tiles
     (3, 64, 18, 33, 128), (2, 64, 9, 75, 128), (2, 128, 9, 131, 256), (2, 256, 5, 47, 512), (1, 64, 18, 750, 128),
     (2, 96, 6, 40, 128),  # three 32-channel weight-gradient tiles
+    (2, 64, 4, 6, 128),   # one ragged tile per row: left and right padding columns in the same tile
+    (1, 64, 3, 70, 128),  # two output rows, the first padded above; 35 output columns (a 3-pixel second tile)
+    (3, 64, 2, 65, 128),  # one output row; odd width: the last valid pixel reads the right padding column
 ]
 
 
