@@ -127,6 +127,10 @@ struct FwdArgs {
   const float* bias_bc;         // per (batch, output channel) bias (B, Cout) (may be null)
   int out_relu;                 // epilogue ReLU (conv -> ReLU -> BN ordering of ecapa_tdnn.py)
   int last_cbase;               // first channel of the last K chunk (Cin - CK when Cin % CK != 0)
+  // K split (blockIdx.y): this launch slice runs chunks [y * kchunks, min(nchunk, (y + 1) * kchunks)) and writes its
+  // partial sums at y + blockIdx.y * ksplit_stride (kchunks >= nchunk, stride 0: the whole sum, the plain case)
+  int kchunks;
+  size_t ksplit_stride;
 };
 
 // CKT = input channels per K chunk (8 for 3x3; more for 1-4 tap kernels so a chunk still
@@ -241,18 +245,19 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       s_shift[e] = a.shift[e];
     }
   }
-  dma(0, 0);
+  const int kc0 = (int)blockIdx.y * a.kchunks, kc1 = min(nchunk, kc0 + a.kchunks);  // this slice of the K loop
+  dma(kc0, 0);
   dma_wait();
   __syncthreads();
   float scn[CKT / 2], shn[CKT / 2];
 #pragma unroll
   for (int st = 0; st < CKT / 2; ++st) {
-    scn[st] = MODE == 1 ? s_scale[2 * st + half] : 1.0f;
-    shn[st] = MODE == 1 ? s_shift[2 * st + half] : 0.0f;
+    scn[st] = MODE == 1 ? s_scale[kc0 * CKT + 2 * st + half] : 1.0f;
+    shn[st] = MODE == 1 ? s_shift[kc0 * CKT + 2 * st + half] : 0.0f;
   }
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int cur = chunk & 1;
-    if (chunk + 1 < nchunk) dma(chunk + 1, cur ^ 1);
+  for (int chunk = kc0; chunk < kc1; ++chunk) {
+    const int cur = (chunk - kc0) & 1;
+    if (chunk + 1 < kc1) dma(chunk + 1, cur ^ 1);
     const float* __restrict__ wl = lds + cur * C::BUF;
     const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCHP;
     // BN scale/shift of this chunk's channels were fetched during the previous chunk
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
       sc[st] = scn[st];
       sh[st] = shn[st];
     }
-    if (MODE == 1 && chunk + 1 < nchunk) {
+    if (MODE == 1 && chunk + 1 < kc1) {
 #pragma unroll
       for (int st = 0; st < CKT / 2; ++st) {
         scn[st] = s_scale[(chunk + 1) * CKT + 2 * st + half];
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   const int wo = wo0 + l31;
   if (wo >= a.Wo) return;
   const size_t oplane = a.oplane;
-  const size_t obase = (size_t)b * a.y_bstride + (size_t)cot * C::BMT * oplane +
+  const size_t obase = (size_t)blockIdx.y * a.ksplit_stride + (size_t)b * a.y_bstride + (size_t)cot * C::BMT * oplane +
                        (size_t)(ho * a.oh_mul) * a.ow_row + (size_t)wo * a.ow_mul + a.o_off;
   const bool full = (cot + 1) * C::BMT <= a.Cout;  // every row of this channel tile is a real channel
   auto emit = [&](const f32x16& acc, int cofs) {
@@ -955,10 +960,10 @@ int pick_ck(int taps, int cin) {
 }
 
 template <int KH, int KW, int S, int CKT, int DIL = 1>
-void launch_fwd(const FwdArgs& a, int mt, hipStream_t st) {
+void launch_fwd(const FwdArgs& a, int mt, int ksplit, hipStream_t st) {
   const int nblk = a.npxg * a.ncot;
 #define AIR_LAUNCH(MODE_, MT_)                                                                   \
-  hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, MODE_, CKT, DIL, MT_>), dim3(nblk),             \
+  hipLaunchKernelGGL((conv_fwd_kernel<KH, KW, S, MODE_, CKT, DIL, MT_>), dim3(nblk, ksplit),     \
                      dim3(NWAVE * 64), 0, st, a)
   if (mt == 2) {
     if (a.scale != nullptr) AIR_LAUNCH(1, 2); else AIR_LAUNCH(0, 2);
@@ -1007,12 +1012,24 @@ struct PackScope {
 inline bool pk_dry() { return g_pk.mode == PK_SIZE || g_pk.mode == PK_COLLECT; }  // no convolution launches
 
 // y = conv(act(x), packed w): shared by fwd and every dgrad
+int reduce_ksplit(const float* partial, float* y, size_t n, int ksplit, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(n, ksplit)), dim3(256), 0, st, partial, y, n, ksplit, 1);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+// ksplit > 1: the K loop in `ksplit` slices of whole chunks, each slice's sums in its own copy of y inside `partial`
+// (ksplit x B x y_bstride floats), summed in slice order by reduce_partials_kernel - for layers whose pixel x channel
+// tiles leave most of the chip's workgroup slots empty (plain convolutions only: no prologue, no epilogue operand)
 int run_fwd(const float* x, const float* wp, float* y, const float* scale, const float* shift,
             int relu, const float* residual, const FwdGeom& g, int ck, int mt, double flops,
-            hipStream_t st) {
+            hipStream_t st, int ksplit = 1, float* partial = nullptr) {
   if (pk_dry()) return AIR_OK;
+  if (ksplit > 1 && !pk_dry() && (partial == nullptr || scale != nullptr || residual != nullptr || g.bias != nullptr ||
+                     g.bias_bc != nullptr || g.out_relu))
+    return AIR_EINVAL;
   FwdArgs a;
-  a.x = x; a.wp = wp; a.y = y; a.scale = scale; a.shift = shift; a.residual = residual;
+  a.x = x; a.wp = wp; a.y = ksplit > 1 ? partial : y; a.scale = scale; a.shift = shift; a.residual = residual;
   a.B = g.B; a.Cin = g.Cin; a.H = g.H; a.W = g.W; a.Cout = g.Cout; a.Ho = g.Ho; a.Wo = g.Wo;
   a.ph = g.ph; a.pw = g.pw; a.relu = relu;
   a.WT = (g.Wo + PXT - 1) / PXT;
@@ -1024,15 +1041,18 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   a.x_bstride = g.x_bstride; a.y_bstride = g.y_bstride;
   a.bias = g.bias; a.out_relu = g.out_relu; a.bias_bc = g.bias_bc;
   a.last_cbase = (g.Cin % ck != 0) ? g.Cin - ck : (g.Cin / ck - 1) * ck;
+  const int nchunk_all = (g.Cin + ck - 1) / ck;
+  a.kchunks = (nchunk_all + ksplit - 1) / ksplit;
+  a.ksplit_stride = ksplit > 1 ? (size_t)g.B * g.y_bstride : 0;
   if (g.Cin < ck) return AIR_EUNSUPPORTED;
   if (g.Cin % ck != 0 && scale != nullptr) return AIR_EUNSUPPORTED;  // ragged Cin: plain input only
   const int key = g.KH * 1000 + g.KW * 100 + g.S * 10 + (g.dil - 1);
 #define AIR_FWD_CASE_D(KH_, KW_, S_, CK_, DIL_, KID_)                         \
   if (key == KH_ * 1000 + KW_ * 100 + S_ * 10 + (DIL_ - 1) && ck == CK_) {      \
     AirProfScope ps(KID_, flops, st);                                           \
-    launch_fwd<KH_, KW_, S_, CK_, DIL_>(a, mt, st);                             \
+    launch_fwd<KH_, KW_, S_, CK_, DIL_>(a, mt, ksplit, st);                     \
     AIR_CHECK_LAUNCH();                                                         \
-    return AIR_OK;                                                              \
+    return ksplit > 1 ? reduce_ksplit(partial, y, (size_t)g.B * g.y_bstride, ksplit, st) : AIR_OK; \
   }
 #define AIR_FWD_CASE(KH_, KW_, S_, CK_, KID_) AIR_FWD_CASE_D(KH_, KW_, S_, CK_, 1, KID_)
   AIR_FWD_CASE(3, 3, 1, 8, AIR_K_CONV_FWD_331)
@@ -1427,6 +1447,12 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   if (direct_ok(p)) return (size_t)p->B * p->Ho * wsz * sizeof(float) + 256;
   if (!generic_ok(p)) return 0;
   size_t fwd = wsz;
+  {  // K-split forward: the weight slab and up to four partial copies of y behind it (fwd_generic)
+    const size_t slab = (size_t)((p->Cout + 63) / 64 * 64) * ((p->Cin + 31) / 32 * 32) * p->KH * p->KW + 64;
+    const int ntiles = p->B * p->Ho * ((p->Wo + PXT - 1) / PXT);
+    if (((ntiles + NWAVE - 1) / NWAVE) * ((p->Cout + 31) / 32) <= 1536)
+      fwd = slab + 4 * (size_t)p->B * p->Cout * p->Ho * p->Wo;
+  }
   size_t dgrad = packed_dgrad_elems(p);
   if (wino_shape(p)) {  // transformed weights are 16/9 the size
     const size_t wf = air_wino_packed_elems(p->Cout, p->Cin), wd = air_wino_packed_elems(p->Cin, p->Cout);
@@ -1468,9 +1494,30 @@ static int wino_kind(const AirConv2d* p, int pass) {
   return 0;
 }
 
+// floats of the forward weight slab (channel tiles and K chunks zero-padded), rounded up to 64
+static size_t fwd_pack_elems(const AirConv2d* p, int ck, int mt) {
+  const int bm = 32 * mt;
+  const size_t n = (size_t)((p->Cout + bm - 1) / bm * bm) * ((p->Cin + ck - 1) / ck * ck) * p->KH * p->KW;
+  return (n + 63) / 64 * 64;
+}
+// K slices of the plain forward (1 = none).  A layer with few pixel x channel tiles and a long K loop - conv5 of the
+// ResNet (resnet.py:140): 384 workgroups of 64 chunks on 256 CUs, one or two waves per SIMD with every chunk-end
+// DMA wait exposed - runs as up to four times as many workgroups of a quarter of the loop, summed in slice order.
+static int fwd_ksplit(const AirConv2d* p, int ck, int mt) {
+  const int ntiles = p->B * p->Ho * ((p->Wo + PXT - 1) / PXT);
+  const int wgs = ((ntiles + NWAVE - 1) / NWAVE) * ((p->Cout + 32 * mt - 1) / (32 * mt));
+  const int nchunk = (p->Cin + ck - 1) / ck;
+  if (p->Cin % ck != 0) return 1;
+  int k = 1536 / (wgs > 0 ? wgs : 1);
+  if (k > 4) k = 4;
+  while (k > 1 && nchunk / k < 8) --k;
+  return k < 1 ? 1 : k;
+}
+
 // forward on the direct kernels (whatever pack mode is current: see PackCtx)
 static int fwd_generic(const AirConv2d* p, const float* x, const float* w, float* y, const float* in_scale,
-                       const float* in_shift, int relu, const float* residual, float* wp, hipStream_t st) {
+                       const float* in_shift, int relu, const float* residual, float* wp, hipStream_t st,
+                       size_t ws_floats = 0) {
   const int taps = p->KH * p->KW;
   // stride-2 3x3: the 65-column patches of 8 channels leave room for ONE workgroup per CU (88 KB of LDS);
   // 4-channel chunks fit three (option CONV_S2, bit 1)
@@ -1481,12 +1528,16 @@ static int fwd_generic(const AirConv2d* p, const float* x, const float* w, float
   for (int t = 0; t < taps; ++t) sel.idx[t] = t;
   // (with 4-channel chunks the 64-channel tile measured faster on every ResNet shape, whatever the round count)
   const int mt = s2ck4 && p->Cout > 32 && !air_opt(AIR_OPT_CONV_MT) ? 2 : mt_for(p->B, p->Ho, p->Wo, p->Cout);
+  float* const ws0 = wp;  // (pack() points wp at the caller's slab under PK_USE)
   int rc = pack(w, wp, p->Cout, p->Cin, taps, 0, ck, mt, sel, st);
   if (rc != AIR_OK) return rc;
+  int ksplit = (in_scale == nullptr && residual == nullptr && !pk_dry()) ? fwd_ksplit(p, ck, mt) : 1;
+  // (a caller that sized its workspace by an older rule gets the unsplit loop)
+  if (ksplit > 1 && ws_floats < fwd_pack_elems(p, ck, mt) + (size_t)ksplit * p->B * p->Cout * p->Ho * p->Wo) ksplit = 1;
   return run_fwd(x, wp, y, in_scale, in_shift, relu, residual,
                  plain_geom(p->B, p->Cin, p->H, p->W, p->Cout, p->KH, p->KW, p->sh, p->ph, p->pw,
                             p->Ho, p->Wo),
-                 ck, mt, conv_flops(p), st);
+                 ck, mt, conv_flops(p), st, ksplit, ksplit > 1 ? ws0 + fwd_pack_elems(p, ck, mt) : nullptr);
 }
 
 // data gradient on the direct kernels (whatever pack mode is current: see PackCtx)
@@ -1664,9 +1715,9 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
   }
   if (w_packed != nullptr && wino_kind(p, 0) == 0) {  // slabs from air_conv2d_prepack (a Winograd-shaped layer's
     PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));  // buffer is not ours)
-    return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st);
+    return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));
   }
-  return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st);
+  return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));
 }
 
 int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
