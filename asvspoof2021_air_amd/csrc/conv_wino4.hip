@@ -152,7 +152,8 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
                                      int dgrad) {
   using P = W4Pos<MH>;
   const int nchunk = Kc / W4_CK;
-  const size_t total = (size_t)M * Kc;
+  const int Mpad = (M + W4_CO - 1) / W4_CO * W4_CO;  // a 16-channel tail runs as a slab whose upper rows are zero
+  const size_t total = (size_t)Mpad * Kc;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (size_t)gridDim.x * blockDim.x) {
     const int col = (int)(e % W4_CO);
@@ -163,7 +164,7 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
     double g[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
-      g[t] = dgrad ? w[((size_t)k * M + m) * 9 + (8 - t)] : w[((size_t)m * Kc + k) * 9 + t];
+      g[t] = m >= M ? 0.0 : (dgrad ? w[((size_t)k * M + m) * 9 + (8 - t)] : w[((size_t)m * Kc + k) * 9 + t]);
     double tmp[6][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -554,6 +555,9 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     for (int yy = 0; yy < MH; ++yy)
       orow[yy] = (wide && ho + yy < a.H) ? obase + (unsigned)(yy * a.W) * 4u : W4_OOB;
     const unsigned chan = (unsigned)a.H * (unsigned)a.W * 4u;
+    // Cout = 32 n + 16 (the ResNet's 64 -> 16 data gradient, resnet.py:56): the last slab's upper 16 rows multiply
+    // zero weights and have no channel to land in - their offsets are out of range (wave-uniform test)
+    const bool tail16 = cot * W4_CO + 16 >= a.Cout;
     asm volatile("s_nop 15");  // the last MFMAs' results (inline asm: no compiler-inserted wait states)
     // The residual and the partner's partial sums are ALWAYS loaded, through descriptors that are empty (every
     // offset out of range: zeros, no memory access) when there is nothing to add: no branches around the loads, so
@@ -566,10 +570,13 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     f32x4 res[8][MH];
     auto load_res = [&](int cr) {  // residual (and the stored partial sums) of channel pair cr, one step ahead
       const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+      const bool gone = (cr >> 2) == 1 && tail16;
 #pragma unroll
-      for (int yy = 0; yy < MH; ++yy)
-        res[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, orow[yy] + coff, 0, 0)) +
-                      __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars_e, orow[yy] + coff, 0, W4_SC1));
+      for (int yy = 0; yy < MH; ++yy) {
+        const unsigned o = gone ? W4_OOB : orow[yy] + coff;
+        res[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, o, 0, 0)) +
+                      __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars_e, o, 0, W4_SC1));
+      }
     };
     load_res(0);
 #pragma unroll
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // (added to the per-lane offset: as the soffset operand of the buffer stores, a non-zero channel offset
       // gave wrong second dwords in lanes 12-15 of every row of 16 on gfx950 - not understood, avoided)
       const unsigned coff = (unsigned)(cb * 16 + r) * chan;
+      const bool gone = cb == 1 && tail16;
       if (cr + 1 < 8) load_res(cr + 1);
       float T[MH][6];
 #pragma unroll
@@ -603,8 +611,9 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
 #pragma unroll
       for (int yy = 0; yy < MH; ++yy) {
         const f32x4 v = Y[yy] + res[cr][yy];
-        if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, W4_SC1);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, orow[yy] + coff, 0, 0);
+        const unsigned o = gone ? W4_OOB : orow[yy] + coff;
+        if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, o, 0, W4_SC1);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, o, 0, 0);
       }
       if (tracing) { __builtin_amdgcn_sched_barrier(0); tS += clock64() - cs; }
       if (part) {  // lanes of the tile column that straddles the right edge
@@ -612,12 +621,12 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         for (int yy = 0; yy < MH; ++yy)
 #pragma unroll
           for (int xx = 0; xx < 3; ++xx) {
-            const unsigned o = (ho + yy < a.H && wo + xx < a.W) ? obase + (unsigned)(yy * a.W + xx) * 4u : W4_OOB;
+            const unsigned o = (ho + yy < a.H && wo + xx < a.W && !gone) ? obase + (unsigned)(yy * a.W + xx) * 4u + coff : W4_OOB;
             float v = Y[yy][xx];
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs_e, o + coff, 0, 0));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars_e, o + coff, 0, W4_SC1));
-            if (partial) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, W4_SC1);
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o + coff, 0, 0);
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs_e, o, 0, 0));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars_e, o, 0, W4_SC1));
+            if (partial) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, W4_SC1);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, 0);
           }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -866,7 +875,7 @@ extern "C" void air_dbg_wino4_trace(long long* p) { g_wino4_trace = p; }
 
 bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
   if (air_opt(AIR_OPT_NO_WINO4) || (air_opt(AIR_OPT_NO_WINOGRAD) & 1)) return false;
-  if (M < W4_CO || M % W4_CO != 0 || Kc < W4_CK || Kc % W4_CK != 0) return false;
+  if (M < 16 || M % 16 != 0 || Kc < W4_CK || Kc % W4_CK != 0) return false;  // (M = 32 n + 16: a half-used last slab)
   // buffer-descriptor staging: byte offsets stay below the out-of-range marker (2 GiB)
   const double ein = (double)B * Kc * H * W, eout = (double)B * M * H * W;
   return ein * 4.0 + 8192.0 < 2147483648.0 && eout * 4.0 + 8192.0 < 2147483648.0 &&
@@ -874,13 +883,14 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
 }
 
 // (either tile height: 36 floats per (co, ci) cover the 32 of the 3-row layout)
-size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)M * Kc * 36 + 1024; }
+size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)((M + W4_CO - 1) / W4_CO * W4_CO) * Kc * 36 + 1024; }
 
 int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st) {
+  const size_t n = (size_t)((M + W4_CO - 1) / W4_CO * W4_CO) * Kc;
   if (w4_tile_rows(H) == 3)
-    hipLaunchKernelGGL(wino4_weights_kernel<3>, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc, dgrad);
+    hipLaunchKernelGGL(wino4_weights_kernel<3>, dim3(w4_grid_for(n)), dim3(256), 0, st, w, up, M, Kc, dgrad);
   else
-    hipLaunchKernelGGL(wino4_weights_kernel<4>, dim3(w4_grid_for((size_t)M * Kc)), dim3(256), 0, st, w, up, M, Kc, dgrad);
+    hipLaunchKernelGGL(wino4_weights_kernel<4>, dim3(w4_grid_for(n)), dim3(256), 0, st, w, up, M, Kc, dgrad);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
@@ -921,7 +931,7 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   a.GRR = (a.SR + trg - 1) / trg;
   a.TWG = (a.TW + 16 / trg - 1) / (16 / trg);
   a.ngroups = a.GRR * a.TWG;
-  a.ncot = M / W4_CO;
+  a.ncot = (M + W4_CO - 1) / W4_CO;
   a.nquad = (a.ngroups + 3) / 4;
   a.cotb = a.ncot < 8 ? a.ncot : 8;
   while (a.ncot % a.cotb != 0) --a.cotb;  // (channel counts here are powers of two times 32: a no-op)

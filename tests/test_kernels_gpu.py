@@ -346,6 +346,34 @@ def test_wino4_item_dealing_options(ops, cfg, opts):
     close(got, want, rtol=wino_conv_bound(), name="wino4 %s" % (opts,))
 
 
+@pytest.mark.parametrize("cfg", [(2, 16, 18, 75, 64), (64, 16, 18, 150, 64), (3, 48, 9, 40, 64), (24, 16, 5, 47, 128)])
+def test_wino4_half_slab(ops, cfg):
+    """Output channel counts 32 n + 16 on the F(3x4 | 4x4, 3x3) kernel: the last 32-channel slab runs half empty (zero
+    weight rows, nothing loaded or stored for them) - the data gradient of the ResNet's 16 -> 64 layer (resnet.py:56)
+    and of a 48-channel neighbour - with an accumulate operand against fp64, the tensors next to the written one
+    untouched; the forward of the same layers beside it."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 11)
+    w = synth_feat((Cout, Cin, 3, 3), 12, scale=0.1)
+    res = synth_feat((B, Cout, H, W), 13)
+    xd = x.double().requires_grad_(True)
+    y = F.conv2d(xd, w.double(), None, 1, 1)
+    dy = synth_feat((B, Cout, H, W), 14)
+    y.backward(dy.double())
+    acc = synth_feat((B, Cin, H, W), 15)
+    wb = wino_conv_bound()
+    for split in (0, 1):
+        with _hip.options(WINO4_SPLIT=split):
+            close(ops.conv2d_fwd(x.cuda(), w.cuda(), 1, 1, residual=res.cuda()), y + res.double(), rtol=wb,
+                  name="fwd + residual")
+            # dx as the middle third of a guarded buffer: a store to a channel that does not exist would land in it
+            buf = torch.full((3,) + tuple(x.shape), 7.0, device="cuda")
+            got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), (B, Cin, H, W), 1, 1, accumulate=acc.cuda(), out=buf[1])
+            close(got, xd.grad + acc.double(), rtol=wb, name="dgrad + accumulate")
+            assert bool((buf[0] == 7.0).all()) and bool((buf[2] == 7.0).all())
+
+
 @pytest.mark.parametrize("cfg", WINO)
 def test_conv2d_winograd(ops, cfg):
     B, Cin, H, W, Cout = cfg
