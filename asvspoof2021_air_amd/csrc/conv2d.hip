@@ -1100,12 +1100,17 @@ double conv_flops(const AirConv2d* p) {
 // stride-2 3x3 wgrad holds a 65-column patch per channel: use 32-channel tiles there
 int wgrad_ct(const AirConv2d* p) { return (p->sh == 2 && p->Cout % 128 == 0) ? 32 : 64; }
 
+// workgroups of the split-K direct weight gradient: one per CU, two for the 1x1 stride-2 layers (16 MFMAs between
+// the barriers of a tile and 50 KB of LDS: a second resident workgroup covers the waits, 240 -> 212 us over the
+// ResNet's three shortcuts)
+int wgrad_wgs(int KH, int KW, int S) { return air_opt(AIR_OPT_WGRAD_WGS) * ((KH == 1 && KW == 1 && S == 2) ? 2 : 1); }
+
 int wgrad_nsplit(const AirConv2d* p) {
   const int WT = (p->Wo + PXT - 1) / PXT;
   const int ntiles = p->B * p->Ho * WT;
   const int ct = wgrad_ct(p);
   const int ncot = p->Cout / (ct == 32 ? 128 : 64), ncit = (p->Cin + ct - 1) / ct;
-  const int total = air_opt(AIR_OPT_WGRAD_WGS);
+  const int total = wgrad_wgs(p->KH, p->KW, p->sh);
   int target = total / (ncot * ncit);  // workgroups in flight over the whole chip
   if (target < 1) target = 1;
   if (target > ntiles) target = ntiles;
@@ -1369,7 +1374,7 @@ int run_wgrad(const WgradGeom& g, const float* x, const float* dy, float* dw, co
   const int ct = (g.S == 2 && g.Cout % 128 == 0) ? 32 : 64;
   a.ncot = g.Cout / (ct == 32 ? 128 : 64);
   a.ncit = (g.Cin + ct - 1) / ct;
-  const int total = air_opt(AIR_OPT_WGRAD_WGS);
+  const int total = g.dil == 1 ? wgrad_wgs(g.KH, g.KW, g.S) : air_opt(AIR_OPT_WGRAD_WGS);
   int nsplit = total / (a.ncot * a.ncit);  // workgroups in flight over the whole chip
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
@@ -1522,7 +1527,9 @@ static int fwd_generic(const AirConv2d* p, const float* x, const float* w, float
   // stride-2 3x3: the 65-column patches of 8 channels leave room for ONE workgroup per CU (88 KB of LDS);
   // 4-channel chunks fit three (option CONV_S2, bit 1)
   const bool s2ck4 = taps == 9 && p->sh == 2 && p->Cin % 4 == 0 && (air_opt(AIR_OPT_CONV_S2) & 1);
-  const int ck = s2ck4 ? 4 : pick_ck(taps, p->Cin);
+  // 1x1 stride 2 (the shortcuts): 32-channel chunks of 63-column rows are 80 KB - one workgroup per CU again; 16 fit three
+  const bool s2ck16 = taps == 1 && p->sh == 2 && p->Cin % 16 == 0 && (air_opt(AIR_OPT_CONV_S2) & 1);
+  const int ck = s2ck4 ? 4 : (s2ck16 ? 16 : pick_ck(taps, p->Cin));
   TapSel sel;
   sel.n = taps;
   for (int t = 0; t < taps; ++t) sel.idx[t] = t;

@@ -59,8 +59,8 @@ int air_abi_version(void);
  *   C1B_PS (7)            bit mask of the persistent bf16 pointwise kernels
  *   C1B_GEMM_PS (1)       256x256 persistent bf16 GEMM
  *   SKINNY_WGRAD (1)      streaming weight gradient of the 16 -> 64 1x1 layer (0: generic 64-channel tiles)
- *   CONV_S2 (1)           bit 1: stride-2 3x3 forward in 4-channel K chunks (three resident workgroups per CU
- *                         instead of one; same arithmetic, chunk boundaries only)
+ *   CONV_S2 (1)           bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (three resident
+ *                         workgroups per CU instead of one; same arithmetic, chunk boundaries only)
  */
 int air_set_option(const char* name, int value);
 int air_get_option(const char* name, int* value_out);
