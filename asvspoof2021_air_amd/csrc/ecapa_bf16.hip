@@ -53,10 +53,20 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return r;
 }
 
+// idx -> (idx / nv, idx % nv) for 0 <= idx < 2^22 without the ~35-instruction integer division sequence: the flat
+// loops below do it once per 8-byte load (rnv = 1.0f / nv; the float quotient is off by at most one)
+__device__ __forceinline__ void divmod_flat(int idx, int nv, float rnv, int& q, int& r) {
+  q = (int)((float)idx * rnv);
+  r = idx - q * nv;
+  if (r < 0) { r += nv; --q; }
+  else if (r >= nv) { r -= nv; ++q; }
+}
+
 int h_splits(int B, int C) {
   int s = 2048 / C;
   if (s < 1) s = 1;
   if (s > B) s = B;
+  if (s < (B + 8190) / 8191) s = (B + 8190) / 8191;  // (utterances per split) x (Tp / 4 <= 512) < 2^22: divmod_flat
   return s;
 }
 bool h_shape_ok(int B, int C, int T, int Tp) {
@@ -76,11 +86,13 @@ __global__ __launch_bounds__(NT) void h_bn_partial_kernel(const u16* __restrict_
   // one flat loop over the split's (utterance, 4-frame vector) pairs, four loads in flight per thread: the Res2
   // branches' tensors are 12 MB, a launch is a handful of vectors per thread and lives on its load latency
   const int total = (b1 - b0) * nv;
+  const float rnv = 1.0f / (float)nv;
   float s1 = 0.0f, s2 = 0.0f;
   const u16* __restrict__ xc = x + (size_t)c * Tp;
 #pragma unroll 4
   for (int idx = threadIdx.x; idx < total; idx += NT) {
-    const int bq = idx / nv, i = idx - bq * nv;
+    int bq, i;
+    divmod_flat(idx, nv, rnv, bq, i);
     float v[4];
     unpack4(row_ld(xc + (size_t)(b0 + bq) * bs)[i], v);
 #pragma unroll
@@ -257,10 +269,12 @@ __global__ __launch_bounds__(NT) void h_bn_bwd_partial_kernel(
   const int nv = (T + 3) >> 2;
   // flat loop over the split's (utterance, 4-frame vector) pairs, as in h_bn_partial_kernel
   const int total = (b1 - b0) * nv;
+  const float rnv = 1.0f / (float)nv;
   float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f, s5 = 0.0f;
 #pragma unroll 2
   for (int idx = threadIdx.x; idx < total; idx += NT) {
-    const int bq = idx / nv, i = idx - bq * nv;
+    int bq, i;
+    divmod_flat(idx, nv, rnv, bq, i);
     const int b = b0 + bq;
     float xv[4], g[4];
     unpack4(row_ld(x + (size_t)b * xbs + (size_t)c * Tp)[i], xv);

@@ -1,4 +1,6 @@
 """Times the bf16-row BatchNorm kernels (air_h_bn_stats / apply / bwd) at ECAPA's two shapes."""
+import sys
+
 import torch
 from asvspoof2021_air_amd import ops_h as oh
 
@@ -16,7 +18,10 @@ def timeit(f, n=50):
     return s.elapsed_time(e) / n * 1e3
 
 
-for B, C, T in ((128, 64, 750), (128, 512, 750)):
+SHAPES = ((128, 64, 750), (128, 512, 750))
+if len(sys.argv) > 1:  # one shape only (per-shape kernel times under tools/kstat.sh)
+    SHAPES = (SHAPES[int(sys.argv[1])],)
+for B, C, T in SHAPES:
     x = oh.from_f32(torch.randn(B, C, T, device="cuda").relu_())
     dy = oh.from_f32(torch.randn(B, C, T, device="cuda"))
     dy2 = oh.from_f32(torch.randn(B, C, T, device="cuda"))
