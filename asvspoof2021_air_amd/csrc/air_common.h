@@ -24,6 +24,31 @@ __device__ __forceinline__ double air_wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// s[q] = sum of p[k * stride + q], k = 0 .. n - 1, in index order - the bits a serial loop returns - by one wave:
+// lane k loads the NQ values of element k (one round trip for the wave instead of n dependent ones in a thread),
+// the fold walks the lanes with v_readlane.  n and p are wave-uniform; every lane holds the totals.  The BatchNorm
+// finalize kernels are a single workgroup between two full-chip passes: their duration is this latency chain.
+template <int NQ>
+__device__ __forceinline__ void air_wave_ordered_sums_d(const double* __restrict__ p, int n, int stride, double (&s)[NQ]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = 0.0;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    int lo[NQ], hi[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const double v = (k0 + lane < n) ? p[(size_t)(k0 + lane) * stride + q] : 0.0;
+      lo[q] = __double2loint(v);
+      hi[q] = __double2hiint(v);
+    }
+    const int m = n - k0 < 64 ? n - k0 : 64;
+    for (int k = 0; k < m; ++k) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        s[q] += __hiloint2double(__builtin_amdgcn_readlane(hi[q], k), __builtin_amdgcn_readlane(lo[q], k));
+    }
+  }
+}
 __device__ __forceinline__ float air_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

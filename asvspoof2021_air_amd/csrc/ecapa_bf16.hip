@@ -116,28 +116,30 @@ __global__ void h_bn_finalize_kernel(const u16* __restrict__ x, int Tp, const do
                                      float eps, float momentum, float* __restrict__ running_mean,
                                      float* __restrict__ running_var, float* __restrict__ mean,
                                      float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel (air_wave_ordered_sum_d)
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    s1 += partial[((size_t)c * nsplit + k) * 2];
-    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
-  }
+  // everything the tail needs is requested in front of the sums: one memory round trip for the kernel
+  const float K = lo_f((unsigned)x[(size_t)c * Tp]), ga = gamma[c], be = beta[c];
+  const float rm = running_mean != nullptr ? running_mean[c] : 0.0f, rv = running_mean != nullptr ? running_var[c] : 0.0f;
+  double s12[2];
+  air_wave_ordered_sums_d<2>(partial + (size_t)c * nsplit * 2, nsplit, 2, s12);
+  const double s1 = s12[0], s2 = s12[1];
+  if ((threadIdx.x & 63) != 0) return;
   const double ms = s1 / N;
   double var = s2 / N - ms * ms;
   if (var < 0.0) var = 0.0;
-  const double m = ms + (double)lo_f((unsigned)x[(size_t)c * Tp]);
+  const double m = ms + (double)K;
   const float mf = (float)m;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = mf;
   invstd[c] = is;
-  const float sc = gamma[c] * is;
+  const float sc = ga * is;
   scale[c] = sc;
-  shift[c] = beta[c] - mf * sc;
+  shift[c] = be - mf * sc;
   if (running_mean != nullptr) {
     const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
-    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
-    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = (1.0f - momentum) * rm + momentum * mf;
+    running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
   }
 }
 
@@ -318,18 +320,26 @@ __global__ void h_bn_bwd_finalize_kernel(const double* __restrict__ partial, int
                                          const float* __restrict__ gamma, const float* __restrict__ invstd,
                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
                                          float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel (air_wave_ordered_sum_d)
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    const double* o = partial + ((size_t)c * nsplit + k) * HNACC;
-    s1 += o[0]; s2 += o[1]; s3 += o[2]; s4 += o[3]; s5 += o[4];
+  const double* o = partial + (size_t)c * nsplit * HNACC;
+  const float ga = gamma[c], is = invstd[c];  // requested together with the partial sums
+  double s1, s2, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+  if (dbias) {
+    double t[5];
+    air_wave_ordered_sums_d<5>(o, nsplit, HNACC, t);
+    s1 = t[0]; s2 = t[1]; s3 = t[2]; s4 = t[3]; s5 = t[4];
+  } else {
+    double t[2];
+    air_wave_ordered_sums_d<2>(o, nsplit, HNACC, t);
+    s1 = t[0]; s2 = t[1];
   }
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   if (dbias) {
     const double k1 = (double)(float)s1 * invN, k2 = (double)(float)s2 * invN;
-    dbias[c] = (float)((double)gamma[c] * (double)invstd[c] * (s3 - k1 * s4 - k2 * s5));
+    dbias[c] = (float)((double)ga * (double)is * (s3 - k1 * s4 - k2 * s5));
   }
 }
 
@@ -652,7 +662,7 @@ int air_h_bn_stats(const unsigned short* x, size_t x_bs, int B, int C, int T, in
   double* partial = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(h_bn_partial_kernel, dim3(C * ns), dim3(NT), 0, st, x, bs_or(x_bs, C, Tp), B, C, T, Tp, ns, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(h_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, x, Tp, partial, ns, C,
+  hipLaunchKernelGGL(h_bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, Tp, partial, ns, C,
                      (double)B * (double)T, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
                      scale, shift);
   AIR_CHECK_LAUNCH();
@@ -716,7 +726,7 @@ int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy,
                      dy2, bs_or(dy2_bs, C, Tp), dy_rowbias, rowbias_scale, B, C, T, Tp, ns, mean, invstd, dbias ? 1 : 0,
                      partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(h_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, ns, C, invN, gamma, invstd,
+  hipLaunchKernelGGL(h_bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, ns, C, invN, gamma, invstd,
                      dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   const size_t rows = (size_t)B * C;

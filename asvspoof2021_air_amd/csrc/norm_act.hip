@@ -122,28 +122,31 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, int S,
                                    float* __restrict__ running_var, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale,
                                    float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per channel (air_wave_ordered_sum_d: the sums of the serial loop over the splits, one round trip)
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    s1 += partial[((size_t)c * nsplit + k) * 2];
-    s2 += partial[((size_t)c * nsplit + k) * 2 + 1];
-  }
+  // everything the tail needs is requested in front of the sums: one memory round trip for the kernel
+  const float K = x[(size_t)c * S], ga = gamma[c], be = beta[c];
+  const float rm = running_mean != nullptr ? running_mean[c] : 0.0f, rv = running_mean != nullptr ? running_var[c] : 0.0f;
+  double s12[2];
+  air_wave_ordered_sums_d<2>(partial + (size_t)c * nsplit * 2, nsplit, 2, s12);
+  const double s1 = s12[0], s2 = s12[1];
+  if ((threadIdx.x & 63) != 0) return;
   const double ms = s1 / N;  // mean of the shifted data
   double var = s2 / N - ms * ms;
   if (var < 0.0) var = 0.0;
-  const double m = ms + (double)x[(size_t)c * S];
+  const double m = ms + (double)K;
   const float mf = (float)m;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = mf;
   invstd[c] = is;
-  const float sc = gamma[c] * is;
+  const float sc = ga * is;
   scale[c] = sc;
-  shift[c] = beta[c] - mf * sc;
+  shift[c] = be - mf * sc;
   if (running_mean != nullptr) {
     const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
-    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
-    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = (1.0f - momentum) * rm + momentum * mf;
+    running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
   }
 }
 
@@ -312,19 +315,27 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per channel, as bn_finalize_kernel
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    const double* o = partial + ((size_t)c * nsplit + k) * NACC;
-    s1 += o[0]; s2 += o[1]; s3 += o[2]; s4 += o[3]; s5 += o[4];
+  const double* o = partial + (size_t)c * nsplit * NACC;
+  const float ga = gamma[c], is = invstd[c];  // requested together with the partial sums
+  double s1, s2, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+  if (dbias) {
+    double t[5];
+    air_wave_ordered_sums_d<5>(o, nsplit, NACC, t);
+    s1 = t[0]; s2 = t[1]; s3 = t[2]; s4 = t[3]; s5 = t[4];
+  } else {
+    double t[2];
+    air_wave_ordered_sums_d<2>(o, nsplit, NACC, t);
+    s1 = t[0]; s2 = t[1];
   }
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   if (dbias) {
     // the apply kernel uses the fp32 dbeta / dgamma just written: mirror its constants
     const double k1 = (double)(float)s1 * invN, k2 = (double)(float)s2 * invN;
-    dbias[c] = (float)((double)gamma[c] * (double)invstd[c] * (s3 - k1 * s4 - k2 * s5));
+    dbias[c] = (float)((double)ga * (double)is * (s3 - k1 * s4 - k2 * s5));
   }
 }
 
@@ -549,7 +560,7 @@ int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, co
   else
     hipLaunchKernelGGL(bn_partial_stats_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, B, C, S, nsplit, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, x, S, partial, nsplit, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, x, S, partial, nsplit, C,
                      (double)B * (double)S, gamma, beta, eps, momentum, running_mean, running_var,
                      mean, invstd, scale, shift);
   AIR_CHECK_LAUNCH();
@@ -620,7 +631,7 @@ int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const flo
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
                        rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nsplit, C, (double)(float)invN,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nsplit, C, (double)(float)invN,
                      gamma, invstd, dgamma, dbeta, dbias);
   AIR_CHECK_LAUNCH();
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
