@@ -57,7 +57,7 @@ def close32(got, want, name, rtol=2e-5):
     assert np.abs(got - want).max() <= rtol * s, "%s: %.3g of scale %.3g" % (name, np.abs(got - want).max(), s)
 
 
-SHAPES = [(3, 64, 96), (2, 128, 750), (5, 64, 401)]
+SHAPES = [(3, 64, 96), (2, 128, 750), (5, 64, 401), (150, 8, 40)]  # the last: 150 splits per channel (three lane chunks)
 
 
 @pytest.mark.parametrize("shape", SHAPES)

@@ -195,7 +195,8 @@ def test_conv1_direct_wgrad_short_rows(ops, W):
     close(gw, w.grad, name="conv1 wgrad W=%d" % W)
 
 
-@pytest.mark.parametrize("shape", [(4, 16, 18, 75), (3, 64, 9, 375), (2, 256, 1, 94), (5, 128, 33)])
+# (160, 8, 5, 12): 160 splits per channel - the finalize kernels' ordered fold walks three 64-lane chunks
+@pytest.mark.parametrize("shape", [(4, 16, 18, 75), (3, 64, 9, 375), (2, 256, 1, 94), (5, 128, 33), (160, 8, 5, 12)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_batchnorm(ops, shape, relu):
     C = shape[1]
