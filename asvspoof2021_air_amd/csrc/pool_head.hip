@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NT) void linear_dx_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
   if (k < K) {
-#pragma unroll 4
+#pragma unroll 16
     for (int n = n_lo; n < n_hi; ++n) {
       const float wv = w[(size_t)n * K + k];
 #pragma unroll
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT) void linear_dw_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < LIN_RB; ++r) s[r] = 0.0f;
   if (k < K) {
-#pragma unroll 4
+#pragma unroll 16
     for (int m = m_lo; m < m_hi; ++m) {
       const float xv = x[(size_t)m * K + k];
 #pragma unroll
