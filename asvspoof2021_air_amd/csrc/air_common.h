@@ -14,6 +14,12 @@
 
 static inline hipStream_t air_stream(air_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units a launch on `st` can occupy: the stream's CU mask (hipExtStreamCreateWithCUMask; for a stream
+// without one HIP reports the process-wide ROC_GLOBAL_CU_MASK or all CUs) capped by the device's CU count -
+// what the persistent kernels size their grids by instead of assuming the 256 CUs of an unpartitioned MI355X
+// (CPX / partitioned modes, masked streams).  api.hip; one query per (device, stream), cached.
+int air_stream_cus(hipStream_t st);
+
 __device__ __forceinline__ float air_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

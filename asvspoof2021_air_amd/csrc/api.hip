@@ -38,6 +38,34 @@ int find_opt(const char* name) {
 }
 }  // namespace
 
+int air_stream_cus(hipStream_t st) {
+  struct Entry { int dev; hipStream_t st; int cus; };
+  static std::mutex mu;
+  static Entry cache[64];
+  static int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n; ++i)
+      if (cache[i].dev == dev && cache[i].st == st) return cache[i].cus;
+  }
+  int total = 0;
+  if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || total <= 0) total = 256;
+  int cus = total;
+  uint32_t mask[32] = {};
+  if (hipExtStreamGetCUMask(st, 32, mask) == hipSuccess) {
+    int bits = 0;
+    for (int i = 0; i < 32; ++i) bits += __builtin_popcount(mask[i]);
+    if (bits > 0 && bits < cus) cus = bits;
+  } else {
+    (void)hipGetLastError();  // a stream type without the query: the device's count stands
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  if (n < 64) cache[n++] = Entry{dev, st, cus};
+  return cus;
+}
+
 int air_opt(AirOption o) {
   std::call_once(g_once, init_opts);
   return g_val[o].load(std::memory_order_relaxed);
@@ -60,6 +88,7 @@ int air_get_option(const char* name, int* value) {
   *value = air_opt((AirOption)i);
   return AIR_OK;
 }
+int air_stream_compute_units(air_stream_t stream) { return air_stream_cus(air_stream(stream)); }
 int air_option_count(void) { return AIR_OPT_COUNT; }
 const char* air_option_name(int index) { return index >= 0 && index < AIR_OPT_COUNT ? kOpts[index].name : nullptr; }
 }

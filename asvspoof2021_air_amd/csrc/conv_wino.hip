@@ -925,7 +925,8 @@ int air_wino_conv(const float* x, const float* w, float* y, const float* residua
   a.ncot = (M + WBM - 1) / WBM;
   a.trace = g_wino_trace;
   a.nitems = (a.ngroups + 1) / 2 * a.ncot;
-  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  const int ncu = air_stream_cus(st);
+  const int nblk = a.nitems < ncu ? a.nitems : ncu;  // one persistent workgroup per CU the stream can use
   const size_t lds1 = (NBUF * WinoCfg<1>::BUF + WinoCfg<1>::NI * 256) * sizeof(float);
   const size_t lds2 = (NBUF * WinoCfg<2>::BUF + WinoCfg<2>::NI * 256) * sizeof(float);
   static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // and a.split: each is cut in two k-halves; workgroups j < rem take the LOWER halves as their last segment,
   // workgroups rem <= j < 2 rem the UPPER halves as their FIRST segment (stored as partial sums into y, flag
   // raised), so a flag is up long before its reader arrives and no workgroup waits on one that waits.
+  // (Which j takes which half: see is_upper / is_lower below - the text above names the roles, not the indices.)
   const int xg = (int)blockIdx.x % a.nxg, j = (int)blockIdx.x / a.nxg;
   const int Wx = ((int)gridDim.x - xg + a.nxg - 1) / a.nxg;
   // xmode 1: group xg owns the contiguous id range [R0, R0 + nx); xmode 2: the quads congruent to xg mod nxg
@@ -314,9 +315,12 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // segments of this workgroup: [upper half of a cut item]? whole items* [lower half | whole tail item]?
   int tail_seg = -1, tail_item = 0, fc = 0, last_end = nchunk, nseg = nround;
   const int full_base = j;
-  const bool is_lower = cut && j < rem, is_upper = cut && j >= rem && j < 2 * rem;
-  if (is_lower) { tail_seg = nround; tail_item = nround * Wx + j; last_end = half; ++nseg; }
-  else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + (j - rem); fc = half; ++nseg; }
+  // (publishers take the LOWER workgroup indices: were fewer CUs free than the launch has workgroups - another
+  // kernel resident, a partitioned device - the dispatcher, which hands out workgroups in index order, starts them
+  // before the owners that will wait for them; speed and robustness only, the protocol does not depend on it)
+  const bool is_upper = cut && j < rem, is_lower = cut && j >= rem && j < 2 * rem;
+  if (is_lower) { tail_seg = nround; tail_item = nround * Wx + (j - rem); last_end = half; ++nseg; }
+  else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + j; fc = half; ++nseg; }
   else if (!cut && j < rem) { tail_seg = nround; tail_item = nround * Wx + j; ++nseg; }
   if (nseg == 0) return;
   const int S = nround * nchunk + (tail_seg < 0 ? 0 : (is_upper ? nchunk - half : (is_lower ? half : nchunk)));
@@ -868,6 +872,30 @@ int w4_launch(W4Args& a, int trg, int nblk, hipStream_t st) {
   return AIR_OK;
 }
 
+// workgroups of wino4_conv_kernel<*, MH> a CU holds (occupancy query, cached per tile height)
+int w4_resident_per_cu(int mh) {
+  static std::atomic<int> cached[2] = {{-1}, {-1}};
+  std::atomic<int>& c = cached[mh == 3 ? 0 : 1];
+  int v = c.load(std::memory_order_relaxed);
+  if (v >= 0) return v;
+  int n = 0;
+  hipError_t e;
+  if (mh == 3) {
+    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<3>::ULDS + W4_PATCHF) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_conv_kernel<1, 3, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wino4_conv_kernel<1, 3, false>, 256, ldsb);
+  } else {
+    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<4>::ULDS + W4_PATCHF) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_conv_kernel<1, 4, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wino4_conv_kernel<1, 4, false>, 256, ldsb);
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  c.store(n, std::memory_order_relaxed);
+  return n;
+}
+
 }  // namespace
 
 static long long* g_wino4_trace = nullptr;
@@ -937,7 +965,9 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   while (a.ncot % a.cotb != 0) --a.cotb;  // (channel counts here are powers of two times 32: a no-op)
   a.nitems = a.nquad * a.ncot;
   a.trace = g_wino4_trace;
-  const int nblk = a.nitems < 256 ? a.nitems : 256;  // one persistent workgroup per CU
+  // one persistent workgroup per CU the stream can use (144 KB of LDS and 4 x 512 registers: one fits)
+  const int ncu = air_stream_cus(st);
+  const int nblk = a.nitems < ncu ? a.nitems : ncu;
   // dealing groups = XCDs (workgroup b runs on XCD b % 8); WINO4_XCD = 0: one group, i.e. round-robin over
   // the whole chip (for A/B measurements of the locality)
   a.xmode = air_opt(AIR_OPT_WINO4_XCD) == 2 ? 2 : 1;
@@ -946,7 +976,10 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   // cut items.  Under stream capture the per-launch epoch and flag slot are frozen into the graph: the reader of
   // a flag resets it, so every replay starts from zero; the ring must exist before the capture (hipMalloc)
   a.split = 0; a.flags = nullptr; a.epoch = 0;
-  if (air_opt(AIR_OPT_WINO4_SPLIT)) {
+  // Only when every workgroup of the launch is resident at once (nblk <= the CUs behind this stream, which holds
+  // by construction above unless the occupancy query says a workgroup does not fit a CU at all): an owner that
+  // spins on a publisher still waiting for a CU would otherwise hold that CU from it.
+  if (air_opt(AIR_OPT_WINO4_SPLIT) && w4_resident_per_cu(mh) >= 1) {
     unsigned* flag_ring = w4_flag_ring(st);
     static std::atomic<unsigned> next_epoch{1};
     if (flag_ring != nullptr) {

@@ -689,6 +689,11 @@ class Res2Net2(nn.Module):
         training = self.training
         det = lambda p: p.detach()
         B, _, T = x.shape
+        if oh.tp(T) > oh.max_tp():
+            # the wave-per-row statistics / pooling kernels of csrc/ecapa_bf16.hip keep a whole row in registers
+            raise _hip.AirError("bf16-resident ECAPA takes utterances of at most %d frames (got T = %d): use "
+                                "set_compute_dtype('bf16c') or 'fp32' for longer inputs (any length, like the "
+                                "reference)" % (oh.max_tp(), T))
         C = self.C
         dev = x.device
         # conv1 (K = 5 on the fp32 features, :159-161) as a pointwise GEMM on the input unfolded into bf16 rows (autocast

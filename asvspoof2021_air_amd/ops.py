@@ -12,6 +12,22 @@ from . import _hip
 from ._hip import AirConv1d, AirConv2d, ci, cf, csz, dptr, stream
 
 _WS = {}
+_WS_GEN = [0]     # bumped whenever a scratch buffer is (re)allocated
+_WS_PINNED = []   # buffers a captured hipGraph may still point into: never freed
+
+
+def workspace_generation():
+    """Changes whenever workspace() replaced a buffer.  A captured hipGraph holds raw pointers into the buffers
+    that existed at capture time (train.Trainer compares this before every replay and re-captures)."""
+    return _WS_GEN[0]
+
+
+def pin_workspaces():
+    """Called when a hipGraph has been captured: from now on a buffer that is outgrown is kept alive instead of
+    freed, so a replay can never write through a dangling scratch pointer."""
+    for buf in _WS.values():
+        if not any(buf is b for b in _WS_PINNED):
+            _WS_PINNED.append(buf)
 
 
 def workspace(nbytes, device):
@@ -24,6 +40,9 @@ def workspace(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
+        _WS_GEN[0] += 1
+        if _WS_PINNED:
+            _WS_PINNED.append(buf)
     return buf
 
 
@@ -319,24 +338,31 @@ def _c1d_bf16(d, device, which):
 
 
 def conv1d_tap_pack(weights, transpose, out=None):
-    """bf16 operand blocks of a list of equally shaped K = 3 conv weights that sit at a regular stride in memory
-    (the Res2 branch convs inside the parameter arena), packed in one launch.  Returns an (n, 3*Cout*Cin) int16
-    tensor whose rows are the w_packed arguments of conv1d_fwd / conv1d_dgrad, or None if the layout is irregular."""
+    """bf16 operand blocks of a list of equally shaped K = 3 conv weights, packed in ONE launch when they sit at a
+    regular stride in memory (the Res2 branch convs inside the parameter arena) and one launch per weight otherwise
+    (parameters re-assigned outside the arena).  Returns an (n, 3*Cout*Cin) int16 tensor whose rows are the w_packed
+    arguments of conv1d_fwd / conv1d_dgrad / ops_h.conv_tap; None only for shapes the tap kernels do not take."""
     w0 = weights[0]
     n = len(weights)
-    stride = (weights[1].data_ptr() - w0.data_ptr()) // 4 if n > 1 else 0
-    for i, w in enumerate(weights):
-        if w.shape != w0.shape or not w.is_contiguous() or w.data_ptr() != w0.data_ptr() + 4 * stride * i:
-            return None
     Cout, Cin, K = w0.shape
-    if K != 3 or (n > 1 and stride <= 0):
+    if K != 3 or any(w.shape != w0.shape or w.dtype != torch.float32 or not w.is_cuda for w in weights):
         return None
+    weights = [w if w.is_contiguous() else w.contiguous() for w in weights]
+    w0 = weights[0]
+    stride = (weights[1].data_ptr() - w0.data_ptr()) // 4 if n > 1 else 0
+    regular = n == 1 or (stride > 0 and all(w.data_ptr() == w0.data_ptr() + 4 * stride * i for i, w in enumerate(weights)))
     per = Cout * Cin * 3
     if out is None:
         out = torch.empty((n, per), device=w0.device, dtype=torch.int16)
-    _hip.check(_hip.lib().air_conv1d_tap_pack_bf16(dptr(w0), csz(stride), ci(n), ci(Cout), ci(Cin),
-                                                   ci(1 if transpose else 0), dptr(out, torch.int16), stream()),
-               "air_conv1d_tap_pack_bf16")
+    tr = ci(1 if transpose else 0)
+    if regular:
+        _hip.check(_hip.lib().air_conv1d_tap_pack_bf16(dptr(w0), csz(stride), ci(n), ci(Cout), ci(Cin), tr,
+                                                       dptr(out, torch.int16), stream()), "air_conv1d_tap_pack_bf16")
+    else:
+        for i, w in enumerate(weights):
+            _hip.check(_hip.lib().air_conv1d_tap_pack_bf16(dptr(w), csz(0), ci(1), ci(Cout), ci(Cin), tr,
+                                                           dptr(out[i], torch.int16), stream()),
+                       "air_conv1d_tap_pack_bf16")
     return out
 
 

@@ -17,6 +17,11 @@ def tp(T):
     return int(_hip.lib().air_h_tp(ci(T)))
 
 
+def max_tp():
+    """Longest row (frames, padded) the row kernels of csrc/ecapa_bf16.hip accept (h_shape_ok: 256 lanes x HMAXV)."""
+    return 2048
+
+
 def rows(B, C, T, device, zero=False):
     """Fresh (B, C, Tp) buffer.  Writers fill every frame of every row they touch (zeros behind T)."""
     f = torch.zeros if zero else torch.empty
@@ -35,16 +40,17 @@ def hv(t, allow_none=False):
 
 
 def from_f32(x, out=None):
-    """(B, C, T) fp32 (or channel-slice view) -> resident rows, rounded to nearest even."""
+    """(B, C, T) fp32 (dense, or a channel-slice view with a batch stride) -> resident rows, rounded to nearest even:
+    ``air_h_unfold`` with a one-tap window (row c = x[c][t], zeros behind T) - one kernel for every T."""
     B, C, T = x.shape
+    if x.dtype != torch.float32 or not x.is_cuda or x.stride(2) != 1 or (C > 1 and x.stride(1) != T):
+        raise _hip.AirError("from_f32: (B, C, T) fp32 GPU tensor with dense rows expected")
     if out is None:
         out = rows(B, C, T, x.device)
-    Tp = out.shape[2]
-    if Tp == int(_hip.lib().air_conv1d_bf16_tp(ci(T))) and out.is_contiguous():
-        return ops.conv1d_cvt_bf16(x, out)
-    tmp = x.contiguous().to(torch.bfloat16).view(torch.int16)  # test-size shapes only (Tp of the two layouts differ)
-    out.zero_()
-    out[:, :, :T] = tmp
+    q, qs = hv(out)
+    xs = x.stride(0) if B > 1 else C * T
+    _hip.check(_hip.lib().air_h_unfold(dptr(x), csz(xs), ci(B), ci(C), ci(T), ci(out.shape[2]), ci(1), ci(1), ci(0),
+                                       ci(C), q, csz(qs), stream()), "air_h_unfold")
     return out
 
 

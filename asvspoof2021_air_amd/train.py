@@ -67,7 +67,7 @@ class Trainer:
         """Same replica everywhere: broadcast rank 0's parameter arena, the loss parameters and every module
         buffer (BatchNorm running statistics, num_batches_tracked).  Called at construction when world > 1 -
         ranks that built their model from a different seed or checkpoint would otherwise train diverged
-        replicas without any error - and before a checkpoint is written."""
+        replicas without any error.  (save_checkpoint runs NO collective: rank 0 saves its own statistics.)"""
         if self.world == 1:
             return
         td.broadcast(self.model.arena().flat, src=0)
@@ -131,7 +131,8 @@ class Trainer:
         world > 1 (round 2 broadcast the buffers first and deadlocked under that pattern): rank 0 writes its
         OWN BatchNorm running statistics, which is what SURVEY.md 8e asks for, and the other ranks keep
         theirs.  When every rank calls it, pass the same ``val_loss`` everywhere (``dist.all_mean``) so that
-        ``prev_loss`` / ``early_stop_cnt`` stay in step."""
+        ``prev_loss`` / ``early_stop_cnt`` stay in step; either way take the early-stop decision through
+        ``should_stop()``, which all-reduces the counter."""
         if self.out_fold is None:
             raise RuntimeError("call set_out_fold() first")
         improved = val_loss is not None and val_loss < self.prev_loss
@@ -148,6 +149,20 @@ class Trainer:
         elif val_loss is not None:
             self.early_stop_cnt += 1
         return improved
+
+    def should_stop(self, patience=500):
+        """main_train.py:711-715's early stop (``early_stop_cnt == 500 -> break``) as a decision EVERY rank takes
+        alike: under ``if rank == 0: save_checkpoint(...)`` only rank 0's counter advances, and a rank that left
+        the loop alone would leave the others blocked in the next all-reduce.  Collective when world > 1 - call it
+        on every rank, once per epoch."""
+        cnt = self.early_stop_cnt
+        if self.world > 1:
+            dev = self.device if td.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([cnt], dtype=torch.int64, device=dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            cnt = int(t.item())
+            self.early_stop_cnt = cnt
+        return cnt >= patience
 
     def set_epoch(self, epoch_num, lr_decay=0.5, interval=30):
         adjust_learning_rate(self.lr0, self.feat_optimizer, epoch_num, lr_decay, interval)
@@ -198,25 +213,44 @@ class Trainer:
         self._graph_warm = 0
         return self
 
+    def _graph_key(self, pcm, labels):
+        """Everything a capture freezes: shapes, the arithmetic mode and the scalars that travel as kernel
+        arguments (loss weight and the OC-Softmax margins / scale)."""
+        return (tuple(pcm.shape), pcm.dtype, tuple(labels.shape), self.model.compute_dtype, self.feat_len,
+                float(self.weight_loss), float(self.loss.r_real), float(self.loss.r_fake), float(self.loss.alpha),
+                self.padding)
+
     def _graphed_step(self, pcm, labels):
-        key = (tuple(pcm.shape), pcm.dtype, tuple(labels.shape), self.model.compute_dtype, self.feat_len)
+        from . import ops
+        key = self._graph_key(pcm, labels)
         g = self._graph
-        if g is None or g["key"] != key:
-            if g is not None and g["key"] != key:
-                self._graph, self._graph_warm = None, 0
+        if g is not None and (g["key"] != key or g["ws_gen"] != ops.workspace_generation()):
+            # another shape / hyper-parameter, or an eager step in between outgrew a scratch buffer the graph
+            # points into (the old buffers are pinned, so nothing dangles; the capture is simply redone)
+            self._graph, self._graph_warm, g = None, 0, None
+        if g is None:
             # two eager steps first: arenas, workspaces, lazy kernel attributes, optimiser state, the side stream
             if self._graph_warm < 2:
                 self._graph_warm += 1
                 return None
             g = self._capture(key, pcm, labels)
+        if not self.model.training:  # an interleaved score() left eval mode behind
+            self.model.train()
+        # The captured kernels write the gradients into the tensors that were p.grad AT CAPTURE (arena views for the
+        # model, a tensor of the graph's private pool for the loss centre).  Any eager step or zero_grad() since then
+        # replaced or dropped them: re-point every p.grad, or the optimisers would apply stale / no gradients.
+        for p, gr in g["grads"]:
+            if p.grad is not gr:
+                p.grad = gr
         g["pcm"].copy_(pcm, non_blocking=True)
         g["labels"].copy_(labels, non_blocking=True)
         g["graph"].replay()
         self.feat_optimizer.step(grad_scale=1.0)
         self.loss_optimizer.step(grad_scale=1.0)
-        return g["loss"].detach().clone(), g["neg"]
+        return g["loss"].detach().clone(), g["neg"].clone()
 
     def _capture(self, key, pcm, labels):
+        from . import ops
         self.model.train()
         s_pcm, s_labels = pcm.detach().clone(), labels.detach().clone()
         self.feat_optimizer.zero_grad()
@@ -227,9 +261,13 @@ class Trainer:
             feats, _ = self.model(self.features(s_pcm, None))
             loss, neg = self.loss(feats, s_labels)
             (loss * self.weight_loss).backward()
-        # p.grad now ARE the views of the gradient arena the captured kernels write: they stay set (no zero_grad
-        # between replays - every gradient is overwritten, none accumulated)
-        self._graph = dict(key=key, graph=graph, pcm=s_pcm, labels=s_labels, loss=loss, neg=neg)
+        # p.grad now ARE the tensors the captured kernels write (no zero_grad between replays - every gradient is
+        # overwritten, none accumulated); kept here so _graphed_step can restore them after eager interludes
+        grads = [(p, p.grad) for p in list(self.model.parameters()) + list(self.loss.parameters())
+                 if p.grad is not None]
+        ops.pin_workspaces()
+        self._graph = dict(key=key, graph=graph, pcm=s_pcm, labels=s_labels, loss=loss, neg=neg, grads=grads,
+                           ws_gen=ops.workspace_generation())
         return self._graph
 
     @torch.no_grad()

@@ -116,10 +116,28 @@ def roofline_leg(trainer, batches):
                            "frac": round(gbs / PEAK_HBM_GBS, 4)}
     lf = [r for r in rows if r["kernel"] == "lfcc_kernel"]
     if lf:
-        gbs = lf[0]["work"] / (lf[0]["total_ms"] * 1e-3) / 1e9
+        # A 35 us kernel inside a single event bracket reads ~20 us long (event -> kernel -> event dependency gaps:
+        # round 3's line said 57.9 us where rocprofv3 says 34.9).  So the front-end kernel is timed over N = 50
+        # back-to-back launches inside ONE bracket on the launch stream (= torch's current stream), the same
+        # fused LFCC + pad + transpose call the train step makes; the single-bracket figure is kept beside it.
+        pcm = batches[0][0]
+        for _ in range(5):
+            trainer.features(pcm)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 50
+        e0.record()
+        for _ in range(nrep):
+            trainer.features(pcm)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / nrep
+        per_launch_bytes = lf[0]["work"] / lf[0]["launches"]
+        gbs = per_launch_bytes / (ms * 1e-3) / 1e9
         out["lfcc_kernel"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": round(gbs / PEAK_HBM_GBS, 4),
-                              "avg_launch_ms": round(lf[0]["total_ms"] / lf[0]["launches"], 4)}
+                              "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(ms, 4),
+                              "timing": "%d back-to-back launches in one event bracket" % nrep,
+                              "algorithmic_bytes": round(per_launch_bytes),
+                              "single_bracket_launch_ms": round(lf[0]["total_ms"] / lf[0]["launches"], 4)}
     out["per_kernel"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // 2,
                           "ms_per_step": round(r["total_ms"] / 2, 3),
                           "algorithmic_rate": round(r["work"] / (r["total_ms"] * 1e-3) / 1e12, 2),
@@ -215,24 +233,32 @@ def cpu_baseline_leg():
         sweep[min(nt, ncpu)] = round(8.0 / (time.perf_counter() - t0), 2)
     cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
-    times = []
+    # 3 warm-up + 10 timed steps, median - taken THREE times, the best median reported (the figure
+    # wandered 35 - 58 utt/s across boxes on identical code: a host that is busy during one window is not the baseline)
+    medians, times = [], []
     t_start = time.perf_counter()
-    for it in range(13):  # 3 warm-up + 10 timed, median
-        t0 = time.perf_counter()
-        tr.step(x, labels, None)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > 30.0 and len(times) >= 4:  # bounded sample
+    for rnd in range(3):
+        times = []
+        for it in range(13 if rnd == 0 else 10):
+            t0 = time.perf_counter()
+            tr.step(x, labels, None)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 30.0 and len(times) >= 4:  # bounded sample
+                break
+        warm = min(3, len(times) - 1) if rnd == 0 else 0
+        medians.append(float(np.median(times[warm:])))
+        if time.perf_counter() - t_start > 30.0:
             break
-    warm = min(3, len(times) - 1)
-    step = float(np.median(times[warm:]))
+    warm = 0
+    step = min(medians)
     per_utt = t_lfcc / 64 + step / 8
     return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
             "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
                       "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, 3 warm-up + "
-                      "%d timed, median %.3f s/step at the fastest of the swept thread counts (%d of %d host threads; "
-                      "PyTorch-CPU conv backward collapses when oversubscribed)" % (
-                          1e3 * t_lfcc / 64, len(times) - warm, step, cores, ncpu),
+                      "10 timed, best of %d medians %.3f s/step (medians %s) at the fastest of the swept thread counts "
+                      "(%d of %d host threads; PyTorch-CPU conv backward collapses when oversubscribed)" % (
+                          1e3 * t_lfcc / 64, len(medians), step, [round(m, 3) for m in medians], cores, ncpu),
             "sweep": {"unit": "train-step utt/s after one warm-up step", "threads": sweep},
             "lfcc_utt_per_s": round(64 / t_lfcc, 1), "train_step_utt_per_s": round(8 / step, 2)}
 
@@ -255,6 +281,9 @@ def main():
     ap.add_argument("--augment", action="store_true",
                     help="on-the-fly IR-convolution channel augmentation of every utterance in the HIP front-end "
                          "(BASELINE configs[4]; 30 synthetic 1024-tap IRs)")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="read the loss back on the host after every timed step, as the reference's loop does "
+                         "(main_train.py:479-481 writes loss.item() to train_loss.log per iteration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
@@ -322,6 +351,8 @@ def main():
         last = None
         for i in range(steps):
             last, _ = trainer.step(*batches[i % nb])
+            if args.sync_each_step:
+                last.item()
         t_host = time.perf_counter() - t0  # all launches issued (the host side of the step; the GPU is behind)
         fence()
         dt = time.perf_counter() - t0
@@ -379,7 +410,7 @@ def main():
         # (a failure of this additional leg must not cost the headline line; with world > 1 every rank takes the
         # same path through its collectives, so an exception there is not caught - it would desynchronise the ranks)
         try:
-            _, e = run_config("ecapa", "bf16", 0, max(2, min(args.steps, 8)), min(args.warmup, 2), False, not args.no_roofline)
+            _, e = run_config("ecapa", "bf16", 0, args.steps, args.warmup, False, not args.no_roofline)
             e["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
             e["dtype"] = "bf16"
             e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16-resident "
@@ -390,8 +421,24 @@ def main():
             if world > 1:
                 raise
             extra["ecapa_bf16_b128"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if args.model == "resnet":
-            from asvspoof2021_air_amd.resnet import ResNet  # noqa: F401  (model for the line below)
+        # the native frame count of 4 s audio ("frame count must be stated with every number"): both models
+        # without the reference's repeat-padding to feat_len 750, same steps / warm-up, no instrumented legs
+        if FEAT_LEN != 401:
+            keep_len = FEAT_LEN
+            for key, (mname, mdt) in (("resnet_f32_b64_t401", ("resnet", None)), ("ecapa_bf16_b128_t401", ("ecapa", "bf16"))):
+                try:
+                    FEAT_LEN = 401
+                    torch.cuda.empty_cache()
+                    _, e = run_config(mname, mdt, 0, args.steps, args.warmup, False, False)
+                    e["dtype"] = "bf16" if mdt else "f32"
+                    e["workload"] = "the same train step at the native T = 401 frames (no repeat-padding)"
+                    extra[key] = e
+                except Exception as exc:  # noqa: BLE001
+                    if world > 1:
+                        raise
+                    extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                finally:
+                    FEAT_LEN = keep_len
         model = None
     BATCH = main_batch
     # roofline.traffic: measured now, by PMC child passes of this same command (N = 1 only: rocprofv3 around one
@@ -422,6 +469,7 @@ def main():
                        "parallelism": "dp%d" % world},
             "final_loss": main_res["final_loss"],
             "host_issue_ms_per_step": main_res["host_issue_ms_per_step"],
+            "sync_each_step": bool(args.sync_each_step),
             "ddp": main_res["ddp"],
         }
         if args.model == "ecapa":

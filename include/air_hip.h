@@ -67,6 +67,13 @@ int air_get_option(const char* name, int* value_out);
 int air_option_count(void);
 const char* air_option_name(int index); /* NULL when out of range */
 
+/* Compute units a launch on `stream` can occupy: the stream's CU mask (hipExtStreamCreateWithCUMask, or the
+ * process-wide ROC_GLOBAL_CU_MASK) capped by the device's CU count.  The persistent kernels (one workgroup per
+ * CU: the Winograd convolutions) size their grids by it, and wino4_conv_kernel cuts tail items between two
+ * workgroups only when every workgroup of the launch is resident at once.  No reference counterpart
+ * (main_train.py:101 pins one whole GPU through CUDA_VISIBLE_DEVICES). */
+int air_stream_compute_units(air_stream_t stream);
+
 /* ------------------------------------------------------------------ LFCC --
  * Replaces LFCC.forward (feature_extraction.py:93-138) incl. delta (:41-58),
  * with the filterbank of LFCC.__init__ (:77-86) and the LinearDCT weight

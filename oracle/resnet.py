@@ -78,13 +78,36 @@ def _bn(x, p, prefix, training, updates):
     return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
 
 
-def preact_block(x, p, prefix, stride, training, updates):
+class ReluProbe:
+    """Test helper (parity of the ReLU decisions, tests/test_resnet_gpu.py): stands in for F.relu in the forward
+    below.  ``masks`` = None: records the sign decision of every ReLU in execution order.  ``masks`` = a list of
+    boolean tensors (the decisions ANOTHER evaluation of the same net took, e.g. the HIP path's): applies those
+    instead of its own - y = x * mask, so the backward pass gates with them too - and counts per ReLU where its
+    own sign would have differed (``flips``) together with the largest |pre-activation| among them."""
+
+    def __init__(self, masks=None):
+        self.masks, self.own, self.flips, self.flip_mag = masks, [], [], []
+
+    def __call__(self, x):
+        own = x.detach() > 0
+        i = len(self.own)
+        self.own.append(own)
+        if self.masks is None:
+            return F.relu(x)
+        m = self.masks[i].to(device=x.device).reshape(x.shape)
+        diff = own != m
+        self.flips.append(int(diff.sum()))
+        self.flip_mag.append(float(x.detach().abs()[diff].max()) if bool(diff.any()) else 0.0)
+        return x * m.to(x.dtype)
+
+
+def preact_block(x, p, prefix, stride, training, updates, relu=F.relu):
     """resnet.py:63-69.  The 1x1 shortcut acts on the ACTIVATED tensor (:64-65)."""
-    out = F.relu(_bn(x, p, prefix + ".bn1", training, updates))
+    out = relu(_bn(x, p, prefix + ".bn1", training, updates))
     key = prefix + ".shortcut.0.weight"
     shortcut = F.conv2d(out, p[key], None, stride) if key in p else x
     out = F.conv2d(out, p[prefix + ".conv1.weight"], None, stride, 1)
-    out = F.conv2d(F.relu(_bn(out, p, prefix + ".bn2", training, updates)),
+    out = F.conv2d(relu(_bn(out, p, prefix + ".bn2", training, updates)),
                    p[prefix + ".conv2.weight"], None, 1, 1)
     return out + shortcut
 
@@ -104,14 +127,16 @@ def self_attention_pool(x, att_weights, noise=None, mean_only=False):
     return torch.cat((avg, std), 1)
 
 
-def resnet18_forward(p, x, training=True, noise=None, updates=None, taps=None):
+def resnet18_forward(p, x, training=True, noise=None, updates=None, taps=None, relu=None):
     """ResNet.forward (resnet.py:174-191).
 
     p: dict of tensors keyed like the reference state_dict.
     x: (B, 1, 60, T).  Returns (feat (B, enc_dim), mu (B, nclasses)).
     ``updates`` (dict) receives new BN running stats when training.
     ``taps`` (dict) receives intermediate activations for layer-wise parity.
+    ``relu``: stand-in for F.relu (a ReluProbe); the 18 ReLUs run in the order stem, (bn1, bn2) per block, bn5.
     """
+    relu = F.relu if relu is None else relu
     def tap(name, t):
         if taps is not None:
             taps[name] = t
@@ -119,15 +144,15 @@ def resnet18_forward(p, x, training=True, noise=None, updates=None, taps=None):
 
     x = F.conv2d(x, p["conv1.weight"], None, (3, 1), (1, 1))  # :176
     tap("conv1", x)
-    x = F.relu(_bn(x, p, "bn1", training, updates))  # :177
+    x = relu(_bn(x, p, "bn1", training, updates))  # :177
     for li, stride in enumerate(LAYER_STRIDES, start=1):
         for bi in range(BLOCKS_PER_LAYER):
             x = preact_block(x, p, "layer%d.%d" % (li, bi), stride if bi == 0 else 1,
-                             training, updates)
+                             training, updates, relu)
         tap("layer%d" % li, x)
     x = F.conv2d(x, p["conv5.weight"], None, 1, (0, 1))  # :182
     tap("conv5", x)
-    x = F.relu(_bn(x, p, "bn5", training, updates)).squeeze(2)  # :183
+    x = relu(_bn(x, p, "bn5", training, updates)).squeeze(2)  # :183
     stats = self_attention_pool(x.permute(0, 2, 1).contiguous(),
                                 p["attention.att_weights"], noise)  # :185
     tap("stats", stats)

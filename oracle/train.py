@@ -50,6 +50,7 @@ class OracleTrainer:
         self.step_count = 0
         self.m = {}
         self.v = {}
+        self.relu = None  # ResNet only: a resnet_oracle.ReluProbe standing in for F.relu (ReLU-decision parity)
 
     def trainable(self):
         return [k for k, v in self.params.items()
@@ -57,7 +58,7 @@ class OracleTrainer:
 
     def forward(self, x, training=True, noise=None, updates=None, taps=None):
         if self.model == "resnet":
-            return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps)
+            return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps, relu=self.relu)
         return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps,
                                           bf16=self.bf16)
 

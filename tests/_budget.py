@@ -25,7 +25,9 @@ import numpy as np
 
 STRICT = {
     "step2_rtol": 1e-4,        # tests/test_resnet_gpu.py::test_trajectory_vs_golden, loss of step 2
-    "g_center_atol": 1e-6,     # ::test_grads_vs_oracle_small, OC-Softmax centre gradient
+    "g_center_atol": 5e-6,     # ::test_grads_vs_oracle_small, OC-Softmax centre gradient: the bound itself (rtol 0)
+                               # on entries up to 1.75 (round 1 wrote 1e-6 next to an rtol of 1e-3 that did the
+                               # binding; measured 3.2e-6 strict, 1.1e-5 default)
     "full_size_slack": 1e-3,   # tests/test_full_size_gpu.py: e_hip <= 3 e_cpu + slack
     "adv_rel_max": 2e-3,       # tests/test_adversarial.py: conv1 / fc gradient, relative to max
     "conv_rtol": 1e-5,         # tests/test_kernels_gpu.py: one 3x3 convolution, of the output scale

@@ -17,6 +17,8 @@ CPU autocast rounds to bf16 at: conv1d (Conv1d weight AND activations, output te
 activation between layers IS a bf16 tensor and every elementwise result is rounded to bf16.  Differences of this
 repo's arithmetic from that rule set are listed in DESIGN.md section 2 from the output of this script.
 
+Round 4 adds the EVAL-mode runs (running statistics: no amplification), which pin the arithmetic sharply.
+
 Usage:  python tests/golden/make_golden_bf16.py        (build container only: needs /root/reference)
 """
 import os
@@ -104,6 +106,64 @@ def main():
             print("  %s oracle(bf16=%s): feat vs autocast %.3g (vs fp32 %.3g), loss %.6f, grads vs autocast median %.3g "
                   "max %.3g (vs fp32 median %.3g max %.3g)" % (tag, mode, rel_l2(fo, fac[0]), rel_l2(fo, f32[0]), lo.item(),
                                                               np.median(da), da.max(), np.median(df), df.max()))
+    # ---- eval mode (round 4): running statistics instead of batch statistics - no ~100x
+    # amplification of the rounding, so HERE a sharp bound holds between any two faithful bf16 evaluations of the
+    # graph.  The real reference module under autocast, eval(), same filler weights and buffers; next to it the fp32
+    # reference and both oracle modes.  tests/test_oracle_golden.py and tests/test_ecapa_gpu.py assert the oracle
+    # and the HIP eval forward against ``feat_autocast_eval_*`` (not against the fp32 golden).
+    for tag, (B, T) in (("small", (2, 96)), ("full", (8, 750))):
+        x = synth_feat((B, 60, T), seed=900 + T)
+        net = ref_ecapa.Res2Net2(ref_ecapa.Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+        fill_module_(net)
+        net.train(False)
+        caps = {}
+        hooks = [getattr(net, n).register_forward_hook(lambda m, i, o, n=n: caps.__setitem__(n, o.detach()))
+                 for n in ("bn1", "layer1")]
+        with torch.no_grad():
+            f32e, o32e = net(x)
+            c32 = dict(caps)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                face, oace = net(x)
+        for h in hooks:
+            h.remove()
+        assert face.dtype == torch.bfloat16 and caps["bn1"].dtype == torch.bfloat16
+        out["feat_autocast_eval_" + tag] = face.float()
+        out["out_autocast_eval_" + tag] = oace.float()
+        out["feat_fp32_eval_" + tag] = f32e
+        if tag == "small":
+            # Where the two rule sets COINCIDE a sharp pin exists.  First layer (conv1 -> ReLU -> bn1, :159-161): both
+            # round the operands to bf16, accumulate in fp32, round the conv output, and round the BatchNorm output -
+            # so utterance 0's (512, 96) bf16 tensor must reproduce bit for bit up to fp32 summation order (a handful
+            # of values on a rounding boundary).  Stored as bf16 BITS.  Behind the first Bottle2neck the rule sets
+            # differ (SE product and residual sum: two roundings under autocast, one here; squeeze mean in bf16 vs
+            # fp32): every 4th channel of utterance 0 as the sample for a relative-L2 bound.
+            out["h0_bits_autocast_eval_small"] = caps["bn1"][0].contiguous().view(torch.int16).numpy().view(np.uint16)
+            out["x1_sample_autocast_eval_small"] = caps["layer1"][0, ::4].float()
+            out["x1_sample_fp32_eval_small"] = c32["layer1"][0, ::4].float()
+        eparams = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        msg = []
+        for mode in modes:
+            taps = {}
+            fo, _ = o_ecapa.ecapa_forward(eparams, x, training=False, bf16=mode, taps=taps)
+            msg.append("oracle(bf16=%s) vs autocast %.3g, vs fp32 %.3g" % (mode, rel_l2(fo, face.float()), rel_l2(fo, f32e)))
+            if "h0" in taps and tag == "small":
+                def mismatches(h0):
+                    hb = h0[0].to(torch.bfloat16)
+                    assert torch.equal(hb.float(), h0[0].float()), "resident h0 is not bf16-representable"
+                    return int((hb.view(torch.int16) != caps["bn1"][0].view(torch.int16)).sum()), hb.numel()
+                n_prod, n_all = mismatches(taps["h0"])
+                o_ecapa.AUTOCAST_BIAS = True   # autocast's rule for the conv bias (oracle/ecapa.py)
+                try:
+                    t2 = {}
+                    o_ecapa.ecapa_forward(eparams, x, training=False, bf16=mode, taps=t2)
+                finally:
+                    o_ecapa.AUTOCAST_BIAS = False
+                n_auto, _ = mismatches(t2["h0"])
+                msg.append("h0 (first layer's stored output): %d of %d values differ from autocast with the bias rounded as "
+                           "autocast does, %d with this build's fp32 bias; x1 vs autocast %.3g (autocast vs fp32 %.3g)" % (
+                               n_auto, n_all, n_prod, rel_l2(taps["x1"][0, ::4], caps["layer1"][0, ::4].float()),
+                               rel_l2(caps["layer1"][0, ::4].float(), c32["layer1"][0, ::4])))
+        print("  eval %s: autocast vs fp32 %.3g; %s" % (tag, rel_l2(face.float(), f32e), "; ".join(msg)))
     save("ecapa_bf16.npz", **out)
 
 

@@ -90,6 +90,13 @@ def _worker(rank, world, port, out):
     ok = torch.equal(ar.grad[:ar.head_total], total * torch.arange(ar.head_total, dtype=torch.float32))
     ok &= bool((ar.grad[ar.head_total:] == 123.0 + rank).all())  # tail untouched
     ok &= bool((centre.grad == total).all())
+    # early stop under `if rank == 0: save_checkpoint(...)`: only rank 0's counter advanced, every rank must stop
+    from asvspoof2021_air_amd.train import Trainer
+    tr = Trainer.__new__(Trainer)
+    tr.world, tr.device, tr.early_stop_cnt = world, torch.device("cpu"), (3 if rank == 0 else 0)
+    ok &= tr.should_stop(patience=4) is False and tr.early_stop_cnt == 3
+    tr.early_stop_cnt += 1 if rank == 0 else 0
+    ok &= tr.should_stop(patience=4) is True
     out[rank] = bool(ok)
     td.barrier()
     td.destroy_process_group()

@@ -241,15 +241,32 @@ def test_ecapa_bf16_oracle_pinned_to_fp32_goldens(golden):
     np.testing.assert_allclose(wa.grad.numpy(), wb.grad.numpy(), atol=1e-12)
 
 
+def _bf16_ulp(a):
+    """Spacing of bf16 values at |a| (8 significant bits)."""
+    return np.exp2(np.floor(np.log2(np.maximum(np.abs(a), 1e-30))) - 7)
+
+
 @pytest.mark.parametrize("mode", [True, "resident"])
 def test_ecapa_bf16_oracle_vs_reference_under_autocast(golden, mode):
-    """X2 pin (round 3): tests/golden/ecapa_bf16.npz holds the REAL reference ``Res2Net2`` run under
-    ``torch.autocast('cpu', bfloat16)`` on the filler weights (make_golden_bf16.py).  On this filler-initialised net
-    bf16 rounding is amplified ~100x, so two bf16 arithmetics agree only statistically - autocast itself sits 0.14
-    (B = 2, T = 96) / 0.056 (B = 8, T = 750) relative L2 from the fp32 reference on the embedding and 0.45 - 0.94
-    (median over tensors) on the gradients.  What can be pinned, and is asserted here: this repo's arithmetic is no
-    farther from the autocast run than the autocast run is from fp32 (x 1.25), its loss is inside the same band, and
-    the eval-mode embedding (no batch statistics, no amplification) is within bf16 tolerance of the fp32 golden."""
+    """X2 pin: tests/golden/ecapa_bf16.npz holds the REAL reference ``Res2Net2`` run under
+    ``torch.autocast('cpu', bfloat16)`` on the filler weights (make_golden_bf16.py).
+
+    TRAIN mode (round 3): on this filler-initialised net batch statistics amplify bf16 rounding ~100x, so two bf16
+    arithmetics agree only statistically - autocast itself sits 0.14 (B = 2, T = 96) relative L2 from the fp32
+    reference on the embedding.  Asserted, all computed HERE from the oracle's output and the reference's tensors:
+    the oracle is no farther from the autocast run than the autocast run is from fp32 (x 1.25), its loss inside the
+    same band.
+
+    EVAL mode (round 4, running statistics: no amplification) - the sharp part:
+    * the bf16 NOISE FLOOR: the reference under autocast sits 1.08e-2 (2, 96) / 1.19e-2 (8, 750) from its own fp32
+      run on the embedding, 6.5e-3 already behind the first Bottle2neck - two independent bf16 evaluations of this
+      graph cannot be closer than that to each other; the oracle must lie inside 1.25e-2 of the autocast run
+      (measured 1.03e-2 / 1.12e-2) AND closer to the fp32 reference than autocast is (<= 6e-3; measured 4.6e-3 /
+      4.2e-3: statistics and biases are kept in fp32 here);
+    * where the rule sets COINCIDE the pin is bit-level: the first layer's stored output (conv1 -> ReLU -> bn1,
+      ecapa_tdnn.py:159-161) of the resident mode reproduces the autocast run's bf16 BITS on all 49,152 values of
+      utterance 0 once the conv bias is rounded the way autocast rounds it (``oracle.ecapa.AUTOCAST_BIAS``), and with
+      this build's fp32 bias at most 5 % of the values move (3.1 %; relative L2 of the tensor 8.9e-4)."""
     g = golden("ecapa_bf16.npz")
     seed, B, T = [int(v) for v in g["x_seed_small"]]
     x = synth_feat((B, 60, T), seed=seed)
@@ -262,18 +279,36 @@ def test_ecapa_bf16_oracle_vs_reference_under_autocast(golden, mode):
     assert d_mine <= 1.25 * d_auto, (d_mine, d_auto)
     la, l32 = float(g["loss_autocast_small"]), float(g["loss_fp32_small"])
     assert abs(loss.item() - la) <= 3.0 * abs(la - l32) + 1e-3 * l32, (loss.item(), la, l32)
-    tag = "%s_" % str(mode).lower()
-    # the recorded figures of the generator run reproduce (same code, same seeds)
-    np.testing.assert_allclose(d_mine, float(g["oracle_feat_rel_autocast_" + tag + "small"]), rtol=0.05)
-    for sz in ("small", "full"):
-        da = g["oracle_grad_rel_autocast_" + tag + sz]
-        ref = g["grad_rel_autocast_vs_fp32_" + sz]
-        assert np.median(da) <= 1.4 * np.median(ref), (sz, np.median(da), np.median(ref))
-        assert float(g["oracle_feat_rel_autocast_" + tag + sz]) <= 1.25 * np.linalg.norm(
-            g["feat_autocast_" + sz].astype(np.float64) - g["feat_fp32_" + sz]) / np.linalg.norm(g["feat_fp32_" + sz])
-    # eval mode (running statistics): bf16 tolerance of the reference's fp32 golden
-    e = golden("ecapa.npz")
-    xe = synth_feat((2, 60, 96), seed=496)
-    fe, _ = o_ecapa.ecapa_forward(fill_state(o_ecapa.ecapa_shapes()), xe, training=False, bf16=mode)
-    rel = np.linalg.norm(fe.numpy() - e["feat_small_eval"]) / np.linalg.norm(e["feat_small_eval"])
-    assert 1e-4 < rel < 2e-2, rel
+    # ---- eval mode
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    params = fill_state(o_ecapa.ecapa_shapes())
+    for tag in ("small", "full"):
+        seed, B, T = [int(v) for v in g["x_seed_" + tag]]
+        xe = synth_feat((B, 60, T), seed=seed)
+        taps = {}
+        fe, _ = o_ecapa.ecapa_forward(params, xe, training=False, bf16=mode, taps=taps)
+        fae, f32e = g["feat_autocast_eval_" + tag].astype(np.float64), g["feat_fp32_eval_" + tag].astype(np.float64)
+        floor = rel(fae, f32e)
+        assert 5e-3 < floor < 1.5e-2            # the reference's own bf16 noise floor (1.08e-2 / 1.19e-2)
+        assert rel(fe.numpy(), fae) <= 1.25e-2, (tag, rel(fe.numpy(), fae))
+        assert rel(fe.numpy(), f32e) <= 6e-3, (tag, rel(fe.numpy(), f32e))
+        if tag == "small" and mode == "resident":
+            x1a, x1f = g["x1_sample_autocast_eval_small"], g["x1_sample_fp32_eval_small"].astype(np.float64)
+            assert rel(taps["x1"][0, ::4].numpy(), x1a.astype(np.float64)) <= 7e-3     # measured 5.6e-3 (floor 6.5e-3)
+            assert rel(taps["x1"][0, ::4].numpy(), x1f) <= 7e-3
+            want = torch.from_numpy(g["h0_bits_autocast_eval_small"].view(np.int16)).view(torch.bfloat16).float().numpy()
+            got = taps["h0"][0].numpy()
+            diff = got != want
+            assert diff.mean() <= 0.05, diff.mean()                                     # measured 3.1 %
+            # each moved value by one ulp of the CONV output it came from (the BatchNorm behind it scales that and can
+            # cancel against beta, so "ulps of the stored value" is not the measure): relative L2 8.9e-4, no entry by
+            # more than one ulp of the tensor's largest value
+            assert rel(got, want.astype(np.float64)) <= 1.5e-3
+            assert np.abs(got - want).max() <= _bf16_ulp(np.abs(want).max())
+            o_ecapa.AUTOCAST_BIAS = True
+            try:
+                t2 = {}
+                o_ecapa.ecapa_forward(params, xe, training=False, bf16=mode, taps=t2)
+            finally:
+                o_ecapa.AUTOCAST_BIAS = False
+            assert int((t2["h0"][0].numpy() != want).sum()) <= 8                        # measured 0 of 49,152

@@ -12,6 +12,13 @@ from _budget import conv_path, record, tol  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+# test_grads_vs_oracle_small, against the fp64 oracle evaluated with the HIP run's own ReLU decisions: 10x the
+# worst per-tensor relative L2 `strict` measures against the plain oracle (1.06e-5, gpurun_out/parity_measured.jsonl)
+MASKED_REL_L2 = 1.1e-4
+MASKED_MAX_ENTRY = 1e-3        # worst single entry of a gradient tensor, relative to the tensor's largest
+FLIP_MAX_PREACT = 1e-3         # |BatchNorm output| (O(1) scale) of a pre-activation whose ReLU decision differs
+FLIP_MAX_COUNT = {"strict": 64, "default": 256}  # of 1.80 M ReLU inputs at (B, T) = (2, 96)
+
 
 def att_T(T):
     for _ in range(3):
@@ -116,20 +123,56 @@ def _grads_vs_oracle_small(golden, path):
         err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
         worst = max(worst, err)
         assert err < tol("grad_rel_l2", path), "%s: relative L2 grad err %.3g" % (k, err)
-        # worst entry: 5 % of the tensor's largest under `strict`.  Under `default` a pre-activation that lands on
-        # the other side of a ReLU (see above) moves the entries of ONE input channel's weights by a whole
-        # product term: isolated outliers among errors of 1e-6 - at most 1 % of a tensor's entries may exceed the
-        # strict bound, none the derived one
+        # worst single entry against the UNMASKED oracle: 5 % of the tensor's largest under `strict`; under `default`
+        # single entries carry no bound of their own here - a pre-activation that lands on the other side of a ReLU
+        # moves whole product terms - they are bounded below, against the oracle evaluated with THIS run's ReLU
+        # decisions, where every entry of every tensor has to agree
         e_abs, scale_k = np.abs(got - ref), np.abs(ref).max()
         if path == "strict":
-            assert e_abs.max() <= 5e-2 * scale_k, k
-        else:
-            assert (e_abs > 5e-2 * scale_k).mean() <= 1e-2, (k, float((e_abs > 5e-2 * scale_k).mean()))
-            assert e_abs.max() <= tol("grad_max_entry", path) * scale_k, (k, float(e_abs.max() / scale_k))
+            assert e_abs.max() <= tol("grad_max_entry", path) * scale_k, k
         np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_" + k], rtol=tol("grad_rel_l2", path))
+    # ---- the ReLU-flip account.  `default` sits ~1000x farther from the fp64 oracle than
+    # `strict` (1.2e-2 against 1.1e-5 worst relative L2) where the convolutions' rounding differs 4.6x.  Claim: all
+    # of the excess comes from pre-activations within rounding of 0 that take the other branch of a ReLU (two
+    # samples per BatchNorm: one flipped element moves a tensor by ~1/sqrt(N)).  Proof: take the sign decisions of
+    # all 18 ReLUs from the HIP run (the activated tensors it saved for backward), evaluate the fp64 oracle WITH
+    # those decisions (oracle/resnet.py::ReluProbe: y = x * mask, forward and backward), and every gradient tensor
+    # must agree to 10x what `strict` measures - under BOTH paths; the probe counts where the oracle's own sign
+    # differed and how far from 0 those pre-activations were.
+    with torch.no_grad():
+        _, _, S = m._forward_impl(x.cuda().contiguous(), None, save=True)
+    masks = [S["blocks"][0][1] > 0]
+    for blk in S["blocks"]:
+        masks += [blk[5] > 0, blk[6] > 0]
+    masks.append((S["a5v"] > 0).unsqueeze(2))
+    probe = o_resnet.ReluProbe([mk.cpu() for mk in masks])
+    trm = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
+    trm.relu = probe
+    _, _, _, gm, gcm, _ = trm.loss_and_grads(x.double(), labels, noise.double())
+    n_act, n_flip = sum(int(mk.numel()) for mk in masks), sum(probe.flips)
+    worst_m, worst_e = 0.0, 0.0
+    for k, p in m.named_parameters():
+        if gm[k] is None:
+            continue
+        ref, got = gm[k].numpy(), p.grad.cpu().double().numpy()
+        err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
+        ent = np.abs(got - ref).max() / np.abs(ref).max()
+        worst_m, worst_e = max(worst_m, err), max(worst_e, ent)
+        assert err <= MASKED_REL_L2, "%s: %.3g relative L2 against the oracle under this run's ReLU decisions" % (k, err)
+        assert ent <= MASKED_MAX_ENTRY, (k, float(ent))
+    gc_err = float(np.abs(lossm.center.grad.cpu().numpy() - gcm.numpy()).max())
+    assert gc_err <= tol("g_center_atol", path)
+    record("resnet_small_relu_flips[%s]" % path, {"flips": n_flip, "of": n_act, "per_relu": probe.flips,
+                                                    "max_abs_preact_of_a_flip": max(probe.flip_mag),
+                                                    "masked_worst_relL2": worst_m, "masked_worst_entry": worst_e,
+                                                    "masked_g_center_abs": gc_err})
+    print("ReLU flips %d of %d, masked worst rel L2 %.3g entry %.3g" % (n_flip, n_act, worst_m, worst_e))
+    # normalised pre-activations are O(1): a flipped one was within rounding of 0, and there are few of them
+    assert max(probe.flip_mag) <= FLIP_MAX_PREACT and n_flip <= FLIP_MAX_COUNT[path], (n_flip, probe.flip_mag)
     record("resnet_small_g_center_abs[%s]" % path, float(np.abs(lossm.center.grad.cpu().numpy() - g["g_center"]).max()))
     record("resnet_small_worst_grad_relL2[%s]" % path, float(worst))
-    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=1e-3, atol=tol("g_center_atol", path))
+    # (rtol = 0: the constant IS the bound - with round 1's rtol 1e-3 on entries of magnitude 1.75 it bound nothing)
+    np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), g["g_center"], rtol=0, atol=tol("g_center_atol", path))
     # gradients live in the flat arena (zero-copy views)
     arena = m.arena()
     assert m.conv1.weight.grad.data_ptr() == arena.grad_view("conv1.weight").data_ptr()
