@@ -563,26 +563,63 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     // zero weights and have no channel to land in - their offsets are out of range (wave-uniform test)
     const bool tail16 = cot * W4_CO + 16 >= a.Cout;
     asm volatile("s_nop 15");  // the last MFMAs' results (inline asm: no compiler-inserted wait states)
-    // The residual and the partner's partial sums are ALWAYS loaded, through descriptors that are empty (every
-    // offset out of range: zeros, no memory access) when there is nothing to add: no branches around the loads, so
-    // the compiler issues a channel pair's loads together and waits for them once (with `if (use_res)` around
-    // each it waited for every single load with vmcnt(0)).
+    // The residual and the partner's partial sums come through descriptors that are empty (every offset out of
+    // range: zeros, no memory access) when that operand does not exist: no per-load branches.
     const bool use_res = has_res && !partial;
     const __amdgpu_buffer_rsrc_t rrs_e = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(has_res ? a.residual : a.y), (short)0, use_res ? (int)ybytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars_e = __builtin_amdgcn_make_buffer_rsrc(a.y, (short)0, accum ? (int)ybytes : 0, 0x00020000);
-    f32x4 res[8][MH];
-    auto load_res = [&](int cr) {  // residual (and the stored partial sums) of channel pair cr, one step ahead
-      const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
-      const bool gone = (cr >> 2) == 1 && tail16;
+    // LOADS FIRST, STORES AFTER.  vmcnt retires in order, so a residual load issued behind an earlier channel pair's
+    // stores is only known to have landed when those stores have been acknowledged by the memory side: round 3
+    // loaded pair cr + 1 next to the stores of pair cr and every pair waited a write round trip (5.5 k of the
+    // epilogue's 10 k cycles, tools/wino4_trace.py; tiles on the right image edge loaded and stored element by
+    // element, 72 dependent round trips per item for those workgroups).  Now every load of the item goes out before
+    // its first store - 16-byte loads for the edge tiles too (the bytes behind the row's end are the next row's, or
+    // out of range = zero, and are not used) - and the stores that follow wait for nothing.  96 registers: V[], raw[]
+    // and the operand registers are dead here.  The branches are wave-uniform; a launch without residual and
+    // without a cut item loads nothing.
+    unsigned lrow[MH];
 #pragma unroll
-      for (int yy = 0; yy < MH; ++yy) {
-        const unsigned o = gone ? W4_OOB : orow[yy] + coff;
-        res[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, o, 0, 0)) +
-                      __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars_e, o, 0, W4_SC1));
+    for (int yy = 0; yy < MH; ++yy)
+      lrow[yy] = (valid && ho + yy < a.H) ? obase + (unsigned)(yy * a.W) * 4u : W4_OOB;
+    f32x4 res[8][MH];
+    if (use_res || accum) {
+#pragma unroll
+      for (int cr = 0; cr < 8; ++cr) {
+        const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+        const bool gone = (cr >> 2) == 1 && tail16;
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) {
+          const unsigned o = gone ? W4_OOB : lrow[yy] + coff;
+          res[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, o, 0, 0));
+        }
       }
-    };
-    load_res(0);
+      if (accum) {  // (a cut item's lower half: rare - two batches of 4 x MH loads in flight)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 ps[4][MH];
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const int cr = 4 * h + c4;
+            const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+            const bool gone = (cr >> 2) == 1 && tail16;
+#pragma unroll
+            for (int yy = 0; yy < MH; ++yy)
+              ps[c4][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                  ars_e, gone ? W4_OOB : lrow[yy] + coff, 0, W4_SC1));
+          }
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int yy = 0; yy < MH; ++yy) res[4 * h + c4][yy] += ps[c4][yy];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cr = 0; cr < 8; ++cr)
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) res[cr][yy] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
 #pragma unroll
     for (int cr = 0; cr < 8; ++cr) {
       const int cb = cr >> 2, r = cr & 3;
@@ -590,7 +627,6 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // gave wrong second dwords in lanes 12-15 of every row of 16 on gfx950 - not understood, avoided)
       const unsigned coff = (unsigned)(cb * 16 + r) * chan;
       const bool gone = cb == 1 && tail16;
-      if (cr + 1 < 8) load_res(cr + 1);
       float T[MH][6];
 #pragma unroll
       for (int jj = 0; jj < 6; ++jj) {
@@ -608,27 +644,24 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       for (int yy = 0; yy < MH; ++yy) {
         float v0, v1, v2, v3;
         w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
-        Y[yy] = (f32x4){v0, v1, v2, v3};
+        Y[yy] = (f32x4){v0, v1, v2, v3} + res[cr][yy];
       }
       long long cs = 0;
       if (tracing) { __builtin_amdgcn_sched_barrier(0); cs = clock64(); }
 #pragma unroll
       for (int yy = 0; yy < MH; ++yy) {
-        const f32x4 v = Y[yy] + res[cr][yy];
         const unsigned o = gone ? W4_OOB : orow[yy] + coff;
-        if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, o, 0, W4_SC1);
-        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, o, 0, 0);
+        if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[yy]), yrs, o, 0, W4_SC1);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[yy]), yrs, o, 0, 0);
       }
       if (tracing) { __builtin_amdgcn_sched_barrier(0); tS += clock64() - cs; }
-      if (part) {  // lanes of the tile column that straddles the right edge
+      if (part) {  // lanes of the tile column that straddles the right edge: W % 4 element stores per row
 #pragma unroll
         for (int yy = 0; yy < MH; ++yy)
 #pragma unroll
           for (int xx = 0; xx < 3; ++xx) {
             const unsigned o = (ho + yy < a.H && wo + xx < a.W && !gone) ? obase + (unsigned)(yy * a.W + xx) * 4u + coff : W4_OOB;
-            float v = Y[yy][xx];
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs_e, o, 0, 0));
-            v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars_e, o, 0, W4_SC1));
+            const float v = Y[yy][xx];
             if (partial) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, W4_SC1);
             else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, 0);
           }

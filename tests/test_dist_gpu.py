@@ -185,3 +185,8 @@ def test_bench_two_ranks_on_one_gpu():
     # kernel reads 20 - 180 ms), so only the presence and sanity of the roofline object is asserted, not its rate
     r = d["roofline"]
     assert r["kernel"].startswith(("wino", "conv")) and r["avg_launch_ms"] > 0 and 0.0 <= r["frac"] <= 1.0
+    # the exchange itself: SURVEY 8d's 49,802,184 bytes (12,450,290 parameters + the 256-float loss centre) less the
+    # 2,056 bytes of fc_mu.* (514 floats), which get no gradient under ang_iso and which SURVEY 8e says to skip
+    comm = d["ddp"]["communication"]
+    assert d["ddp"]["world"] == 2 and comm["allreduce_bytes_per_step"] == 49_802_184 - 2_056
+    assert comm["step_ms_without_exchange"] > 0 and "exposed_ms" in comm and comm["overlap"] is True
