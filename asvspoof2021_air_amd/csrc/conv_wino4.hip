@@ -61,10 +61,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W4_CO = 32;                       // output channels per workgroup
 constexpr int W4_CK = 4;                        // input channels per k-step (MFMA K)
-constexpr int W4_NI = 8;                        // patch DMAs per thread: 4 groups x 4 planes x 128 chunks
-constexpr int W4_PLF = 512;                     // floats per (group, ci) plane (multiple of 64: bank-aligned)
-constexpr int W4_GRPF = W4_CK * W4_PLF;         // floats per tile group
-constexpr int W4_PATCHF = 4 * W4_GRPF;          // floats per patch buffer
 constexpr int W4_NBUF = 3;
 // Partial sums of a cut item travel between two workgroups that may sit on different XCDs, whose L2s are not
 // coherent with each other: stored and loaded with the sc1 (agent-scope) cache policy they go through to the
@@ -93,7 +89,6 @@ struct W4Pos {
   static constexpr int USLAB = MH == 4 ? W4_CK * W4_CO * NP : W4_CK * NQ * W4_CO * 4;  // floats per k-step
   static constexpr int NU = (USLAB + 1023) / 1024;  // DMAs (256 threads x 16 bytes) per slab
   static constexpr int ULDS = NU * 1024;        // LDS pitch of a slab
-  static constexpr int ND = NU + W4_NI;         // DMAs per thread and k-step
   static constexpr int NACC = 2 * NP;           // accumulators per wave: 2 row blocks x positions
   // float offset of (ci k, channel col, position p) inside a slab
   __host__ __device__ static constexpr int uoff(int k, int col, int p) {
@@ -109,7 +104,17 @@ struct W4Cfg {
   static constexpr int NPR = MH + 2;            // input rows of one tile row
   static constexpr int BANDC = NPR * RC;        // chunks per band
   static constexpr int BANDF = 4 * BANDC;
-  static_assert(TRG * BANDC <= 128, "a plane holds 128 chunks");
+  // A (group, ci) plane = TRG bands, rounded up to 16 chunks (64 floats: planes stay bank-aligned for the 16-byte
+  // reads).  Round 3 gave every plane 128 chunks: 8 DMAs per thread and k-step of which the 1 x 16 groups of three
+  // of the ResNet's four layers used 90 / 128 - and an LDS-DMA costs the issuing wave ~50 - 60 cycles between its
+  // MFMAs whether its lanes fetch or not.  Now the 16 planes are packed back to back and the 256 threads walk the
+  // flat chunk index: 6 DMAs (MH = 3, 1 x 16), 7 (MH = 3, 2 x 8 and MH = 4, 1 x 16) or 8 (MH = 4, 2 x 8).
+  static constexpr int PLC = (TRG * BANDC + 15) / 16 * 16;  // chunks per plane
+  static constexpr int PLF = 4 * PLC;           // floats per (group, ci) plane
+  static constexpr int GRPF = W4_CK * PLF;      // floats per tile group
+  static constexpr int PATCHF = 4 * GRPF;       // floats per patch buffer
+  static constexpr int NI = 16 * PLC / 256;     // patch DMAs per thread and k-step
+  static_assert(16 * PLC % 256 == 0 && PLC <= 128, "16 planes = a whole number of 256-thread DMAs");
 };
 
 // Textbook interpolation points (0, +-1, +-2, inf):
@@ -284,7 +289,8 @@ template <int TRG, int MH, bool TRACE = false>
 __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   using C = W4Cfg<TRG, MH>;
   using P = W4Pos<MH>;
-  constexpr int NPR = P::NPR, NP = P::NP, NQ = P::NQ, ND = P::ND, NU = P::NU;
+  constexpr int NPR = P::NPR, NP = P::NP, NQ = P::NQ, NU = P::NU, NI = C::NI, ND = NU + NI;  // ND: DMAs per thread and k-step
+  constexpr int W4_PLF = C::PLF, W4_GRPF = C::GRPF, W4_PATCHF = C::PATCHF;
   constexpr int ULDS = P::ULDS, USLAB = P::USLAB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(2 * ND <= 63, "vmcnt is a 6-bit counter");
@@ -351,39 +357,27 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
 
   // ---- staging cursors.  Behind the end of the stream they stay on the last k-step (restaged into free
   // buffers), so issue counts - and with them the vmcnt waits - never vary.
-  unsigned voff[W4_NI];  // byte offsets of this thread's 8 patch chunks (out of range = zeros)
-  // thread -> (ci low bit pair, band, row, chunk) of its slot in a 128-chunk plane: DMA i stages plane
-  // ci = 2 (i & 1) + (tid >> 7) of group i >> 1
+  unsigned voff[NI];  // byte offsets of this thread's patch chunks (out of range = zeros)
+  // DMA i, thread t stages flat chunk f = 256 i + t of the buffer: plane f / PLC = 4 group + ci, slot f % PLC =
+  // (band, row, chunk) of that plane.  Everything is re-derived from the thread index per item and not kept live
+  // (the k-step loop has no register to spare: see conv_wino.hip).
   auto set_voff = [&](int item) {
     int t = tid;
-    asm volatile("" : "+v"(t));  // re-derived per item, not kept live (see conv_wino.hip)
-    const int rem2 = t & 127, cilo = t >> 7;
-    const int band = rem2 / C::BANDC, rem3 = rem2 - band * C::BANDC;
-    const int row = rem3 / C::RC, cc = rem3 - row * C::RC;
-    const bool slot_ok = rem2 < TRG * C::BANDC;
+    asm volatile("" : "+v"(t));
     const int quad = item_quad(item);
 #pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-      const int g = 4 * quad + grp;
+    for (int i = 0; i < NI; ++i) {
+      const int f = i * 256 + t;
+      const int pl = f / C::PLC, slot = f - pl * C::PLC;
+      const int band = slot / C::BANDC, rem3 = slot - band * C::BANDC;
+      const int row = rem3 / C::RC, cc = rem3 - row * C::RC;
+      const int g = 4 * quad + (pl >> 2);
       const int gr = g % a.GRR, twg = g / a.GRR;
-      int b, th;
-      bool ok = slot_ok && g < a.ngroups;
-      if (TRG == 1) {
-        const int sr = gr;
-        b = sr / a.TH;
-        th = sr - b * a.TH;
-      } else {
-        const int sr0 = gr * TRG, sr1 = sr0 + 1;
-        const int b0 = sr0 / a.TH, b1 = sr1 / a.TH;
-        b = band ? b1 : b0;
-        th = band ? sr1 - b1 * a.TH : sr0 - b0 * a.TH;
-        ok = ok && (band ? sr1 : sr0) < a.SR;
-      }
-      const int hi = MH * th - 1 + row, col0 = 4 * C::TCG * twg - 4 + 4 * cc;
-      ok = ok && hi >= 0 && hi < a.H && col0 >= 0 && col0 < a.W;
-      const unsigned off = (unsigned)((((b * a.Cin + cilo) * a.H + hi) * a.W + col0) * 4);
-      voff[2 * grp] = ok ? off : W4_OOB;
-      voff[2 * grp + 1] = ok ? off + 2u * (unsigned)HWi * 4u : W4_OOB;
+      const int sr = gr * TRG + band;
+      const int b = sr / a.TH, th = sr - b * a.TH;
+      const int hi = MH * th - 1 + row, col = 4 * C::TCG * twg - 4 + 4 * cc;
+      const bool ok = slot < TRG * C::BANDC && g < a.ngroups && sr < a.SR && hi >= 0 && hi < a.H && col >= 0 && col < a.W;
+      voff[i] = ok ? (unsigned)((((b * a.Cin + (pl & 3)) * a.H + hi) * a.W + col) * 4) : W4_OOB;
     }
   };
   int pSeg = 0, pChunk = c0, pBuf = 0, pLeft = S;
@@ -695,7 +689,10 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     const int nxt = cur + 1 == W4_NBUF ? 0 : cur + 1;
     long long c0_ = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     if (tracing) c0_ = clock64();
-    // U(s) and patch(s+1) have landed (loads retire in order; the group issued last step may still fly)
+    // U(s) and patch(s+1) have landed (loads retire in order; the group issued last step may still fly).
+    // (Round 4, measured and dropped: the first AHEAD operand reads of step s + 1 issued at the END of step s, across
+    // the barrier - needs U(s+1) landed one step earlier, vmcnt(NI) here - layer3 0.281 -> 0.285 ms: the LDS round
+    // trip behind the barrier is not what the k-step waits for.)
     w4_wait<ND>();
     if (tracing) c1 = clock64();
     __syncthreads();
@@ -881,7 +878,9 @@ int w4_tile_rows(int H) {
 
 template <int MH>
 int w4_launch(W4Args& a, int trg, int nblk, hipStream_t st) {
-  const size_t ldsb = (size_t)W4_NBUF * (W4Pos<MH>::ULDS + W4_PATCHF) * sizeof(float);
+  // (sized for the 2 x 8 groups' planes, the larger of the two layouts: one attribute for all four instances)
+  const size_t ldsb = (size_t)W4_NBUF * (W4Pos<MH>::ULDS + W4Cfg<2, MH>::PATCHF) * sizeof(float);
+  static_assert(W4Cfg<2, MH>::PATCHF >= W4Cfg<1, MH>::PATCHF, "the 2 x 8 layout is the larger one");
   static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
     const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, false>),
                          reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, false>),
@@ -914,12 +913,12 @@ int w4_resident_per_cu(int mh) {
   int n = 0;
   hipError_t e;
   if (mh == 3) {
-    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<3>::ULDS + W4_PATCHF) * sizeof(float);
+    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<3>::ULDS + W4Cfg<2, 3>::PATCHF) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_conv_kernel<1, 3, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wino4_conv_kernel<1, 3, false>, 256, ldsb);
   } else {
-    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<4>::ULDS + W4_PATCHF) * sizeof(float);
+    const size_t ldsb = (size_t)W4_NBUF * (W4Pos<4>::ULDS + W4Cfg<2, 4>::PATCHF) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_conv_kernel<1, 4, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wino4_conv_kernel<1, 4, false>, 256, ldsb);

@@ -192,7 +192,11 @@ def test_tap_weights_packed_in_one_launch(ops):
         d0 = ops.conv1d_dgrad(x, ws[i], 3, 3, bf16=True)
         d1 = ops.conv1d_dgrad(x, ws[i], 3, 3, bf16=True, w_packed=wpt[i])
         assert torch.equal(d0, d1)
-    assert ops.conv1d_tap_pack([ws[0], ws[2], ws[1]], transpose=False) is None  # irregular stride: caller packs per layer
+    # irregular stride (parameters re-assigned outside the arena): one launch per weight, same blocks (the
+    # resident path indexes the result, it must never be None)
+    irr = ops.conv1d_tap_pack([ws[0], ws[2], ws[1]], transpose=False)
+    assert torch.equal(irr[0], wp[0]) and torch.equal(irr[1], wp[2]) and torch.equal(irr[2], wp[1])
+    assert ops.conv1d_tap_pack([ws[0].repeat(1, 1, 2)[:, :, :5].contiguous()], transpose=False) is None  # K != 3
 
 
 @pytest.mark.parametrize("shape", [(4, 32, 750), (3, 16, 375), (2, 8, 1024)])
