@@ -71,6 +71,14 @@ constexpr int W4_SC1 = 16;
 #ifndef W4_DMA_PLACE
 #define W4_DMA_PLACE 0  // A/B: 0 = one DMA per MFMA group boundary; 1 = inside the transform; 2 = two per boundary
 #endif
+// TIMING-ONLY experiment builds (results are garbage; python -m asvspoof2021_air_amd.build --variant ...; never the
+// default library).  W4_EXP_RETILE = R emulates the staging stream of a workgroup tile of 32 R output channels x
+// 64 / R tiles on this kernel's schedule: every weight-slab DMA is issued R times (from R different channel slabs),
+// only NI / R (rounded up) of the patch DMAs go out.  W4_EXP_NOXF additionally drops the input transform - the
+// upper bound of what sharing V between the waves of such a tile could save.  profiles/r04_wino4_retile.md.
+#ifndef W4_EXP_RETILE
+#define W4_EXP_RETILE 1
+#endif
 #ifndef W4_PATCH_FIRST
 #define W4_PATCH_FIRST 0  // A/B: 1 = round 2's order (patch reads, then the first operand reads)
 #endif
@@ -289,7 +297,9 @@ template <int TRG, int MH, bool TRACE = false>
 __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   using C = W4Cfg<TRG, MH>;
   using P = W4Pos<MH>;
-  constexpr int NPR = P::NPR, NP = P::NP, NQ = P::NQ, NU = P::NU, NI = C::NI, ND = NU + NI;  // ND: DMAs per thread and k-step
+  constexpr int NPR = P::NPR, NP = P::NP, NQ = P::NQ, NU = P::NU, NI = C::NI;
+  constexpr int NIX = (NI + W4_EXP_RETILE - 1) / W4_EXP_RETILE;  // (= NI in every product build)
+  constexpr int ND = W4_EXP_RETILE * NU + NIX;  // DMAs per thread and k-step
   constexpr int W4_PLF = C::PLF, W4_GRPF = C::GRPF, W4_PATCHF = C::PATCHF;
   constexpr int ULDS = P::ULDS, USLAB = P::USLAB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -395,8 +405,16 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // the last one, out of range; MH = 3: exactly four), NU .. NU + 7 = the patches.
   auto dma_unit = [&](auto unit_tag) {
     constexpr int u = decltype(unit_tag)::value;
+#if W4_EXP_RETILE > 1
+    // flat unit index: R NU weight DMAs (slab unit u / R, from channel slab + u % R), then NIX patch DMAs
+    if constexpr (u < W4_EXP_RETILE * NU)
+      w4_dma16<(u / W4_EXP_RETILE) * 4096>(urs, uso + (unsigned)(u / W4_EXP_RETILE) * 4096u +
+                                           (unsigned)(u % W4_EXP_RETILE) * (unsigned)nchunk * (USLAB * 4u), mU, uvoff);
+    else if constexpr (u < ND) w4_dma16<(u - W4_EXP_RETILE * NU) * 4096>(xrs, xso, mP, voff[u - W4_EXP_RETILE * NU]);
+#else
     if constexpr (u < NU) w4_dma16<u * 4096>(urs, uso + (unsigned)u * 4096u, mU, uvoff);
     else if constexpr (u < ND) w4_dma16<(u - NU) * 4096>(xrs, xso, mP, voff[u - NU]);
+#endif
   };
   auto adv_patch = [&]() {
     pBuf = pBuf + 1 == W4_NBUF ? 0 : pBuf + 1;
@@ -425,14 +443,21 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     mU = __builtin_amdgcn_readfirstlane(mU0 + (unsigned)uBuf * (ULDS * 4u));
   };
 #define W4_UNIT(U_) dma_unit(std::integral_constant<int, U_>{})
+  constexpr int NUX = W4_EXP_RETILE * NU;  // (= NU in every product build)
   auto dma_u = [&]() {
     W4_UNIT(0); W4_UNIT(1); W4_UNIT(2); W4_UNIT(3);
-    if constexpr (NU > 4) W4_UNIT(4);
+    if constexpr (NUX > 4) W4_UNIT(4);
+#if W4_EXP_RETILE > 1
+    W4_UNIT(5); W4_UNIT(6); W4_UNIT(7);
+    if constexpr (NUX > 8) { W4_UNIT(8); W4_UNIT(9); W4_UNIT(10); W4_UNIT(11); W4_UNIT(12); W4_UNIT(13); W4_UNIT(14); W4_UNIT(15); }
+    if constexpr (NUX > 16) { W4_UNIT(16); W4_UNIT(17); W4_UNIT(18); W4_UNIT(19); }
+    static_assert(NUX <= 20, "experiment builds: R <= 4");
+#endif
     adv_u();
   };
   auto dma_patch = [&]() {
-    W4_UNIT(NU + 0); W4_UNIT(NU + 1); W4_UNIT(NU + 2); W4_UNIT(NU + 3);
-    W4_UNIT(NU + 4); W4_UNIT(NU + 5); W4_UNIT(NU + 6); W4_UNIT(NU + 7);
+    W4_UNIT(NUX + 0); W4_UNIT(NUX + 1); W4_UNIT(NUX + 2); W4_UNIT(NUX + 3);
+    W4_UNIT(NUX + 4); W4_UNIT(NUX + 5); W4_UNIT(NUX + 6); W4_UNIT(NUX + 7);
     adv_patch();
   };
 
@@ -743,7 +768,14 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // restaging, one DMA per group boundary so the memory pipeline takes them one at a time (issued back
       // to back by all four waves, 52 KB queue up in front of it and every issue stalls): U(s+2) into the
       // buffer U(s-1) left, patch(s+3) into the buffer patch(s) left
-#if W4_DMA_PLACE == 0
+#if W4_EXP_RETILE > 1
+      // ND units spread evenly over the NG group boundaries
+#define W4_FLAT(K_) if ((K_) * NG / ND == g || (ND > NG && ((K_) * NG) / ND == g)) W4_UNIT(K_)
+      W4_FLAT(0); W4_FLAT(1); W4_FLAT(2); W4_FLAT(3); W4_FLAT(4); W4_FLAT(5); W4_FLAT(6); W4_FLAT(7); W4_FLAT(8);
+      W4_FLAT(9); W4_FLAT(10); W4_FLAT(11); W4_FLAT(12); W4_FLAT(13); W4_FLAT(14); W4_FLAT(15); W4_FLAT(16);
+      W4_FLAT(17); W4_FLAT(18); W4_FLAT(19); W4_FLAT(20); W4_FLAT(21); W4_FLAT(22); W4_FLAT(23);
+#undef W4_FLAT
+#elif W4_DMA_PLACE == 0
       switch (g) {
         case 0: W4_UNIT(0); break;
         case 1: W4_UNIT(1); break;
@@ -795,7 +827,14 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     adv_u();
     adv_patch();
     if (tracing) c4 = clock64();
+#ifndef W4_EXP_NOXF
     if constexpr (!LAST) transform(std::false_type{});
+#else
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) V[p] = raw[p];
+    }
+#endif
 #endif
     __builtin_amdgcn_sched_barrier(0);
     if (tracing) {
