@@ -61,6 +61,7 @@ class Trainer:
         self._graph = None
         self._graph_warm = 0
         self.use_graph = False
+        self._overlap_saved = None
 
     # ------------------------------------------------------------------ data parallel
     def sync_from_rank0(self):
@@ -211,6 +212,18 @@ class Trainer:
         self.use_graph = bool(on) and isinstance(self.model, Res2Net2)
         self._graph = None
         self._graph_warm = 0
+        if self.use_graph:
+            # Round 4, root cause of "replay slower than eager" (tools/exp_ecapa_graph.sh): with the weight gradients
+            # on the side stream the captured graph has a fork / join pair per layer, and ROCm replays such a graph
+            # through several internal streams with a signal per edge - hipGraphLaunch itself took 5.4 ms of host time
+            # per replay and the step 8.41 ms against eager's 8.16.  Captured as ONE chain (no side stream: ECAPA's
+            # weight-gradient GEMMs gain nothing from the overlap, eager 8.16 with it, 8.11 without) the replay costs
+            # 0.22 ms of host time and the step 8.08 ms (6.19 ms at T = 401, eager 6.24).
+            self._overlap_saved = getattr(self.model, "overlap_wgrad", None)
+            self.model.overlap_wgrad = False
+        elif getattr(self, "_overlap_saved", None) is not None:
+            self.model.overlap_wgrad = self._overlap_saved
+            self._overlap_saved = None
         return self
 
     def _graph_key(self, pcm, labels):
