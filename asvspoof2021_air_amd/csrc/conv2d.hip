@@ -1681,12 +1681,21 @@ int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, 
                    : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
 }
 
+size_t air_conv2d_fwd_stats_bytes(const AirConv2d* p) {
+  if (!p || !shape_ok(p) || direct_ok(p) || !generic_ok(p)) return 0;
+  if (!wino_shape(p) || !air_wino4_ok(p->B, p->Cin, p->H, p->W, p->Cout) || p->Cout % 32 != 0) return 0;
+  return air_wino4_stats_bytes(p->B, p->H, p->W, p->Cout);
+}
+
 int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
                        const float* in_scale, const float* in_shift, int relu, const float* residual,
                        double* stats, void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!p || !x || !w || !y || !shape_ok(p)) return AIR_EINVAL;
   if ((in_scale == nullptr) != (in_shift == nullptr)) return AIR_EINVAL;
-  if (stats != nullptr) return AIR_EUNSUPPORTED;  // fused BN statistics: not in this build
+  // fused BatchNorm statistics: from the Winograd F(4x4 / 3x4, 3x3) epilogue only (air_conv2d_fwd_stats_bytes says
+  // whether this layer takes that path under the current dispatch options)
+  if (stats != nullptr && air_conv2d_fwd_stats_bytes(p) == 0) return AIR_EUNSUPPORTED;
+  if (stats != nullptr && in_scale != nullptr) return AIR_EUNSUPPORTED;
   hipStream_t st = air_stream(stream);
   if (direct_ok(p)) {
     if (in_scale || relu || residual) return AIR_EUNSUPPORTED;
@@ -1708,9 +1717,10 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
     if (ws_bytes < air_wino4_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
     if (w_packed)  // transformed earlier (air_conv2d_prepack): no weights kernel in front of the conv
       return air_wino4_conv(x, nullptr, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0,
-                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
+                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st,
+                            reinterpret_cast<float*>(stats));
     return air_wino4_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
-                          conv_flops(p), st);
+                          conv_flops(p), st, reinterpret_cast<float*>(stats));
   }
   if (in_scale == nullptr && wino_shape(p) && air_wino_ok(p->B, p->Cin, p->H, p->W, p->Cout)) {
     if (ws_bytes < air_wino_packed_elems(p->Cout, p->Cin) * sizeof(float)) return AIR_EWORKSPACE;
@@ -1768,6 +1778,31 @@ int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, co
 int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float* dx,
                      const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream) {
   return air_conv2d_dgrad_pre(p, dy, w, nullptr, dx, accumulate, ws, ws_bytes, stream);
+}
+
+size_t air_conv2d_dgrad_bn_sums_bytes(const AirConv2d* p) {
+  if (!p || !shape_ok(p) || !generic_ok(p)) return 0;
+  // the Winograd F(3x4 / 4x4, 3x3) data-gradient kernel, whole 32-channel slabs of dx
+  if (!wino_shape(p) || !air_wino4_ok(p->B, p->Cout, p->H, p->W, p->Cin) || p->Cin % 32 != 0) return 0;
+  return air_wino4_stats_bytes(p->B, p->H, p->W, p->Cin);
+}
+
+int air_conv2d_dgrad_bn(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
+                        const float* accumulate, const float* bn_x, const float* bn_mean, const float* bn_invstd,
+                        const float* bn_gamma, const float* bn_beta, void* sums, void* ws, size_t ws_bytes,
+                        air_stream_t stream) {
+  if (!p || !dy || !w || !dx || !shape_ok(p) || !bn_x || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !sums)
+    return AIR_EINVAL;
+  if (air_conv2d_dgrad_bn_sums_bytes(p) == 0) return AIR_EUNSUPPORTED;
+  if (ws_bytes < air_wino4_packed_elems(p->Cin, p->Cout) * sizeof(float) || !ws) return AIR_EWORKSPACE;
+  const float* bn[5] = {bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta};
+  hipStream_t st = air_stream(stream);
+  if (w_packed)
+    return air_wino4_conv(dy, nullptr, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1,
+                          const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st,
+                          reinterpret_cast<float*>(sums), bn);
+  return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, reinterpret_cast<float*>(ws),
+                        conv_flops(p), st, reinterpret_cast<float*>(sums), bn);
 }
 
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

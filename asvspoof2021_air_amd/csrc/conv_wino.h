@@ -30,7 +30,13 @@ int air_wino_wgrad_partials(const float* x, const float* dy, float* partial, int
 // its own packing (36 transformed weights per (co, ci)); preferred over F(2x2,3x3) where it applies.
 bool air_wino4_ok(int B, int Kc, int H, int W, int M);
 size_t air_wino4_packed_elems(int M, int Kc);
+// stats (forward only, 16-byte aligned, air_wino4_stats_bytes(B, H, W, M) bytes; nullptr = none): per-(channel,
+// tile group) BatchNorm statistics records of y written by the epilogue, for bn_stats_from_records (norm_act.hip)
+// bn (data-gradient launches with stats): {bnx, mean, invstd, gamma, beta} - the records become the two sums of the
+// BatchNorm backward of relu(batchnorm(bnx)) whose output gradient this launch writes (W4Args::stats_mode 2)
 int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
-                   int W, int M, int dgrad, float* up, double flops, hipStream_t st);
+                   int W, int M, int dgrad, float* up, double flops, hipStream_t st, float* stats = nullptr,
+                   const float* const* bn = nullptr);
+size_t air_wino4_stats_bytes(int B, int H, int W, int M);
 // H: image height of the launch the weights are for (it picks the 4- or 3-row tile layout)
 int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st);

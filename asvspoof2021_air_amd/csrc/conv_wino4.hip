@@ -219,6 +219,18 @@ struct W4Args {
   unsigned* flags;        // split: one word per cut item, raised to `epoch` when its upper-half sums are in y
   unsigned epoch;
   long long* trace;       // debug: cycle totals of workgroup 0 (null in production)
+  // BatchNorm statistics of y from the epilogue (forward only; null = none): a header {G, Cout, 0, 0} and then one
+  // record {n, K, sum(y - K), sum((y - K)^2)} per (channel c, tile group g) at [c * G + g], G = 4 * nquad: the
+  // (n, mean, M2) of the group's valid outputs in shifted form, merged in fp64 by bn_finalize_records_kernel
+  // (norm_act.hip) - the pass over y that air_bn_stats otherwise makes.  air_wino4_stats_bytes() sizes it.
+  float* stats;
+  // stats_mode 2 (data-gradient launches; same buffer layout): y is dA, the gradient with respect to the OUTPUT of
+  // relu(batchnorm(bnx)); the records are {sum g, sum g * xhat, 0, 0} with g = dA where the ReLU passed and
+  // xhat = (bnx - mean) * invstd - the two sums of the BatchNorm backward (bn_bwd_partial_kernel, norm_act.hip,
+  // same mask and xhat arithmetic), taken while dA is written instead of in a pass that re-reads dA and bnx.
+  int stats_mode;          // 0 none, 1 forward statistics, 2 BatchNorm-backward sums
+  const float* bnx;        // (B, Cout, H, W): the BatchNorm's input
+  const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta;  // (Cout,)
 };
 
 __device__ __forceinline__ i32x4 w4_rsrc(const void* base, unsigned bytes) {
@@ -293,7 +305,7 @@ __device__ __forceinline__ void w4_at5(float m0, float m1, float m2, float m3, f
   y2 = __builtin_fmaf(4.0f, m3, s1) + m4;
 }
 
-template <int TRG, int MH, bool TRACE = false>
+template <int TRG, int MH, bool TRACE = false, bool BST = false>
 __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   using C = W4Cfg<TRG, MH>;
   using P = W4Pos<MH>;
@@ -338,6 +350,13 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   if (is_lower) { tail_seg = nround; tail_item = nround * Wx + (j - rem); last_end = half; ++nseg; }
   else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + j; fc = half; ++nseg; }
   else if (!cut && j < rem) { tail_seg = nround; tail_item = nround * Wx + j; ++nseg; }
+  if (a.stats != nullptr && blockIdx.x == 0 && tid == 0) {  // header of the statistics buffer, once per launch
+    int* h = reinterpret_cast<int*>(a.stats);
+    h[0] = 4 * a.nquad;
+    h[1] = a.Cout;
+    h[2] = 0;
+    h[3] = 0;
+  }
   if (nseg == 0) return;
   const int S = nround * nchunk + (tail_seg < 0 ? 0 : (is_upper ? nchunk - half : (is_lower ? half : nchunk)));
   const int flag_idx = xg * 32 + (tail_item - nround * Wx);  // cut items of this launch: < 8 * 32
@@ -536,6 +555,14 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
     }
   };
 
+  // v += the same value of the other 15 lanes of its row of 16 (xor 1, xor 2, mirror within 8, mirror within 16)
+  auto rowsum16 = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+  };
   // Y = A_h^T M A_w per lane; D row (l >> 4) * 4 + r -> channel, D column l & 15 -> tile.
   // Output rows go out as 16-byte buffer stores whose offset is pushed out of range for lanes / rows that
   // do not exist (the store is dropped, the residual load returns zero): no branches in the common path.
@@ -601,6 +628,132 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
 #pragma unroll
     for (int yy = 0; yy < MH; ++yy)
       lrow[yy] = (valid && ho + yy < a.H) ? obase + (unsigned)(yy * a.W) * 4u : W4_OOB;
+    // statistics records of this wave's tile group (see W4Args::stats)
+    const bool do_stats = a.stats != nullptr && a.stats_mode == 1 && !partial;
+    const bool do_bst = a.stats != nullptr && a.stats_mode == 2 && !partial;
+    const bool st_ok = valid;
+    const int st_G = 4 * a.nquad;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        a.stats, (short)0, (do_stats || do_bst) ? (int)(16u + (unsigned)a.Cout * (unsigned)st_G * 16u) : 0, 0x00020000);
+    const unsigned st_chan = (unsigned)st_G * 16u;  // bytes between the records of consecutive channels
+    const unsigned st_base = 16u + ((unsigned)co0 * (unsigned)st_G + (unsigned)g) * 16u;
+    float st_cnt = 0.0f;
+    bool all_in = false;
+    if (do_stats || do_bst) {
+      int n_in = 0;
+#pragma unroll
+      for (int yy = 0; yy < MH; ++yy)
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx) n_in += (st_ok && ho + yy < a.H && wo + xx < a.W) ? 1 : 0;
+      all_in = __builtin_amdgcn_ballot_w64(n_in != MH * 4) == 0;  // wave-uniform: no masks needed below
+      float c = (float)n_in;
+      st_cnt = rowsum16(c);
+    }
+    if constexpr (BST) {
+      // Data-gradient launch that also takes the BatchNorm-backward sums (W4Args::stats_mode 2).  Per channel pair:
+      // load the residual / partner sums, the BatchNorm input at the same positions and the channel's constants
+      // (one pair ahead), form dA and the two sums - and keep dA in registers: NOTHING is stored until every load of
+      // the item has been issued (a load behind a store waits for the store's acknowledgement, see below), then the
+      // 8 x MH stores go out back to back.  96 registers of dA + two pairs of operands in flight; the instances
+      // without the sums keep the round-3 register budget.
+      const __amdgpu_buffer_rsrc_t xbrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(do_bst ? a.bnx : a.y), (short)0, do_bst ? (int)ybytes : 0, 0x00020000);
+      f32x4 Yall[8][MH];
+      f32x4 xn[MH], rn[MH];
+      float cmu = 0.0f, cis = 0.0f, cga = 0.0f, cbe = 0.0f;
+      auto fetch = [&](int cr) {
+        const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+        const bool gone = (cr >> 2) == 1 && tail16;
+        int c = co0 + (cr >> 2) * 16 + (cr & 3);
+        c = c < a.Cout ? c : a.Cout - 1;
+        cmu = a.bn_mean[c]; cis = a.bn_invstd[c]; cga = a.bn_gamma[c]; cbe = a.bn_beta[c];
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) {
+          const unsigned o = gone ? W4_OOB : lrow[yy] + coff;
+          xn[yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xbrs, o, 0, 0));
+          rn[yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs_e, o, 0, 0)) +
+                   __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars_e, o, 0, W4_SC1));
+        }
+      };
+      fetch(0);
+#pragma unroll
+      for (int cr = 0; cr < 8; ++cr) {
+        const int cb = cr >> 2, r = cr & 3;
+        const bool gone = cb == 1 && tail16;
+        f32x4 xc[MH], rc[MH];
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) { xc[yy] = xn[yy]; rc[yy] = rn[yy]; }
+        const float mu = cmu, is = cis;
+        const float sc = cga * is;
+        const float shf = cbe - mu * sc;
+        if (cr + 1 < 8) fetch(cr + 1);
+        float T[MH][6];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+          float m[NPR];
+#pragma unroll
+          for (int i = 0; i < NPR; ++i) {
+            const int acc = cb * NP + 6 * i + jj;
+            m[i] = acc < 64 ? accA[acc < 64 ? acc : 0][r] : accV[acc >= 64 ? acc - 64 : 0][r];
+          }
+          if constexpr (MH == 4) w4_at6(m[0], m[1], m[2], m[3], m[4], m[5], T[0][jj], T[1][jj], T[2][jj], T[3][jj]);
+          else w4_at5(m[0], m[1], m[2], m[3], m[4], T[0][jj], T[1][jj], T[2][jj]);
+        }
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) {
+          float v0, v1, v2, v3;
+          w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
+          const f32x4 Yv = (f32x4){v0, v1, v2, v3} + rc[yy];
+          Yall[cr][yy] = Yv;
+          if (do_bst) {
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+              const float xe = xc[yy][xx];
+              float gg = Yv[xx];
+              if (!(xe * sc + shf > 0.0f)) gg = 0.0f;  // (the mask of bn_bwd_partial / bn_bwd_apply, verbatim)
+              if (!all_in) gg = (st_ok && ho + yy < a.H && wo + xx < a.W) ? gg : 0.0f;
+              const float xh = (xe - mu) * is;
+              s1 += gg;
+              s2 += gg * xh;
+            }
+          }
+        }
+        if (do_bst) {
+          s1 = rowsum16(s1);
+          s2 = rowsum16(s2);
+          // (records are 16-byte stores as well - but nothing is loaded behind them: the operands of pair cr + 1
+          // were requested above)
+          const unsigned so = (jl == 0 && !gone) ? st_base + (unsigned)(cb * 16 + r) * st_chan : W4_OOB;
+          const f32x4 rec = {s1, s2, st_cnt, 0.0f};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), srs, so, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int cr = 0; cr < 8; ++cr) {
+        const int cb = cr >> 2, r = cr & 3;
+        const unsigned coff = (unsigned)(cb * 16 + r) * chan;
+        const bool gone = cb == 1 && tail16;
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy) {
+          const unsigned o = gone ? W4_OOB : orow[yy] + coff;
+          if (partial) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Yall[cr][yy]), yrs, o, 0, W4_SC1);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Yall[cr][yy]), yrs, o, 0, 0);
+        }
+        if (part) {
+#pragma unroll
+          for (int yy = 0; yy < MH; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < 3; ++xx) {
+              const unsigned o = (ho + yy < a.H && wo + xx < a.W && !gone) ? obase + (unsigned)(yy * a.W + xx) * 4u + coff : W4_OOB;
+              const float v = Yall[cr][yy][xx];
+              if (partial) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, W4_SC1);
+              else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, 0);
+            }
+        }
+      }
+      return;
+    }
     f32x4 res[8][MH];
     if (use_res || accum) {
 #pragma unroll
@@ -664,6 +817,27 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
         float v0, v1, v2, v3;
         w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
         Y[yy] = (f32x4){v0, v1, v2, v3} + res[cr][yy];
+      }
+      if (do_stats) {  // wave-uniform: forward launch with a statistics buffer, not the upper half of a cut item
+        // channel (cb, r) of this lane's row of 16 tiles; K = the row's first tile's first output (any finite value
+        // serves as the shift; one near the data keeps (y - K)^2 from cancelling in the merge)
+        const float K = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            0, __builtin_bit_cast(int, Y[0][0]), 0x150 /* row_newbcast:0 */, 0xf, 0xf, false));
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int yy = 0; yy < MH; ++yy)
+#pragma unroll
+          for (int xx = 0; xx < 4; ++xx) {
+            float d = Y[yy][xx] - K;
+            if (!all_in) d = (st_ok && ho + yy < a.H && wo + xx < a.W) ? d : 0.0f;
+            s1 += d;
+            s2 = __builtin_fmaf(d, d, s2);
+          }
+        s1 = rowsum16(s1);
+        s2 = rowsum16(s2);
+        const unsigned so = (jl == 0 && !gone) ? st_base + (unsigned)(cb * 16 + r) * st_chan : W4_OOB;
+        const f32x4 rec = {st_cnt, K, s1, s2};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), srs, so, 0, 0);
       }
       long long cs = 0;
       if (tracing) { __builtin_amdgcn_sched_barrier(0); cs = clock64(); }
@@ -921,17 +1095,22 @@ int w4_launch(W4Args& a, int trg, int nblk, hipStream_t st) {
   const size_t ldsb = (size_t)W4_NBUF * (W4Pos<MH>::ULDS + W4Cfg<2, MH>::PATCHF) * sizeof(float);
   static_assert(W4Cfg<2, MH>::PATCHF >= W4Cfg<1, MH>::PATCHF, "the 2 x 8 layout is the larger one");
   static const bool attr_ok = [=] {  // > 64 KB of dynamic LDS needs the opt-in, once per kernel
-    const void* ks[4] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, false>),
+    const void* ks[6] = {reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, false>),
                          reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, false>),
                          reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, true>),
-                         reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, true>)};
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, true>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<1, MH, false, true>),
+                         reinterpret_cast<const void*>(wino4_conv_kernel<2, MH, false, true>)};
     bool ok = true;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 6; ++i)
       ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) == hipSuccess;
     return ok;
   }();
   if (!attr_ok) return AIR_ELAUNCH;
-  if (a.trace != nullptr) {
+  if (a.stats_mode == 2) {  // data gradient + BatchNorm-backward sums: its own instances (deferred stores)
+    if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, MH, false, true>), dim3(nblk), dim3(256), ldsb, st, a);
+    else hipLaunchKernelGGL((wino4_conv_kernel<1, MH, false, true>), dim3(nblk), dim3(256), ldsb, st, a);
+  } else if (a.trace != nullptr) {
     if (trg == 2) hipLaunchKernelGGL((wino4_conv_kernel<2, MH, true>), dim3(nblk), dim3(256), ldsb, st, a);
     else hipLaunchKernelGGL((wino4_conv_kernel<1, MH, true>), dim3(nblk), dim3(256), ldsb, st, a);
   } else if (trg == 2) {
@@ -1012,16 +1191,9 @@ static unsigned* w4_flag_ring(hipStream_t st) {
   return rings[dev];
 }
 
-int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
-                   int W, int M, int dgrad, float* up, double flops, hipStream_t st) {
-  if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino4_weights)
-    const int rc = air_wino4_weights(w, up, M, Kc, H, dgrad, st);
-    if (rc != AIR_OK) return rc;
-  }
-  const int mh = w4_tile_rows(H);
-  W4Args a;
-  a.x = x; a.up = up; a.y = y; a.residual = residual;
-  a.B = B; a.Cin = Kc; a.H = H; a.W = W; a.Cout = M;
+// tile geometry of a launch (shared by the launch and the statistics-buffer size query); returns TRG
+static int w4_geometry(W4Args& a, int B, int H, int W, int M, int mh) {
+  a.B = B; a.H = H; a.W = W; a.Cout = M;
   a.TH = (H + mh - 1) / mh; a.TW = (W + 3) / 4;
   a.SR = B * a.TH;
   // 1 x 16 or 2 x 8 tiles per group: fewer groups = less padding waste
@@ -1032,6 +1204,36 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   a.ngroups = a.GRR * a.TWG;
   a.ncot = (M + W4_CO - 1) / W4_CO;
   a.nquad = (a.ngroups + 3) / 4;
+  return trg;
+}
+
+size_t air_wino4_stats_bytes(int B, int H, int W, int M) {
+  W4Args a;
+  w4_geometry(a, B, H, W, M, w4_tile_rows(H));
+  return 16 + (size_t)M * (size_t)(4 * a.nquad) * 16;
+}
+
+int air_wino4_conv(const float* x, const float* w, float* y, const float* residual, int B, int Kc, int H,
+                   int W, int M, int dgrad, float* up, double flops, hipStream_t st, float* stats,
+                   const float* const* bn) {
+  if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino4_weights)
+    const int rc = air_wino4_weights(w, up, M, Kc, H, dgrad, st);
+    if (rc != AIR_OK) return rc;
+  }
+  // forward launches take forward statistics (bn == nullptr), data-gradient launches BatchNorm-backward sums
+  // (bn = {bnx, mean, invstd, gamma, beta})
+  if (stats != nullptr && ((dgrad != 0) != (bn != nullptr) || (reinterpret_cast<size_t>(stats) & 15) ||
+                           air_wino4_stats_bytes(B, H, W, M) >= 0x80000000ull))
+    return AIR_EINVAL;
+  if (stats == nullptr && bn != nullptr) return AIR_EINVAL;
+  const int mh = w4_tile_rows(H);
+  W4Args a;
+  a.x = x; a.up = up; a.y = y; a.residual = residual; a.stats = stats;
+  a.stats_mode = stats == nullptr ? 0 : (bn != nullptr ? 2 : 1);
+  a.bnx = bn ? bn[0] : nullptr; a.bn_mean = bn ? bn[1] : nullptr; a.bn_invstd = bn ? bn[2] : nullptr;
+  a.bn_gamma = bn ? bn[3] : nullptr; a.bn_beta = bn ? bn[4] : nullptr;
+  a.Cin = Kc;
+  const int trg = w4_geometry(a, B, H, W, M, mh);
   a.cotb = a.ncot < 8 ? a.ncot : 8;
   while (a.ncot % a.cotb != 0) --a.cotb;  // (channel counts here are powers of two times 32: a no-op)
   a.nitems = a.nquad * a.ncot;

@@ -150,6 +150,77 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, int S,
   }
 }
 
+// Batch statistics from the records a convolution epilogue wrote (air_conv2d_fwd, `stats`): header {G, C, 0, 0},
+// then per channel G records {n, K, sum(y - K), sum((y - K)^2)} - the count, mean (K + s1 / n) and M2
+// (s2 - s1^2 / n) of one tile group's outputs.  One workgroup per channel: thread t merges the records t, t + 256, ...
+// in fp64 relative to the channel's first shift K0 (d = mean_i - K0: A += n d, Q += M2_i + n d^2), the sums meet in
+// a fixed order: mean = K0 + A / N, var = Q / N - (A / N)^2 (Chan et al.; in fp64 the last subtraction
+// has 29 bits to spare over the fp32 records).  The data itself is not read.  `bad` (device flag) is raised when the
+// header does not match the caller's C or the counts do not add up to N - a buffer from another tensor.
+__global__ __launch_bounds__(256) void bn_finalize_records_kernel(
+    const float* __restrict__ rec, int C, double N, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  // one workgroup per channel: thread t merges the records t, t + 256, ... (four loads in flight), the four waves'
+  // sums meet in LDS in wave order (a wave per channel walked layer1's 4608 records in 72 dependent round trips)
+  __shared__ double sh[3][4];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int G = reinterpret_cast<const int*>(rec)[0], Ch = reinterpret_cast<const int*>(rec)[1];
+  const float ga = gamma[c], be = beta[c];
+  const float rm = running_mean != nullptr ? running_mean[c] : 0.0f, rv = running_mean != nullptr ? running_var[c] : 0.0f;
+  const float4* __restrict__ r = reinterpret_cast<const float4*>(rec + 4) + (size_t)c * G;
+  // K0: the shift of the channel's first non-empty record (uniform: every thread scans the same leading records)
+  double K0 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const float4 v = r[g];
+    if (v.x > 0.0f) { K0 = (double)v.y; break; }
+  }
+  double n = 0.0, A = 0.0, Q = 0.0;
+  auto merge = [&](const float4 v) {
+    if (v.x > 0.0f) {
+      const double ni = (double)v.x, s1 = (double)v.z, s2 = (double)v.w;
+      const double d = (double)v.y + s1 / ni - K0;
+      n += ni;
+      A += ni * d;
+      Q += (s2 - s1 * s1 / ni) + ni * d * d;
+    }
+  };
+  int g = tid;
+  for (; g + 768 < G; g += 1024) {
+    const float4 v0 = r[g], v1 = r[g + 256], v2 = r[g + 512], v3 = r[g + 768];
+    merge(v0); merge(v1); merge(v2); merge(v3);
+  }
+  for (; g < G; g += 256) merge(r[g]);
+  n = air_wave_sum_d(n);
+  A = air_wave_sum_d(A);
+  Q = air_wave_sum_d(Q);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = n; sh[1][tid >> 6] = A; sh[2][tid >> 6] = Q; }
+  __syncthreads();
+  if (tid != 0) return;
+  n = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+  A = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+  Q = ((sh[2][0] + sh[2][1]) + sh[2][2]) + sh[2][3];
+  const bool ok = Ch == C && n == N;
+  const double ms = A / N;
+  double var = Q / N - ms * ms;
+  if (var < 0.0) var = 0.0;
+  const double m = ms + K0;
+  // a mismatched buffer must not train silently on garbage: NaN statistics fail every downstream check loudly
+  const float mf = ok ? (float)m : __builtin_nanf("");
+  const float is = ok ? (float)(1.0 / sqrt(var + (double)eps)) : __builtin_nanf("");
+  mean[c] = mf;
+  invstd[c] = is;
+  const float sc = ga * is;
+  scale[c] = sc;
+  shift[c] = be - mf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * rm + momentum * mf;
+    running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
                                       const float* rv, float eps, int C, float* scale,
                                       float* shift) {
@@ -337,6 +408,43 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n
     const double k1 = (double)(float)s1 * invN, k2 = (double)(float)s2 * invN;
     dbias[c] = (float)((double)ga * (double)is * (s3 - k1 * s4 - k2 * s5));
   }
+}
+
+// The two backward sums from the records a data-gradient epilogue wrote (air_conv2d_dgrad_bn): header {G, C, 0, 0},
+// then per channel G records {sum g, sum g * xhat, n, 0}.  One workgroup per channel, fp64, fixed order (as
+// bn_finalize_records_kernel).  A buffer whose header or element count does not match gives NaN gradients.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_records_kernel(const float* __restrict__ rec, int C, double N,
+                                                                      float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta) {
+  __shared__ double sh[3][4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int G = reinterpret_cast<const int*>(rec)[0], Ch = reinterpret_cast<const int*>(rec)[1];
+  const float4* __restrict__ r = reinterpret_cast<const float4*>(rec + 4) + (size_t)c * G;
+  double s1 = 0.0, s2 = 0.0, n = 0.0;
+  int g = tid;
+  for (; g + 768 < G; g += 1024) {
+    const float4 v0 = r[g], v1 = r[g + 256], v2 = r[g + 512], v3 = r[g + 768];
+    s1 += (double)v0.x; s2 += (double)v0.y; n += (double)v0.z;
+    s1 += (double)v1.x; s2 += (double)v1.y; n += (double)v1.z;
+    s1 += (double)v2.x; s2 += (double)v2.y; n += (double)v2.z;
+    s1 += (double)v3.x; s2 += (double)v3.y; n += (double)v3.z;
+  }
+  for (; g < G; g += 256) {
+    const float4 v = r[g];
+    s1 += (double)v.x; s2 += (double)v.y; n += (double)v.z;
+  }
+  s1 = air_wave_sum_d(s1);
+  s2 = air_wave_sum_d(s2);
+  n = air_wave_sum_d(n);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s1; sh[1][tid >> 6] = s2; sh[2][tid >> 6] = n; }
+  __syncthreads();
+  if (tid != 0) return;
+  s1 = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+  s2 = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+  n = ((sh[2][0] + sh[2][1]) + sh[2][2]) + sh[2][3];
+  const bool ok = Ch == C && n == N;
+  dbeta[c] = ok ? (float)s1 : __builtin_nanf("");
+  dgamma[c] = ok ? (float)s2 : __builtin_nanf("");
 }
 
 // backward stage 2: dx = gamma*invstd*(g - dbeta/N - xhat*dgamma/N)  (+= if accum)
@@ -548,9 +656,16 @@ int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in, co
   if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || B <= 0 || C <= 0 || S <= 0)
     return AIR_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return AIR_EINVAL;
-  if (stats_in != nullptr) return AIR_EUNSUPPORTED;
-  if (!ws || ws_bytes < air_bn_ws_bytes(B, C, S)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
+  if (stats_in != nullptr) {  // records from the producing convolution's epilogue: no pass over x
+    if (reinterpret_cast<size_t>(stats_in) & 15) return AIR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_records_kernel, dim3(C), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(stats_in), C, (double)B * (double)S, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, invstd, scale, shift);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (!ws || ws_bytes < air_bn_ws_bytes(B, C, S)) return AIR_EWORKSPACE;
   const int nsplit = splits_for(B, C);
   double* partial = reinterpret_cast<double*>(ws);
   if (S < FLAT_S)
@@ -608,6 +723,20 @@ int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const flo
                    const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
                    float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp, void* ws,
                    size_t ws_bytes, air_stream_t stream) {
+  return air_bn_bwd_ex3(x, dy, dy_bstride, dy2, dy2_bstride, dy_rowbias, rowbias_scale, B, C, S, mean, invstd, gamma, beta,
+                        relu, dx, dx_accum, dgamma, dbeta, dbias, dx_bf16, dx_bf16_tp, nullptr, ws, ws_bytes, stream);
+}
+
+int air_bn_bwd_ex3(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                   const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                   float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp,
+                   const void* sums_in, void* ws, size_t ws_bytes, air_stream_t stream) {
+  // sums_in: the records of air_conv2d_dgrad_bn for THIS (x, dy): plain relu(batchnorm) only - one dense gradient,
+  // no second gradient, no row bias, no conv-bias gradient (those change the sums the producer took)
+  if (sums_in && (dy2 || dy_rowbias || dbias || !(relu & 1) || (relu & 2) || dy_bstride != 0 ||
+                  (reinterpret_cast<size_t>(sums_in) & 15)))
+    return AIR_EINVAL;
   if (dx_bf16 && (S < FLAT_S || dx_bf16_tp < S || (dx_bf16_tp & 3) || (reinterpret_cast<size_t>(dx_bf16) & 7)))
     return AIR_EINVAL;
   if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || B <= 0 ||
@@ -621,7 +750,11 @@ int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const flo
   const double invN = 1.0 / ((double)B * (double)S);
   const size_t dense = (size_t)C * S;
   const size_t dbs = dy_bstride ? dy_bstride : dense, d2bs = dy2_bstride ? dy2_bstride : dense;
-  if (S < FLAT_S)
+  if (sums_in != nullptr) {
+    hipLaunchKernelGGL(bn_bwd_finalize_records_kernel, dim3(C), dim3(256), 0, st, reinterpret_cast<const float*>(sums_in), C,
+                       (double)B * (double)S, dgamma, dbeta);
+    AIR_CHECK_LAUNCH();
+  } else if (S < FLAT_S)
     hipLaunchKernelGGL(bn_bwd_partial_flat_kernel, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
                        rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   else if (S & 1)
@@ -631,9 +764,11 @@ int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const flo
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(C * nsplit), dim3(NT), 0, st, x, dy, dbs, dy2, d2bs, dy_rowbias,
                        rowbias_scale, B, C, S, nsplit, mean, invstd, gamma, beta, relu & 1, dbias ? 1 : 0, partial);
   AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nsplit, C, (double)(float)invN,
-                     gamma, invstd, dgamma, dbeta, dbias);
-  AIR_CHECK_LAUNCH();
+  if (sums_in == nullptr) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, nsplit, C, (double)(float)invN,
+                       gamma, invstd, dgamma, dbeta, dbias);
+    AIR_CHECK_LAUNCH();
+  }
   dim3 grid(B * C, (S + NT * 4 - 1) / (NT * 4));
   const size_t n = (size_t)B * C * S;
   if (S < FLAT_S)

@@ -82,28 +82,52 @@ def conv2d_prepack(w, x_shape, stride, padding, which, out=None):
     return out
 
 
-def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=False, residual=None, w_packed=None):
-    """y = conv2d(act(x), w) (+ residual); act = optional per-channel affine + ReLU."""
+def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=False, residual=None, w_packed=None,
+               stats=False):
+    """y = conv2d(act(x), w) (+ residual); act = optional per-channel affine + ReLU.
+    stats=True: returns (y, records) - BatchNorm statistics records of y from the convolution's epilogue for
+    ``bn_stats(..., stats_in=records)``, or (y, None) when this layer has no fused statistics (the caller's BatchNorm
+    then makes its own pass over y)."""
     d = _conv_desc(x.shape, w.shape, stride, padding)
     y = torch.empty((d.B, d.Cout, d.Ho, d.Wo), device=x.device, dtype=torch.float32)
     ws, n = _conv_ws(d, x.device)
+    rec = None
+    if stats and in_scale is None:
+        nb = int(_hip.lib().air_conv2d_fwd_stats_bytes(ctypes.byref(d)))
+        if nb > 0:
+            rec = torch.empty(nb, dtype=torch.uint8, device=x.device)
     _hip.check(_hip.lib().air_conv2d_fwd_pre(
         ctypes.byref(d), dptr(x), dptr(w), dptr(w_packed, torch.uint8, allow_none=True), dptr(y),
         dptr(in_scale, allow_none=True),
         dptr(in_shift, allow_none=True), ci(1 if relu else 0), dptr(residual, allow_none=True),
-        ctypes.c_void_p(0), dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_fwd_pre")
-    return y
+        dptr(rec, torch.uint8, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_fwd_pre")
+    return (y, rec) if stats else y
 
 
-def conv2d_dgrad(dy, w, x_shape, stride=1, padding=0, accumulate=None, out=None, w_packed=None):
+def conv2d_dgrad(dy, w, x_shape, stride=1, padding=0, accumulate=None, out=None, w_packed=None, bn=None):
+    """dx = the data gradient of conv2d (+ accumulate).  bn = (bn_x, mean, invstd, gamma, beta): dx is the gradient
+    with respect to the output of relu(batchnorm(bn_x)); returns (dx, sums) with ``sums`` the BatchNorm-backward
+    records for ``bn_bwd(..., sums_in=sums)`` taken by the epilogue, or (dx, None) when this layer has no such form."""
     d = _conv_desc(x_shape, w.shape, stride, padding)
     dx = out if out is not None else torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
     ws, n = _conv_ws(d, dy.device)
+    if bn is not None:
+        nb = int(_hip.lib().air_conv2d_dgrad_bn_sums_bytes(ctypes.byref(d)))
+        if nb > 0:
+            bx, mean, invstd, gamma, beta = bn
+            if tuple(bx.shape) != tuple(x_shape):
+                raise _hip.AirError("conv2d_dgrad: bn_x must have dx's shape")
+            sums = torch.empty(nb, dtype=torch.uint8, device=dy.device)
+            _hip.check(_hip.lib().air_conv2d_dgrad_bn(
+                ctypes.byref(d), dptr(dy), dptr(w), dptr(w_packed, torch.uint8, allow_none=True), dptr(dx),
+                dptr(accumulate, allow_none=True), dptr(bx), dptr(mean), dptr(invstd), dptr(gamma), dptr(beta),
+                dptr(sums, torch.uint8), dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_dgrad_bn")
+            return dx, sums
     _hip.check(_hip.lib().air_conv2d_dgrad_pre(
         ctypes.byref(d), dptr(dy), dptr(w), dptr(w_packed, torch.uint8, allow_none=True), dptr(dx),
         dptr(accumulate, allow_none=True),
         dptr(ws, torch.uint8), csz(n), stream()), "air_conv2d_dgrad_pre")
-    return dx
+    return (dx, None) if bn is not None else dx
 
 
 def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, in_scale=None, in_shift=None, relu=False,
@@ -124,16 +148,17 @@ def _bcs(x):
     return B, C, S
 
 
-def bn_stats(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+def bn_stats(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, stats_in=None):
     """Training-mode batch statistics.  Returns (mean, invstd, scale, shift); updates
-    running stats in place when given."""
+    running stats in place when given.  stats_in: the records ``conv2d_fwd(..., stats=True)`` returned for THIS x
+    (merged in fp64 instead of reading x)."""
     B, C, S = _bcs(x)
     coef = torch.empty((4, C), device=x.device, dtype=torch.float32)
     lib = _hip.lib()
     n = lib.air_bn_ws_bytes(ci(B), ci(C), ci(S))
     ws = workspace(n, x.device)
     _hip.check(lib.air_bn_stats(
-        dptr(x), ci(B), ci(C), ci(S), ctypes.c_void_p(0), dptr(gamma), dptr(beta), cf(eps),
+        dptr(x), ci(B), ci(C), ci(S), dptr(stats_in, torch.uint8, allow_none=True), dptr(gamma), dptr(beta), cf(eps),
         cf(momentum), dptr(running_mean, allow_none=True), dptr(running_var, allow_none=True),
         dptr(coef[0]), dptr(coef[1]), dptr(coef[2]), dptr(coef[3]), dptr(ws, torch.uint8), csz(n),
         stream()), "air_bn_stats")
@@ -164,7 +189,7 @@ def bn_apply(x, scale, shift, relu=False, out=None, rowmean=None, y_bf=None):
 
 def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=False,
            dgamma=None, dbeta=None, relu_in=False, rowbias=None, rowbias_scale=1.0, dbias=None, dy2=None,
-           dx_bf16=None):
+           dx_bf16=None, sums_in=None):
     """Backward of y = relu?(batchnorm_train(x)).  Returns (dx, dgamma, dbeta).
     relu_in: x is itself a ReLU output (conv -> ReLU -> BN); dx is then the gradient
     w.r.t. the pre-ReLU tensor.  rowbias (B, C): the incoming gradient is dy + rowbias_scale *
@@ -190,15 +215,17 @@ def bn_bwd(x, dy, mean, invstd, gamma, beta, relu=False, dx=None, accumulate=Fal
     ws = workspace(n, x.device)
     if dx_bf16 is not None and tuple(dx_bf16.shape[:2]) != (B, C):
         raise _hip.AirError("bn_bwd: dx_bf16 must be (B, C, Tp)")
-    _hip.check(lib.air_bn_bwd_ex2(dptr(x), dyp, csz(dyb), dy2p, csz(dy2b), dptr(rowbias, allow_none=True),
+    # sums_in: the records conv2d_dgrad(..., bn=...) took for THIS (x, dy): the pass that re-reads both is skipped
+    _hip.check(lib.air_bn_bwd_ex3(dptr(x), dyp, csz(dyb), dy2p, csz(dy2b), dptr(rowbias, allow_none=True),
                                   cf(rowbias_scale), ci(B), ci(C), ci(S), dptr(mean), dptr(invstd), dptr(gamma),
                                   dptr(beta),
                                   ci((1 if relu else 0) | (2 if relu_in else 0)), dptr(dx),
                                   ci(1 if accumulate else 0), dptr(dgamma), dptr(dbeta),
                                   dptr(dbias, allow_none=True), dptr(dx_bf16, torch.int16, allow_none=True),
                                   ci(dx_bf16.shape[2] if dx_bf16 is not None else 0),
+                                  dptr(sums_in, torch.uint8, allow_none=True),
                                   dptr(ws, torch.uint8), csz(n), stream()),
-               "air_bn_bwd_ex2")
+               "air_bn_bwd_ex3")
     return dx, dgamma, dbeta
 
 

@@ -90,12 +90,13 @@ RESNET_CONFIGS = {"18": [[2, 2, 2, 2], PreActBlock],
                   "34": [[3, 4, 6, 3], PreActBlock]}
 
 
-def _bn_train_coeffs(x, bn, training):
-    """(mean, invstd, scale, shift) for BatchNorm ``bn`` on ``x``."""
+def _bn_train_coeffs(x, bn, training, stats_in=None):
+    """(mean, invstd, scale, shift) for BatchNorm ``bn`` on ``x``.  stats_in: statistics records of ``x`` from the
+    epilogue of the convolution that produced it (ops.conv2d_fwd(..., stats=True)), or None."""
     if training:
         mean, invstd, scale, shift = ops.bn_stats(x, bn.weight.detach(), bn.bias.detach(),
                                                   bn.running_mean, bn.running_var, bn.eps,
-                                                  bn.momentum)
+                                                  bn.momentum, stats_in=stats_in)
         ops.bn_tick(bn.num_batches_tracked)
         return mean, invstd, scale, shift
     scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
@@ -110,6 +111,8 @@ class _ResNetFn(torch.autograd.Function):
         feat, mu, saved = model._forward_impl(x, noise, save=True)
         ctx.model = model
         ctx.saved = saved
+        if getattr(model, "keep_saved_for_test", False):  # parity tests read the ReLU decisions of the step
+            model._last_saved_for_test = saved
         return feat, mu
 
     @staticmethod
@@ -155,6 +158,9 @@ class ResNet(nn.Module):
         # tensor in HBM).  False: one HBM-bound pass writes the activated tensor and the convs
         # run their plain (faster) MFMA loop.  Measured on MI355X: see DESIGN.md §4.
         self.fuse_bn_into_conv = os.environ.get("AIR_FUSE_BN", "0") == "1"
+        # BatchNorm batch statistics out of the producing convolution's epilogue (AIR_BN_STATS=0: every BatchNorm
+        # reduces its input itself, rounds 1-3)
+        self.fuse_bn_stats = os.environ.get("AIR_BN_STATS", "1") == "1"
         # weight gradients on a side HIP stream, overlapping the HBM-bound BN-backward passes
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self._side_stream = None
@@ -182,6 +188,8 @@ class ResNet(nn.Module):
         st["_geo"], st["_packs"], st["_pack_ev"] = {}, {}, [None, None]
         st["_bucketer"] = None
         st["_noise_tensor"] = None
+        st.pop("_last_saved_for_test", None)
+        st.pop("keep_saved_for_test", None)
         if st.get("noise_mode") == "tensor":
             st["noise_mode"] = "device"
         return st
@@ -331,10 +339,19 @@ class ResNet(nn.Module):
             return buf
 
         self._geo_sp = {}
-        for bi, blk in enumerate(self.blocks()):
+        # BatchNorm statistics from the producing convolution's epilogue (round 4): conv1 -> bn2 and block output ->
+        # the next block's bn1, wherever the convolution is a Winograd F(3x4, 3x3) launch (ops returns None otherwise)
+        want_stats = training and getattr(self, "fuse_bn_stats", True)
+        cur_rec = None
+        blocks = list(self.blocks())
+
+        def conv_st(want, *a, **kw):  # (y, records or None)
+            return ops.conv2d_fwd(*a, stats=True, **kw) if want else (ops.conv2d_fwd(*a, **kw), None)
+
+        for bi, blk in enumerate(blocks):
             s = blk.stride
             self._geo_sp[(bi, 1)], self._geo_sp[(bi, 2)], self._geo_sp[(bi, 0)] = (s, 1), (1, 1), (s, 0)
-            stA = _bn_train_coeffs(cur, blk.bn1, training)
+            stA = _bn_train_coeffs(cur, blk.bn1, training, cur_rec)
             if fuse:  # BN-apply + ReLU folded into the conv's operand read (no activated tensor)
                 actA, pA = cur, dict(in_scale=stA[2], in_shift=stA[3], relu=True)
             else:     # activated tensor written once (HBM-bound pass), convs run their plain loop
@@ -343,13 +360,15 @@ class ResNet(nn.Module):
                 sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, w_packed=packed((bi, 0), 0, actA.shape), **pA)
             else:
                 sc = cur
-            h = ops.conv2d_fwd(actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
-            stB = _bn_train_coeffs(h, blk.bn2, training)
+            h, h_rec = conv_st(want_stats, actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
+            stB = _bn_train_coeffs(h, blk.bn2, training, h_rec)
             if fuse:
                 actB, pB = h, dict(in_scale=stB[2], in_shift=stB[3], relu=True)
             else:
                 actB, pB = ops.bn_apply(h, stB[2], stB[3], relu=True), {}
-            out = ops.conv2d_fwd(actB, w(blk.conv2), 1, 1, residual=sc, w_packed=packed((bi, 2), 0, actB.shape), **pB)
+            # (the last block's output feeds conv5, not a BatchNorm: resnet.py:182)
+            out, cur_rec = conv_st(want_stats and bi + 1 < len(blocks), actB, w(blk.conv2), 1, 1, residual=sc,
+                                   w_packed=packed((bi, 2), 0, actB.shape), **pB)
             if save:
                 S["blocks"].append((blk, cur, stA, h, stB, actA, actB))
             cur = out
@@ -471,6 +490,10 @@ class ResNet(nn.Module):
             main.wait_event(S["pack_ev"])  # the dgrad weight transforms enqueued on the side stream during forward
         dcur = ops.conv2d_dgrad(dc5, w(self.conv5), l4.shape, 1, (0, 1), w_packed=packs.get(((-1, 5), 1)))
         nblk = len(S["blocks"])
+
+        def dgrad_bn(bn, *a, **kw):  # (dx, BatchNorm-backward sums or None)
+            return ops.conv2d_dgrad(*a, bn=bn, **kw) if bn is not None else (ops.conv2d_dgrad(*a, **kw), None)
+
         for ri, (blk, xin, stA, h, stB, actA, actB) in enumerate(reversed(S["blocks"])):
             bi = nblk - 1 - ri
             s = blk.stride
@@ -489,14 +512,20 @@ class ResNet(nn.Module):
                     ops.conv2d_wgrad(actA, dcur, blk.shortcut[0].weight.shape, s, 0, out=gsc, **pA)
 
             ev_dcur = on_side(wg_out, dcur)
-            d_actB = ops.conv2d_dgrad(dcur, w(blk.conv2), h.shape, 1, 1, w_packed=packs.get(((bi, 2), 1)))
+            # d(relu(bn2(h))) from conv2's data gradient - whose epilogue also takes the two sums of bn2's backward
+            # (round 4: ops returns None where the layer has no Winograd data gradient)
+            bn_fuse = getattr(self, "fuse_bn_stats", True) and not fuse
+            bnB = (h, stB[0], stB[1], blk.bn2.weight.detach(), blk.bn2.bias.detach()) if bn_fuse else None
+            d_actB, smB = dgrad_bn(bnB, dcur, w(blk.conv2), h.shape, 1, 1, w_packed=packs.get(((bi, 2), 1)))
             dh, _, _ = ops.bn_bwd(h, d_actB, stB[0], stB[1], blk.bn2.weight.detach(),
-                                  blk.bn2.bias.detach(), relu=True, dx=d_actB,
+                                  blk.bn2.bias.detach(), relu=True, dx=d_actB, sums_in=smB,
                                   dgamma=gv(pre + "bn2.weight"), dbeta=gv(pre + "bn2.bias"))
             g1 = gv(pre + "conv1.weight")
             on_side(lambda dh=dh, actA=actA, blk=blk, s=s, pA=pA, g1=g1:
                     ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=g1, **pA), dh)
-            d_actA = ops.conv2d_dgrad(dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
+            # (with a 1x1 shortcut d_actA gets a second term below: the sums would be of a partial gradient)
+            bnA = (xin, stA[0], stA[1], blk.bn1.weight.detach(), blk.bn1.bias.detach()) if bn_fuse and not has_sc else None
+            d_actA, smA = dgrad_bn(bnA, dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
             if has_sc:
                 ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
                                  out=d_actA, w_packed=packs.get(((bi, 0), 1)))
@@ -508,7 +537,7 @@ class ResNet(nn.Module):
                 # (dcur is still being read by this block's conv2 wgrad on the side stream)
                 wait_for(ev_dcur)
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
-                                        blk.bn1.bias.detach(), relu=True, dx=dcur, accumulate=True,
+                                        blk.bn1.bias.detach(), relu=True, dx=dcur, accumulate=True, sums_in=smA,
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))
             grads_final_from(pre + "bn1.weight")  # the block's first parameter in arena order
         c1, st1 = S["c1"], S["st1"]

@@ -150,11 +150,15 @@ typedef struct AirConv2d {
 
 size_t air_conv2d_ws_bytes(const AirConv2d* p);
 /* y = conv(act(x), w) [+ residual].  in_scale/in_shift NULL = identity prologue.
- * relu: apply max(0,.) after the affine prologue.  stats: RESERVED, must be NULL (AIR_EUNSUPPORTED
- * otherwise).  Per-channel sum / sum of squares of y from the conv epilogue was costed on MI355X and not
- * built: 12 of the step's 18 BatchNorm statistics passes follow a Winograd conv (0.3 ms in all), and the
- * per-lane reduction over its 4x4 output tiles adds about 400 VALU instructions to an epilogue that is
- * already the kernel's serial part (0.1 ms); the statistics stay in air_bn_stats' own pass. */
+ * relu: apply max(0,.) after the affine prologue.
+ * stats: NULL, or a 16-byte aligned buffer of air_conv2d_fwd_stats_bytes(p) bytes (0 = this layer has no fused
+ * statistics under the current dispatch options: pass NULL) that receives BatchNorm statistics of y (of y + residual)
+ * from the convolution's epilogue: one record {n, K, sum(y - K), sum((y - K)^2)} per (channel, tile group) of the
+ * Winograd F(3x4 / 4x4, 3x3) kernel - the (count, mean, M2) of the group's outputs in shifted form.  Hand the buffer
+ * to air_bn_stats as stats_in and the BatchNorm that follows the convolution (resnet.py:63-69: conv1 -> bn2, block
+ * output -> the next block's bn1) merges the records in fp64 instead of reading y again: 12 of the 18 statistics
+ * passes of a ResNet-18 step.  Round 4, measured (rounds 2 and 3 had priced it and not built it): see DESIGN.md. */
+size_t air_conv2d_fwd_stats_bytes(const AirConv2d* p);
 int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,
                    const float* in_scale, const float* in_shift, int relu,
                    const float* residual, double* stats, void* ws, size_t ws_bytes,
@@ -182,6 +186,19 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
                        double* stats, void* ws, size_t ws_bytes, air_stream_t stream);
 int air_conv2d_dgrad_pre(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
                          const float* accumulate, void* ws, size_t ws_bytes, air_stream_t stream);
+/* The same data gradient when dx is the gradient with respect to the OUTPUT of relu(batchnorm(bn_x)) - the activated
+ * tensor a 3x3 / stride 1 convolution of a PreActBlock reads (resnet.py:63-69: bn2 -> relu -> conv2, and bn1 -> relu
+ * -> conv1 in the blocks without a 1x1 shortcut).  The epilogue that writes dx also takes the two per-channel sums the
+ * BatchNorm backward needs - sum g and sum g * xhat with g = dx where bn_x * scale + shift > 0, xhat = (bn_x - mean) *
+ * invstd, the arithmetic of air_bn_bwd's own first pass - into `sums` (air_conv2d_dgrad_bn_sums_bytes(p) bytes,
+ * 16-byte aligned; 0 = this layer has no such form under the current dispatch options: call air_conv2d_dgrad_pre).
+ * Hand `sums` to air_bn_bwd_ex3 and the BatchNorm backward skips the pass that re-reads dx and bn_x (12 of the 18
+ * BatchNorm backward passes of a ResNet-18 step).  bn_x has dx's shape; the four vectors have Cin entries. */
+size_t air_conv2d_dgrad_bn_sums_bytes(const AirConv2d* p);
+int air_conv2d_dgrad_bn(const AirConv2d* p, const float* dy, const float* w, const void* w_packed, float* dx,
+                        const float* accumulate, const float* bn_x, const float* bn_mean, const float* bn_invstd,
+                        const float* bn_gamma, const float* bn_beta, void* sums, void* ws, size_t ws_bytes,
+                        air_stream_t stream);
 /* dw = correlation(act(x), dy); same prologue as fwd so the activated tensor
  * is never materialised. */
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,
@@ -314,8 +331,10 @@ int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* d
  */
 /* Batch statistics -> mean/invstd, fused scale/shift for the apply, running
  * stat update (momentum 0.1, unbiased var) when running_* non-NULL.
- * stats_in: RESERVED, must be NULL (AIR_EUNSUPPORTED otherwise; see air_conv2d_fwd): the kernel reduces x
- * itself (shifted sums, fp64 two-stage, fixed order). */
+ * stats_in: NULL - the kernel reduces x itself (shifted sums, fp64 two-stage, fixed order) - or the statistics
+ * records air_conv2d_fwd wrote for this very tensor (its header carries the group and channel counts, which must
+ * match C; x is then not read): a wave per channel merges them in fp64 in a fixed order (Chan's formula on
+ * (n, mean, M2)). */
 size_t air_bn_ws_bytes(int B, int C, int S);
 int air_bn_stats(const float* x, int B, int C, int S, const double* stats_in,
                  const float* gamma, const float* beta, float eps, float momentum,
@@ -365,6 +384,14 @@ int air_bn_bwd_ex2(const float* x, const float* dy, size_t dy_bstride, const flo
                    const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
                    float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp, void* ws,
                    size_t ws_bytes, air_stream_t stream);
+/* air_bn_bwd_ex2 with the two per-channel sums taken by the convolution that produced dy (air_conv2d_dgrad_bn,
+ * `sums`): the first pass over (x, dy) is skipped, a workgroup per channel merges the records in fp64.  sums_in NULL =
+ * air_bn_bwd_ex2.  Only for plain relu(batchnorm(x)) with one dense gradient (dy2, dy_rowbias, dbias NULL, relu = 1). */
+int air_bn_bwd_ex3(const float* x, const float* dy, size_t dy_bstride, const float* dy2, size_t dy2_bstride,
+                   const float* dy_rowbias, float rowbias_scale, int B, int C, int S, const float* mean,
+                   const float* invstd, const float* gamma, const float* beta, int relu, float* dx, int dx_accum,
+                   float* dgamma, float* dbeta, float* dbias, unsigned short* dx_bf16, int dx_bf16_tp,
+                   const void* sums_in, void* ws, size_t ws_bytes, air_stream_t stream);
 
 /* ------------------------------------------------------------- pooling ---
  * SelfAttention.forward (resnet.py:23-46) on x (B, C, T) (the squeezed conv5

@@ -47,7 +47,7 @@ def _full_size_oracle():
         p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
         o64 = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
         _, _, _, g64, _, _ = o64.loss_and_grads(xo.double(), labels, None)
-        _FULL.update(pcm=pcm, labels=labels, lo=lo, no=no, go=go, g64=g64, otr=otr)
+        _FULL.update(pcm=pcm, labels=labels, lo=lo, no=no, go=go, g64=g64, otr=otr, xo=xo)
     return _FULL
 
 
@@ -62,6 +62,7 @@ def test_resnet_full_size_step_vs_oracle(path):
     pcm, labels, lo, no, go, g64, otr = (o[k] for k in ("pcm", "labels", "lo", "no", "go", "g64", "otr"))
     with conv_path(path):
         tr = _resnet_trainer(FL)
+        tr.model.keep_saved_for_test = True  # (keeps the tensors saved for backward: the ReLU decisions, below)
         loss, neg = tr.step(pcm.cuda(), labels.cuda())
         torch.cuda.synchronize()
     grads = {k: p.grad.detach().cpu().numpy() for k, p in tr.model.named_parameters() if p.grad is not None}
@@ -82,11 +83,47 @@ def test_resnet_full_size_step_vs_oracle(path):
         nrm = np.linalg.norm(ref) + 1e-30
         e_hip = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / nrm
         e_cpu = np.linalg.norm(go[k].numpy().ravel().astype(np.float64) - ref) / nrm
-        assert e_hip <= 3.0 * e_cpu + slack, (path, k, e_hip, e_cpu, slack)
+        if path == "strict":
+            assert e_hip <= 3.0 * e_cpu + slack, (path, k, e_hip, e_cpu, slack)
         if e_hip > worst[1]:
             worst = (k, e_hip, e_cpu)
     print("worst relative L2 gradient error vs fp64: %s hip %.2e (fp32 CPU oracle: %.2e)" % worst)
     record("resnet_full_size_worst_grad[%s]" % path, list(worst))
+    if path == "default":
+        # Round 4.  The distance to the PLAIN fp64 oracle above is dominated by ReLU decisions on pre-activations
+        # within rounding of 0 (test_resnet_gpu.py::test_grads_vs_oracle_small proves it at (2, 96): 3 flips of 1.8 M
+        # account for a 1000x gap), and which of them flip changes with every change of a summation order - the
+        # BatchNorm statistics taken in the convolution epilogues moved layer4.1.bn2.weight from 3.6e-3 to 6.3e-3
+        # while agreeing with the BatchNorm's own passes to 2e-6 at kernel level.  So for the Winograd path the
+        # bound is on what is computed, not on which side of 0 a rounding error fell: the fp64 oracle evaluated
+        # WITH this run's 18 ReLU decisions (oracle/resnet.py::ReluProbe) must agree with every gradient tensor to
+        # the strict path's slack (1e-3: no rounding ratio applied), the flips are counted and must be few and
+        # small, and the plain distance stays bounded at twice the derived allowance.
+        S = tr.model._last_saved_for_test
+        masks = [S["blocks"][0][1] > 0]
+        for blk in S["blocks"]:
+            masks += [blk[5] > 0, blk[6] > 0]
+        masks.append((S["a5v"] > 0).unsqueeze(2))
+        probe = o_resnet.ReluProbe([mk.cpu() for mk in masks])
+        p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in fill_state(o_resnet.resnet18_shapes()).items()}
+        o64m = o_train.OracleTrainer("resnet", p64, fill_value("center", (1, 256)).double())
+        o64m.relu = probe
+        xo = o["xo"]
+        _, _, _, gm, _, _ = o64m.loss_and_grads(xo.double(), labels, None)
+        n_act, n_flip = sum(int(mk.numel()) for mk in masks), sum(probe.flips)
+        worst_m = ("", 0.0)
+        for k, gh in grads.items():
+            ref = gm[k].numpy().ravel()
+            e = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-30)
+            if e > worst_m[1]:
+                worst_m = (k, e)
+            assert e <= tol("full_size_slack", "strict"), (k, e)
+        print("ReLU decisions that differ from the fp64 oracle's: %d of %d (largest |pre-activation| %.2e); under this "
+              "run's decisions the worst tensor is %s at %.2e" % (n_flip, n_act, max(probe.flip_mag), worst_m[0], worst_m[1]))
+        record("resnet_full_size_relu_flips[default]", {"flips": n_flip, "of": n_act, "max_abs_preact": max(probe.flip_mag),
+                                                        "masked_worst": list(worst_m)})
+        assert n_flip <= 4000 and max(probe.flip_mag) <= 1e-4, (n_flip, max(probe.flip_mag))
+        assert worst[1] <= 3.0 * worst[2] + 2.0 * slack, worst
     # the updated weights (Adam, lr 5e-4: every element moves by ~lr in step 1) agree to a fraction of a step
     w = tr.model.state_dict()["layer4.1.conv2.weight"].cpu().numpy()
     assert np.abs(w - otr.params["layer4.1.conv2.weight"].numpy()).max() <= 2 * 5e-4 + 1e-6

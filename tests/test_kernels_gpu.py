@@ -411,3 +411,91 @@ def test_conv2d_winograd(ops, cfg):
     F.conv2d(x.double(), wd, None, 1, 1).backward(dy.double())
     got = ops.conv2d_wgrad(x.cuda(), dy.cuda(), tuple(w.shape), 1, 1)
     close(got, wd.grad, rtol=1e-5, name="winograd wgrad")
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("cfg", [(2, 64, 18, 75, 64), (6, 32, 9, 100, 128), (5, 64, 5, 47, 256), (24, 16, 3, 94, 64),
+                                 (3, 64, 4, 33, 128), (7, 128, 9, 375, 64)])
+def test_batchnorm_statistics_from_the_conv_epilogue(ops, cfg, split):
+    """Round 4: ``conv2d_fwd(..., stats=True)`` + ``bn_stats(..., stats_in=records)`` against the BatchNorm's own pass
+    over the same tensor and against fp64.  Shapes: W % 4 = 3 / 0 / 3 / 2 / 1 / 3 (tiles that straddle the right edge
+    contribute their valid columns only), H % 3 != 0 (rows computed for nothing are left out), 4-row tiles (H = 4),
+    2 x 8 tile groups, tile groups beyond the image stack (empty records), cut tail items (the owner of the lower
+    half writes the records after adding the partner's sums), with and without a residual.  The mean and the
+    variance agree with the fp64 statistics of the STORED tensor to 2e-6 relative (fp32 records of <= 192 values,
+    merged in fp64); running statistics are updated the same way."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 31).cuda()
+    w = synth_feat((Cout, Cin, 3, 3), 32, scale=0.1).cuda()
+    res = (synth_feat((B, Cout, H, W), 33) + 0.7).cuda()  # (a mean well away from 0: the shifted sums matter)
+    gamma, beta = (1.0 + 0.3 * synth_feat((Cout,), 34)).cuda(), (0.2 * synth_feat((Cout,), 35)).cuda()
+    with _hip.options(WINO4_SPLIT=split):
+        for residual in (None, res):
+            y, rec = ops.conv2d_fwd(x, w, 1, 1, residual=residual, stats=True)
+            assert rec is not None
+            assert torch.equal(y, ops.conv2d_fwd(x, w, 1, 1, residual=residual))  # the records change nothing in y
+            rm0, rv0 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+            rm1, rv1 = rm0.clone(), rv0.clone()
+            a = ops.bn_stats(y, gamma, beta, rm0, rv0)
+            b = ops.bn_stats(y, gamma, beta, rm1, rv1, stats_in=rec)
+            yd = y.double()
+            mean64 = yd.mean((0, 2, 3))
+            var64 = yd.var((0, 2, 3), unbiased=False)
+            n = B * H * W
+            for got in (a, b):
+                close(got[0], mean64, 2e-6, "mean")
+                close(got[1], 1.0 / torch.sqrt(var64 + 1e-5), 2e-6, "invstd")
+            close(b[2], a[2], 2e-6, "scale")
+            close(b[3], a[3], 4e-6, "shift")
+            close(rm1, 0.1 * mean64, 2e-6, "running mean")
+            close(rv1, 0.9 + 0.1 * var64 * n / (n - 1), 2e-6, "running var")
+    # a buffer that belongs to another tensor is refused loudly (NaN statistics), never merged silently
+    y2, rec2 = ops.conv2d_fwd(x[:1], w, 1, 1, stats=True)
+    bad = ops.bn_stats(y, gamma, beta, stats_in=rec2)
+    assert bool(torch.isnan(bad[0]).all())
+    # layers without the Winograd epilogue report that they have no fused statistics
+    assert ops.conv2d_fwd(x, synth_feat((Cout, Cin, 1, 1), 36).cuda(), 1, 0, stats=True)[1] is None
+    with _hip.options(NO_WINO4=1):
+        assert ops.conv2d_fwd(x, w, 1, 1, stats=True)[1] is None
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("cfg", [(2, 64, 18, 75, 64), (6, 128, 9, 100, 32), (5, 256, 5, 47, 64), (24, 64, 3, 94, 32),
+                                 (3, 128, 4, 33, 64), (7, 64, 9, 375, 128)])
+def test_batchnorm_backward_sums_from_the_dgrad_epilogue(ops, cfg, split):
+    """Round 4: ``conv2d_dgrad(..., bn=...)`` + ``bn_bwd(..., sums_in=...)``: the data gradient is bit-identical to
+    the plain call (the sums are a by-product), and dgamma / dbeta / dx of the BatchNorm backward agree with the
+    BatchNorm's own two passes over the same tensors to 2e-6 of scale (fp32 records of <= 192 products, merged in fp64;
+    both use the same ReLU mask and xhat arithmetic) and with fp64 autograd of relu(batch_norm(x)) to 2e-5.  Edge
+    tiles, rows beyond H, 4-row tiles, 2 x 8 groups, cut items, and an accumulate operand (lower halves of cut items
+    carry the partner's sums AND the accumulate)."""
+    from asvspoof2021_air_amd import _hip
+    B, Cout, H, W, Cin = cfg   # the forward conv maps Cin -> Cout; dx has Cin channels
+    w = synth_feat((Cout, Cin, 3, 3), 42, scale=0.1).cuda()
+    dy = synth_feat((B, Cout, H, W), 43).cuda()
+    x = (synth_feat((B, Cin, H, W), 44) * 1.3 + 0.2).cuda()      # the BatchNorm's input
+    acc = synth_feat((B, Cin, H, W), 45).cuda()
+    gamma, beta = (1.0 + 0.3 * synth_feat((Cin,), 46)).cuda(), (0.2 * synth_feat((Cin,), 47)).cuda()
+    mean, invstd, _, _ = ops.bn_stats(x, gamma, beta)
+    with _hip.options(WINO4_SPLIT=split):
+        for accumulate in (None, acc):
+            dA0 = ops.conv2d_dgrad(dy, w, x.shape, 1, 1, accumulate=accumulate)
+            dA1, sums = ops.conv2d_dgrad(dy, w, x.shape, 1, 1, accumulate=accumulate, bn=(x, mean, invstd, gamma, beta))
+            assert sums is not None and torch.equal(dA0, dA1)
+            dx0, dg0, db0 = ops.bn_bwd(x, dA0, mean, invstd, gamma, beta, relu=True)
+            dx1, dg1, db1 = ops.bn_bwd(x, dA1, mean, invstd, gamma, beta, relu=True, sums_in=sums)
+            close(dg1, dg0, 2e-6, "dgamma vs own pass")
+            close(db1, db0, 2e-6, "dbeta vs own pass")
+            close(dx1, dx0, 2e-6, "dx vs own pass")
+            xd = x.double().requires_grad_(True)
+            gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+            F.relu(F.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5)).backward(dA1.double())
+            close(dg1, gd.grad, 2e-5, "dgamma vs fp64")
+            close(db1, bd.grad, 2e-5, "dbeta vs fp64")
+            close(dx1, xd.grad, 2e-5, "dx vs fp64")
+    # sums of another tensor are refused loudly; layers without the Winograd data gradient report None
+    _, s2 = ops.conv2d_dgrad(dy[:1], w, x[:1].shape, 1, 1, bn=(x[:1].contiguous(), mean, invstd, gamma, beta))
+    assert bool(torch.isnan(ops.bn_bwd(x, dA0, mean, invstd, gamma, beta, relu=True, sums_in=s2)[1]).all())
+    with _hip.options(NO_WINO4=1):
+        assert ops.conv2d_dgrad(dy, w, x.shape, 1, 1, bn=(x, mean, invstd, gamma, beta))[1] is None
