@@ -97,8 +97,8 @@ def test_resnet_full_size_step_vs_oracle(path):
         # while agreeing with the BatchNorm's own passes to 2e-6 at kernel level.  So for the Winograd path the
         # bound is on what is computed, not on which side of 0 a rounding error fell: the fp64 oracle evaluated
         # WITH this run's 18 ReLU decisions (oracle/resnet.py::ReluProbe) must agree with every gradient tensor to
-        # the strict path's slack (1e-3: no rounding ratio applied), the flips are counted and must be few and
-        # small, and the plain distance stays bounded at twice the derived allowance.
+        # 5e-4 relative L2 (a tenth of the derived allowance; measured 1.04e-4), the flips are counted and must be few
+        # and small, and the plain distance stays bounded at twice the derived allowance.
         S = tr.model._last_saved_for_test
         masks = [S["blocks"][0][1] > 0]
         for blk in S["blocks"]:
@@ -117,12 +117,13 @@ def test_resnet_full_size_step_vs_oracle(path):
             e = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-30)
             if e > worst_m[1]:
                 worst_m = (k, e)
-            assert e <= tol("full_size_slack", "strict"), (k, e)
+            assert e <= 5e-4, (k, e)   # measured 1.04e-4 (bn1.weight); the plain distance of the same run is 1.5e-2
         print("ReLU decisions that differ from the fp64 oracle's: %d of %d (largest |pre-activation| %.2e); under this "
               "run's decisions the worst tensor is %s at %.2e" % (n_flip, n_act, max(probe.flip_mag), worst_m[0], worst_m[1]))
         record("resnet_full_size_relu_flips[default]", {"flips": n_flip, "of": n_act, "max_abs_preact": max(probe.flip_mag),
                                                         "masked_worst": list(worst_m)})
-        assert n_flip <= 4000 and max(probe.flip_mag) <= 1e-4, (n_flip, max(probe.flip_mag))
+        # measured: 557 of 450,289,664 ReLU inputs, the largest |BatchNorm output| among them 4.7e-5
+        assert n_flip <= 2500 and max(probe.flip_mag) <= 2e-4, (n_flip, max(probe.flip_mag))
         assert worst[1] <= 3.0 * worst[2] + 2.0 * slack, worst
     # the updated weights (Adam, lr 5e-4: every element moves by ~lr in step 1) agree to a fraction of a step
     w = tr.model.state_dict()["layer4.1.conv2.weight"].cpu().numpy()
