@@ -754,7 +754,14 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     dma_wait();
     __syncthreads();
   }
-  auto stage_body = [&](auto first_tag, int s, int cur) {
+  // HALF: the stage lies in the last tile row of an image with an odd row count - the dy tiles' second row is beyond
+  // the image (zeros), so row 3 of G' g G'^T is zero and the four products M[3][*] with it: 12 MFMAs per k-step
+  // instead of 16 (F(3x3, 1x2) in effect).  The ResNet's 9 / 5 / 3-row maps have 1 of 5 / 3 / 2 tile rows like that:
+  // 5 / 8 / 12.5 % of the launch's MFMAs (round 4).
+  // (a wave-uniform branch around those four MFMAs, not a second instantiation of the stage: the 256 accumulator
+  // registers + 256 VGPRs are full, and a duplicated body tripled the spills - 0.31 -> 0.42 ms on layer1, which has
+  // no such row at all)
+  auto stage_body = [&](auto first_tag, bool hs, int s, int cur) {
     constexpr bool FIRST = decltype(first_tag)::value;
     float* bcur = lds + cur * WG_BUF;
     if (edge_col >= 0) fix_edge(bcur, edge_col);
@@ -781,7 +788,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
         if (ks < 4 && (j & 1) == 0 && more) dma_unit(ks * 8 + j / 2);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        if (FIRST && ks == 0)
+        if (j >= 12 && hs) {
+          if (FIRST && ks == 0) acc[j] = (f32x16){0};
+        } else if (FIRST && ks == 0)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA(cs, j >> 2, j & 3), V[cs][j >> 1][j & 1],
                                                        (f32x16){0}, 0, 0, 0);
         else
@@ -797,10 +806,14 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(WinoWgArgs a) {
     dma_wait();
     __syncthreads();
   };
+#ifndef W2_HALF_ROWS
+#define W2_HALF_ROWS 1  // A/B: 0 = every stage issues all 16 products (rounds 1 - 3)
+#endif
+  auto is_half = [&](int s) { return W2_HALF_ROWS && 2 * ((s / a.NTS) % a.TH) + 1 >= a.H; };
   if (s0 < s1) {
-    stage_body(std::true_type{}, s0, 0);
+    stage_body(std::true_type{}, is_half(s0), s0, 0);
     int cur = 1;
-    for (int s = s0 + 1; s < s1; ++s, cur ^= 1) stage_body(std::false_type{}, s, cur);
+    for (int s = s0 + 1; s < s1; ++s, cur ^= 1) stage_body(std::false_type{}, is_half(s), s, cur);
   } else {
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = (f32x16){0};
