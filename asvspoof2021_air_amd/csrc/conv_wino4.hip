@@ -658,6 +658,85 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       // without the sums keep the round-3 register budget.
       const __amdgpu_buffer_rsrc_t xbrs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(do_bst ? a.bnx : a.y), (short)0, do_bst ? (int)ybytes : 0, 0x00020000);
+      if (do_bst && !(use_res || accum)) {
+        // The common case - no residual, not the lower half of a cut item (every eligible launch of the ResNet's
+        // backward pass but those halves): the 8 x MH loads of the BatchNorm input and the 32 channel constants all
+        // go out first (the residual's 96 registers are free), then each channel pair is formed, summed and STORED
+        // at once - no load follows a store.  (With one pair in flight the loads' latency was exposed eight times
+        // per item and the stores went out as one burst: +45 us per launch on layer1.)
+        f32x4 xa[8][MH];
+        float kmu[8], kis[8], ksc[8], ksh[8];
+#pragma unroll
+        for (int cr = 0; cr < 8; ++cr) {
+          const unsigned coff = (unsigned)((cr >> 2) * 16 + (cr & 3)) * chan;
+          const bool gone = (cr >> 2) == 1 && tail16;
+          int c = co0 + (cr >> 2) * 16 + (cr & 3);
+          c = c < a.Cout ? c : a.Cout - 1;
+          kmu[cr] = a.bn_mean[c]; kis[cr] = a.bn_invstd[c]; ksc[cr] = a.bn_gamma[c]; ksh[cr] = a.bn_beta[c];
+#pragma unroll
+          for (int yy = 0; yy < MH; ++yy)
+            xa[cr][yy] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xbrs, gone ? W4_OOB : lrow[yy] + coff, 0, 0));
+        }
+#pragma unroll
+        for (int cr = 0; cr < 8; ++cr) {
+          const int cb = cr >> 2, r = cr & 3;
+          const unsigned coff = (unsigned)(cb * 16 + r) * chan;
+          const bool gone = cb == 1 && tail16;
+          const float mu = kmu[cr], is = kis[cr];
+          const float sc = ksc[cr] * is;
+          const float shf = ksh[cr] - mu * sc;
+          float T[MH][6];
+#pragma unroll
+          for (int jj = 0; jj < 6; ++jj) {
+            float m[NPR];
+#pragma unroll
+            for (int i = 0; i < NPR; ++i) {
+              const int acc = cb * NP + 6 * i + jj;
+              m[i] = acc < 64 ? accA[acc < 64 ? acc : 0][r] : accV[acc >= 64 ? acc - 64 : 0][r];
+            }
+            if constexpr (MH == 4) w4_at6(m[0], m[1], m[2], m[3], m[4], m[5], T[0][jj], T[1][jj], T[2][jj], T[3][jj]);
+            else w4_at5(m[0], m[1], m[2], m[3], m[4], T[0][jj], T[1][jj], T[2][jj]);
+          }
+          float s1 = 0.0f, s2 = 0.0f;
+          f32x4 Yv[MH];
+#pragma unroll
+          for (int yy = 0; yy < MH; ++yy) {
+            float v0, v1, v2, v3;
+            w4_at6(T[yy][0], T[yy][1], T[yy][2], T[yy][3], T[yy][4], T[yy][5], v0, v1, v2, v3);
+            Yv[yy] = (f32x4){v0, v1, v2, v3};
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+              const float xe = xa[cr][yy][xx];
+              float gg = Yv[yy][xx];
+              if (!(xe * sc + shf > 0.0f)) gg = 0.0f;  // (the mask of bn_bwd_partial / bn_bwd_apply, verbatim)
+              if (!all_in) gg = (st_ok && ho + yy < a.H && wo + xx < a.W) ? gg : 0.0f;
+              const float xh = (xe - mu) * is;
+              s1 += gg;
+              s2 += gg * xh;
+            }
+          }
+          s1 = rowsum16(s1);
+          s2 = rowsum16(s2);
+          const unsigned so = (jl == 0 && !gone) ? st_base + (unsigned)(cb * 16 + r) * st_chan : W4_OOB;
+          const f32x4 rec = {s1, s2, st_cnt, 0.0f};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rec), srs, so, 0, 0);
+#pragma unroll
+          for (int yy = 0; yy < MH; ++yy)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Yv[yy]), yrs, gone ? W4_OOB : orow[yy] + coff, 0, 0);
+          if (part) {
+#pragma unroll
+            for (int yy = 0; yy < MH; ++yy)
+#pragma unroll
+              for (int xx = 0; xx < 3; ++xx) {
+                const unsigned o = (ho + yy < a.H && wo + xx < a.W && !gone) ? obase + (unsigned)(yy * a.W + xx) * 4u + coff : W4_OOB;
+                const float v = Yv[yy][xx];  // (bit_cast of the element expression itself reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, o, 0, 0);
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
       f32x4 Yall[8][MH];
       f32x4 xn[MH], rn[MH];
       float cmu = 0.0f, cis = 0.0f, cga = 0.0f, cbe = 0.0f;

@@ -2,7 +2,7 @@
 # Run on the GPU box (gpurun): bench lines, rocprofv3 kernel traces and PMC traffic passes.
 # Usage: tools/profile_round.sh <tag>   -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -10,9 +10,9 @@ cd $GRAFT_REPO_ROOT
 export PYTHONPATH=$GRAFT_REPO_ROOT
 timeout 300 python bench.py > $OUT/bench_resnet.json 2> $OUT/bench_resnet.err
 timeout 300 python bench.py --feat-len 401 --no-cpu-baseline --no-extra-configs --no-pmc > $OUT/bench_resnet_t401.json 2>> $OUT/bench_resnet.err
-timeout 300 python bench.py --model ecapa --steps 8 > $OUT/bench_ecapa_bf16.json 2> $OUT/bench_ecapa.err
-timeout 300 python bench.py --model ecapa --steps 8 --feat-len 401 --no-pmc > $OUT/bench_ecapa_bf16_t401.json 2>> $OUT/bench_ecapa.err
-timeout 300 python bench.py --model ecapa --steps 8 --augment --no-roofline > $OUT/bench_ecapa_bf16_aug.json 2>> $OUT/bench_ecapa.err
+timeout 300 python bench.py --model ecapa --steps 20 > $OUT/bench_ecapa_bf16.json 2> $OUT/bench_ecapa.err
+timeout 300 python bench.py --model ecapa --steps 20 --feat-len 401 --no-pmc > $OUT/bench_ecapa_bf16_t401.json 2>> $OUT/bench_ecapa.err
+timeout 300 python bench.py --model ecapa --steps 20 --augment --no-roofline > $OUT/bench_ecapa_bf16_aug.json 2>> $OUT/bench_ecapa.err
 timeout 300 python bench.py --model ecapa --dtype bf16c --steps 8 --no-roofline > $OUT/bench_ecapa_bf16c.json 2>> $OUT/bench_ecapa.err
 timeout 300 python bench.py --model ecapa --dtype fp32 --steps 8 --no-roofline > $OUT/bench_ecapa_fp32.json 2>> $OUT/bench_ecapa.err
 for m in resnet ecapa; do
