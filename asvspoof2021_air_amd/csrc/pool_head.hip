@@ -230,6 +230,14 @@ __global__ __launch_bounds__(NT) void linear_fwd_kernel(const float* __restrict_
   float s[LIN_MB];
 #pragma unroll
   for (int i = 0; i < LIN_MB; ++i) s[i] = 0.0f;
+// (LIN_FWD_UNROLL: A/B builds.  Round 3 reported that `#pragma unroll` here "hung the GPU test run".  Round 4: plain
+// `#pragma unroll` compiles to the identical ISA (the per-lane trip count is not unrollable); `unroll 4` / `16` give a
+// per-lane remainder loop in front of the unrolled one whose exec-mask logic reads correct, and both builds pass
+// test_linear (incl. K = 40 / 100 / 130 / 1100: idle lanes, ragged trip counts) and the ResNet / ECAPA model suites on
+// hardware - not reproduced, not a miscompile of this loop.)
+#ifdef LIN_FWD_UNROLL
+#pragma unroll LIN_FWD_UNROLL
+#endif
   for (int k = lane; k < K; k += 64) {
     const float wv = wr[k];
 #pragma unroll
