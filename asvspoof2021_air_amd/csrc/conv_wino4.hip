@@ -1346,6 +1346,9 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   // algorithmic bytes: x and the transformed weights read once, y written once, the residual read once
   const double abytes = 4.0 * ((double)B * Kc * H * W + (double)B * M * H * W * (residual ? 2.0 : 1.0) +
                                (double)M * Kc * (mh == 3 ? 32.0 : 36.0));
-  AirProfScope ps(AIR_K_CONV_WINO4, flops, st, issued, abytes);
+  // (launches that also do a BatchNorm reduction's work are timed under their own id: bench.py reports the family's
+  // issued-FLOP fraction over all launches and the plain launches' beside it)
+  AirProfScope ps(stats ? AIR_K_CONV_WINO4_BN : AIR_K_CONV_WINO4, flops, st, issued,
+                  abytes + (bn ? 4.0 * (double)B * M * H * W : 0.0));
   return mh == 3 ? w4_launch<3>(a, trg, nblk, st) : w4_launch<4>(a, trg, nblk, st);
 }

@@ -82,6 +82,18 @@ def roofline_leg(trainer, batches):
                          "issued": issued.value if issued.value != work.value else WINO_ISSUE.get(name, 1.0) * work.value,
                          "bytes": nbytes.value})
     lib.air_prof_enable(0)
+    # wino4_conv_kernel launches whose epilogue also takes BatchNorm statistics (forward) or the BatchNorm-backward
+    # sums (data gradient) are timed under "wino4_conv_kernel+bn": ONE family for the roofline - the same kernel, the
+    # same MFMA work, plus a reduction that used to be a separate HBM pass - with the split reported beside it
+    w4 = [r for r in rows if r["kernel"].startswith("wino4_conv_kernel")]
+    split = None
+    if len(w4) == 2:
+        split = {r["kernel"]: {"launches_per_step": r["launches"] // 2, "avg_launch_ms": round(r["total_ms"] / r["launches"], 4),
+                               "frac": round(r["issued"] / (r["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)} for r in w4}
+        merged = {"kernel": "wino4_conv_kernel"}
+        for k in ("launches", "total_ms", "work", "issued", "bytes"):
+            merged[k] = w4[0][k] + w4[1][k]
+        rows = [r for r in rows if not r["kernel"].startswith("wino4_conv_kernel")] + [merged]
     convs = [r for r in rows if r["kernel"].startswith(("conv", "wino", "c1b"))]
     dom = max(convs, key=lambda r: r["total_ms"])
     algorithmic = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
@@ -107,6 +119,8 @@ def roofline_leg(trainer, batches):
     # "traffic" (measured HBM-side bytes per launch) is filled in by pmc_traffic_leg() from PMC passes of THIS run
     if dom["bytes"] > 0:
         out["algorithmic_bytes"] = round(dom["bytes"] / dom["launches"])
+    if split is not None and dom["kernel"] == "wino4_conv_kernel":
+        out["instances"] = split
     if dom["kernel"] == "c1b_fwd_kernel":
         # ECAPA: the fused 512-channel pointwise kernel is HBM-bound on the fp32 tensors (127 FLOP per
         # algorithmic byte < 312 FLOP/B machine balance): price it on bytes as well.  4*(Cin+Cout) bytes
