@@ -12,7 +12,13 @@ main_train.py:175-176,272 with its own step decay (main_train.py:144-147), start
   dataset.py:519-522), batch 64, 512 training utterances, 12 epochs (--interval 3), 1024 held-out.
 
 Stored: per-epoch mean loss, held-out scores / labels / EER and the number of misclassified trials at the EER
-threshold on both sides.  Build container only.  Usage: make_golden_eer3.py [eer3|eer4s] [resnet|ecapa]
+threshold on both sides.  Build container only.  Usage: make_golden_eer3.py [eer3|eer4s] [resnet|ecapa] [spread]
+
+``spread``: the reference's own run-to-run spread (runs from initial weights with one element moved by 1e-7) as
+synth_<name>_<model>_spread.npz.  A CPU run's trajectory also depends on its thread count, so the commands that made the
+committed files are part of the fixture: eer3 (round 3) with the defaults (EER_THREADS=6, EER_SPREAD=6 / 7);
+``EER_THREADS=5 EER_SPREAD=4 make_golden_eer3.py eer4s resnet spread`` for synth_eer4s_resnet_spread.npz (round 4:
+wrong trials of 1024 held-out: 1 / 3 / 1 / 3 beside the unperturbed run's 3; final-epoch losses 0.078 - 0.084).
 """
 import os
 import sys
