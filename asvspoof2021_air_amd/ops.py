@@ -82,6 +82,17 @@ def conv2d_prepack(w, x_shape, stride, padding, which, out=None):
     return out
 
 
+def _check_packed(d, w_packed, which):
+    """A prepacked weight buffer must be at least what the layer consumes under the CURRENT dispatch options
+    (options can change between prepack and use; the library walks the buffer without a size)."""
+    if w_packed is not None:
+        need = int(_hip.lib().air_conv2d_prepack_bytes(ctypes.byref(d), ci(which)))
+        if w_packed.numel() * w_packed.element_size() < need:
+            raise _hip.AirError("conv2d: w_packed holds %d bytes, the layer consumes %d under the current dispatch "
+                                "options (prepack again after air_set_option)" % (
+                                    w_packed.numel() * w_packed.element_size(), need))
+
+
 def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=False, residual=None, w_packed=None,
                stats=False):
     """y = conv2d(act(x), w) (+ residual); act = optional per-channel affine + ReLU.
@@ -89,6 +100,7 @@ def conv2d_fwd(x, w, stride=1, padding=0, in_scale=None, in_shift=None, relu=Fal
     ``bn_stats(..., stats_in=records)``, or (y, None) when this layer has no fused statistics (the caller's BatchNorm
     then makes its own pass over y)."""
     d = _conv_desc(x.shape, w.shape, stride, padding)
+    _check_packed(d, w_packed, 0)
     y = torch.empty((d.B, d.Cout, d.Ho, d.Wo), device=x.device, dtype=torch.float32)
     ws, n = _conv_ws(d, x.device)
     rec = None
@@ -109,6 +121,7 @@ def conv2d_dgrad(dy, w, x_shape, stride=1, padding=0, accumulate=None, out=None,
     with respect to the output of relu(batchnorm(bn_x)); returns (dx, sums) with ``sums`` the BatchNorm-backward
     records for ``bn_bwd(..., sums_in=sums)`` taken by the epilogue, or (dx, None) when this layer has no such form."""
     d = _conv_desc(x_shape, w.shape, stride, padding)
+    _check_packed(d, w_packed, 1)
     dx = out if out is not None else torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
     ws, n = _conv_ws(d, dy.device)
     if bn is not None:

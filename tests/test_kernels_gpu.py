@@ -131,6 +131,10 @@ def test_conv2d_prepack(ops, cfg):
     dx2 = ops.conv2d_dgrad(dy, w_gone, x.shape, s, p, accumulate=acc, w_packed=pd)
     assert torch.equal(y, y2)
     assert torch.equal(dx, dx2)
+    # a buffer smaller than what the layer consumes (e.g. prepacked under other dispatch options) is refused, not walked
+    from asvspoof2021_air_amd import _hip
+    with pytest.raises(_hip.AirError):
+        ops.conv2d_fwd(x, w, s, p, w_packed=pf[:pf.numel() // 2].clone())
 
 
 @pytest.mark.parametrize("cfg", CONVS)
