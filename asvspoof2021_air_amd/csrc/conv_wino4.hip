@@ -330,8 +330,18 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // workgroups rem <= j < 2 rem the UPPER halves as their FIRST segment (stored as partial sums into y, flag
   // raised), so a flag is up long before its reader arrives and no workgroup waits on one that waits.
   // (Which j takes which half: see is_upper / is_lower below - the text above names the roles, not the indices.)
-  const int xg = (int)blockIdx.x % a.nxg, j = (int)blockIdx.x / a.nxg;
+  const int xg = (int)blockIdx.x % a.nxg;
   const int Wx = ((int)gridDim.x - xg + a.nxg - 1) / a.nxg;
+  // j: this workgroup's index inside its dealing group, counted from the END of the group: the dispatcher hands out
+  // workgroups in index order, so were fewer CUs free than the launch has workgroups (another kernel resident, a
+  // partitioned device) the owners of the lower halves of cut items - j < rem, the only workgroups that ever wait -
+  // start LAST, behind the publishers they wait for (j in [rem, 2 rem)).  Round 4 first swapped the two roles
+  // instead; same protection, but layer4 then fetched 838 MB per launch against 670 (tools/exp_l4_traffic.sh:
+  // W4_ROLE 2 / 1 / this, 0).
+#ifndef W4_ROLE
+#define W4_ROLE 0  // A/B: 1 = round 3 (index from the front), 2 = index from the front with the two roles swapped
+#endif
+  const int j = W4_ROLE == 0 ? Wx - 1 - (int)blockIdx.x / a.nxg : (int)blockIdx.x / a.nxg;
   // xmode 1: group xg owns the contiguous id range [R0, R0 + nx); xmode 2: the quads congruent to xg mod nxg
   // (nqx of them, every channel slab), numbered locally the same way.  Items below are LOCAL ids 0 .. nx - 1.
   const int nqx = (a.nquad - xg + a.nxg - 1) / a.nxg;
@@ -343,12 +353,11 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
   // segments of this workgroup: [upper half of a cut item]? whole items* [lower half | whole tail item]?
   int tail_seg = -1, tail_item = 0, fc = 0, last_end = nchunk, nseg = nround;
   const int full_base = j;
-  // (publishers take the LOWER workgroup indices: were fewer CUs free than the launch has workgroups - another
-  // kernel resident, a partitioned device - the dispatcher, which hands out workgroups in index order, starts them
-  // before the owners that will wait for them; speed and robustness only, the protocol does not depend on it)
-  const bool is_upper = cut && j < rem, is_lower = cut && j >= rem && j < 2 * rem;
-  if (is_lower) { tail_seg = nround; tail_item = nround * Wx + (j - rem); last_end = half; ++nseg; }
-  else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + j; fc = half; ++nseg; }
+  const bool is_upper = cut && (W4_ROLE == 2 ? j < rem : (j >= rem && j < 2 * rem));
+  const bool is_lower = cut && (W4_ROLE == 2 ? (j >= rem && j < 2 * rem) : j < rem);
+  const int jt = j >= rem ? j - rem : j;  // index of the cut item this workgroup shares
+  if (is_lower) { tail_seg = nround; tail_item = nround * Wx + jt; last_end = half; ++nseg; }
+  else if (is_upper) { tail_seg = 0; tail_item = nround * Wx + jt; fc = half; ++nseg; }
   else if (!cut && j < rem) { tail_seg = nround; tail_item = nround * Wx + j; ++nseg; }
   if (a.stats != nullptr && blockIdx.x == 0 && tid == 0) {  // header of the statistics buffer, once per launch
     int* h = reinterpret_cast<int*>(a.stats);
