@@ -24,6 +24,7 @@ enum AirKernelId {
   AIR_K_CONV_WINO4,        // wino4_conv_kernel: 3x3 s1 forward and dgrad, Winograd F(4x4,3x3)
   AIR_K_C1B_TAPW,          // c1b_tapw_kernel: bf16 weight gradient of the dilated K=3 Res2 convs, all branches of a block (ECAPA)
   AIR_K_CONV_WINO4_BN,     // wino4_conv_kernel launches whose epilogue also takes BatchNorm statistics / backward sums (round 4)
+  AIR_K_CONV_S2_DGRAD,     // conv_s2_dgrad_kernel: 3x3 stride-2 data gradient (+ the 1x1 shortcut's), all parity classes in one pass
   AIR_K_COUNT
 };
 

@@ -383,6 +383,226 @@ __global__ __launch_bounds__(NWAVE * 64) void conv_fwd_kernel(FwdArgs a) {
   if (MT == 2) emit(acc1, 32);
 }
 
+// ------------------------------------------------- stride-2 3x3 data gradient
+// dx of a 3x3 / stride 2 / pad 1 convolution (resnet.py:56 conv1 of layer2-4's first block), optionally joined with
+// the data gradient of the block's 1x1 / stride 2 shortcut (resnet.py:61-66), in ONE pass over dy.
+// Input pixel (2i + a, 2j + b) sees the taps kh = 1 (a = 0, dy row i) or kh = 2, 0 (a = 1, dy rows i, i + 1), same
+// along w: four parity classes with 1, 2, 2 and 4 taps.  Rounds 1-3 ran each class as its own dense launch of
+// conv_fwd_kernel (dy read four times, every class writing every other float of dx) and the shortcut as a fifth
+// read-modify-write launch.  Here a wave owns 32 consecutive columns j of one dy row i and keeps the four classes'
+// 64 x 32 tiles in registers (8 accumulators): every staged dy element feeds all its taps, the K loop is one stream
+// of 9 (10 with the shortcut: its dy is a third patch row, its weights a tenth tap that lands in class (0, 0))
+// taps x 4 channel pairs x 2 MFMAs per 8-channel chunk, and the epilogue writes rows 2i and 2i + 1 of dx as
+// consecutive floats.  The sums are the same fmaf chains in a different order (class by class before, tap-major now).
+struct S2dArgs {
+  const float* dy;          // (B, K, Ho, Wo)
+  const float* dysc;        // (B, K, Ho, Wo) gradient of the shortcut's output (SC)
+  const float* wp;          // packed [cot][chunk][9][CKT][BMT] (pack_weights_kernel, roles swapped)
+  const float* wpsc;        // packed [cot][chunk][1][CKT][BMT]
+  float* dx;                // (B, M, H, W)
+  const float* accumulate;  // like dx, may alias it (may be null)
+  int B, K, M, H, W, Ho, Wo;
+  int WT, ntiles, npxg, ncot;
+  int pair;                 // W even and dx / accumulate 8-byte aligned: classes (a, 0), (a, 1) leave as one float2
+};
+
+template <int CKT, int MT, bool SC>
+struct S2dCfg {
+  static constexpr int TAPS = SC ? 10 : 9;
+  static constexpr int BMT = 32 * MT;
+  static constexpr int PW = PXT + 1;                    // dy columns j0 .. j0 + 32
+  static constexpr int ROWS = SC ? 3 : 2;               // dy rows i, i + 1 (+ the shortcut's dy row i)
+  static constexpr int CHS = ROWS * PW;
+  static constexpr int NE = CKT * CHS;
+  static constexpr int NI = (NE + 63) / 64;
+  static constexpr int PATCHP = NI * 64;
+  static constexpr int WSLAB = TAPS * CKT * BMT;
+  static constexpr int W9 = 9 * CKT * BMT;              // the 3x3 part of a slab
+  static constexpr int NWV = (WSLAB / 4 + NWAVE * 64 - 1) / (NWAVE * 64);
+  static constexpr int BUF = WSLAB + NWAVE * PATCHP;
+};
+
+// (two resident workgroups per CU at 64 channels - 128 accumulator registers of <= 256 - and three at 32)
+template <int CKT, int MT, bool SC>
+__global__ __launch_bounds__(NWAVE * 64, MT == 2 ? 2 : 3) void conv_s2_dgrad_kernel(S2dArgs a) {
+  using C = S2dCfg<CKT, MT, SC>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * C::BUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lb % a.ncot;
+  const int pxg = lb / a.ncot;
+  const int nt = pxg * NWAVE + wave;
+  const bool tile_ok = nt < a.ntiles;
+  const int ntc = min(nt, a.ntiles - 1);  // (a wave past the last tile stages that tile again and writes nothing)
+  const int wt = ntc % a.WT;
+  const int rowid = ntc / a.WT;
+  const int i = rowid % a.Ho;
+  const int b = rowid / a.Ho;
+  const int j0 = wt * PXT;
+  const size_t HWo = (size_t)a.Ho * a.Wo;
+  const int nchunk = a.K / CKT;
+
+  // staging: LDS-DMA from clamped addresses (conv_fwd_kernel's scheme); what lies outside dy is masked at operand read
+  const float* gp[C::NI];
+#pragma unroll
+  for (int n = 0; n < C::NI; ++n) {
+    const int e = lane + 64 * n;
+    const int cil = min(e / C::CHS, CKT - 1);
+    const int rem = e % C::CHS;
+    const int r = rem / C::PW;
+    const int c = rem - r * C::PW;
+    const int row = min(i + (r == 1 ? 1 : 0), a.Ho - 1), col = min(j0 + c, a.Wo - 1);
+    const float* __restrict__ src = (SC && r == 2) ? a.dysc : a.dy;
+    gp[n] = src + ((size_t)b * a.K + cil) * HWo + (size_t)row * a.Wo + col;
+  }
+  const float* __restrict__ w9 = a.wp + (size_t)cot * nchunk * C::W9;
+  const float* __restrict__ w1 = SC ? a.wpsc + (size_t)cot * nchunk * (CKT * C::BMT) : nullptr;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+  auto dma = [&](int chunk, int buf) {
+    const unsigned base = lds0 + 4u * (buf * C::BUF);
+    const unsigned pl = base + 4u * (C::WSLAB + wave * C::PATCHP);
+    const size_t coff = (size_t)chunk * CKT * HWo;
+#pragma unroll
+    for (int n = 0; n < C::NI; ++n) dma4(gp[n] + coff, pl + 256u * n);
+    const float* __restrict__ ws9 = w9 + (size_t)chunk * C::W9;
+#pragma unroll
+    for (int n = 0; n < C::NWV; ++n) {
+      const int e0 = (wave + NWAVE * n) * 64;  // first float4 of this wave's DMA (wave-uniform)
+      if (e0 < C::W9 / 4) {
+        dma16(ws9 + 4 * (e0 + lane), base + 16u * e0);
+      } else if (SC && e0 < C::WSLAB / 4) {
+        dma16(w1 + (size_t)chunk * (CKT * C::BMT) + 4 * (e0 - C::W9 / 4 + lane), base + 16u * e0);
+      }
+    }
+  };
+  static_assert((C::W9 / 4) % 64 == 0 && (C::WSLAB / 4) % 64 == 0, "slabs are whole wave DMAs");
+
+  // masks per patch position (r, c): dy row i + 1 / column j + 1 may lie outside
+  const bool ok_r1 = i + 1 < a.Ho, ok_c1 = j0 + l31 + 1 < a.Wo;
+
+  f32x16 acc[4][MT];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.0f;
+
+  dma(0, 0);
+  dma_wait();
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int cur = chunk & 1;
+    if (chunk + 1 < nchunk) dma(chunk + 1, cur ^ 1);
+    const float* __restrict__ wl = lds + cur * C::BUF;
+    const float* __restrict__ pl = wl + C::WSLAB + wave * C::PATCHP;
+    constexpr int NSTEP = C::TAPS * (CKT / 2);
+    // k-step n = (tap, channel pair): tap t < 9 is (kh, kw) = (t / 3, t % 3); kh = 0 reads dy row i + 1, kw = 0
+    // column j + 1; tap 9 is the shortcut's dy (patch row 2)
+    auto ld = [&](int n, float& a0, float& a1, float& bv) {
+      const int tap = n / (CKT / 2), st = n % (CKT / 2);
+      const int r = tap == 9 ? 2 : (tap / 3 == 0 ? 1 : 0);
+      const int c = tap == 9 ? 0 : (tap % 3 == 0 ? 1 : 0);
+      const int cil = 2 * st + half;
+      bv = pl[cil * C::CHS + r * C::PW + c + l31];
+      a0 = wl[(tap * CKT + cil) * C::BMT + l31];
+      a1 = MT == 2 ? wl[(tap * CKT + cil) * C::BMT + 32 + l31] : 0.0f;
+    };
+    // (one code path: the select that zeroes what lies outside dy costs one VALU instruction per 2 MFMAs of 64 cycles;
+    // a mask-free copy of the 80-MFMA body for interior tiles made the register allocator shuttle the accumulators)
+    auto msk = [&](int n, float bv) -> float {
+      const int tap = n / (CKT / 2);
+      if (tap == 9) return bv;
+      const bool r1 = tap / 3 == 0, c1 = tap % 3 == 0;
+      if (!r1 && !c1) return bv;
+      const bool ok = (!r1 || ok_r1) && (!c1 || ok_c1);
+      return ok ? bv : 0.0f;
+    };
+    float ra0[3], ra1[3], rb[3];
+    ld(0, ra0[0], ra1[0], rb[0]);
+    ld(1, ra0[1], ra1[1], rb[1]);
+    rb[0] = msk(0, rb[0]);
+#pragma unroll
+    for (int n = 0; n < NSTEP; ++n) {
+      if (n + 2 < NSTEP) ld(n + 2, ra0[(n + 2) % 3], ra1[(n + 2) % 3], rb[(n + 2) % 3]);
+      if (n + 1 < NSTEP) rb[(n + 1) % 3] = msk(n + 1, rb[(n + 1) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int tap = n / (CKT / 2);
+      const int cls = tap == 9 ? 0 : ((tap / 3 != 1 ? 2 : 0) + (tap % 3 != 1 ? 1 : 0));
+      acc[cls][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[n % 3], rb[n % 3], acc[cls][0], 0, 0, 0);
+      if (MT == 2)
+        acc[cls][MT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[n % 3], rb[n % 3], acc[cls][MT - 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dma_wait();
+    __syncthreads();
+  }
+
+  // epilogue: D row (r & 3) + 8 * (r >> 2) + 4 * half -> dx channel, column l31 -> dy column j; classes (a, 0) and
+  // (a, 1) of a lane are neighbours in dx row 2i + a
+  if (!tile_ok) return;
+  const int j = j0 + l31;
+  if (j >= a.Wo) return;
+  const size_t plane = (size_t)a.H * a.W;
+  const bool full = (cot + 1) * C::BMT <= a.M;
+  const bool ok_b1 = 2 * j + 1 < a.W;
+  const bool pair = a.pair != 0;  // rows start on even floats: the two classes go out as one 8-byte store
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa) {
+    const int h = 2 * i + pa;
+    if (h >= a.H) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int cb = cot * C::BMT + 32 * m + 4 * half;
+      const size_t o0 = ((size_t)b * a.M + cb) * plane + (size_t)h * a.W + 2 * j;
+      float v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] = acc[2 * pa][m][r];
+        v1[r] = acc[2 * pa + 1][m][r];
+      }
+      if (a.accumulate != nullptr) {  // every load of the tile before its first store
+        float t0[16], t1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = (r & 3) + 8 * (r >> 2);
+          const bool okc = full || cb + ch < a.M;
+          if (pair) {
+            const float2 t = okc ? *reinterpret_cast<const float2*>(a.accumulate + o0 + (size_t)ch * plane)
+                                 : make_float2(0.0f, 0.0f);
+            t0[r] = t.x;
+            t1[r] = t.y;
+          } else {
+            t0[r] = okc ? a.accumulate[o0 + (size_t)ch * plane] : 0.0f;
+            t1[r] = (okc && ok_b1) ? a.accumulate[o0 + (size_t)ch * plane + 1] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v0[r] += t0[r];
+          v1[r] += t1[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2);
+        if (!full && cb + ch >= a.M) continue;
+        float* __restrict__ o = a.dx + o0 + (size_t)ch * plane;
+        if (pair) {
+          *reinterpret_cast<float2*>(o) = make_float2(v0[r], v1[r]);
+        } else {
+          o[0] = v0[r];
+          if (ok_b1) o[1] = v1[r];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------- wgrad
 // dW[co][ci][tap] = sum_px dy[co][px] * act(x)[ci][px shifted by tap]
 // GEMM M = co (64 per workgroup), N = (ci, tap) with 32-channel MFMA column
@@ -1547,6 +1767,42 @@ static int fwd_generic(const AirConv2d* p, const float* x, const float* w, float
                  ck, mt, conv_flops(p), st, ksplit, ksplit > 1 ? ws0 + fwd_pack_elems(p, ck, mt) : nullptr);
 }
 
+// stride-2 3x3 data gradient in one pass (conv_s2_dgrad_kernel); option CONV_S2 bit 2, 0 = the four class launches
+constexpr int S2D_CK = 8;
+static bool s2d_ok(const AirConv2d* p) {
+  return p->KH == 3 && p->KW == 3 && p->sh == 2 && p->sw == 2 && p->ph == 1 && p->pw == 1 && p->Cout % S2D_CK == 0 &&
+         (air_opt(AIR_OPT_CONV_S2) & 2) != 0;
+}
+static int s2d_mt(const AirConv2d* p) { return mt_for(p->B, p->Ho, p->Wo, p->Cin); }
+
+// wp / wpsc: the 3x3 and the 1x1 weights as pack() lays them out for (S2D_CK, mt), roles swapped; dysc / wpsc null =
+// no shortcut term
+static int run_s2d(const AirConv2d* p, const float* dy, const float* dysc, const float* wp, const float* wpsc, float* dx,
+                   const float* accumulate, int mt, hipStream_t st) {
+  if (pk_dry()) return AIR_OK;
+  S2dArgs a;
+  a.dy = dy; a.dysc = dysc; a.wp = wp; a.wpsc = wpsc; a.dx = dx; a.accumulate = accumulate;
+  a.B = p->B; a.K = p->Cout; a.M = p->Cin; a.H = p->H; a.W = p->W; a.Ho = p->Ho; a.Wo = p->Wo;
+  a.WT = (p->Wo + PXT - 1) / PXT;
+  a.ntiles = p->B * p->Ho * a.WT;
+  a.npxg = (a.ntiles + NWAVE - 1) / NWAVE;
+  a.ncot = (p->Cin + 32 * mt - 1) / (32 * mt);
+  a.pair = (p->W % 2 == 0) && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(accumulate)) & 7) == 0;
+  const int nblk = a.npxg * a.ncot;
+  const double flops = conv_flops(p) * (dysc ? 10.0 / 9.0 : 1.0);
+  AirProfScope ps(AIR_K_CONV_S2_DGRAD, flops, st);
+#define AIR_S2D(MT_, SC_) \
+  hipLaunchKernelGGL((conv_s2_dgrad_kernel<S2D_CK, MT_, SC_>), dim3(nblk), dim3(NWAVE * 64), 0, st, a)
+  if (mt == 2) {
+    if (dysc) AIR_S2D(2, true); else AIR_S2D(2, false);
+  } else {
+    if (dysc) AIR_S2D(1, true); else AIR_S2D(1, false);
+  }
+#undef AIR_S2D
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 // data gradient on the direct kernels (whatever pack mode is current: see PackCtx)
 static int dgrad_generic(const AirConv2d* p, const float* dy, const float* w, float* dx, const float* accumulate,
                          float* wp, hipStream_t st) {
@@ -1616,6 +1872,15 @@ static int dgrad_generic(const AirConv2d* p, const float* dy, const float* w, fl
     g.oh_mul = 2; g.ow_row = p->W; g.ow_mul = 2; g.o_off = 0; g.oplane = plane;
     g.y_bstride = (size_t)p->Cin * plane;
     return run_fwd(dy, wp, dx, nullptr, nullptr, 0, dx, g, ck, mt, conv_flops(p), st);
+  }
+  if (s2d_ok(p)) {
+    TapSel sel;
+    sel.n = 9;
+    for (int t = 0; t < 9; ++t) sel.idx[t] = t;
+    const int mt = s2d_mt(p);
+    int rc = pack(w, wp, p->Cout, p->Cin, 9, 1, S2D_CK, mt, sel, st);
+    if (rc != AIR_OK) return rc;
+    return run_s2d(p, dy, nullptr, wp, nullptr, dx, accumulate, mt, st);
   }
   for (int a = 0; a < 2; ++a) {
     for (int b = 0; b < 2; ++b) {
@@ -1803,6 +2068,53 @@ int air_conv2d_dgrad_bn(const AirConv2d* p, const float* dy, const float* w, con
                           reinterpret_cast<float*>(sums), bn);
   return air_wino4_conv(dy, w, dx, accumulate, p->B, p->Cout, p->H, p->W, p->Cin, 1, reinterpret_cast<float*>(ws),
                         conv_flops(p), st, reinterpret_cast<float*>(sums), bn);
+}
+
+static size_t s2d_pack_elems(const AirConv2d* p, int taps) {
+  const int bm = 32 * s2d_mt(p);
+  return (size_t)((p->Cin + bm - 1) / bm * bm) * p->Cout * taps;
+}
+
+size_t air_conv2d_dgrad_s2_pair_prepack_bytes(const AirConv2d* p) {
+  if (!p || !shape_ok(p) || !generic_ok(p) || !s2d_ok(p)) return 0;
+  return (s2d_pack_elems(p, 9) + s2d_pack_elems(p, 1)) * sizeof(float);
+}
+
+int air_conv2d_dgrad_s2_pair_prepack(const AirConv2d* p, const float* w, const float* w_sc, void* out, size_t out_bytes,
+                                     air_stream_t stream) {
+  if (!p || !w || !w_sc || !out || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_dgrad_s2_pair_prepack_bytes(p);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  if (out_bytes < need) return AIR_EWORKSPACE;
+  hipStream_t st = air_stream(stream);
+  const int mt = s2d_mt(p);
+  float* w9 = reinterpret_cast<float*>(out);
+  float* w1 = w9 + s2d_pack_elems(p, 9);
+  TapSel s9, s1;
+  s9.n = 9;
+  for (int t = 0; t < 9; ++t) s9.idx[t] = t;
+  s1.n = 1;
+  s1.idx[0] = 0;
+  PackScope run(PK_RUN, nullptr);
+  int rc = pack(w, w9, p->Cout, p->Cin, 9, 1, S2D_CK, mt, s9, st);
+  if (rc != AIR_OK) return rc;
+  return pack(w_sc, w1, p->Cout, p->Cin, 1, 1, S2D_CK, mt, s1, st);
+}
+
+int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w, const float* dy_sc, const float* w_sc,
+                             const void* packed, float* dx, const float* accumulate, void* ws, size_t ws_bytes,
+                             air_stream_t stream) {
+  if (!p || !dy || !w || !dy_sc || !w_sc || !dx || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_dgrad_s2_pair_prepack_bytes(p);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  const float* w9 = reinterpret_cast<const float*>(packed);
+  if (w9 == nullptr) {
+    if (!ws || ws_bytes < need) return AIR_EWORKSPACE;
+    const int rc = air_conv2d_dgrad_s2_pair_prepack(p, w, w_sc, ws, ws_bytes, stream);
+    if (rc != AIR_OK) return rc;
+    w9 = reinterpret_cast<const float*>(ws);
+  }
+  return run_s2d(p, dy, dy_sc, w9, w9 + s2d_pack_elems(p, 9), dx, accumulate, s2d_mt(p), air_stream(stream));
 }
 
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

@@ -23,7 +23,7 @@ const char* const kNames[AIR_K_COUNT] = {
     "conv_fwd_kernel<parity class>", "conv_fwd_kernel<conv1d>",
     "conv_wgrad_kernel<conv1d>", "lfcc_kernel", "wino_conv_kernel", "wino_wgrad_kernel",
     "c1b_fwd_kernel", "c1b_gemm_kernel", "c1b_tap_kernel", "wino4_conv_kernel",
-    "c1b_tapw_kernel", "wino4_conv_kernel+bn"};
+    "c1b_tapw_kernel", "wino4_conv_kernel+bn", "conv_s2_dgrad_kernel"};
 }  // namespace
 
 bool air_prof_on() { return g_on; }

@@ -301,6 +301,19 @@ class ResNet(nn.Module):
                     # (bi, 1 | 2): a block's 3x3 convs; (bi, 0): its 1x1 shortcut; (-1, 5): conv5
                     conv = self.conv5 if bi < 0 else (blocks[bi].shortcut[0] if ci == 0 else
                                                       blocks[bi].conv1 if ci == 1 else blocks[bi].conv2)
+                    if which == 1 and bi >= 0 and s == 2 and ci in (0, 1) and hasattr(blocks[bi], "shortcut"):
+                        # a stride-2 block's conv1 and shortcut share ONE data-gradient launch (round 4): their
+                        # weights travel together under (bi, 1); the shortcut has no buffer of its own then
+                        if ci == 0 and ops.conv2d_dgrad_s2_pair_ok(blocks[bi].conv1.weight.shape, shape):
+                            continue
+                        if ci == 1:
+                            buf = ops.conv2d_dgrad_s2_pair_prepack(conv.weight.detach(), blocks[bi].shortcut[0].weight.detach(),
+                                                                   shape, out=self._packs.get(((bi, ci), "pair")))
+                            if buf is not None:
+                                self._packs[((bi, ci), "pair")] = buf
+                                live[((bi, ci), which)] = buf
+                                self._geo_live[(bi, ci)] = shape
+                                continue
                     buf = ops.conv2d_prepack(conv.weight.detach(), shape, s, pad, which, out=self._packs.get(((bi, ci), which)))
                     if buf is not None:
                         self._packs[((bi, ci), which)] = buf
@@ -389,7 +402,10 @@ class ResNet(nn.Module):
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
             S.update(l4=cur, c5=c5, st5=st5, a5v=a5v, noise=nz, pooled=pooled, alpha=alpha, feat=feat,
-                     packs={k: v for k, v in live.items() if k[1] == 1 and self._geo_live.get(k[0]) is not None},
+                     # (data-gradient buffers only for the geometry THIS forward saw: a direct kernel's slab layout
+                     # depends on the batch size through its tile heuristic - the short last batch of an epoch)
+                     packs={k: v for k, v in live.items() if k[1] == 1 and self._geo_live.get(k[0]) is not None and
+                            self._geo_live.get(k[0]) == self._geo.get(k[0], (None,))[0]},
                      pack_ev=self._pack_ev[1] if live else None)
         ops.bn_flush()
         return feat, mu, S
@@ -525,10 +541,16 @@ class ResNet(nn.Module):
                     ops.conv2d_wgrad(actA, dh, blk.conv1.weight.shape, s, 1, out=g1, **pA), dh)
             # (with a 1x1 shortcut d_actA gets a second term below: the sums would be of a partial gradient)
             bnA = (xin, stA[0], stA[1], blk.bn1.weight.detach(), blk.bn1.bias.detach()) if bn_fuse and not has_sc else None
-            d_actA, smA = dgrad_bn(bnA, dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
+            pair = has_sc and s == 2 and ops.conv2d_dgrad_s2_pair_ok(blk.conv1.weight.shape, xin.shape)
+            if pair:  # conv1's and the shortcut's data gradients in one pass over (dh, dcur)
+                d_actA, smA = ops.conv2d_dgrad_s2_pair(dh, w(blk.conv1), dcur, w(blk.shortcut[0]), xin.shape,
+                                                       packed=packs.get(((bi, 1), 1))), None
+            else:
+                d_actA, smA = dgrad_bn(bnA, dh, w(blk.conv1), xin.shape, s, 1, w_packed=packs.get(((bi, 1), 1)))
             if has_sc:
-                ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
-                                 out=d_actA, w_packed=packs.get(((bi, 0), 1)))
+                if not pair:
+                    ops.conv2d_dgrad(dcur, w(blk.shortcut[0]), xin.shape, s, 0, accumulate=d_actA,
+                                     out=d_actA, w_packed=packs.get(((bi, 0), 1)))
                 dcur, _, _ = ops.bn_bwd(xin, d_actA, stA[0], stA[1], blk.bn1.weight.detach(),
                                         blk.bn1.bias.detach(), relu=True, dx=d_actA,
                                         dgamma=gv(pre + "bn1.weight"), dbeta=gv(pre + "bn1.bias"))

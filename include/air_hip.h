@@ -199,6 +199,20 @@ int air_conv2d_dgrad_bn(const AirConv2d* p, const float* dy, const float* w, con
                         const float* accumulate, const float* bn_x, const float* bn_mean, const float* bn_invstd,
                         const float* bn_gamma, const float* bn_beta, void* sums, void* ws, size_t ws_bytes,
                         air_stream_t stream);
+/* The data gradient of a PreActBlock's stride-2 pair in one pass (resnet.py:56-66: conv1 3x3 / stride 2 / pad 1 and
+ * the 1x1 / stride 2 shortcut read the same activated tensor): dx = conv_transpose(dy, w) + conv_transpose(dy_sc, w_sc)
+ * [+ accumulate].  p describes the 3x3 convolution; the shortcut has its Cin, Cout, input and output shape.  A wave
+ * keeps all four parity classes of its dx tile in registers, so dy is read once and dx leaves as whole rows (rounds 1-3:
+ * four class launches + a read-modify-write launch for the shortcut).  `packed`: NULL (the weights are packed into ws,
+ * air_conv2d_dgrad_s2_pair_prepack_bytes(p) bytes, in front of the launch) or the buffer air_conv2d_dgrad_s2_pair_prepack
+ * wrote under the same dispatch options.  _prepack_bytes 0 / AIR_EUNSUPPORTED: not this shape, or option CONV_S2 bit 2
+ * is off - call air_conv2d_dgrad twice.  air_conv2d_dgrad itself takes the same kernel for a lone 3x3 / stride 2. */
+size_t air_conv2d_dgrad_s2_pair_prepack_bytes(const AirConv2d* p);
+int air_conv2d_dgrad_s2_pair_prepack(const AirConv2d* p, const float* w, const float* w_sc, void* out, size_t out_bytes,
+                                     air_stream_t stream);
+int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w, const float* dy_sc, const float* w_sc,
+                             const void* packed, float* dx, const float* accumulate, void* ws, size_t ws_bytes,
+                             air_stream_t stream);
 /* dw = correlation(act(x), dy); same prologue as fwd so the activated tensor
  * is never materialised. */
 int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float* dw,

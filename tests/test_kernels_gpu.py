@@ -112,6 +112,50 @@ def test_conv2d_stride2_options(ops, cfg, fused, s2):
     close(gw, w.grad, rtol=1e-5, name="conv2d_wgrad stride 2")
 
 
+@pytest.mark.parametrize("cfg", S2 + [(2, 40, 7, 66, 64), (1, 24, 5, 9, 64)])  # + input-channel counts that fill no 32-channel tile
+@pytest.mark.parametrize("one_pass", [True, False])
+def test_conv2d_stride2_dgrad_one_pass(ops, cfg, one_pass):
+    """Option CONV_S2 bit 2: the 3x3 / stride 2 data gradient with all four parity classes in one pass over dy
+    (conv_s2_dgrad_kernel) or as four class launches; alone, with `accumulate`, and joined with the 1x1 / stride 2
+    shortcut's data gradient (air_conv2d_dgrad_s2_pair, resnet.py:56-66) - each against the fp64 autograd of
+    F.conv2d, held to the direct kernels' constant (1e-5 of the output scale).  Prepacked weights: bit-identical."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 1).double().requires_grad_(True)
+    w = synth_feat((Cout, Cin, 3, 3), 2, scale=0.1)
+    wsc = synth_feat((Cout, Cin, 1, 1), 3, scale=0.2)
+    y = F.conv2d(x, w.double(), None, 2, 1)
+    ysc = F.conv2d(x, wsc.double(), None, 2, 0)
+    assert y.shape == ysc.shape
+    dy, dysc = synth_feat(tuple(y.shape), 6), synth_feat(tuple(y.shape), 8)
+    g3, = torch.autograd.grad(y, x, dy.double())
+    gsc, = torch.autograd.grad(ysc, x, dysc.double())
+    acc = synth_feat((B, Cin, H, W), 7)
+    xs = (B, Cin, H, W)
+    with _hip.options(CONV_S2=3 if one_pass else 1):
+        assert ops.conv2d_dgrad_s2_pair_ok(w.shape, xs) == one_pass
+        got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), xs, 2, 1)
+        close(got, g3, rtol=1e-5, name="stride-2 dgrad")
+        got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), xs, 2, 1, accumulate=acc.cuda())
+        close(got, g3 + acc.double(), rtol=1e-5, name="stride-2 dgrad + accumulate")
+        pd = ops.conv2d_prepack(w.cuda(), xs, 2, 1, 1)
+        assert torch.equal(ops.conv2d_dgrad(dy.cuda(), torch.full_like(w, float("nan")).cuda(), xs, 2, 1,
+                                            accumulate=acc.cuda(), w_packed=pd), got)
+        pair = ops.conv2d_dgrad_s2_pair(dy.cuda(), w.cuda(), dysc.cuda(), wsc.cuda(), xs)
+        if not one_pass:
+            assert pair is None and ops.conv2d_dgrad_s2_pair_prepack(w.cuda(), wsc.cuda(), xs) is None
+            return
+        close(pair, g3 + gsc, rtol=1e-5, name="stride-2 pair dgrad")
+        inplace = acc.cuda().clone()  # accumulate aliasing dx
+        ops.conv2d_dgrad_s2_pair(dy.cuda(), w.cuda(), dysc.cuda(), wsc.cuda(), xs, accumulate=inplace, out=inplace)
+        close(inplace, g3 + gsc + acc.double(), rtol=1e-5, name="stride-2 pair dgrad + accumulate")
+        pk = ops.conv2d_dgrad_s2_pair_prepack(w.cuda(), wsc.cuda(), xs)
+        nan = torch.full_like(w, float("nan")).cuda()
+        assert torch.equal(ops.conv2d_dgrad_s2_pair(dy.cuda(), nan, dysc.cuda(), nan[:, :, :1, :1].contiguous(), xs, packed=pk), pair)
+        with pytest.raises(_hip.AirError):
+            ops.conv2d_dgrad_s2_pair(dy.cuda(), w.cuda(), dysc.cuda(), wsc.cuda(), xs, packed=pk[:pk.numel() // 2].clone())
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv2d_prepack(ops, cfg):
     """air_conv2d_prepack for every layer kind (Winograd transforms or the direct kernels' slabs - one or several per

@@ -242,6 +242,30 @@ def test_full_path_pcm_to_loss():
     np.testing.assert_allclose(neg.cpu().numpy(), no.numpy(), atol=1e-4)
 
 
+def test_changing_batch_geometry_never_reuses_stale_weight_buffers():
+    """The weight transforms are enqueued at the start of a forward for the geometry the PREVIOUS forward saw.  A
+    direct kernel's slab layout depends on the batch size and width through its tile heuristic (the short last batch
+    of an epoch, resnet.py's variable feat_len): a step whose geometry differs must transform in place, not walk the
+    earlier geometry's buffers.  Gradients of every step equal, bit for bit, those of a model that never prepacks."""
+    a, b = make_model(), make_model()
+    b.prepack_weights = False
+    for m in (a, b):
+        m.train()
+        m.set_attention_noise(None)
+    # (layer2.0's stride-2 data gradient runs 32-channel tiles at (16, 200) and 64-channel tiles at (8, 200): same buffer
+    # size, another layout)
+    for step, (B, T) in enumerate([(16, 200), (16, 200), (8, 200), (16, 200), (3, 96), (16, 200)]):
+        x = synth_feat((B, 1, 60, T), 50 + step).cuda()
+        grads = []
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            feat, mu = m(x)
+            (feat.sum() + 2.0 * mu.sum()).backward()
+            grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+        for n in grads[0]:
+            assert torch.equal(grads[0][n], grads[1][n]), (step, B, T, n)
+
+
 def test_whole_module_pickle_roundtrip(tmp_path):
     """main_train.py:675-704 saves whole modules with torch.save and generate_score.py:46-48 loads them:
     after a training step (arenas bound, side stream created) the module still pickles, and the loaded copy
