@@ -287,6 +287,45 @@ __device__ __forceinline__ void w4_bt5(float d0, float d1, float d2, float d3, f
   t3 = e;
   t4 = __builtin_fmaf(-2.0f, e, d4 - d2);
 }
+// two columns of B^T d at once, 5 points: the same 9 operations as v_pk_add_f32 / v_pk_fma_f32 (the f32 MFMA and the
+// VALU share one issue port - every VALU instruction of the input transform is 4+ cycles the matrix pipe idles)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 w4_fma2(float k, f32x2 a, f32x2 b) {
+  return __builtin_elementwise_fma(f32x2{k, k}, a, b);
+}
+__device__ __forceinline__ void w4_bt5x2(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2& t0, f32x2& t1,
+                                         f32x2& t2, f32x2& t3, f32x2& t4) {
+  const f32x2 e = d3 - d1;
+  t0 = w4_fma2(2.0f, d0 - d2, e);
+  t1 = w4_fma2(-2.0f, d1, d3 - d2);
+  t2 = w4_fma2(2.0f, d1, w4_fma2(-3.0f, d2, d3));
+  t3 = e;
+  t4 = w4_fma2(-2.0f, e, d4 - d2);
+}
+// one row of B^T d, 6 points, on the pairs the packed column pass leaves: E = {d0, d5}, R0 = {d1, d2}, R1 = {d3, d4}.
+// 4 packed + 4 scalar instructions for w4_bt6's 12 (the halves are picked with op_sel, no moves):
+//   {b, a} = -4 R0 + R1;  {t1, t2} = {a + b, a - b};  {e, c} = R1 - R0;  {t3, t4} = {c + 2 e, c - 2 e}
+__device__ __forceinline__ void w4_bt6p(f32x2 E, f32x2 R0, f32x2 R1, float& t0, float& t1, float& t2, float& t3,
+                                        float& t4, float& t5) {
+  const f32x2 X = __builtin_elementwise_fma(f32x2{-4.0f, -4.0f}, R0, R1);
+  const f32x2 t12 = __builtin_elementwise_fma(f32x2{1.0f, -1.0f}, __builtin_shufflevector(X, X, 0, 0),
+                                              __builtin_shufflevector(X, X, 1, 1));
+  const f32x2 Y = R1 - R0;
+  const f32x2 t34 = __builtin_elementwise_fma(f32x2{2.0f, -2.0f}, __builtin_shufflevector(Y, Y, 0, 0),
+                                              __builtin_shufflevector(Y, Y, 1, 1));
+  t0 = __builtin_fmaf(4.0f, E[0], __builtin_fmaf(-5.0f, R0[1], R1[1]));
+  t5 = __builtin_fmaf(4.0f, R0[0], __builtin_fmaf(-5.0f, R1[0], E[1]));
+  t1 = t12[0]; t2 = t12[1]; t3 = t34[0]; t4 = t34[1];
+}
+#ifndef W4_PK
+// A/B: 0 = scalar transform; 1 = rows scalar, then two columns at a time - bit-identical to 0, 3.3 % off the kernel
+// (tools/exp_wino4_pk.sh: layer1-4 forward 0.289 / 0.243 / 0.288 / 0.306 -> 0.280 / 0.235 / 0.278 / 0.297 ms);
+// 2 = columns first (pairs as the 16-byte patch reads deliver them), then the rows on those pairs: 1-2 % more on
+// layers 3-4, nothing on 1-2 (the 30 packed intermediates cost 17 more AGPR parkings per transform), and the 6-point
+// pass - constants 4 and 5 - then amplifies the 5-point pass's rounding: 1.54e-5 of the output scale at K = 512
+// against 1.05e-5, outside the bound tests/_budget.py derives from the emulation.  Not the default.
+#define W4_PK 1
+#endif
 // one row / column of A^T m, 6 points -> 4 outputs: 10 operations
 __device__ __forceinline__ void w4_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& y0,
                                        float& y1, float& y2, float& y3) {
@@ -544,6 +583,22 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       if constexpr (WITH_DMA) { __builtin_amdgcn_sched_barrier(0); dma_unit(u_tag); __builtin_amdgcn_sched_barrier(0); }
     };
 #define W4_TU(U_) unit(std::integral_constant<int, U_>{})
+    if constexpr (MH == 3 && W4_PK == 2 && !WITH_DMA) {
+      // down the columns first, two at a time: (0, 5), (1, 2), (3, 4) - the second and third pair are the halves of
+      // the row's 16-byte read - then along each row on those pairs: 27 + 40 instructions for 54 + 60.  (Another order
+      // of the same sums than rounds 2-3: the rounding differs in the last bits, the error budget does not.)
+      f32x2 E[5], R0[5], R1[5];
+      w4_bt5x2(f32x2{raw[0], raw[5]}, f32x2{raw[6], raw[11]}, f32x2{raw[12], raw[17]}, f32x2{raw[18], raw[23]},
+               f32x2{raw[24], raw[29]}, E[0], E[1], E[2], E[3], E[4]);
+      w4_bt5x2(f32x2{raw[1], raw[2]}, f32x2{raw[7], raw[8]}, f32x2{raw[13], raw[14]}, f32x2{raw[19], raw[20]},
+               f32x2{raw[25], raw[26]}, R0[0], R0[1], R0[2], R0[3], R0[4]);
+      w4_bt5x2(f32x2{raw[3], raw[4]}, f32x2{raw[9], raw[10]}, f32x2{raw[15], raw[16]}, f32x2{raw[21], raw[22]},
+               f32x2{raw[27], raw[28]}, R1[0], R1[1], R1[2], R1[3], R1[4]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        w4_bt6p(E[i], R0[i], R1[i], V[6 * i], V[6 * i + 1], V[6 * i + 2], V[6 * i + 3], V[6 * i + 4], V[6 * i + 5]);
+      return;
+    }
     W4_TU(0);
 #pragma unroll
     for (int r = 0; r < NPR; ++r) {  // along the row: t[r][j] = sum_c BT[j][c] d[r][c]
@@ -552,6 +607,19 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
       switch (r) { case 0: W4_TU(1); break; case 1: W4_TU(2); break; case 2: W4_TU(3); break; case 3: W4_TU(4); break;
                    case 4: W4_TU(5); break; default: W4_TU(6); break; }
     }
+    if constexpr (MH == 3 && W4_PK == 1 && !WITH_DMA) {
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {  // down two columns at a time
+        f32x2 o0, o1, o2, o3, o4;
+        w4_bt5x2(f32x2{t[c], t[c + 1]}, f32x2{t[6 + c], t[7 + c]}, f32x2{t[12 + c], t[13 + c]}, f32x2{t[18 + c], t[19 + c]},
+                 f32x2{t[24 + c], t[25 + c]}, o0, o1, o2, o3, o4);
+        V[c] = o0[0]; V[c + 1] = o0[1];
+        V[6 + c] = o1[0]; V[7 + c] = o1[1];
+        V[12 + c] = o2[0]; V[13 + c] = o2[1];
+        V[18 + c] = o3[0]; V[19 + c] = o3[1];
+        V[24 + c] = o4[0]; V[25 + c] = o4[1];
+      }
+    } else
 #pragma unroll
     for (int c = 0; c < 6; ++c) {  // down the column: V[i][j] = sum_r BT_h[i][r] t[r][j]
       if constexpr (MH == 4)
