@@ -54,16 +54,17 @@ struct TapSel {
   int idx[9];
 };
 
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                    int Cin, int taps_full, int transpose, int ck, int bm,
-                                    TapSel sel) {
+// (bid of nb blocks: the launch's own grid, or this slab's share of a batched launch)
+__device__ __forceinline__ void pack_weights_body(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                                  int Cin, int taps_full, int transpose, int ck, int bm,
+                                                  const TapSel& sel, int bid, int nb) {
   // logical (M = "out" role, Kc = "in" role)
   const int M = transpose ? Cin : Cout;
   const int Kc = transpose ? Cout : Cin;
   const int Mpad = (M + bm - 1) / bm * bm;  // channel tiles (bm = 64 or 32) are zero-padded
   const size_t total = (size_t)Mpad * ((Kc + ck - 1) / ck * ck) * sel.n;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (size_t)gridDim.x * blockDim.x) {
+  for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)nb * blockDim.x) {
     const int col = (int)(e % bm);
     size_t r = e / bm;
     const int cil = (int)(r % ck);
@@ -86,6 +87,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     }
     wp[e] = v;
   }
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                    int Cin, int taps_full, int transpose, int ck, int bm,
+                                    TapSel sel) {
+  pack_weights_body(w, wp, Cout, Cin, taps_full, transpose, ck, bm, sel, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the slabs of several layers in one launch (air_conv2d_prepack_begin / _flush): job j owns blocks [blk0[j], blk0[j+1])
+constexpr int PK_JOBS = 32;
+struct PackJobs {
+  const float* w[PK_JOBS];
+  float* wp[PK_JOBS];
+  int Cout[PK_JOBS], Cin[PK_JOBS];
+  unsigned char taps_full[PK_JOBS], transpose[PK_JOBS], ck[PK_JOBS], bm[PK_JOBS];
+  unsigned char seln[PK_JOBS], selidx[PK_JOBS][9];
+  int blk0[PK_JOBS + 1];
+  int n;
+};
+__global__ void pack_weights_batch_kernel(const PackJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.n && (int)blockIdx.x >= jb.blk0[j + 1]) ++j;
+  TapSel sel;
+  sel.n = jb.seln[j];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sel.idx[t] = jb.selidx[j][t];
+  pack_weights_body(jb.w[j], jb.wp[j], jb.Cout[j], jb.Cin[j], jb.taps_full[j], jb.transpose[j], jb.ck[j], jb.bm[j], sel,
+                    (int)blockIdx.x - jb.blk0[j], jb.blk0[j + 1] - jb.blk0[j]);
 }
 
 // zero-upsample dy (B,C,Ho,Wo) -> (B,C,Hu,Wu) with u[2i][2j] = dy[i][j]
@@ -1298,6 +1327,17 @@ int run_fwd(const float* x, const float* wp, float* y, const float* scale, const
   return AIR_EUNSUPPORTED;
 }
 
+// air_conv2d_prepack_begin .. _flush: slabs are recorded (this thread) and packed by one launch per 32 at the flush
+thread_local bool g_pk_defer = false;
+thread_local PackJobs g_pk_jobs;
+int pack_run_jobs(hipStream_t st) {
+  if (g_pk_jobs.n == 0) return AIR_OK;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(g_pk_jobs.blk0[g_pk_jobs.n]), dim3(256), 0, st, g_pk_jobs);
+  g_pk_jobs.n = 0;
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
 int pack(const float* w, float*& wp, int Cout, int Cin, int taps_full, int transpose, int ck,
          int mt, const TapSel& sel, hipStream_t st) {
   const int M = transpose ? Cin : Cout, Kc = transpose ? Cout : Cin;
@@ -1306,6 +1346,21 @@ int pack(const float* w, float*& wp, int Cout, int Cin, int taps_full, int trans
   if (g_pk.mode == PK_SIZE) { g_pk.used += n; return AIR_OK; }
   if (g_pk.mode == PK_USE) { wp = g_pk.cur + g_pk.used; g_pk.used += n; return AIR_OK; }
   if (g_pk.mode == PK_COLLECT) { wp = g_pk.cur + g_pk.used; g_pk.used += n; }
+  if (g_pk_defer && g_pk.mode != PK_RUN) {  // (only slabs that go to a caller's buffer: a workspace slab is consumed at once)
+    if (g_pk_jobs.n == PK_JOBS) {
+      const int rc = pack_run_jobs(st);
+      if (rc != AIR_OK) return rc;
+      g_pk_jobs.blk0[0] = 0;
+    }
+    const int j = g_pk_jobs.n++;
+    g_pk_jobs.w[j] = w; g_pk_jobs.wp[j] = wp; g_pk_jobs.Cout[j] = Cout; g_pk_jobs.Cin[j] = Cin;
+    g_pk_jobs.taps_full[j] = (unsigned char)taps_full; g_pk_jobs.transpose[j] = (unsigned char)transpose;
+    g_pk_jobs.ck[j] = (unsigned char)ck; g_pk_jobs.bm[j] = (unsigned char)bm;
+    g_pk_jobs.seln[j] = (unsigned char)sel.n;
+    for (int t = 0; t < 9; ++t) g_pk_jobs.selidx[j][t] = (unsigned char)(t < sel.n ? sel.idx[t] : 0);
+    g_pk_jobs.blk0[j + 1] = g_pk_jobs.blk0[j] + grid_for(n);
+    return AIR_OK;
+  }
   hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, wp, Cout, Cin,
                      taps_full, transpose, ck, bm, sel);
   AIR_CHECK_LAUNCH();
@@ -1942,7 +1997,7 @@ int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, 
     return pass ? dgrad_generic(p, nullptr, w, nullptr, nullptr, none, air_stream(stream))
                 : fwd_generic(p, nullptr, w, nullptr, nullptr, nullptr, 0, nullptr, none, air_stream(stream));
   }
-  return kind == 4 ? air_wino4_weights(w, up, M, Kc, p->H, pass, air_stream(stream))
+  return kind == 4 ? air_wino4_weights(w, up, M, Kc, p->H, pass, air_stream(stream), true)
                    : air_wino_weights(w, up, M, Kc, pass, air_stream(stream));
 }
 
@@ -2095,10 +2150,27 @@ int air_conv2d_dgrad_s2_pair_prepack(const AirConv2d* p, const float* w, const f
   for (int t = 0; t < 9; ++t) s9.idx[t] = t;
   s1.n = 1;
   s1.idx[0] = 0;
-  PackScope run(PK_RUN, nullptr);
+  PackScope collect(PK_COLLECT, w9);  // (the two slabs back to back in `out`; deferred like any prepack between begin / flush)
   int rc = pack(w, w9, p->Cout, p->Cin, 9, 1, S2D_CK, mt, s9, st);
   if (rc != AIR_OK) return rc;
   return pack(w_sc, w1, p->Cout, p->Cin, 1, 1, S2D_CK, mt, s1, st);
+}
+
+int air_conv2d_prepack_begin(void) {
+  g_pk_defer = true;
+  g_pk_jobs.n = 0;
+  g_pk_jobs.blk0[0] = 0;
+  air_wino4_weights_defer(true);
+  return AIR_OK;
+}
+
+int air_conv2d_prepack_flush(air_stream_t stream) {
+  hipStream_t st = air_stream(stream);
+  g_pk_defer = false;
+  const int rc = pack_run_jobs(st);
+  const int rc4 = air_wino4_weights_flush(st);
+  air_wino4_weights_defer(false);
+  return rc != AIR_OK ? rc : rc4;
 }
 
 int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w, const float* dy_sc, const float* w_sc,
@@ -2109,6 +2181,7 @@ int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w
   if (need == 0) return AIR_EUNSUPPORTED;
   const float* w9 = reinterpret_cast<const float*>(packed);
   if (w9 == nullptr) {
+    if (g_pk_defer) return AIR_EINVAL;  // between air_conv2d_prepack_begin and _flush nothing is packed yet
     if (!ws || ws_bytes < need) return AIR_EWORKSPACE;
     const int rc = air_conv2d_dgrad_s2_pair_prepack(p, w, w_sc, ws, ws_bytes, stream);
     if (rc != AIR_OK) return rc;

@@ -39,4 +39,8 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
                    const float* const* bn = nullptr);
 size_t air_wino4_stats_bytes(int B, int H, int W, int M);
 // H: image height of the launch the weights are for (it picks the 4- or 3-row tile layout)
-int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st);
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st, bool may_defer);
+// defer(true): air_wino4_weights(may_defer = true) calls of this thread are recorded instead of launched; flush runs what was recorded as
+// one launch (32 layers per launch); defer(false) drops the mode.  See air_conv2d_prepack_begin (conv2d.hip).
+void air_wino4_weights_defer(bool on);
+int air_wino4_weights_flush(hipStream_t st);

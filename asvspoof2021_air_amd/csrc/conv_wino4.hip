@@ -160,15 +160,16 @@ __device__ __forceinline__ void w4_g5(double g0, double g1, double g2, double& u
 
 // U = G_h g G_w^T in double, rounded once (G_h: 6 or 5 points along H, G_w: 6 points along W).
 // Packed [cot][chunk][slab of W4Pos<MH>].
+// (bid of nb blocks: the launch's own grid, or this layer's share of a batched launch)
 template <int MH>
-__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int Kc,
-                                     int dgrad) {
+__device__ __forceinline__ void w4_weights_body(const float* __restrict__ w, float* __restrict__ up, int M, int Kc,
+                                                int dgrad, int bid, int nb) {
   using P = W4Pos<MH>;
   const int nchunk = Kc / W4_CK;
   const int Mpad = (M + W4_CO - 1) / W4_CO * W4_CO;  // a 16-channel tail runs as a slab whose upper rows are zero
   const size_t total = (size_t)Mpad * Kc;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (size_t)gridDim.x * blockDim.x) {
+  for (size_t e = (size_t)bid * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)nb * blockDim.x) {
     const int col = (int)(e % W4_CO);
     size_t r = e / W4_CO;
     const int k = (int)(r % Kc);
@@ -197,6 +198,32 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
       for (int p = P::NP; p < 4 * P::NQ; ++p) o[P::uoff(kk, col, p)] = 0.0f;
     }
   }
+}
+
+template <int MH>
+__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ up, int M, int Kc,
+                                     int dgrad) {
+  w4_weights_body<MH>(w, up, M, Kc, dgrad, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The transforms of SEVERAL layers in one launch (air_conv2d_prepack_begin / _flush, conv2d.hip): the ResNet's 26
+// per-step launches of 5 - 25 us each sit between the persistent convolution kernels of the other stream, which leave
+// no CU for them until a workgroup retires - each costs its own gap.  Job j owns blocks [blk0[j], blk0[j + 1]).
+constexpr int W4_WJOBS = 32;
+struct W4WeightJobs {
+  const float* w[W4_WJOBS];
+  float* up[W4_WJOBS];
+  int M[W4_WJOBS], Kc[W4_WJOBS];
+  unsigned char dgrad[W4_WJOBS], mh[W4_WJOBS];
+  int blk0[W4_WJOBS + 1];
+  int n;
+};
+__global__ void wino4_weights_batch_kernel(const W4WeightJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.n && (int)blockIdx.x >= jb.blk0[j + 1]) ++j;
+  const int bid = (int)blockIdx.x - jb.blk0[j], nb = jb.blk0[j + 1] - jb.blk0[j];
+  if (jb.mh[j] == 3) w4_weights_body<3>(jb.w[j], jb.up[j], jb.M[j], jb.Kc[j], jb.dgrad[j], bid, nb);
+  else w4_weights_body<4>(jb.w[j], jb.up[j], jb.M[j], jb.Kc[j], jb.dgrad[j], bid, nb);
 }
 
 struct W4Args {
@@ -1319,8 +1346,40 @@ bool air_wino4_ok(int B, int Kc, int H, int W, int M) {
 // (either tile height: 36 floats per (co, ci) cover the 32 of the 3-row layout)
 size_t air_wino4_packed_elems(int M, int Kc) { return (size_t)((M + W4_CO - 1) / W4_CO * W4_CO) * Kc * 36 + 1024; }
 
-int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st) {
+// deferred transforms of this thread (air_wino4_weights_defer): recorded here, run by air_wino4_weights_flush
+namespace {
+thread_local bool g_w4_defer = false;
+thread_local W4WeightJobs g_w4_jobs;
+int w4_run_jobs(hipStream_t st) {
+  if (g_w4_jobs.n == 0) return AIR_OK;
+  hipLaunchKernelGGL(wino4_weights_batch_kernel, dim3(g_w4_jobs.blk0[g_w4_jobs.n]), dim3(256), 0, st, g_w4_jobs);
+  g_w4_jobs.n = 0;
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+}  // namespace
+
+void air_wino4_weights_defer(bool on) {
+  g_w4_defer = on;
+  g_w4_jobs.n = 0;
+  g_w4_jobs.blk0[0] = 0;
+}
+int air_wino4_weights_flush(hipStream_t st) { return w4_run_jobs(st); }
+
+int air_wino4_weights(const float* w, float* up, int M, int Kc, int H, int dgrad, hipStream_t st, bool may_defer) {
   const size_t n = (size_t)((M + W4_CO - 1) / W4_CO * W4_CO) * Kc;
+  if (g_w4_defer && may_defer) {
+    if (g_w4_jobs.n == W4_WJOBS) {
+      const int rc = w4_run_jobs(st);
+      if (rc != AIR_OK) return rc;
+      g_w4_jobs.blk0[0] = 0;
+    }
+    const int j = g_w4_jobs.n++;
+    g_w4_jobs.w[j] = w; g_w4_jobs.up[j] = up; g_w4_jobs.M[j] = M; g_w4_jobs.Kc[j] = Kc;
+    g_w4_jobs.dgrad[j] = (unsigned char)dgrad; g_w4_jobs.mh[j] = (unsigned char)w4_tile_rows(H);
+    g_w4_jobs.blk0[j + 1] = g_w4_jobs.blk0[j] + w4_grid_for(n);
+    return AIR_OK;
+  }
   if (w4_tile_rows(H) == 3)
     hipLaunchKernelGGL(wino4_weights_kernel<3>, dim3(w4_grid_for(n)), dim3(256), 0, st, w, up, M, Kc, dgrad);
   else
@@ -1373,7 +1432,7 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
                    int W, int M, int dgrad, float* up, double flops, hipStream_t st, float* stats,
                    const float* const* bn) {
   if (w != nullptr) {  // w == nullptr: `up` already holds the transformed weights (air_wino4_weights)
-    const int rc = air_wino4_weights(w, up, M, Kc, H, dgrad, st);
+    const int rc = air_wino4_weights(w, up, M, Kc, H, dgrad, st, false);  // consumed by the launch below: never deferred
     if (rc != AIR_OK) return rc;
   }
   // forward launches take forward statistics (bn == nullptr), data-gradient launches BatchNorm-backward sums

@@ -82,6 +82,20 @@ def conv2d_prepack(w, x_shape, stride, padding, which, out=None):
     return out
 
 
+class prepack_batch:
+    """``with ops.prepack_batch():`` the conv2d_prepack / conv2d_dgrad_s2_pair_prepack calls inside only record their
+    transforms; leaving the block runs them on the current stream as one launch per 32 (air_conv2d_prepack_begin /
+    _flush).  The buffers are valid behind the block in stream order."""
+
+    def __enter__(self):
+        _hip.check(_hip.lib().air_conv2d_prepack_begin(), "air_conv2d_prepack_begin")
+        return self
+
+    def __exit__(self, *exc):
+        _hip.check(_hip.lib().air_conv2d_prepack_flush(stream()), "air_conv2d_prepack_flush")
+        return False
+
+
 def _check_packed(d, w_packed, which):
     """A prepacked weight buffer must be at least what the layer consumes under the CURRENT dispatch options
     (options can change between prepack and use; the library walks the buffer without a size)."""

@@ -297,28 +297,29 @@ class ResNet(nn.Module):
             for which in (0, 1):
                 if which == 0 and fuse:
                     continue
-                for (bi, ci), (shape, s, pad) in self._geo.items():
-                    # (bi, 1 | 2): a block's 3x3 convs; (bi, 0): its 1x1 shortcut; (-1, 5): conv5
-                    conv = self.conv5 if bi < 0 else (blocks[bi].shortcut[0] if ci == 0 else
-                                                      blocks[bi].conv1 if ci == 1 else blocks[bi].conv2)
-                    if which == 1 and bi >= 0 and s == 2 and ci in (0, 1) and hasattr(blocks[bi], "shortcut"):
-                        # a stride-2 block's conv1 and shortcut share ONE data-gradient launch (round 4): their
-                        # weights travel together under (bi, 1); the shortcut has no buffer of its own then
-                        if ci == 0 and ops.conv2d_dgrad_s2_pair_ok(blocks[bi].conv1.weight.shape, shape):
-                            continue
-                        if ci == 1:
-                            buf = ops.conv2d_dgrad_s2_pair_prepack(conv.weight.detach(), blocks[bi].shortcut[0].weight.detach(),
-                                                                   shape, out=self._packs.get(((bi, ci), "pair")))
-                            if buf is not None:
-                                self._packs[((bi, ci), "pair")] = buf
-                                live[((bi, ci), which)] = buf
-                                self._geo_live[(bi, ci)] = shape
+                with ops.prepack_batch():  # one launch per 32 transforms instead of one per layer
+                    for (bi, ci), (shape, s, pad) in self._geo.items():
+                        # (bi, 1 | 2): a block's 3x3 convs; (bi, 0): its 1x1 shortcut; (-1, 5): conv5
+                        conv = self.conv5 if bi < 0 else (blocks[bi].shortcut[0] if ci == 0 else
+                                                          blocks[bi].conv1 if ci == 1 else blocks[bi].conv2)
+                        if which == 1 and bi >= 0 and s == 2 and ci in (0, 1) and hasattr(blocks[bi], "shortcut"):
+                            # a stride-2 block's conv1 and shortcut share ONE data-gradient launch (round 4): their
+                            # weights travel together under (bi, 1); the shortcut has no buffer of its own then
+                            if ci == 0 and ops.conv2d_dgrad_s2_pair_ok(blocks[bi].conv1.weight.shape, shape):
                                 continue
-                    buf = ops.conv2d_prepack(conv.weight.detach(), shape, s, pad, which, out=self._packs.get(((bi, ci), which)))
-                    if buf is not None:
-                        self._packs[((bi, ci), which)] = buf
-                        live[((bi, ci), which)] = buf
-                        self._geo_live[(bi, ci)] = shape
+                            if ci == 1:
+                                buf = ops.conv2d_dgrad_s2_pair_prepack(conv.weight.detach(), blocks[bi].shortcut[0].weight.detach(),
+                                                                       shape, out=self._packs.get(((bi, ci), "pair")))
+                                if buf is not None:
+                                    self._packs[((bi, ci), "pair")] = buf
+                                    live[((bi, ci), which)] = buf
+                                    self._geo_live[(bi, ci)] = shape
+                                    continue
+                        buf = ops.conv2d_prepack(conv.weight.detach(), shape, s, pad, which, out=self._packs.get(((bi, ci), which)))
+                        if buf is not None:
+                            self._packs[((bi, ci), which)] = buf
+                            live[((bi, ci), which)] = buf
+                            self._geo_live[(bi, ci)] = shape
                 self._pack_ev[which] = torch.cuda.Event()
                 self._pack_ev[which].record(side)
         return live

@@ -181,6 +181,11 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
 size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass);
 int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes,
                        air_stream_t stream);
+/* Between _begin and _flush the air_conv2d_prepack / air_conv2d_dgrad_s2_pair_prepack calls of the calling thread only
+ * RECORD their transforms; _flush runs them on `stream` as one launch per 32 Winograd transforms and one per 32 direct
+ * slabs (a ResNet-18 step: 3 launches for 47).  The output buffers are valid behind _flush in stream order. */
+int air_conv2d_prepack_begin(void);
+int air_conv2d_prepack_flush(air_stream_t stream);
 int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const void* w_packed, float* y,
                        const float* in_scale, const float* in_shift, int relu, const float* residual,
                        double* stats, void* ws, size_t ws_bytes, air_stream_t stream);

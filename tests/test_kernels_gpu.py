@@ -196,6 +196,42 @@ def test_conv2d_dgrad(ops, cfg):
     close(got2, x.grad + acc.double(), name="conv2d_dgrad+acc")
 
 
+def test_conv2d_prepack_batch(ops):
+    """air_conv2d_prepack_begin / _flush: the weight transforms of many layers recorded and run as one launch per 32
+    (Winograd transforms and direct slabs apart) - every buffer bit-identical to the layer's own prepack launch; more
+    than 32 jobs of a kind (the table of one launch) flush on the way; a data gradient that would have to pack in place
+    inside the block is refused instead of running on weights that are not there yet."""
+    from asvspoof2021_air_amd import _hip
+    jobs = []
+    for rep in range(3):
+        for B, Cin, H, W, Cout, k, s, p in CONVS:
+            w = synth_feat((Cout, Cin) + k, 20 + rep, scale=0.1).cuda()
+            for which in (0, 1):
+                jobs.append((w, (B, Cin, H, W), s, p, which))
+    sizes = [ops.conv2d_prepack(w, xs, s, p, which) for w, xs, s, p, which in jobs]
+    assert sum(a is not None for a in sizes) > 64
+    # (into zeroed buffers: a layout's alignment gaps are never written)
+    zeros = lambda a: None if a is None else torch.zeros_like(a)
+    alone = [ops.conv2d_prepack(w, xs, s, p, which, out=zeros(a)) for (w, xs, s, p, which), a in zip(jobs, sizes)]
+    wsc = synth_feat((128, 64, 1, 1), 5, scale=0.2).cuda()
+    w3 = synth_feat((128, 64, 3, 3), 6, scale=0.1).cuda()
+    pair_alone = ops.conv2d_dgrad_s2_pair_prepack(w3, wsc, (2, 64, 18, 75))
+    pair_alone = ops.conv2d_dgrad_s2_pair_prepack(w3, wsc, (2, 64, 18, 75), out=torch.zeros_like(pair_alone))
+    with ops.prepack_batch():
+        batched = [ops.conv2d_prepack(w, xs, s, p, which, out=zeros(a)) for (w, xs, s, p, which), a in zip(jobs, sizes)]
+        pair_batched = ops.conv2d_dgrad_s2_pair_prepack(w3, wsc, (2, 64, 18, 75), out=torch.zeros_like(pair_alone))
+        dy = synth_feat((2, 128, 9, 38), 7).cuda()
+        with pytest.raises(_hip.AirError):
+            ops.conv2d_dgrad_s2_pair(dy, w3, dy, wsc, (2, 64, 18, 75))
+    for a, b in zip(alone, batched):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert torch.equal(pair_alone, pair_batched)
+    # outside the block everything launches at once again
+    assert torch.equal(ops.conv2d_prepack(*jobs[0], out=zeros(sizes[0])), alone[0])
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 @pytest.mark.parametrize("fused", [False, True])
 def test_conv2d_wgrad(ops, cfg, fused):
