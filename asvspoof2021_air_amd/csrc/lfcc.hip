@@ -55,24 +55,45 @@ struct LfccPlan {
   float dctT[MAXF * MAXF];    // [j][i] = dct[i][j]
 };
 
-struct cf {
-  float re, im;
-};
-__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cf cmul(cf a, cf b) {
-  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+// complex value as a register pair: sums, differences and the partial products of a complex multiply are
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on (re, im) - the same roundings as the scalar forms (the LFCC parity
+// tests are unchanged), 512 floating-point VALU instructions per wave for 863 (round 4).  Measured: the launch stays
+// at 31 us (B = 64): the kernel is NOT bound by its arithmetic - 2172 instructions per wave are ~4 us of issue at 4
+// waves per SIMD - but by the latency chain of a workgroup (tables and PCM staged from L2 / HBM, two barriers, the
+// strided feature-row stores) at two 70 KB workgroups per CU over 1.9 rounds.
+typedef float cf __attribute__((ext_vector_type(2)));
+// Swapped / negated halves are written as a shuffle and a product with (+-1, +-1) - exact, so every result keeps the
+// scalar form's roundings - which hipcc folds into the op_sel / neg modifiers of ONE v_pk_fma_f32 / v_pk_mul_f32
+// (left a bare negation of one half it builds the operand with v_mov + v_xor instead).
+#define LFCC_SWAP(v) __builtin_shufflevector(v, v, 1, 0)
+#define LFCC_LO(v) __builtin_shufflevector(v, v, 0, 0)
+#define LFCC_HI(v) __builtin_shufflevector(v, v, 1, 1)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {  // a + (-i) b = (a.x + b.y, a.y - b.x)
+  return __builtin_elementwise_fma(LFCC_SWAP(b), cf{1.0f, -1.0f}, a);
 }
-__device__ __forceinline__ cf mul_mi(cf a) { return {a.im, -a.re}; }  // * (-i)
-__device__ __forceinline__ cf mul_pi(cf a) { return {-a.im, a.re}; }  // * (+i)
+__device__ __forceinline__ cf add_pi(cf a, cf b) {  // a + (+i) b = (a.x - b.y, a.y + b.x)
+  return __builtin_elementwise_fma(LFCC_SWAP(b), cf{-1.0f, 1.0f}, a);
+}
+__device__ __forceinline__ cf cmul(cf a, cf b) {  // (ar br - ai bi, ar bi + ai br): the scalar form's six roundings
+  const cf t1 = LFCC_LO(a) * b;             // (ar br, ar bi)
+  const cf t2 = LFCC_HI(a) * LFCC_SWAP(b);  // (ai bi, ai br)
+  return __builtin_elementwise_fma(t2, cf{-1.0f, 1.0f}, t1);
+}
+__device__ __forceinline__ cf mul_mi(cf a) { return LFCC_SWAP(a) * cf{1.0f, -1.0f}; }  // * (-i) = (a.y, -a.x)
+// a w16^2 = R2 (a.x + a.y, a.y - a.x);  a w16^6 = (R2 (a.y - a.x), -R2 (a.x + a.y))
+__device__ __forceinline__ cf mul_w2(cf a, float r2) { return add_mi(a, a) * r2; }
+__device__ __forceinline__ cf mul_w6(cf a, float r2) {
+  const cf t = add_mi(a, a);
+  return LFCC_SWAP(t) * cf{r2, -r2};
+}
 
 // forward 4-point DFT (w4 = -i), natural order in and out
 __device__ __forceinline__ void fft4(cf& a0, cf& a1, cf& a2, cf& a3) {
   cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = a1 - a3;
   a0 = t0 + t2;
   a2 = t0 - t2;
-  a1 = t1 + mul_mi(t3);
-  a3 = t1 + mul_pi(t3);
+  a1 = add_mi(t1, t3);
+  a3 = add_pi(t1, t3);
 }
 
 constexpr float C1 = 0.92387953251128674f;  // cos(pi/8)
@@ -81,15 +102,15 @@ constexpr float R2 = 0.70710678118654752f;  // sqrt(1/2)
 
 // y[m1*4+q2] *= w16^(m1*q2), w16 = e^{-2 pi i/16}
 __device__ __forceinline__ void twiddle16(cf (&y)[16]) {
-  y[5] = cmul(y[5], cf{C1, -S1});                               // w^1
-  y[6] = cf{R2 * (y[6].re + y[6].im), R2 * (y[6].im - y[6].re)};  // w^2
-  y[7] = cmul(y[7], cf{S1, -C1});                               // w^3
-  y[9] = cf{R2 * (y[9].re + y[9].im), R2 * (y[9].im - y[9].re)};  // w^2
-  y[10] = mul_mi(y[10]);                                        // w^4
-  y[11] = cf{R2 * (y[11].im - y[11].re), -R2 * (y[11].re + y[11].im)};  // w^6
-  y[13] = cmul(y[13], cf{S1, -C1});                             // w^3
-  y[14] = cf{R2 * (y[14].im - y[14].re), -R2 * (y[14].re + y[14].im)};  // w^6
-  y[15] = cmul(y[15], cf{-C1, S1});                             // w^9
+  y[5] = cmul(y[5], cf{C1, -S1});   // w^1
+  y[6] = mul_w2(y[6], R2);          // w^2: R2 (re + im, im - re)
+  y[7] = cmul(y[7], cf{S1, -C1});   // w^3
+  y[9] = mul_w2(y[9], R2);          // w^2
+  y[10] = mul_mi(y[10]);            // w^4
+  y[11] = mul_w6(y[11], R2);        // w^6: R2 (im - re, -(re + im))
+  y[13] = cmul(y[13], cf{S1, -C1}); // w^3
+  y[14] = mul_w6(y[14], R2);        // w^6
+  y[15] = cmul(y[15], cf{-C1, S1}); // w^9
 }
 
 // 16-point forward DFT, natural order in x[m] and out X[q].
@@ -105,16 +126,16 @@ __device__ __forceinline__ void fft16(cf (&x)[16]) {
       cf t0 = a0 + a2, t1 = a0 - a2;
       y[m1 * 4 + 0] = t0 + a1;
       y[m1 * 4 + 2] = t0 - a1;
-      y[m1 * 4 + 1] = t1 + mul_mi(a1);
-      y[m1 * 4 + 3] = t1 + mul_pi(a1);
+      y[m1 * 4 + 1] = add_mi(t1, a1);
+      y[m1 * 4 + 3] = add_pi(t1, a1);
     }
 #pragma unroll
     for (int m1 = 2; m1 < 4; ++m1) {  // inputs m1, m1+4 only
       cf a0 = x[m1], a1 = x[m1 + 4];
       y[m1 * 4 + 0] = a0 + a1;
       y[m1 * 4 + 2] = a0 - a1;
-      y[m1 * 4 + 1] = a0 + mul_mi(a1);
-      y[m1 * 4 + 3] = a0 + mul_pi(a1);
+      y[m1 * 4 + 1] = add_mi(a0, a1);
+      y[m1 * 4 + 3] = add_pi(a0, a1);
     }
   } else {
 #pragma unroll
@@ -267,13 +288,13 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
     // transpose through LDS: row q, column g - real parts, then imaginary parts through the same 4.3 KB
     float xre[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].re;
+    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].x;
     air_wave_lds_fence();
 #pragma unroll
     for (int l = 0; l < 16; ++l) xre[l] = xch[(f * 16 + g) * XROW + l];
     air_wave_lds_fence();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].im;
+    for (int q = 0; q < 16; ++q) xch[(f * 16 + q) * XROW + g] = x[q].y;
     air_wave_lds_fence();
 #pragma unroll
     for (int l = 0; l < 16; ++l) x[l] = cf{xre[l], xch[(f * 16 + g) * XROW + l]};
@@ -287,25 +308,29 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
       // bin k = g + 16 p pairs with 256 - k: lane (16-g)&15, index 15-p  (g != 0)
       //                                      own lane, index (16-p)&15   (g == 0)
       const int pp = 15 - p;
-      float bre = __shfl(x[pp].re, partner, 64);
-      float bim = __shfl(x[pp].im, partner, 64);
+      float bre = __shfl(x[pp].x, partner, 64);
+      float bim = __shfl(x[pp].y, partner, 64);
       const int p0 = (16 - p) & 15;
       if (g == 0) {
-        bre = x[p0].re;
-        bim = x[p0].im;
+        bre = x[p0].x;
+        bim = x[p0].y;
       }
-      // E2 = A + conj(B), O2 = A - conj(B);  2X = E2 - i w512^k O2
-      const float ere = x[p].re + bre, eim = x[p].im - bim;
-      const float ore = x[p].re - bre, oim = x[p].im + bim;
-      const float c = cq * W32C[p] - sq * W32S[p];  // cos(2 pi k/512)
-      const float s = sq * W32C[p] + cq * W32S[p];  // sin(2 pi k/512)
-      const float xr = ere + c * oim - s * ore;
-      const float xi = eim - c * ore - s * oim;
+      // E2 = A + conj(B), O2 = A - conj(B);  2X = E2 - i w512^k O2 - on register pairs (same roundings as the scalar
+      // form: xr = (ere + c oim) - s ore, xi = (eim - c ore) - s oim)
+      const cf A = x[p], Bv = cf{bre, bim};
+      const cf E = __builtin_elementwise_fma(Bv, cf{1.0f, -1.0f}, A);  // (A.re + bre, A.im - bim)
+      const cf O = __builtin_elementwise_fma(Bv, cf{-1.0f, 1.0f}, A);  // (A.re - bre, A.im + bim)
+      const cf cs = cmul(cf{cq, sq}, cf{W32C[p], W32S[p]});  // (cos, sin)(2 pi k / 512)
+      const cf P1 = LFCC_LO(cs) * LFCC_SWAP(O);              // (c oim, c ore)
+      const cf X1 = __builtin_elementwise_fma(P1, cf{1.0f, -1.0f}, E);
+      const cf X = X1 - LFCC_HI(cs) * O;                     // - (s ore, s oim)
+      const cf X2 = X * X;
+      const float xr2 = X2.x, xi2 = X2.y;
       // reference: norm(.,2,-1).pow(2)  (feature_extraction.py:113)
-      const float mag = 0.5f * sqrtf(xr * xr + xi * xi);
+      const float mag = 0.5f * sqrtf(xr2 + xi2);
       xch[f * PROW + g + 16 * p] = mag * mag;
       if (p == 0) {
-        const float ny = x[0].re - x[0].im;  // X[256] = Re Z0 - Im Z0 (real)
+        const float ny = x[0].x - x[0].y;  // X[256] = Re Z0 - Im Z0 (real)
         pnyq = ny * ny;
       }
     }
