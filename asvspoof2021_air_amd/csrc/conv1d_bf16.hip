@@ -1151,7 +1151,16 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
       slot ^= 1;
     }
 #ifdef G2_X_NOEPI
-    if (acc[0][0][0] + acc[3][1][15] + acc[1][0][7] + acc[2][1][3] == 12345.678f) p.out_bf[0] = 1;
+    {  // (every accumulator feeds the test: with four of them, round 3's form, hipcc dropped the MFMAs of the other half)
+      float chk = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) chk += acc[i][j][e];
+      if (chk == 12345.678f) p.out_bf[0] = 1;
+    }
     zero();
     continue;
 #endif
