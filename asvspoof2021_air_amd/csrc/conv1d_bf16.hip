@@ -1263,6 +1263,9 @@ struct C1bTap {
   size_t x_bs, y_bs;
   int B, M, K, T, dil, relu, tiles_m, tiles_t, total, per_xcd;
   int Tp;  // c1b_tap_kernel<true>: x and y are bf16 rows of Tp frames (x / y point at unsigned short)
+  // c1b_tap_kernel<true>, optional: BatchNorm statistics of the STORED output - per (channel m, 32-frame segment r) the
+  // pair {sum, sum of squares} at stats[(m * NR + r) * 2], NR = B * tiles_t * 4, r = (b * tiles_t + tile) * 4 + wave
+  float* stats;
 };
 
 // fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
@@ -1383,7 +1386,9 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&sA[cur][(tap * 64 + i * 32 + r31) * LDK + kk * 16 + kgl * 8]);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+          // HIO: operands swapped - the accumulators come out transposed (a lane = one channel, see the epilogue)
+          acc[i] = HIO ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[i], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
         }
       }
     }
@@ -1393,22 +1398,70 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
 #undef TAP_FETCH
 #undef TAP_STASH
 
-  const int t = t0 + wave * 32 + r31;
   if (HIO) {
-    if (t >= p.Tp) return;
+    // Round 4.  With the operands swapped the sums are the same products in the same k order, but transposed: a lane
+    // holds channel m0 + 32 i + r31 and 16 frames of it - t0 + 32 wave + (q & 3) + 8 (q >> 2) + 4 kgl, i.e. four groups
+    // of 4 consecutive frames.  A group is rounded once and goes to LDS as one 8-byte piece of a [64 channels][128
+    // frames] bf16 tile (in the operand buffers the k-loop has left); the tile leaves as 16-byte row pieces, 16 lanes
+    // per 256-byte row (round 3: one 2-byte store per value, 32 store instructions per wave - 3.7 of the launch's
+    // 13.3 us).  A channel's BatchNorm sums over the wave's 32 frames are 16 in-lane additions and one exchange
+    // with the lane that holds the other 16: the statistics pass over the stored tensor (h_bn_partial_kernel) is not
+    // needed when p.stats is given.
+    constexpr int TPITCH = BN + 8;
+    static_assert(64 * TPITCH <= 2 * 3 * 64 * LDK, "the output tile fits the A operand buffers");
+    u16* tile = &sA[0][0];
+    const int fl = wave * 32 + 4 * kgl;  // local frame of group 0
+    float s1[2], s2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ml = i * 32 + r31;
+      const float bv = p.bias ? p.bias[m0 + ml] : 0.0f;
+      s1[i] = 0.0f;
+      s2[i] = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][4 * g + e] + bv;
+          if (p.relu) v[e] = fmaxf(v[e], 0.0f);
+          if (t0 + fl + 8 * g + e >= p.T) v[e] = 0.0f;
+        }
+        const unsigned w0 = pack2(v[0], v[1]), w1 = pack2(v[2], v[3]);
+        if (p.stats != nullptr) {  // of the values as stored (zeros behind T add nothing)
+          const float r0 = __builtin_bit_cast(float, w0 << 16), r1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
+          const float r2 = __builtin_bit_cast(float, w1 << 16), r3 = __builtin_bit_cast(float, w1 & 0xffff0000u);
+          s1[i] += (r0 + r1) + (r2 + r3);
+          s2[i] = fmaf(r0, r0, s2[i]);
+          s2[i] = fmaf(r1, r1, s2[i]);
+          s2[i] = fmaf(r2, r2, s2[i]);
+          s2[i] = fmaf(r3, r3, s2[i]);
+        }
+        *reinterpret_cast<uint2*>(&tile[ml * TPITCH + fl + 8 * g]) = make_uint2(w0, w1);
+      }
+    }
+    if (p.stats != nullptr) {
+      const int NR = p.B * p.tiles_t * 4, ridx = (b * p.tiles_t + tt) * 4 + wave;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float a1 = s1[i] + __shfl_xor(s1[i], 32, 64), a2 = s2[i] + __shfl_xor(s2[i], 32, 64);
+        if (kgl == 0)
+          *reinterpret_cast<float2*>(p.stats + ((size_t)(m0 + i * 32 + r31) * NR + ridx) * 2) = make_float2(a1, a2);
+      }
+    }
+    __syncthreads();
     u16* __restrict__ yh = reinterpret_cast<u16*>(p.y) + (size_t)b * p.y_bs;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kgl;
-        float v = acc[i][q] + (p.bias ? p.bias[m] : 0.0f);
-        if (p.relu) v = fmaxf(v, 0.0f);
-        if (t >= p.T) v = 0.0f;
-        yh[(size_t)m * p.Tp + t] = (u16)(pack2(v, 0.0f) & 0xffffu);
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + 256 * k;
+      const int row = c >> 4, col = (c & 15) * 8;
+      if (t0 + col < p.Tp)
+        *reinterpret_cast<uint4*>(yh + (size_t)(m0 + row) * p.Tp + t0 + col) =
+            *reinterpret_cast<const uint4*>(&tile[row * TPITCH + col]);
+    }
     return;
   }
+  const int t = t0 + wave * 32 + r31;
   if (t >= p.T) return;
   float* __restrict__ yb = p.y + (size_t)b * p.y_bs;
   const float* __restrict__ ab = p.acc ? p.acc + (size_t)b * p.y_bs : nullptr;
@@ -1450,6 +1503,7 @@ int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
   AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
   p.Tp = 0;
+  p.stats = nullptr;
   hipLaunchKernelGGL(c1b_tap_kernel<false>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
@@ -1832,16 +1886,29 @@ int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* x
 
 /* Dilated K = 3 conv of a Res2 branch on bf16-resident rows: forward (dgrad = 0: y = relu?(W * x + bias)) or data
  * gradient (dgrad = 1, w_packed from air_conv1d_tap_pack_bf16(transpose = 1): dx = W^T * dy).  w_packed required. */
+size_t air_h_conv1d_tap_stats_bytes(int B, int Cout, int Tp) {
+  if (B <= 0 || Cout <= 0 || Tp <= 0 || Tp % BN != 0) return 0;
+  return (size_t)Cout * B * (Tp / BN) * 4 * 2 * sizeof(float);
+}
+
 int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
                      const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y, size_t y_bs,
                      air_stream_t stream) {
+  return air_h_conv1d_tap_ex(B, Cin, Cout, T, Tp, dil, x, x_bs, w_packed, dgrad, bias, relu, y, y_bs, nullptr, stream);
+}
+
+int air_h_conv1d_tap_ex(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                        const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                        size_t y_bs, void* stats, air_stream_t stream) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || Tp < T || Tp % BN != 0) return AIR_EINVAL;
+  if (stats != nullptr && (reinterpret_cast<size_t>(stats) & 7)) return AIR_EINVAL;
   const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
   if (dil < 1 || dil > TAP_MAXD || M % 64 != 0 || K % BK != 0) return AIR_EUNSUPPORTED;
   C1bTap p;
   p.x = reinterpret_cast<const float*>(x); p.a = w_packed; p.y = reinterpret_cast<float*>(y); p.bias = bias; p.acc = nullptr;
   p.x_bs = x_bs ? x_bs : (size_t)K * Tp; p.y_bs = y_bs ? y_bs : (size_t)M * Tp;
   p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu; p.Tp = Tp;
+  p.stats = reinterpret_cast<float*>(stats);
   p.tiles_m = M / 64;
   p.tiles_t = Tp / BN;
   p.total = B * p.tiles_t * p.tiles_m;

@@ -143,6 +143,56 @@ __global__ void h_bn_finalize_kernel(const u16* __restrict__ x, int Tp, const do
   }
 }
 
+// The same finalisation from the records a convolution's epilogue wrote (air_h_conv1d_tap_ex, `stats`): per channel
+// NR pairs {sum, sum of squares} of 32 stored values each (fp32, values O(1): exact to ~1e-7), merged in fp64 in a
+// fixed order by one workgroup per channel.  Unshifted sums: the variance is formed in fp64.
+__global__ __launch_bounds__(256) void h_bn_finalize_records_kernel(
+    const float* __restrict__ rec, int NR, int C, double N, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift) {
+  __shared__ double sh[2][4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float2* __restrict__ r = reinterpret_cast<const float2*>(rec) + (size_t)c * NR;
+  const float ga = gamma[c], be = beta[c];
+  const float rm = running_mean != nullptr ? running_mean[c] : 0.0f, rv = running_mean != nullptr ? running_var[c] : 0.0f;
+  double s1 = 0.0, s2 = 0.0;
+  int g = tid;
+  for (; g + 768 < NR; g += 1024) {
+    const float2 v0 = r[g], v1 = r[g + 256], v2 = r[g + 512], v3 = r[g + 768];
+    s1 += (double)v0.x; s2 += (double)v0.y;
+    s1 += (double)v1.x; s2 += (double)v1.y;
+    s1 += (double)v2.x; s2 += (double)v2.y;
+    s1 += (double)v3.x; s2 += (double)v3.y;
+  }
+  for (; g < NR; g += 256) {
+    const float2 v = r[g];
+    s1 += (double)v.x; s2 += (double)v.y;
+  }
+  s1 = air_wave_sum_d(s1);
+  s2 = air_wave_sum_d(s2);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s1; sh[1][tid >> 6] = s2; }
+  __syncthreads();
+  if (tid != 0) return;
+  s1 = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+  s2 = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+  const double m = s1 / N;
+  double var = s2 / N - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)m;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = mf;
+  invstd[c] = is;
+  const float sc = ga * is;
+  scale[c] = sc;
+  shift[c] = be - mf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
+    running_mean[c] = (1.0f - momentum) * rm + momentum * mf;
+    running_var[c] = (1.0f - momentum) * rv + momentum * (float)unbiased;
+  }
+}
+
 // ---- y = bf16(x * scale[c] + shift[c]); rowmean[b * C + c] (optional) = mean over t of the STORED values
 __global__ __launch_bounds__(NT) void h_bn_apply_kernel(const u16* __restrict__ x, size_t xbs, int C, int T, int Tp,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -654,8 +704,26 @@ int air_h_bn_stats(const unsigned short* x, size_t x_bs, int B, int C, int T, in
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
                    air_stream_t stream) {
+  return air_h_bn_stats_ex(x, x_bs, B, C, T, Tp, nullptr, 0, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                           invstd, scale, shift, ws, ws_bytes, stream);
+}
+
+int air_h_bn_stats_ex(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const void* stats_in,
+                      size_t stats_bytes, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || !h_shape_ok(B, C, T, Tp)) return AIR_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return AIR_EINVAL;
+  if (stats_in != nullptr) {  // the records of air_h_conv1d_tap_ex for THIS tensor: no pass over x
+    if (Tp % 128 != 0) return AIR_EINVAL;
+    const int NR = B * (Tp / 128) * 4;
+    if (stats_bytes != (size_t)C * NR * 2 * sizeof(float)) return AIR_EINVAL;
+    hipLaunchKernelGGL(h_bn_finalize_records_kernel, dim3(C), dim3(256), 0, air_stream(stream),
+                       reinterpret_cast<const float*>(stats_in), NR, C, (double)B * (double)T, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, invstd, scale, shift);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
   if (!ws || ws_bytes < air_h_bn_ws_bytes(B, C)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
   const int ns = h_splits(B, C);

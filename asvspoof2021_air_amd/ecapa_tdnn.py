@@ -208,6 +208,7 @@ class Res2Net2(nn.Module):
         # weight gradients on a side HIP stream (they feed nothing until the optimiser): the MFMA-bound GEMMs and the
         # small K = 3 kernels overlap the HBM-bound BatchNorm / pooling backward passes of the main stream
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
+        self.fuse_tap_stats = os.environ.get("AIR_TAP_STATS", "1") == "1"  # Res2 branch statistics from the conv epilogue
         self._side_stream = None
 
     def enable_ddp_overlap(self, bucket_bytes=8 << 20):
@@ -629,10 +630,12 @@ class Res2Net2(nn.Module):
         ops.add_strided(m.view(self.C, 1, R0)[:, :, :nk], w.view(self.C, 1, nk))
         return m
 
-    def _bn_h(self, x, T, bn, training):
-        """BatchNorm1d on resident rows: (mean, invstd, scale, shift)."""
+    def _bn_h(self, x, T, bn, training, stats_in=None):
+        """BatchNorm1d on resident rows: (mean, invstd, scale, shift).  stats_in: statistics records of x from the
+        epilogue of the convolution that produced it."""
         if training:
-            st = oh.bn_stats(x, T, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+            st = oh.bn_stats(x, T, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                             stats_in=stats_in)
             ops.bn_tick(bn.num_batches_tracked)
             return st
         scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
@@ -653,8 +656,11 @@ class Res2Net2(nn.Module):
         wp = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=False)
         t_list, r_list, st_list = [], [], []
         for i in range(nums):
-            r_i = oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True)
-            st_i = self._bn_h(r_i, T, blk.bns[i], training)
+            # (round 4: the branch's BatchNorm statistics leave the conv's epilogue - no pass over r_i)
+            fuse = training and getattr(self, "fuse_tap_stats", True)
+            r_i, rec_i = oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True, stats=True) if fuse \
+                else (oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True), None)
+            st_i = self._bn_h(r_i, T, blk.bns[i], training, stats_in=rec_i)
             if i + 1 < nums:
                 t_next = oh.rows(B, w, T, dev)
                 oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w],

@@ -119,17 +119,24 @@ def conv_wgrad(x, dy, T, out):
     return out
 
 
-def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None):
+def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None, stats=False):
+    """stats=True: returns (y, records) - the BatchNorm statistics of the stored y from the epilogue, for
+    ``bn_stats(y, ..., stats_in=records)``."""
     B, K, Tp = x.shape
     M = Cin if dgrad else Cout
     if out is None:
         out = torch.empty((B, M, Tp), device=x.device, dtype=torch.int16)
     xp, xb = hv(x)
     yp, yb = hv(out)
-    _hip.check(_hip.lib().air_h_conv1d_tap(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
-                                           dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
-                                           ci(1 if relu else 0), yp, csz(yb), stream()), "air_h_conv1d_tap")
-    return out
+    rec = None
+    if stats:
+        rec = torch.empty(int(_hip.lib().air_h_conv1d_tap_stats_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8,
+                          device=x.device)
+    _hip.check(_hip.lib().air_h_conv1d_tap_ex(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
+                                              dptr(w_packed, torch.int16), ci(1 if dgrad else 0),
+                                              dptr(bias, allow_none=True), ci(1 if relu else 0), yp, csz(yb),
+                                              dptr(rec, torch.uint8, allow_none=True), stream()), "air_h_conv1d_tap_ex")
+    return (out, rec) if stats else out
 
 
 def conv_tap_wgrad(xs, dys, T, dil, outs):
@@ -183,17 +190,20 @@ def _bn_ws(B, C, device):
     return ops.workspace(n, device), n
 
 
-def bn_stats(x, T, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
-    """(mean, invstd, scale, shift) of a resident tensor; updates the running statistics in place."""
+def bn_stats(x, T, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, stats_in=None):
+    """(mean, invstd, scale, shift) of a resident tensor; updates the running statistics in place.  stats_in: the
+    records ``conv_tap(..., stats=True)`` returned for THIS x (merged in fp64 instead of reading x)."""
     B, C, Tp = x.shape
     dev = x.device
     mean, invstd, scale, shift = torch.empty((4, C), device=dev, dtype=torch.float32).unbind(0)  # one allocation
     ws, n = _bn_ws(B, C, dev)
     p, bs = hv(x)
-    _hip.check(_hip.lib().air_h_bn_stats(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp), dptr(gamma), dptr(beta), cf(eps),
-                                         cf(momentum), dptr(running_mean, allow_none=True),
-                                         dptr(running_var, allow_none=True), dptr(mean), dptr(invstd), dptr(scale),
-                                         dptr(shift), dptr(ws, torch.uint8), csz(n), stream()), "air_h_bn_stats")
+    _hip.check(_hip.lib().air_h_bn_stats_ex(p, csz(bs), ci(B), ci(C), ci(T), ci(Tp),
+                                            dptr(stats_in, torch.uint8, allow_none=True),
+                                            csz(0 if stats_in is None else stats_in.numel()), dptr(gamma), dptr(beta),
+                                            cf(eps), cf(momentum), dptr(running_mean, allow_none=True),
+                                            dptr(running_var, allow_none=True), dptr(mean), dptr(invstd), dptr(scale),
+                                            dptr(shift), dptr(ws, torch.uint8), csz(n), stream()), "air_h_bn_stats_ex")
     return mean, invstd, scale, shift
 
 

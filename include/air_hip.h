@@ -540,6 +540,14 @@ int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned s
 int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
                      const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y, size_t y_bs,
                      air_stream_t stream);
+/* Same, and the epilogue that stores y also leaves the BatchNorm statistics of the STORED tensor (ecapa_tdnn.py:47-48,
+ * 79-81: conv -> ReLU -> BatchNorm1d of a Res2 branch) as {sum, sum of squares} per (channel, 32-frame segment) in
+ * `stats` (air_h_conv1d_tap_stats_bytes(B, Cout, Tp) bytes, 8-byte aligned; NULL = air_h_conv1d_tap).  Hand it to
+ * air_h_bn_stats_ex as stats_in and the BatchNorm makes no pass over y (round 4: 21 passes per ECAPA step). */
+size_t air_h_conv1d_tap_stats_bytes(int B, int Cout, int Tp);
+int air_h_conv1d_tap_ex(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                        const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                        size_t y_bs, void* stats, air_stream_t stream);
 /* Weight gradients of the n_branches dilated K = 3 convs of one Res2 block (ecapa_tdnn.py:46, W -> W channels,
  * padding = dilation) in ONE launch: dw[i] (W, W, 3) fp32 = sum_{b,t} dy[i][b][co][t] x[i][b][ci][t + (k - 1) dil],
  * bf16 MFMA over the resident operands (products exact, fp32 sums, fixed-order split over the utterances) - the
@@ -556,6 +564,12 @@ int air_h_bn_stats(const unsigned short* x, size_t x_bs, int B, int C, int T, in
                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                    float* mean, float* invstd, float* scale, float* shift, void* ws, size_t ws_bytes,
                    air_stream_t stream);
+/* stats_in / stats_bytes: the records air_h_conv1d_tap_ex wrote for x (merged in fp64, a workgroup per channel; x is
+ * not read), or NULL / 0 = air_h_bn_stats. */
+int air_h_bn_stats_ex(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const void* stats_in,
+                      size_t stats_bytes, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                      void* ws, size_t ws_bytes, air_stream_t stream);
 /* ... y = bf16(x * scale[c] + shift[c]); rowmean (B*C, may be NULL) = mean over t of the STORED y (the SE squeeze) */
 int air_h_bn_apply(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* scale,
                    const float* shift, unsigned short* y, size_t y_bs, float* rowmean, air_stream_t stream);

@@ -120,7 +120,7 @@ def run(name, which, perturb=0):
     print("  %s %s held-out EER %.5f (threshold %.4f; %d of %d bona fide and %d of %d spoofed trials wrong)" % (
         name, which, eer, thr, miss_bona, int((lab_ho == 0).sum()), miss_spoof, int((lab_ho == 1).sum())), flush=True)
     if perturb:
-        return eer, [miss_bona, miss_spoof], epoch_loss[-1]
+        return eer, [miss_bona, miss_spoof], epoch_loss[-1], list(epoch_loss)
     save("synth_%s_%s.npz" % (name, which), epoch_loss=np.array(epoch_loss), scores=scores, labels=lab_ho, eer=np.array(eer),
          thr=np.array(thr), errors=np.array([miss_bona, miss_spoof]), cfg=np.array([L, B, NTR, NHO, EPOCHS, INTERVAL, FL]),
          mix_lo=np.array(MIX_LO), seed=np.array(SEED),
@@ -137,6 +137,7 @@ if __name__ == "__main__":
             if "spread" in sys.argv[1:]:
                 res = [run(n, m, perturb=k) for k in range(1, 1 + int(os.environ.get("EER_SPREAD", "6")))]
                 save("synth_%s_%s_spread.npz" % (n, m), eer=np.array([r[0] for r in res]),
-                     errors=np.array([r[1] for r in res]), final_loss=np.array([r[2] for r in res]))
+                     errors=np.array([r[1] for r in res]), final_loss=np.array([r[2] for r in res]),
+                     epoch_loss=np.array([r[3] for r in res]))  # (round 4: the whole curves - the envelope check's yardstick)
             else:
                 run(n, m)

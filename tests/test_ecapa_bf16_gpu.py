@@ -241,6 +241,41 @@ def test_tap_conv(oh, cfg):
     assert int(wide[:, :C].abs().max()) == 0 and int(wide[:, 2 * C:3 * C].abs().max()) == 0
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (5, 128, 401, 4), (130, 64, 200, 2)])
+def test_tap_conv_statistics_from_the_epilogue(oh, cfg):
+    """air_h_conv1d_tap_ex: the Res2 branch conv (ecapa_tdnn.py:46-48, conv -> ReLU -> BatchNorm1d) leaves the BatchNorm
+    statistics of its STORED output in its epilogue; air_h_bn_stats_ex merges the records in fp64.  The stored tensor
+    is bit-identical to the plain call's; mean / invstd / scale / shift and the running statistics equal the pass over
+    the tensor to 2e-6 (both are fp64 merges of fp32 partial sums of the same bf16 values, grouped differently) and
+    an fp64 evaluation of the stored values to 3e-6."""
+    from asvspoof2021_air_amd import ops
+    B, C, T, d = cfg
+    x, _ = res(oh, synth_feat((B, C, T), 51))
+    w = synth_feat((C, C, 3), 52, scale=0.1)
+    bias = 0.1 * synth_feat((C,), 53)
+    wp = ops.conv1d_tap_pack([w.cuda()], transpose=False)
+    gamma, beta = (1.0 + 0.2 * synth_feat((C,), 54)).cuda(), (0.3 * synth_feat((C,), 55)).cuda()
+    y0 = oh.conv_tap(x, wp[0], T, d, C, C, bias=bias.cuda(), relu=True)
+    y1, rec = oh.conv_tap(x, wp[0], T, d, C, C, bias=bias.cuda(), relu=True, stats=True)
+    assert torch.equal(y0, y1)
+    rm0, rv0 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    st0 = oh.bn_stats(y0, T, gamma, beta, rm0, rv0)
+    st1 = oh.bn_stats(y1, T, gamma, beta, rm1, rv1, stats_in=rec)
+    yd = val(y0, T).double()
+    mean = yd.mean((0, 2))
+    var = yd.var((0, 2), unbiased=False)
+    want = [mean, 1.0 / torch.sqrt(var + 1e-5)]
+    for k, name in enumerate(("mean", "invstd", "scale", "shift")):
+        a, b = st0[k].double().cpu(), st1[k].double().cpu()
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), name
+        if k < 2:
+            assert float((b - want[k]).abs().max()) <= 3e-6 * max(1.0, float(want[k].abs().max())), name
+    assert float((rm0 - rm1).abs().max()) <= 2e-6 and float((rv0 - rv1).abs().max()) <= 2e-6
+    with pytest.raises(Exception):  # records of another geometry are refused
+        oh.bn_stats(y1, T, gamma, beta, stats_in=rec[:rec.numel() // 2].clone())
+
+
 @pytest.mark.parametrize("cfg", [(3, 64, 96, 2, 3), (2, 64, 750, 3, 7), (5, 128, 401, 4, 2), (130, 64, 200, 2, 7)])
 def test_tap_conv_wgrad_all_branches(oh, cfg):
     """air_h_conv1d_tap_wgrad: every branch of a block in one launch, operands as channel slices of wider tensors
