@@ -1266,6 +1266,16 @@ struct C1bTap {
   // c1b_tap_kernel<true>, optional: BatchNorm statistics of the STORED output - per (channel m, 32-frame segment r) the
   // pair {sum, sum of squares} at stats[(m * NR + r) * 2], NR = B * tiles_t * 4, r = (b * tiles_t + tile) * 4 + wave
   float* stats;
+  // c1b_tap_kernel<true>, optional (data-gradient launches of the Res2 chain): y is the gradient that joins bn_dy on
+  // its way into the BatchNorm whose input was bn_x (conv -> ReLU -> BatchNorm of the PREVIOUS branch); the epilogue
+  // also leaves that BatchNorm's five backward sums (h_bn_bwd_partial_kernel's, same arithmetic) per (channel,
+  // 32-frame segment) at bsums[(m * NR + r) * 8 + 0..4]
+  const unsigned short* bn_x;
+  const unsigned short* bn_dy;
+  size_t bn_x_bs, bn_dy_bs;
+  const float* bn_mean;
+  const float* bn_invstd;
+  float* bsums;
 };
 
 // fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
@@ -1409,15 +1419,35 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
     // needed when p.stats is given.
     constexpr int TPITCH = BN + 8;
     static_assert(64 * TPITCH <= 2 * 3 * 64 * LDK, "the output tile fits the A operand buffers");
+    static_assert(64 * TPITCH <= 2 * TAP_ROWS * LDK, "a second tile fits the B operand buffers");
     u16* tile = &sA[0][0];
     const int fl = wave * 32 + 4 * kgl;  // local frame of group 0
+    const bool bsum = p.bsums != nullptr;
+    if (bsum) {  // the previous branch's BatchNorm input and the other half of its output gradient: row pieces -> LDS
+      u16* tileD = &sB[0][0];
+      const u16* __restrict__ gx = p.bn_x + (size_t)b * p.bn_x_bs;
+      const u16* __restrict__ gd = p.bn_dy + (size_t)b * p.bn_dy_bs;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = tid + 256 * k;
+        const int row = c >> 4, col = (c & 15) * 8;
+        const size_t go = (size_t)(m0 + row) * p.Tp + t0 + col;
+        *reinterpret_cast<uint4*>(&tile[row * TPITCH + col]) = *reinterpret_cast<const uint4*>(gx + go);
+        *reinterpret_cast<uint4*>(&tileD[row * TPITCH + col]) = *reinterpret_cast<const uint4*>(gd + go);
+      }
+      __syncthreads();
+    }
     float s1[2], s2[2];
+    float q1[2], q2[2], q3[2], q4[2], q5[2];  // bsum: sum g, sum g xhat, sum_{x>0} g, count_{x>0}, sum_{x>0} xhat
+    unsigned wq[2][4][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ml = i * 32 + r31;
       const float bv = p.bias ? p.bias[m0 + ml] : 0.0f;
+      const float mu = bsum ? p.bn_mean[m0 + ml] : 0.0f, is = bsum ? p.bn_invstd[m0 + ml] : 0.0f;
       s1[i] = 0.0f;
       s2[i] = 0.0f;
+      q1[i] = q2[i] = q3[i] = q4[i] = q5[i] = 0.0f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float v[4];
@@ -1428,18 +1458,61 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
           if (t0 + fl + 8 * g + e >= p.T) v[e] = 0.0f;
         }
         const unsigned w0 = pack2(v[0], v[1]), w1 = pack2(v[2], v[3]);
+        wq[i][g][0] = w0;
+        wq[i][g][1] = w1;
+        const float r0 = __builtin_bit_cast(float, w0 << 16), r1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float r2 = __builtin_bit_cast(float, w1 << 16), r3 = __builtin_bit_cast(float, w1 & 0xffff0000u);
         if (p.stats != nullptr) {  // of the values as stored (zeros behind T add nothing)
-          const float r0 = __builtin_bit_cast(float, w0 << 16), r1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
-          const float r2 = __builtin_bit_cast(float, w1 << 16), r3 = __builtin_bit_cast(float, w1 & 0xffff0000u);
           s1[i] += (r0 + r1) + (r2 + r3);
           s2[i] = fmaf(r0, r0, s2[i]);
           s2[i] = fmaf(r1, r1, s2[i]);
           s2[i] = fmaf(r2, r2, s2[i]);
           s2[i] = fmaf(r3, r3, s2[i]);
         }
-        *reinterpret_cast<uint2*>(&tile[ml * TPITCH + fl + 8 * g]) = make_uint2(w0, w1);
+        if (bsum) {
+          const uint2 ux = *reinterpret_cast<const uint2*>(&tile[ml * TPITCH + fl + 8 * g]);
+          const uint2 ud = *reinterpret_cast<const uint2*>(&(&sB[0][0])[ml * TPITCH + fl + 8 * g]);
+          const float xv[4] = {__builtin_bit_cast(float, ux.x << 16), __builtin_bit_cast(float, ux.x & 0xffff0000u),
+                               __builtin_bit_cast(float, ux.y << 16), __builtin_bit_cast(float, ux.y & 0xffff0000u)};
+          const float dv[4] = {__builtin_bit_cast(float, ud.x << 16), __builtin_bit_cast(float, ud.x & 0xffff0000u),
+                               __builtin_bit_cast(float, ud.y << 16), __builtin_bit_cast(float, ud.y & 0xffff0000u)};
+          const float rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (t0 + fl + 8 * g + e < p.T) {
+              const float gg = dv[e] + rr[e];  // (h_bn_bwd_partial_kernel: g = dy + dy2)
+              const float xh = (xv[e] - mu) * is;
+              q1[i] += gg;
+              q2[i] = fmaf(gg, xh, q2[i]);
+              if (xv[e] > 0.0f) {
+                q3[i] += gg;
+                q4[i] += 1.0f;
+                q5[i] += xh;
+              }
+            }
+        }
       }
     }
+    if (bsum) {
+      const int NR = p.B * p.tiles_t * 4, ridx = (b * p.tiles_t + tt) * 4 + wave;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float a1 = q1[i] + __shfl_xor(q1[i], 32, 64), a2 = q2[i] + __shfl_xor(q2[i], 32, 64);
+        const float a3 = q3[i] + __shfl_xor(q3[i], 32, 64), a4 = q4[i] + __shfl_xor(q4[i], 32, 64);
+        const float a5 = q5[i] + __shfl_xor(q5[i], 32, 64);
+        if (kgl == 0) {
+          float* o = p.bsums + ((size_t)(m0 + i * 32 + r31) * NR + ridx) * 8;
+          *reinterpret_cast<float4*>(o) = make_float4(a1, a2, a3, a4);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(a5, 0.0f, 0.0f, 0.0f);
+        }
+      }
+      __syncthreads();  // everyone has read the staged tiles: the output tile takes the first one's place
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<uint2*>(&tile[(i * 32 + r31) * TPITCH + fl + 8 * g]) = make_uint2(wq[i][g][0], wq[i][g][1]);
     if (p.stats != nullptr) {
       const int NR = p.B * p.tiles_t * 4, ridx = (b * p.tiles_t + tt) * 4 + wave;
 #pragma unroll
@@ -1504,6 +1577,8 @@ int run_tap(const float* x, size_t x_bs, const float* w, int transpose, float* y
   AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
   p.Tp = 0;
   p.stats = nullptr;
+  p.bsums = nullptr; p.bn_x = nullptr; p.bn_dy = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
+  p.bn_x_bs = p.bn_dy_bs = 0;
   hipLaunchKernelGGL(c1b_tap_kernel<false>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
@@ -1900,8 +1975,26 @@ int air_h_conv1d_tap(int B, int Cin, int Cout, int T, int Tp, int dil, const uns
 int air_h_conv1d_tap_ex(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
                         size_t y_bs, void* stats, air_stream_t stream) {
+  return air_h_conv1d_tap_ex2(B, Cin, Cout, T, Tp, dil, x, x_bs, w_packed, dgrad, bias, relu, y, y_bs, stats, nullptr, 0,
+                              nullptr, 0, nullptr, nullptr, nullptr, stream);
+}
+
+size_t air_h_conv1d_tap_bwd_sums_bytes(int B, int C, int Tp) {
+  if (B <= 0 || C <= 0 || Tp <= 0 || Tp % BN != 0) return 0;
+  return (size_t)C * B * (Tp / BN) * 4 * 8 * sizeof(float);
+}
+
+int air_h_conv1d_tap_ex2(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                         size_t y_bs, void* stats, const unsigned short* bn_x, size_t bn_x_bs,
+                         const unsigned short* bn_dy, size_t bn_dy_bs, const float* bn_mean, const float* bn_invstd,
+                         void* bn_sums, air_stream_t stream) {
   if (!x || !w_packed || !y || B <= 0 || T <= 0 || Tp < T || Tp % BN != 0) return AIR_EINVAL;
   if (stats != nullptr && (reinterpret_cast<size_t>(stats) & 7)) return AIR_EINVAL;
+  if (bn_sums != nullptr && (!bn_x || !bn_dy || !bn_mean || !bn_invstd || (reinterpret_cast<size_t>(bn_sums) & 15) ||
+                             ((reinterpret_cast<size_t>(bn_x) | reinterpret_cast<size_t>(bn_dy)) & 15) ||
+                             bn_x_bs % 8 || bn_dy_bs % 8))
+    return AIR_EINVAL;
   const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
   if (dil < 1 || dil > TAP_MAXD || M % 64 != 0 || K % BK != 0) return AIR_EUNSUPPORTED;
   C1bTap p;
@@ -1909,6 +2002,9 @@ int air_h_conv1d_tap_ex(int B, int Cin, int Cout, int T, int Tp, int dil, const 
   p.x_bs = x_bs ? x_bs : (size_t)K * Tp; p.y_bs = y_bs ? y_bs : (size_t)M * Tp;
   p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu; p.Tp = Tp;
   p.stats = reinterpret_cast<float*>(stats);
+  p.bsums = reinterpret_cast<float*>(bn_sums);
+  p.bn_x = bn_x; p.bn_dy = bn_dy; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+  p.bn_x_bs = bn_x_bs ? bn_x_bs : (size_t)M * Tp; p.bn_dy_bs = bn_dy_bs ? bn_dy_bs : (size_t)M * Tp;
   p.tiles_m = M / 64;
   p.tiles_t = Tp / BN;
   p.total = B * p.tiles_t * p.tiles_m;

@@ -393,6 +393,39 @@ __global__ void h_bn_bwd_finalize_kernel(const double* __restrict__ partial, int
   }
 }
 
+// The same finalisation from the records of a data-gradient epilogue (air_h_conv1d_tap_ex2, bn_sums): per channel NR
+// records of 8 floats {sum g, sum g xhat, sum_{x>0} g, count_{x>0}, sum_{x>0} xhat, 0, 0, 0} over 32 frames each,
+// merged in fp64 in a fixed order by one workgroup per channel.
+__global__ __launch_bounds__(256) void h_bn_bwd_finalize_records_kernel(
+    const float* __restrict__ rec, int NR, int C, double invN, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+  __shared__ double sh[5][4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float4* __restrict__ r = reinterpret_cast<const float4*>(rec) + (size_t)c * NR * 2;
+  const float ga = gamma[c], is = invstd[c];
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+  for (int g = tid; g < NR; g += 256) {
+    const float4 a = r[2 * g], b = r[2 * g + 1];
+    s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w; s[4] += (double)b.x;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    s[k] = air_wave_sum_d(s[k]);
+    if ((tid & 63) == 0) sh[k][tid >> 6] = s[k];
+  }
+  __syncthreads();
+  if (tid != 0) return;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) s[k] = ((sh[k][0] + sh[k][1]) + sh[k][2]) + sh[k][3];
+  dbeta[c] = (float)s[0];
+  dgamma[c] = (float)s[1];
+  if (dbias) {
+    const double k1 = (double)(float)s[0] * invN, k2 = (double)(float)s[1] * invN;
+    dbias[c] = (float)((double)ga * (double)is * (s[2] - k1 * s[3] - k2 * s[4]));
+  }
+}
+
 // dx = bf16(gamma invstd (g - dbeta / N - xhat dgamma / N)), zero where the ReLU in front of the BN clipped
 __global__ __launch_bounds__(NT) void h_bn_bwd_apply_kernel(
     const u16* __restrict__ x, size_t xbs, const u16* dy, size_t dybs, const u16* dy2, size_t dy2bs,
@@ -783,6 +816,15 @@ int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy,
                  const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
                  size_t dx_bs, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
                  air_stream_t stream) {
+  return air_h_bn_bwd_ex(x, x_bs, dy, dy_bs, dy2, dy2_bs, dy_rowbias, rowbias_scale, B, C, T, Tp, mean, invstd, gamma,
+                         relu_in, dx, dx_bs, dgamma, dbeta, dbias, nullptr, 0, ws, ws_bytes, stream);
+}
+
+int air_h_bn_bwd_ex(const unsigned short* x, size_t x_bs, const unsigned short* dy, size_t dy_bs, const unsigned short* dy2,
+                    size_t dy2_bs, const float* dy_rowbias, float rowbias_scale, int B, int C, int T, int Tp,
+                    const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
+                    size_t dx_bs, float* dgamma, float* dbeta, float* dbias, const void* sums_in, size_t sums_bytes,
+                    void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!x || !dy || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !h_shape_ok(B, C, T, Tp)) return AIR_EINVAL;
   if (dbias && !relu_in) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_h_bn_ws_bytes(B, C)) return AIR_EWORKSPACE;
@@ -790,13 +832,22 @@ int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy,
   const int ns = h_splits(B, C);
   double* partial = reinterpret_cast<double*>(ws);
   const double invN = 1.0 / ((double)B * (double)T);
-  hipLaunchKernelGGL(h_bn_bwd_partial_kernel, dim3(C * ns), dim3(NT), 0, st, x, bs_or(x_bs, C, Tp), dy, bs_or(dy_bs, C, Tp),
-                     dy2, bs_or(dy2_bs, C, Tp), dy_rowbias, rowbias_scale, B, C, T, Tp, ns, mean, invstd, dbias ? 1 : 0,
-                     partial);
-  AIR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(h_bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, ns, C, invN, gamma, invstd,
-                     dgamma, dbeta, dbias);
-  AIR_CHECK_LAUNCH();
+  if (sums_in != nullptr) {
+    if (!relu_in || dy_rowbias != nullptr || dy2 == nullptr || Tp % 128 != 0) return AIR_EUNSUPPORTED;
+    const int NR = B * (Tp / 128) * 4;
+    if (sums_bytes != (size_t)C * NR * 8 * sizeof(float)) return AIR_EINVAL;
+    hipLaunchKernelGGL(h_bn_bwd_finalize_records_kernel, dim3(C), dim3(256), 0, st, reinterpret_cast<const float*>(sums_in),
+                       NR, C, invN, gamma, invstd, dgamma, dbeta, dbias);
+    AIR_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL(h_bn_bwd_partial_kernel, dim3(C * ns), dim3(NT), 0, st, x, bs_or(x_bs, C, Tp), dy, bs_or(dy_bs, C, Tp),
+                       dy2, bs_or(dy2_bs, C, Tp), dy_rowbias, rowbias_scale, B, C, T, Tp, ns, mean, invstd, dbias ? 1 : 0,
+                       partial);
+    AIR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(h_bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partial, ns, C, invN, gamma, invstd,
+                       dgamma, dbeta, dbias);
+    AIR_CHECK_LAUNCH();
+  }
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(h_bn_bwd_apply_kernel, dim3(h_row_grid(rows)), dim3(NT), 0, st, x, bs_or(x_bs, C, Tp), dy,
                      bs_or(dy_bs, C, Tp), dy2, bs_or(dy2_bs, C, Tp), dy_rowbias, rowbias_scale, C, T, Tp, (float)invN, mean,

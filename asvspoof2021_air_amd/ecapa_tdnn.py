@@ -769,14 +769,23 @@ class Res2Net2(nn.Module):
         on_side(lambda: oh.conv_wgrad(S["cat"], dc3, T, gv("conv3.weight")), dc3)
         dcat = oh.conv_pointwise(dc3, det(blk.conv3.weight), T, dgrad=True)  # becomes d(o1) slice by slice
         wpt = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=True)
-        din_next = None
+        din_next = sums_next = None
         dcs = [None] * nums
+        fuse = getattr(self, "fuse_tap_stats", True)
         for i in reversed(range(nums)):
             st_i = S["st"][i]
             dc_i = oh.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], T, st_i[0], st_i[1], det(blk.bns[i].weight),
-                             gv("bns.%d.weight" % i), gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i))
+                             gv("bns.%d.weight" % i), gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i),
+                             sums_in=sums_next)
             dcs[i] = dc_i
-            din = oh.conv_tap(dc_i, wpt[i], T, d, w, w, dgrad=True, out=dcat[:, i * w:(i + 1) * w])
+            if i > 0 and fuse:
+                # (round 4) the data gradient that joins branch i - 1's slice of the concat gradient on its way into that
+                # branch's BatchNorm: the sums of that BatchNorm's backward leave this launch's epilogue
+                st_p = S["st"][i - 1]
+                din, sums_next = oh.conv_tap(dc_i, wpt[i], T, d, w, w, dgrad=True, out=dcat[:, i * w:(i + 1) * w],
+                                             bn=(S["r"][i - 1], dcat[:, (i - 1) * w:i * w], st_p[0], st_p[1]))
+            else:
+                din, sums_next = oh.conv_tap(dc_i, wpt[i], T, d, w, w, dgrad=True, out=dcat[:, i * w:(i + 1) * w]), None
             din_next = din if i > 0 else None
         # the K = 3 weight gradients of all branches in one launch: bf16 MFMA on the resident operands (exact
         # products, fp32 sums = the fp32 contraction of the widened operands, without widened copies)

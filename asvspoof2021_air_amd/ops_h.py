@@ -119,23 +119,34 @@ def conv_wgrad(x, dy, T, out):
     return out
 
 
-def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None, stats=False):
+def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None, stats=False, bn=None):
     """stats=True: returns (y, records) - the BatchNorm statistics of the stored y from the epilogue, for
-    ``bn_stats(y, ..., stats_in=records)``."""
+    ``bn_stats(y, ..., stats_in=records)``.  bn = (bn_x, bn_dy, mean, invstd) on a data-gradient launch: returns
+    (y, sums) - the backward sums of the BatchNorm whose output gradient is bn_dy + y, for ``bn_bwd(..., sums_in=sums)``."""
     B, K, Tp = x.shape
     M = Cin if dgrad else Cout
     if out is None:
         out = torch.empty((B, M, Tp), device=x.device, dtype=torch.int16)
     xp, xb = hv(x)
     yp, yb = hv(out)
-    rec = None
+    lib = _hip.lib()
+    rec = sums = None
     if stats:
-        rec = torch.empty(int(_hip.lib().air_h_conv1d_tap_stats_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8,
-                          device=x.device)
-    _hip.check(_hip.lib().air_h_conv1d_tap_ex(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
-                                              dptr(w_packed, torch.int16), ci(1 if dgrad else 0),
-                                              dptr(bias, allow_none=True), ci(1 if relu else 0), yp, csz(yb),
-                                              dptr(rec, torch.uint8, allow_none=True), stream()), "air_h_conv1d_tap_ex")
+        rec = torch.empty(int(lib.air_h_conv1d_tap_stats_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8, device=x.device)
+    bxp, bxb, bdp, bdb, mean, invstd = None, 0, None, 0, None, None
+    if bn is not None:
+        bn_x, bn_dy, mean, invstd = bn
+        sums = torch.empty(int(lib.air_h_conv1d_tap_bwd_sums_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8, device=x.device)
+        bxp, bxb = hv(bn_x)
+        bdp, bdb = hv(bn_dy)
+    _hip.check(lib.air_h_conv1d_tap_ex2(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
+                                        dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+                                        ci(1 if relu else 0), yp, csz(yb), dptr(rec, torch.uint8, allow_none=True),
+                                        bxp, csz(bxb), bdp, csz(bdb), dptr(mean, allow_none=True),
+                                        dptr(invstd, allow_none=True), dptr(sums, torch.uint8, allow_none=True), stream()),
+               "air_h_conv1d_tap_ex2")
+    if bn is not None:
+        return out, sums
     return (out, rec) if stats else out
 
 
@@ -219,7 +230,8 @@ def bn_apply(x, T, scale, shift, out=None, rowmean=None):
 
 
 def bn_bwd(x, dy, T, mean, invstd, gamma, dgamma, dbeta, dx=None, dy2=None, rowbias=None, rowbias_scale=1.0,
-           dbias=None, relu_in=True):
+           dbias=None, relu_in=True, sums_in=None):
+    """sums_in: the records ``conv_tap(..., dgrad=True, bn=...)`` returned for THIS BatchNorm (no first pass)."""
     B, C, Tp = x.shape
     if dx is None:
         dx = torch.empty((B, C, Tp), device=x.device, dtype=torch.int16)
@@ -228,11 +240,12 @@ def bn_bwd(x, dy, T, mean, invstd, gamma, dgamma, dbeta, dx=None, dy2=None, rowb
     gp, gb = hv(dy)
     g2p, g2b = hv(dy2, True)
     dp, db = hv(dx)
-    _hip.check(_hip.lib().air_h_bn_bwd(xp, csz(xb), gp, csz(gb), g2p, csz(g2b), dptr(rowbias, allow_none=True),
-                                       cf(rowbias_scale), ci(B), ci(C), ci(T), ci(Tp), dptr(mean), dptr(invstd),
-                                       dptr(gamma), ci(1 if relu_in else 0), dp, csz(db), dptr(dgamma), dptr(dbeta),
-                                       dptr(dbias, allow_none=True), dptr(ws, torch.uint8), csz(n), stream()),
-               "air_h_bn_bwd")
+    _hip.check(_hip.lib().air_h_bn_bwd_ex(xp, csz(xb), gp, csz(gb), g2p, csz(g2b), dptr(rowbias, allow_none=True),
+                                          cf(rowbias_scale), ci(B), ci(C), ci(T), ci(Tp), dptr(mean), dptr(invstd),
+                                          dptr(gamma), ci(1 if relu_in else 0), dp, csz(db), dptr(dgamma), dptr(dbeta),
+                                          dptr(dbias, allow_none=True), dptr(sums_in, torch.uint8, allow_none=True),
+                                          csz(0 if sums_in is None else sums_in.numel()), dptr(ws, torch.uint8), csz(n),
+                                          stream()), "air_h_bn_bwd_ex")
     return dx
 
 

@@ -548,6 +548,20 @@ size_t air_h_conv1d_tap_stats_bytes(int B, int Cout, int Tp);
 int air_h_conv1d_tap_ex(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
                         size_t y_bs, void* stats, air_stream_t stream);
+/* Same, for the DATA-GRADIENT launches of the Res2 chain (ecapa_tdnn.py:79-85 backward): y = d(input of branch i) is
+ * the second half of the gradient that enters the BatchNorm of branch i - 1 (the first half, bn_dy, is that branch's
+ * slice of the concat gradient; bn_x is the BatchNorm's input, the branch's ReLU output).  The epilogue also leaves
+ * the five sums of that BatchNorm's backward pass - sum g, sum g xhat, and over bn_x > 0: sum g, the count, sum xhat
+ * (g = bn_dy + y as stored, xhat = (bn_x - mean) invstd) - per (channel, 32-frame segment) in bn_sums
+ * (air_h_conv1d_tap_bwd_sums_bytes(B, C, Tp) bytes, 16-byte aligned; bn_x / bn_dy 16-byte aligned rows).  Hand it to
+ * air_h_bn_bwd_ex as sums_in: the BatchNorm backward then makes no first pass over (bn_x, bn_dy, y).  bn_sums NULL =
+ * air_h_conv1d_tap_ex. */
+size_t air_h_conv1d_tap_bwd_sums_bytes(int B, int C, int Tp);
+int air_h_conv1d_tap_ex2(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                         size_t y_bs, void* stats, const unsigned short* bn_x, size_t bn_x_bs,
+                         const unsigned short* bn_dy, size_t bn_dy_bs, const float* bn_mean, const float* bn_invstd,
+                         void* bn_sums, air_stream_t stream);
 /* Weight gradients of the n_branches dilated K = 3 convs of one Res2 block (ecapa_tdnn.py:46, W -> W channels,
  * padding = dilation) in ONE launch: dw[i] (W, W, 3) fp32 = sum_{b,t} dy[i][b][co][t] x[i][b][ci][t + (k - 1) dil],
  * bf16 MFMA over the resident operands (products exact, fp32 sums, fixed-order split over the utterances) - the
@@ -581,6 +595,13 @@ int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy,
                  const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
                  size_t dx_bs, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
                  air_stream_t stream);
+/* sums_in / sums_bytes: the records air_h_conv1d_tap_ex2 wrote for this BatchNorm (merged in fp64, a workgroup per
+ * channel; the first pass over x / dy / dy2 is skipped), or NULL / 0 = air_h_bn_bwd.  Needs relu_in = 1, no row bias. */
+int air_h_bn_bwd_ex(const unsigned short* x, size_t x_bs, const unsigned short* dy, size_t dy_bs, const unsigned short* dy2,
+                    size_t dy2_bs, const float* dy_rowbias, float rowbias_scale, int B, int C, int T, int Tp,
+                    const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
+                    size_t dx_bs, float* dgamma, float* dbeta, float* dbias, const void* sums_in, size_t sums_bytes,
+                    void* ws, size_t ws_bytes, air_stream_t stream);
 /* Res2 chain step (ecapa_tdnn.py:78-83): y1 = bf16(x * scale + shift); y2 = bf16(y1 + add) (add, y2 both or neither) */
 int air_h_res2_bn_apply(const unsigned short* x, size_t x_bs, int B, int C, int T, int Tp, const float* scale,
                         const float* shift, unsigned short* y1, size_t y1_bs, const unsigned short* add, size_t add_bs,

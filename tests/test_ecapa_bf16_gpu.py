@@ -276,6 +276,41 @@ def test_tap_conv_statistics_from_the_epilogue(oh, cfg):
         oh.bn_stats(y1, T, gamma, beta, stats_in=rec[:rec.numel() // 2].clone())
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (5, 128, 401, 4), (130, 64, 200, 2)])
+def test_tap_dgrad_batchnorm_backward_sums_from_the_epilogue(oh, cfg):
+    """air_h_conv1d_tap_ex2 on a data-gradient launch of the Res2 chain (ecapa_tdnn.py:79-85 backward): the gradient it
+    writes joins the previous branch's slice of the concat gradient on the way into that branch's BatchNorm, and the
+    epilogue leaves the five sums of that BatchNorm's backward.  The stored gradient is bit-identical to the plain
+    call's; dgamma / dbeta / dbias of air_h_bn_bwd_ex(sums_in) equal the three-pass form's to 3e-6 of their scale
+    (fp64 merges of fp32 partial sums of the same values, grouped differently) and the dx it writes to one bf16 ulp."""
+    from asvspoof2021_air_amd import ops
+    B, C, T, d = cfg
+    wide = oh.rows(B, 2 * C, T, "cuda", zero=True)  # [slice of branch i - 1 | slice of branch i] of the concat gradient
+    dcat_prev, _ = res(oh, synth_feat((B, C, T), 61))
+    wide[:, :C] = dcat_prev
+    dc, _ = res(oh, synth_feat((B, C, T), 62))             # d(conv output of branch i)
+    r_prev, _ = res(oh, synth_feat((B, C, T), 63).relu())  # ReLU output of branch i - 1 = its BatchNorm's input
+    w = synth_feat((C, C, 3), 64, scale=0.1)
+    wpt = ops.conv1d_tap_pack([w.cuda()], transpose=True)
+    gamma = (1.0 + 0.2 * synth_feat((C,), 65)).cuda()
+    mean, invstd, _, _ = oh.bn_stats(r_prev, T, gamma, torch.zeros(C, device="cuda"))
+    plain = oh.conv_tap(dc, wpt[0], T, d, C, C, dgrad=True)
+    din, sums = oh.conv_tap(dc, wpt[0], T, d, C, C, dgrad=True, out=wide[:, C:], bn=(r_prev, wide[:, :C], mean, invstd))
+    assert torch.equal(plain, wide[:, C:].contiguous())
+    outs = []
+    for s_in in (None, sums):
+        dg, db_, dbias = (torch.zeros(C, device="cuda") for _ in range(3))
+        dx = oh.bn_bwd(r_prev, wide[:, :C], T, mean, invstd, gamma, dg, db_, dy2=wide[:, C:], dbias=dbias, sums_in=s_in)
+        outs.append((dg, db_, dbias, dx))
+    for k, name in enumerate(("dgamma", "dbeta", "dbias")):
+        a, b_ = outs[0][k].double().cpu(), outs[1][k].double().cpu()
+        assert float((a - b_).abs().max()) <= 3e-6 * max(1.0, float(a.abs().max())), name
+    a, b_ = val(outs[0][3], T), val(outs[1][3], T)
+    assert float(((a - b_).abs() / (a.abs() + 1e-3)).max()) <= 2.0 ** -7, "dx"
+    with pytest.raises(Exception):
+        oh.bn_bwd(r_prev, wide[:, :C], T, mean, invstd, gamma, dg, db_, dy2=wide[:, C:], sums_in=sums[:sums.numel() // 2].clone())
+
+
 @pytest.mark.parametrize("cfg", [(3, 64, 96, 2, 3), (2, 64, 750, 3, 7), (5, 128, 401, 4, 2), (130, 64, 200, 2, 7)])
 def test_tap_conv_wgrad_all_branches(oh, cfg):
     """air_h_conv1d_tap_wgrad: every branch of a block in one launch, operands as channel slices of wider tensors
