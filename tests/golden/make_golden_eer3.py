@@ -19,6 +19,10 @@ synth_<name>_<model>_spread.npz.  A CPU run's trajectory also depends on its thr
 committed files are part of the fixture: eer3 (round 3) with the defaults (EER_THREADS=6, EER_SPREAD=6 / 7);
 ``EER_THREADS=5 EER_SPREAD=4 make_golden_eer3.py eer4s resnet spread`` for synth_eer4s_resnet_spread.npz (round 4:
 wrong trials of 1024 held-out: 1 / 3 / 1 / 3 beside the unperturbed run's 3; final-epoch losses 0.078 - 0.084).
+Round 4, second half: ``EER_THREADS=6 EER_SPREAD=5 make_golden_eer3.py eer3 resnet spread`` now also stores the perturbed
+runs' whole epoch-loss curves (``epoch_loss`` (5, 16): the envelope check's yardstick); the committed
+synth_eer3_resnet_spread.npz holds round 3's five samples (eer / errors / final_loss only - they do not regenerate on
+this container's CPU mix) followed by these five.
 """
 import os
 import sys

@@ -109,8 +109,9 @@ def _spread(golden, fixture):
 
 
 class _Samples(list):
-    """EERs of further HIP runs (a list of floats, as before) that also carries their final-epoch losses."""
+    """EERs of further HIP runs (a list of floats, as before) that also carries their final-epoch losses and curves."""
     final_loss = ()
+    epoch_loss = ()
 
 
 def _more_eers(g, which, dtype, n=2):
@@ -119,6 +120,7 @@ def _more_eers(g, which, dtype, n=2):
     runs = [_run(g, which, dtype, perturb=k) for k in range(1, n + 1)]
     out = _Samples(float(r[5]) for r in runs)
     out.final_loss = tuple(float(r[3][-1]) for r in runs)
+    out.epoch_loss = tuple(np.asarray(r[3], dtype=np.float64) for r in runs)
     return out
 
 
@@ -162,10 +164,29 @@ def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol, spread=None, mo
     # run.  What is stable is the envelope: the running minimum of the epoch loss stays within a factor
     # curve_rtol[1] of the reference's, no epoch climbs back above the first one, and both converge to the same
     # place (the final-epoch check above).
-    ratio = np.minimum.accumulate(epoch_loss) / np.minimum.accumulate(g["epoch_loss"])
+    ref_min = np.minimum.accumulate(g["epoch_loss"])
+    ratio = np.minimum.accumulate(epoch_loss) / ref_min
     # (slower than the reference by at most curve_rtol[1]; FASTER is bounded more loosely - three builds of this round,
     # differing only in summation orders, gave running-minimum ratios between 0.27 and 2.4)
-    assert ratio.max() <= curve_rtol[1] and ratio.min() >= 1.0 / (1.5 * curve_rtol[1]), ratio
+    hi, lo = curve_rtol[1], 1.0 / (1.5 * curve_rtol[1])
+    worst, best = float(ratio.max()), float(ratio.min())
+    if spread is not None and "epoch_loss" in getattr(spread, "files", ()):
+        # The yardstick where it exists (round 4: the spread fixture carries whole curves): the REFERENCE'S OWN perturbed
+        # runs against its unperturbed curve lag it by up to 2.3x and lead it by up to 3x.  Samples are compared with
+        # samples here too: the MEDIAN over this path's runs (the unperturbed one + `more`) of the worst lag / lead
+        # must stay inside the reference's own range + 25 % (a build of round 4 that only changed the tap order inside
+        # the stride-2 data gradient sat one run on a transient at epoch 8 - 3.8x - while its perturbed runs, its
+        # final loss, its EER and every other check agreed with the reference).
+        own = np.array([np.minimum.accumulate(c) / ref_min for c in spread["epoch_loss"]])
+        mine = [ratio] + [np.minimum.accumulate(c) / ref_min for c in getattr(more, "epoch_loss", ())]
+        worst = float(np.median([r.max() for r in mine]))
+        best = float(np.median([r.min() for r in mine]))
+        print("running-minimum ratio: this path's runs max %s min %s; the reference's own runs max %s min %s" % (
+            np.round([r.max() for r in mine], 2).tolist(), np.round([r.min() for r in mine], 2).tolist(),
+            np.round(own.max(1), 2).tolist(), np.round(own.min(1), 2).tolist()))
+        record("curve_envelope[%s]" % name, {"hip_max": [float(r.max()) for r in mine], "ref_max": own.max(1).tolist()})
+        hi, lo = max(hi, 1.25 * float(own.max())), min(lo, float(own.min()) / 1.25)
+    assert worst <= hi and best >= lo, (ratio, worst, best, hi, lo)
     assert epoch_loss[1:].max() <= epoch_loss[0], epoch_loss
     # the two systems rank the held-out set alike: the reference's threshold-free separation carries over
     bona, spoof = scores[lab_ho == 0], scores[lab_ho == 1]
@@ -237,8 +258,10 @@ def test_synthetic_corpus_eer_at_baseline_shape(golden, which, dtype):
     against the real reference trained the same way (synth_eer4s_*.npz)."""
     g = golden("synth_eer4s_%s.npz" % which)
     tr, model, lossm, epoch_loss, scores, eer, lab_ho, pcm_ho = _run(g, which, dtype)
-    # (round 4: the reference's own spread exists for the ResNet at this shape - synth_eer4s_resnet_spread.npz - and
-    # with it this path is sampled three times as well; ECAPA bf16 stays a single sample against a single run)
+    # (round 4: this path is sampled three times at this shape - the unperturbed run and two from initial weights with
+    # one element moved by 1e-7 - and its MEDIAN is what is compared; the reference's own spread exists for both
+    # models: synth_eer4s_{resnet,ecapa}_spread.npz.  A single bf16 ECAPA run of a build that only regrouped the
+    # BatchNorm statistics' partial sums made 9 wrong trials of 1010 where the reference's single run makes 3.)
     spread = _spread(golden, "synth_eer4s_%s.npz" % which)
-    more = _more_eers(g, which, dtype, 2) if spread is not None else ()
+    more = _more_eers(g, which, dtype, 2)
     _check(g, epoch_loss, scores, eer, lab_ho, "%s %s 4 s" % (which, dtype), (0.25, 3.5), spread, more)
