@@ -814,6 +814,9 @@ struct NtGemm {
   int m_valid;
   size_t a_rs, a_ss, a_bs, b_rs, b_ss, b_bs, o_rs, o_bs;
   int M, n_valid, kseg, nseg_per_batch, nseg_total, relu, tiles_m, tiles_n, total, per_xcd;
+  // c1b_gemm_ps_kernel<BKM, true>, optional: BatchNorm statistics of the STORED output - per (row m, 64-frame segment r)
+  // the pair {sum, sum of squares} at hstats[(m * NR + r) * 2], NR = batches * tiles_n * 4, r = (batch * tiles_n + tile) * 4 + wn
+  float* hstats;
 };
 
 typedef const __attribute__((address_space(1))) void* c1b_gptr;
@@ -1013,13 +1016,33 @@ __device__ __forceinline__ void g2_hout_epilogue(const NtGemm& p, const G2Tile& 
           if (n + 2 * q + 1 >= p.n_valid) vv[q][1] = 0.0f;
         }
       }
+      const uint4 ow = make_uint4(pack2(vv[0][0], vv[0][1]), pack2(vv[1][0], vv[1][1]), pack2(vv[2][0], vv[2][1]),
+                                  pack2(vv[3][0], vv[3][1]));
 #ifdef G2_X_NOSTORE
-      if (pack2(vv[0][0], vv[0][1]) == 0x12345678u)
+      if (ow.x == 0x12345678u)
 #endif
-      if (m < p.m_valid)
-        *reinterpret_cast<uint4*>(ob + (size_t)m * p.out_bf_rs + n) =
-            make_uint4(pack2(vv[0][0], vv[0][1]), pack2(vv[1][0], vv[1][1]), pack2(vv[2][0], vv[2][1]),
-                       pack2(vv[3][0], vv[3][1]));
+      if (m < p.m_valid) *reinterpret_cast<uint4*>(ob + (size_t)m * p.out_bf_rs + n) = ow;
+      if (p.hstats != nullptr) {  // (wave-uniform) of the 8 values as stored; the row's 8 lanes are neighbours
+        const unsigned wd[4] = {ow.x, ow.y, ow.z, ow.w};
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __builtin_bit_cast(float, wd[q] << 16), hi = __builtin_bit_cast(float, wd[q] & 0xffff0000u);
+          s1 += lo + hi;
+          s2 = fmaf(lo, lo, s2);
+          s2 = fmaf(hi, hi, s2);
+        }
+        // (DPP: lane ^ 1, lane ^ 2, mirror within the row's 8 lanes - no trip through LDS as __shfl_xor makes)
+#define G2_DPP_ADD(v, ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+        G2_DPP_ADD(s1, 0xB1); G2_DPP_ADD(s2, 0xB1);
+        G2_DPP_ADD(s1, 0x4E); G2_DPP_ADD(s2, 0x4E);
+        G2_DPP_ADD(s1, 0x141); G2_DPP_ADD(s2, 0x141);
+#undef G2_DPP_ADD
+        if ((lane & 7) == 0 && m < p.m_valid) {
+          const int NR = p.nseg_total * p.tiles_n * 4, ridx = (tl.batch * p.tiles_n + tl.n0 / G2_BN) * 4 + wn;
+          *reinterpret_cast<float2*>(p.hstats + ((size_t)m * NR + ridx) * 2) = make_float2(s1, s2);
+        }
+      }
     }
   }
 }
@@ -1712,6 +1735,7 @@ int run_fwd_gemm(const float* x, size_t x_bs, const float* w, int transpose, flo
   hipLaunchKernelGGL(c1b_cvt_t_kernel, dim3(Tp / 64, K / 64, B), dim3(256), 0, st, x, x_bs, K, T, Tp, vec_t, xt);
   AIR_CHECK_LAUNCH();
   NtGemm g;
+  g.hstats = nullptr;
   g.a = a; g.b = xt; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = acc;
   g.acc2 = nullptr; g.acc_bs = y_bs; g.acc2_bs = 0;
   g.out_bf = y_bf; g.out_bf_rs = Tp;
@@ -1945,6 +1969,7 @@ int air_conv1d_pointwise_bf16_kmajor(const AirConv1d* p, const unsigned short* x
   hipLaunchKernelGGL(c1b_pack_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, w, a, M, K, dgrad ? 1 : 0);
   AIR_CHECK_LAUNCH();
   NtGemm g;
+  g.hstats = nullptr;
   g.a = a; g.b = xb; g.out = y; g.bias = bias; g.bias_bc = bias_bc; g.acc = accumulate; g.acc2 = accumulate2;
   g.out_bf = y_bf16; g.out_bf_rs = Tp;
   g.a_rs = K; g.a_ss = 0; g.a_bs = 0;
@@ -2070,7 +2095,22 @@ int air_h_conv1d_pointwise(int B, int Cin, int Cout, int T, int Tp, const unsign
                            int dgrad, const float* bias, const float* bias_bc, int relu, const unsigned short* acc,
                            size_t acc_bs, const unsigned short* acc2, size_t acc2_bs, unsigned short* y, size_t y_bs,
                            void* ws, size_t ws_bytes, air_stream_t stream) {
+  return air_h_conv1d_pointwise_ex(B, Cin, Cout, T, Tp, x, x_bs, w, dgrad, bias, bias_bc, relu, acc, acc_bs, acc2, acc2_bs,
+                                   y, y_bs, nullptr, ws, ws_bytes, stream);
+}
+
+size_t air_h_conv1d_pointwise_stats_bytes(int B, int Cout, int Tp) {
+  if (B <= 0 || Cout <= 0 || Tp <= 0 || Tp % G2_BN != 0) return 0;
+  return (size_t)Cout * B * (Tp / G2_BN) * 4 * 2 * sizeof(float);
+}
+
+int air_h_conv1d_pointwise_ex(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs,
+                              const float* w, int dgrad, const float* bias, const float* bias_bc, int relu,
+                              const unsigned short* acc, size_t acc_bs, const unsigned short* acc2, size_t acc2_bs,
+                              unsigned short* y, size_t y_bs, void* stats, void* ws, size_t ws_bytes,
+                              air_stream_t stream) {
   if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || Tp < T) return AIR_EINVAL;
+  if (stats != nullptr && (reinterpret_cast<size_t>(stats) & 7)) return AIR_EINVAL;
   const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
   if (Tp % G2_BN != 0 || K % GK != 0 || M % 8 != 0 || !air_opt(AIR_OPT_C1B_GEMM_PS)) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_h_conv1d_ws_bytes(dgrad ? Cin : Cout, dgrad ? Cout : Cin)) return AIR_EWORKSPACE;
@@ -2090,6 +2130,7 @@ int air_h_conv1d_pointwise(int B, int Cin, int Cout, int T, int Tp, const unsign
   g.b_rs = Tp; g.b_ss = 0; g.b_bs = x_bs ? x_bs : (size_t)K * Tp;
   g.o_rs = Tp; g.o_bs = g.out_bf_bs;
   g.M = M; g.n_valid = T; g.kseg = K; g.nseg_per_batch = 1; g.nseg_total = B; g.relu = relu;
+  g.hstats = reinterpret_cast<float*>(stats);
   const size_t a_bytes = (size_t)M * K * 2, b_bytes = ((size_t)(B - 1) * g.b_bs + (size_t)K * Tp) * 2;
   // 16-byte rows everywhere: row pitch Tp % 8 == 0 (above), bases and batch strides multiples of 8 elements
   if (((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(acc) |
@@ -2232,6 +2273,7 @@ int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* d
     if (rc != AIR_OK) return rc;
   }
   NtGemm g;
+  g.hstats = nullptr;
   g.a = dys; g.b = xs; g.out = nsplit > 1 ? partial : dw; g.bias = nullptr; g.bias_bc = nullptr; g.acc = nullptr;
   g.acc2 = nullptr; g.acc_bs = 0; g.acc2_bs = 0;
   g.out_bf = nullptr; g.out_bf_rs = 0;

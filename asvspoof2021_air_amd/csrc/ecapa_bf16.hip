@@ -747,10 +747,11 @@ int air_h_bn_stats_ex(const unsigned short* x, size_t x_bs, int B, int C, int T,
                       void* ws, size_t ws_bytes, air_stream_t stream) {
   if (!x || !gamma || !beta || !mean || !invstd || !scale || !shift || !h_shape_ok(B, C, T, Tp)) return AIR_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return AIR_EINVAL;
-  if (stats_in != nullptr) {  // the records of air_h_conv1d_tap_ex for THIS tensor: no pass over x
-    if (Tp % 128 != 0) return AIR_EINVAL;
-    const int NR = B * (Tp / 128) * 4;
-    if (stats_bytes != (size_t)C * NR * 2 * sizeof(float)) return AIR_EINVAL;
+  if (stats_in != nullptr) {  // the records of air_h_conv1d_tap_ex / air_h_conv1d_pointwise_ex for THIS tensor: no pass over x
+    if (Tp % 128 != 0 || stats_bytes % ((size_t)C * 2 * sizeof(float)) != 0) return AIR_EINVAL;
+    const int NR = (int)(stats_bytes / ((size_t)C * 2 * sizeof(float)));
+    // (32-frame segments of the tap kernel's 128-frame tiles, or 64-frame segments of the GEMM's 256-frame tiles)
+    if (NR != B * (Tp / 128) * 4 && !(Tp % 256 == 0 && NR == B * (Tp / 256) * 4)) return AIR_EINVAL;
     hipLaunchKernelGGL(h_bn_finalize_records_kernel, dim3(C), dim3(256), 0, air_stream(stream),
                        reinterpret_cast<const float*>(stats_in), NR, C, (double)B * (double)T, gamma, beta, eps, momentum,
                        running_mean, running_var, mean, invstd, scale, shift);

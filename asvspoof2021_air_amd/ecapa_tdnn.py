@@ -209,6 +209,7 @@ class Res2Net2(nn.Module):
         # small K = 3 kernels overlap the HBM-bound BatchNorm / pooling backward passes of the main stream
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self.fuse_tap_stats = os.environ.get("AIR_TAP_STATS", "1") == "1"  # Res2 branch statistics from the conv epilogue
+        self.fuse_pw_stats = os.environ.get("AIR_PW_STATS", "1") == "1"    # K = 1 convs: statistics from the GEMM epilogue
         self._side_stream = None
 
     def enable_ddp_overlap(self, bucket_bytes=8 << 20):
@@ -641,6 +642,15 @@ class Res2Net2(nn.Module):
         scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
         return None, None, scale, shift
 
+    def _pw_bn_h(self, x, w, T, bias, bn, training, bias_bc=None):
+        """conv (K = 1) -> ReLU -> BatchNorm statistics on resident rows: (r, st); in training the statistics leave the
+        GEMM's epilogue (round 4) instead of a pass over r."""
+        if training and getattr(self, "fuse_pw_stats", True):
+            r, rec = oh.conv_pointwise(x, w, T, bias=bias, bias_bc=bias_bc, relu=True, stats=True)
+            return r, self._bn_h(r, T, bn, training, stats_in=rec)
+        r = oh.conv_pointwise(x, w, T, bias=bias, bias_bc=bias_bc, relu=True)
+        return r, self._bn_h(r, T, bn, training)
+
     def _block_fwd_h(self, blk, inp, out, T, training, save):
         """Bottle2neck (ecapa_tdnn.py:64-95) on resident rows.  ``inp`` / ``out`` may be channel-slice views.
         o1 = bn1(relu(conv1(inp))) is written into the buffer that becomes the concat: branch i's BatchNorm output
@@ -649,8 +659,7 @@ class Res2Net2(nn.Module):
         w, d, nums = blk.width, blk.dilation, blk.nums
         det = lambda p: p.detach()
         dev = inp.device
-        r1 = oh.conv_pointwise(inp, det(blk.conv1.weight), T, bias=det(blk.conv1.bias), relu=True)
-        st1 = self._bn_h(r1, T, blk.bn1, training)
+        r1, st1 = self._pw_bn_h(inp, det(blk.conv1.weight), T, det(blk.conv1.bias), blk.bn1, training)
         cat = oh.bn_apply(r1, T, st1[2], st1[3])
         t_i = oh.copy(cat[:, :w], oh.rows(B, w, T, dev))  # branch 0's input outlives its slice (weight gradient)
         wp = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=False)
@@ -672,8 +681,7 @@ class Res2Net2(nn.Module):
             r_list.append(r_i)
             st_list.append(st_i)
             t_i = t_next
-        r3 = oh.conv_pointwise(cat, det(blk.conv3.weight), T, bias=det(blk.conv3.bias), relu=True)
-        st3 = self._bn_h(r3, T, blk.bn3, training)
+        r3, st3 = self._pw_bn_h(cat, det(blk.conv3.weight), T, det(blk.conv3.bias), blk.bn3, training)
         m = torch.empty((B, C), device=dev, dtype=torch.float32)
         o3 = oh.bn_apply(r3, T, st3[2], st3[3], rowmean=m)  # + the SE squeeze of the stored tensor
         se = blk.se.se
@@ -705,8 +713,7 @@ class Res2Net2(nn.Module):
         # conv1 (K = 5 on the fp32 features, :159-161) as a pointwise GEMM on the input unfolded into bf16 rows (autocast
         # runs this layer in bf16 as well): its ReLU output and its BatchNorm output are resident tensors like the rest
         xcol = oh.unfold(x.contiguous(), self.conv1.kernel_size[0], 1, self.conv1.padding[0], self._conv1_rows())
-        r0 = oh.conv_pointwise(xcol, self._conv1_matrix(), T, bias=det(self.conv1.bias), relu=True)
-        st0 = self._bn_h(r0, T, self.bn1, training)
+        r0, st0 = self._pw_bn_h(xcol, self._conv1_matrix(), T, det(self.conv1.bias), self.bn1, training)
         h = oh.bn_apply(r0, T, st0[2], st0[3])
         cat123 = oh.rows(B, 3 * C, T, dev)
         blocks = []
@@ -723,8 +730,7 @@ class Res2Net2(nn.Module):
         w_x = ops.add_strided(torch.empty((128, 1, 1536), device=dev), w0[:, :1536].unsqueeze(1)).view(128, 1536, 1)
         w_c = ops.add_strided(torch.empty((128, 1, 3072), device=dev), w0[:, 1536:].unsqueeze(1)).view(128, 3072)
         ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std], a per-utterance bias
-        a1 = oh.conv_pointwise(x4, w_x, T, bias=det(a0.bias), bias_bc=ctxb, relu=True)  # attention.0 + ReLU
-        stA = self._bn_h(a1, T, self.attention[2], training)
+        a1, stA = self._pw_bn_h(x4, w_x, T, det(a0.bias), self.attention[2], training, bias_bc=ctxb)  # attention.0 + ReLU
         a1n = oh.bn_apply(a1, T, stA[2], stA[3])
         wts = oh.conv_pointwise(a1n, det(a3.weight), T, bias=det(a3.bias))  # logits -> softmax weights below
         pooled = oh.asp_fwd(x4, wts, T)  # :184-187 (mu | sg)

@@ -81,9 +81,10 @@ def copy(x, out):
     return out
 
 
-def conv_pointwise(x, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, acc=None, acc2=None, out=None):
+def conv_pointwise(x, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, acc=None, acc2=None, out=None, stats=False):
     """K = 1 conv on resident rows.  w: the layer's (Cout, Cin, 1) fp32 weight.  Forward: x (B, Cin, Tp) ->
-    (B, Cout, Tp); dgrad: x = dy (B, Cout, Tp) -> (B, Cin, Tp) (+ acc + acc2, resident rows / slices)."""
+    (B, Cout, Tp); dgrad: x = dy (B, Cout, Tp) -> (B, Cin, Tp) (+ acc + acc2, resident rows / slices).
+    stats=True (forward): returns (y, records) - BatchNorm statistics of the stored y for ``bn_stats(stats_in=...)``."""
     Cout, Cin = w.shape[0], w.shape[1]
     B, K, Tp = x.shape
     M = Cin if dgrad else Cout
@@ -98,11 +99,17 @@ def conv_pointwise(x, w, T, dgrad=False, bias=None, bias_bc=None, relu=False, ac
     ap, ab = hv(acc, True)
     a2p, a2b = hv(acc2, True)
     yp, yb = hv(out)
-    _hip.check(lib.air_h_conv1d_pointwise(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), xp, csz(xb), dptr(w), ci(1 if dgrad else 0),
-                                          dptr(bias, allow_none=True), dptr(bias_bc, allow_none=True), ci(1 if relu else 0),
-                                          ap, csz(ab), a2p, csz(a2b), yp, csz(yb), dptr(ws, torch.uint8), csz(n), stream()),
-               "air_h_conv1d_pointwise")
-    return out
+    rec = None
+    if stats:
+        if dgrad:
+            raise _hip.AirError("conv_pointwise: statistics records are a forward-launch feature")
+        rec = torch.empty(int(lib.air_h_conv1d_pointwise_stats_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8, device=x.device)
+    _hip.check(lib.air_h_conv1d_pointwise_ex(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), xp, csz(xb), dptr(w),
+                                             ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+                                             dptr(bias_bc, allow_none=True), ci(1 if relu else 0), ap, csz(ab), a2p, csz(a2b),
+                                             yp, csz(yb), dptr(rec, torch.uint8, allow_none=True), dptr(ws, torch.uint8),
+                                             csz(n), stream()), "air_h_conv1d_pointwise_ex")
+    return (out, rec) if stats else out
 
 
 def conv_wgrad(x, dy, T, out):

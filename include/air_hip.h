@@ -532,6 +532,16 @@ int air_h_conv1d_pointwise(int B, int Cin, int Cout, int T, int Tp, const unsign
                            int dgrad, const float* bias, const float* bias_bc, int relu, const unsigned short* acc,
                            size_t acc_bs, const unsigned short* acc2, size_t acc2_bs, unsigned short* y, size_t y_bs,
                            void* ws, size_t ws_bytes, air_stream_t stream);
+/* Same, and the epilogue that stores y also leaves the BatchNorm statistics of the STORED tensor (the conv -> ReLU ->
+ * BatchNorm1d pairs of ecapa_tdnn.py:67-69,87-89,159-161,148-150) as {sum, sum of squares} per (channel, 64-frame
+ * segment) in `stats` (air_h_conv1d_pointwise_stats_bytes(B, Cout, Tp) bytes, 8-byte aligned; NULL = the plain call);
+ * air_h_bn_stats_ex takes it as stats_in.  Forward launches only (dgrad = 0). */
+size_t air_h_conv1d_pointwise_stats_bytes(int B, int Cout, int Tp);
+int air_h_conv1d_pointwise_ex(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs,
+                              const float* w, int dgrad, const float* bias, const float* bias_bc, int relu,
+                              const unsigned short* acc, size_t acc_bs, const unsigned short* acc2, size_t acc2_bs,
+                              unsigned short* y, size_t y_bs, void* stats, void* ws, size_t ws_bytes,
+                              air_stream_t stream);
 /* dw[co][ci] = sum_{b,t} dy x (fp32 out, split-K in fixed order); ws >= air_conv1d_bf16_ws_bytes of the layer. */
 int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned short* x, size_t x_bs,
                        const unsigned short* dy, size_t dy_bs, float* dw, void* ws, size_t ws_bytes, air_stream_t stream);

@@ -241,6 +241,35 @@ def test_tap_conv(oh, cfg):
     assert int(wide[:, :C].abs().max()) == 0 and int(wide[:, 2 * C:3 * C].abs().max()) == 0
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, 512, 96), (2, 512, 512, 750), (2, 1536, 128, 401), (9, 128, 1536, 200)])
+def test_pointwise_conv_statistics_from_the_epilogue(oh, cfg):
+    """air_h_conv1d_pointwise_ex: the K = 1 conv -> ReLU -> BatchNorm1d pairs (ecapa_tdnn.py:67-69,87-89,148-150,159-161)
+    take the BatchNorm's statistics from the GEMM's epilogue.  Stored tensor bit-identical to the plain call's; the four
+    coefficient vectors and the running statistics equal the pass over the tensor to 2e-6, an fp64 evaluation to 3e-6."""
+    B, Cin, Cout, T = cfg
+    x, _ = res(oh, synth_feat((B, Cin, T), 71))
+    w = synth_feat((Cout, Cin, 1), 72, scale=0.05).cuda()
+    bias, bbc = (0.1 * synth_feat((Cout,), 73)).cuda(), (0.1 * synth_feat((B, Cout), 74)).cuda()
+    gamma, beta = (1.0 + 0.2 * synth_feat((Cout,), 75)).cuda(), (0.3 * synth_feat((Cout,), 76)).cuda()
+    y0 = oh.conv_pointwise(x, w, T, bias=bias, bias_bc=bbc, relu=True)
+    y1, rec = oh.conv_pointwise(x, w, T, bias=bias, bias_bc=bbc, relu=True, stats=True)
+    assert torch.equal(y0, y1)
+    rm0, rv0 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    st0 = oh.bn_stats(y0, T, gamma, beta, rm0, rv0)
+    st1 = oh.bn_stats(y1, T, gamma, beta, rm1, rv1, stats_in=rec)
+    yd = val(y0, T).double()
+    want = [yd.mean((0, 2)), 1.0 / torch.sqrt(yd.var((0, 2), unbiased=False) + 1e-5)]
+    for k, name in enumerate(("mean", "invstd", "scale", "shift")):
+        a, b = st0[k].double().cpu(), st1[k].double().cpu()
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())), name
+        if k < 2:
+            assert float((b - want[k]).abs().max()) <= 3e-6 * max(1.0, float(want[k].abs().max())), name
+    assert float((rm0 - rm1).abs().max()) <= 2e-6 and float((rv0 - rv1).abs().max()) <= 2e-6
+    with pytest.raises(Exception):
+        oh.conv_pointwise(x, w.transpose(0, 1).contiguous(), T, dgrad=True, stats=True)
+
+
 @pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (5, 128, 401, 4), (130, 64, 200, 2)])
 def test_tap_conv_statistics_from_the_epilogue(oh, cfg):
     """air_h_conv1d_tap_ex: the Res2 branch conv (ecapa_tdnn.py:46-48, conv -> ReLU -> BatchNorm1d) leaves the BatchNorm
@@ -272,8 +301,8 @@ def test_tap_conv_statistics_from_the_epilogue(oh, cfg):
         if k < 2:
             assert float((b - want[k]).abs().max()) <= 3e-6 * max(1.0, float(want[k].abs().max())), name
     assert float((rm0 - rm1).abs().max()) <= 2e-6 and float((rv0 - rv1).abs().max()) <= 2e-6
-    with pytest.raises(Exception):  # records of another geometry are refused
-        oh.bn_stats(y1, T, gamma, beta, stats_in=rec[:rec.numel() // 2].clone())
+    with pytest.raises(Exception):  # records of another geometry are refused (half of them would be a GEMM epilogue's count)
+        oh.bn_stats(y1, T, gamma, beta, stats_in=rec[:rec.numel() // 4].clone())
 
 
 @pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (5, 128, 401, 4), (130, 64, 200, 2)])
