@@ -22,7 +22,8 @@ wrong trials of 1024 held-out: 1 / 3 / 1 / 3 beside the unperturbed run's 3; fin
 Round 4, second half: ``EER_THREADS=6 EER_SPREAD=5 make_golden_eer3.py eer3 resnet spread`` now also stores the perturbed
 runs' whole epoch-loss curves (``epoch_loss`` (5, 16): the envelope check's yardstick); the committed
 synth_eer3_resnet_spread.npz holds round 3's five samples (eer / errors / final_loss only - they do not regenerate on
-this container's CPU mix) followed by these five.
+this container's CPU mix) followed by these five.  ``EER_THREADS=8 EER_SPREAD=2 make_golden_eer3.py eer4s ecapa spread``
+for synth_eer4s_ecapa_spread.npz (both perturbed fp32 runs: 3 wrong trials of 1024, as the unperturbed one).
 """
 import os
 import sys
