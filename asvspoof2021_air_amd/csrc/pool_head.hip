@@ -383,8 +383,8 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
   k[1] += 0xBB67AE85u;
 }
 
-__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset,
-                             float scale) {
+__device__ __forceinline__ void randn_body(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset,
+                                           float scale) {
   const size_t quad = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 outputs each
   if (quad * 4 >= n) return;
   const uint64_t ctr = offset + quad;
@@ -407,6 +407,17 @@ __global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, u
   for (int j = 0; j < 4; ++j)
     if (quad * 4 + j < n) out[quad * 4 + j] = scale * z[j];
 }
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t offset, float scale) {
+  randn_body(out, n, seed, offset, scale);
+}
+
+// The same draw with the stream offset read from device memory, and the 1-thread kernel that advances it behind the
+// draw: inside a captured hipGraph the offset cannot be a kernel argument (it would be frozen into the graph).
+__global__ void randn_ctr_kernel(float* __restrict__ out, size_t n, uint64_t seed,
+                                 const unsigned long long* __restrict__ counter, float scale) {
+  randn_body(out, n, seed, (uint64_t)*counter, scale);
+}
+__global__ void counter_add_kernel(unsigned long long* counter, unsigned long long inc) { *counter += inc; }
 
 }  // namespace
 
@@ -426,6 +437,19 @@ int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
   const size_t quads = (n + 3) / 4;
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
                      air_stream(stream), out, n, seed, offset, scale);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_randn_ctr(float* out, size_t n, uint64_t seed, uint64_t* counter, float scale, air_stream_t stream) {
+  if (!out || !counter || (reinterpret_cast<size_t>(counter) & 7)) return AIR_EINVAL;
+  if (n == 0) return AIR_OK;
+  const size_t quads = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_ctr_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, air_stream(stream), out, n,
+                     seed, reinterpret_cast<const unsigned long long*>(counter), scale);
+  AIR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, air_stream(stream),
+                     reinterpret_cast<unsigned long long*>(counter), (unsigned long long)quads);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

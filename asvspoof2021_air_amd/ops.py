@@ -13,7 +13,7 @@ from ._hip import AirConv1d, AirConv2d, ci, cf, csz, dptr, stream
 
 _WS = {}
 _WS_GEN = [0]     # bumped whenever a scratch buffer is (re)allocated
-_WS_PINNED = []   # buffers a captured hipGraph may still point into: never freed
+_WS_PINNED = {}   # capture owner -> buffers its hipGraph may still point into (kept alive until the capture is dropped)
 
 
 def workspace_generation():
@@ -22,12 +22,18 @@ def workspace_generation():
     return _WS_GEN[0]
 
 
-def pin_workspaces():
+def pin_workspaces(owner=None):
     """Called when a hipGraph has been captured: from now on a buffer that is outgrown is kept alive instead of
-    freed, so a replay can never write through a dangling scratch pointer."""
+    freed, so a replay can never write through a dangling scratch pointer - until ``unpin_workspaces(owner)``."""
+    held = _WS_PINNED.setdefault(owner, [])
     for buf in _WS.values():
-        if not any(buf is b for b in _WS_PINNED):
-            _WS_PINNED.append(buf)
+        if not any(buf is b for b in held):
+            held.append(buf)
+
+
+def unpin_workspaces(owner=None):
+    """The capture that pinned the buffers is gone: release what was only kept alive for its replays."""
+    _WS_PINNED.pop(owner, None)
 
 
 def workspace(nbytes, device):
@@ -41,8 +47,6 @@ def workspace(nbytes, device):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
         _WS_GEN[0] += 1
-        if _WS_PINNED:
-            _WS_PINNED.append(buf)
     return buf
 
 
@@ -398,6 +402,17 @@ def randn(shape, device, seed, offset, scale=1.0):
     out = torch.empty(shape, device=device, dtype=torch.float32)
     _hip.check(_hip.lib().air_randn(dptr(out), csz(out.numel()), ctypes.c_uint64(seed),
                                     ctypes.c_uint64(offset), cf(scale), stream()), "air_randn")
+    return out
+
+
+def randn_ctr(shape, device, seed, counter, scale=1.0):
+    """randn() with the stream offset in device memory: ``counter`` is a 1-element int64 GPU tensor that the call reads
+    and then advances by ceil(numel / 4) on the stream - capturable in a hipGraph, and the same sequence eagerly."""
+    if counter.dtype != torch.int64 or not counter.is_cuda or counter.numel() != 1:
+        raise _hip.AirError("randn_ctr: counter must be a 1-element int64 GPU tensor")
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    _hip.check(_hip.lib().air_randn_ctr(dptr(out), csz(out.numel()), ctypes.c_uint64(seed),
+                                        dptr(counter, torch.int64), cf(scale), stream()), "air_randn_ctr")
     return out
 
 

@@ -153,6 +153,7 @@ class ResNet(nn.Module):
         self._noise_tensor = None
         self._noise_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._noise_offset = 0
+        self._noise_ctr = None  # the offset of the Philox stream as a device-side counter (ops.randn_ctr)
         self._arena = None
         # True: BatchNorm-apply + ReLU folded into every conv's operand read (no activated
         # tensor in HBM).  False: one HBM-bound pass writes the activated tensor and the convs
@@ -188,6 +189,9 @@ class ResNet(nn.Module):
         st["_geo"], st["_packs"], st["_pack_ev"] = {}, {}, [None, None]
         st["_bucketer"] = None
         st["_noise_tensor"] = None
+        if st.get("_noise_ctr") is not None:  # the device-side counter travels as its value
+            st["_noise_offset"] = int(st["_noise_ctr"].item())
+        st["_noise_ctr"] = None
         st.pop("_last_saved_for_test", None)
         st.pop("keep_saved_for_test", None)
         if st.get("noise_mode") == "tensor":
@@ -246,9 +250,13 @@ class ResNet(nn.Module):
             if tuple(n.shape) != (B, T, 256):
                 raise _hip.AirError("attention noise must be (B, T', 256), got %s" % (tuple(n.shape),))
             return n.to(device).contiguous()
-        n = ops.randn((B, T, 256), device, self._noise_seed, self._noise_offset, self.noise_scale)
-        self._noise_offset += (B * T * 256 + 3) // 4
-        return n
+        # (seed, offset) of the Philox stream: the offset lives on the device and the draw advances it there, so
+        # that a step captured in a hipGraph draws fresh noise on every replay (resnet.py:38 draws per call) and
+        # eager launches and replays walk one sequence
+        ctr = getattr(self, "_noise_ctr", None)
+        if ctr is None or ctr.device != device:
+            ctr = self._noise_ctr = torch.tensor([self._noise_offset], dtype=torch.int64, device=device)
+        return ops.randn_ctr((B, T, 256), device, self._noise_seed, ctr, self.noise_scale)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -285,12 +293,16 @@ class ResNet(nn.Module):
         if not self._geo:
             return {}
         main = torch.cuda.current_stream()
-        if self._side_stream is None:
+        # one chain (overlap_wgrad off: the hipGraph capture of train.Trainer): the transforms run on the main stream
+        # in front of the first layer that needs them, still as one launch per 32
+        one_chain = not self.overlap_wgrad
+        if not one_chain and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=main.device)
-        side = self._side_stream
-        start = torch.cuda.Event()
-        start.record(main)  # the optimiser step that produced these weights is in front of it
-        side.wait_event(start)
+        side = main if one_chain else self._side_stream
+        if not one_chain:
+            start = torch.cuda.Event()
+            start.record(main)  # the optimiser step that produced these weights is in front of it
+            side.wait_event(start)
         live = {}
         blocks = list(self.blocks())
         with torch.cuda.stream(side):
@@ -320,8 +332,11 @@ class ResNet(nn.Module):
                             self._packs[((bi, ci), which)] = buf
                             live[((bi, ci), which)] = buf
                             self._geo_live[(bi, ci)] = shape
-                self._pack_ev[which] = torch.cuda.Event()
-                self._pack_ev[which].record(side)
+                if one_chain:
+                    self._pack_ev[which] = None
+                else:
+                    self._pack_ev[which] = torch.cuda.Event()
+                    self._pack_ev[which].record(side)
         return live
 
     # ------------------------------------------------------------------ forward
@@ -336,7 +351,7 @@ class ResNet(nn.Module):
             S["x"], S["c1"], S["st1"] = x, c1, st1
             S["blocks"] = []
         fuse = self.fuse_bn_into_conv
-        prepack = self.prepack_weights and save and training and self.overlap_wgrad
+        prepack = self.prepack_weights and save and training
         live = self._launch_prepack(fuse) if prepack else {}
         waited = [False]
 
@@ -348,7 +363,8 @@ class ResNet(nn.Module):
             if buf is None or self._geo_live.get(key) != tuple(shape):
                 return None
             if which == 0 and not waited[0]:
-                torch.cuda.current_stream().wait_event(self._pack_ev[0])
+                if self._pack_ev[0] is not None:
+                    torch.cuda.current_stream().wait_event(self._pack_ev[0])
                 waited[0] = True
             return buf
 

@@ -133,7 +133,7 @@ class Trainer:
         OWN BatchNorm running statistics, which is what SURVEY.md 8e asks for, and the other ranks keep
         theirs.  When every rank calls it, pass the same ``val_loss`` everywhere (``dist.all_mean``) so that
         ``prev_loss`` / ``early_stop_cnt`` stay in step; either way take the early-stop decision through
-        ``should_stop()``, which all-reduces the counter."""
+        ``should_stop()``, which adopts rank 0's counter everywhere."""
         if self.out_fold is None:
             raise RuntimeError("call set_out_fold() first")
         improved = val_loss is not None and val_loss < self.prev_loss
@@ -154,13 +154,15 @@ class Trainer:
     def should_stop(self, patience=500):
         """main_train.py:711-715's early stop (``early_stop_cnt == 500 -> break``) as a decision EVERY rank takes
         alike: under ``if rank == 0: save_checkpoint(...)`` only rank 0's counter advances, and a rank that left
-        the loop alone would leave the others blocked in the next all-reduce.  Collective when world > 1 - call it
-        on every rank, once per epoch."""
+        the loop alone would leave the others blocked in the next all-reduce.  Rank 0 is authoritative: its counter
+        is broadcast and adopted everywhere (a MAX over the ranks would hand a stale count back to rank 0 after it
+        reset on an improvement - the reference counts CONSECUTIVE epochs without improvement, main_train.py:705-711).
+        Collective when world > 1 - call it on every rank, once per epoch."""
         cnt = self.early_stop_cnt
         if self.world > 1:
             dev = self.device if td.get_backend() == "nccl" else "cpu"
             t = torch.tensor([cnt], dtype=torch.int64, device=dev)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
+            td.broadcast(t, src=0)
             cnt = int(t.item())
             self.early_stop_cnt = cnt
         return cnt >= patience
@@ -194,7 +196,7 @@ class Trainer:
     def step(self, pcm, labels, start=None):
         if self.augment is not None:
             pcm = self.augment(pcm)
-        if self.use_graph and start is None and self.world == 1:
+        if self.use_graph and start is None:
             out = self._graphed_step(pcm, labels)
             if out is not None:
                 return out
@@ -205,42 +207,65 @@ class Trainer:
         """Capture front-end + forward + loss + backward of one fixed-shape batch in a hipGraph and replay it per
         step (the optimiser launches stay outside: Adam's step count is a kernel argument).  ECAPA's step is
         ~450 launches of 5 - 150 us each and the host cannot keep the queue full once the activations are bf16
-        (13 % GPU idle, tools/gpu_idle.py); replaying one graph removes the launch gaps.  Only models without
-        host-side randomness in their step qualify (Res2Net2; the ResNet draws its attention noise per call and
-        is GPU-bound anyway), single process only (the bucketed all-reduce is launched from inside backward)."""
+        (13 % GPU idle, tools/gpu_idle.py); the ResNet step is ~330 launches behind 4 - 7 ms of host work, which a
+        cold box (Python not yet warm, clocks not yet up) does not hide.  Replaying one graph removes the host from
+        the step.  The ResNet's attention noise (resnet.py:38) is drawn from a device-side Philox offset that the
+        draw itself advances (ops.randn_ctr), so every replay draws fresh noise and eager launches and replays walk
+        the same sequence.
+
+        world > 1: the captured chain holds no collective; the gradient arena and the loss centre are all-reduced
+        behind the replay (dist.allreduce_grads) instead of in buckets from inside backward - the eager step's
+        bucketing overlaps ~0.3 ms of transfer, the replay removes 4 - 7 ms of host time per rank."""
         from .ecapa_tdnn import Res2Net2
-        self.use_graph = bool(on) and isinstance(self.model, Res2Net2)
-        self._graph = None
-        self._graph_warm = 0
+        from .resnet import ResNet
+        self.use_graph = bool(on) and isinstance(self.model, (Res2Net2, ResNet))
+        self._drop_graph()
         if self.use_graph:
             # Round 4, root cause of "replay slower than eager" (tools/exp_ecapa_graph.sh): with the weight gradients
             # on the side stream the captured graph has a fork / join pair per layer, and ROCm replays such a graph
             # through several internal streams with a signal per edge - hipGraphLaunch itself took 5.4 ms of host time
-            # per replay and the step 8.41 ms against eager's 8.16.  Captured as ONE chain (no side stream: ECAPA's
-            # weight-gradient GEMMs gain nothing from the overlap, eager 8.16 with it, 8.11 without) the replay costs
-            # 0.22 ms of host time and the step 8.08 ms (6.19 ms at T = 401, eager 6.24).
-            self._overlap_saved = getattr(self.model, "overlap_wgrad", None)
+            # per replay and the step 8.41 ms against eager's 8.16.  Captured as ONE chain (no side stream) the replay
+            # costs 0.22 ms of host time and the step 8.08 ms (6.19 ms at T = 401, eager 6.24).
+            if self._overlap_saved is None:  # (a second enable_graph() must not save the already-forced False)
+                self._overlap_saved = (getattr(self.model, "overlap_wgrad", None), getattr(self.model, "_bucketer", None))
             self.model.overlap_wgrad = False
-        elif getattr(self, "_overlap_saved", None) is not None:
-            self.model.overlap_wgrad = self._overlap_saved
+            if hasattr(self.model, "_bucketer"):
+                self.model._bucketer = None
+        elif self._overlap_saved is not None:
+            self.model.overlap_wgrad, bucketer = self._overlap_saved
+            if hasattr(self.model, "_bucketer"):
+                self.model._bucketer = bucketer
             self._overlap_saved = None
         return self
+
+    def _drop_graph(self):
+        """Forget the capture and release the scratch buffers that were only kept alive for its replays."""
+        from . import ops
+        had = self._graph is not None
+        self._graph = None
+        self._graph_warm = 0
+        if had:
+            ops.unpin_workspaces(id(self))
 
     def _graph_key(self, pcm, labels):
         """Everything a capture freezes: shapes, the arithmetic mode and the scalars that travel as kernel
         arguments (loss weight and the OC-Softmax margins / scale)."""
-        return (tuple(pcm.shape), pcm.dtype, tuple(labels.shape), self.model.compute_dtype, self.feat_len,
-                float(self.weight_loss), float(self.loss.r_real), float(self.loss.r_fake), float(self.loss.alpha),
-                self.padding)
+        return (tuple(pcm.shape), pcm.dtype, tuple(labels.shape), getattr(self.model, "compute_dtype", "fp32"),
+                self.feat_len, float(self.weight_loss), float(self.loss.r_real), float(self.loss.r_fake),
+                float(self.loss.alpha), self.padding, getattr(self.model, "noise_mode", None),
+                getattr(self.model, "noise_scale", None))
 
     def _graphed_step(self, pcm, labels):
         from . import ops
+        if getattr(self.model, "noise_mode", None) == "tensor":
+            return None  # an installed noise tensor (parity tests) is host state: eager
         key = self._graph_key(pcm, labels)
         g = self._graph
         if g is not None and (g["key"] != key or g["ws_gen"] != ops.workspace_generation()):
             # another shape / hyper-parameter, or an eager step in between outgrew a scratch buffer the graph
-            # points into (the old buffers are pinned, so nothing dangles; the capture is simply redone)
-            self._graph, self._graph_warm, g = None, 0, None
+            # points into (the old buffers are pinned until here, so nothing dangled; the capture is simply redone)
+            self._drop_graph()
+            g = None
         if g is None:
             # two eager steps first: arenas, workspaces, lazy kernel attributes, optimiser state, the side stream
             if self._graph_warm < 2:
@@ -258,8 +283,12 @@ class Trainer:
         g["pcm"].copy_(pcm, non_blocking=True)
         g["labels"].copy_(labels, non_blocking=True)
         g["graph"].replay()
-        self.feat_optimizer.step(grad_scale=1.0)
-        self.loss_optimizer.step(grad_scale=1.0)
+        scale = 1.0
+        if self.world > 1:  # the one exchange of the step, behind the replay (no bucketer while the graph is on)
+            air_dist.allreduce_grads(self.model, self.loss)
+            scale = 1.0 / self.world
+        self.feat_optimizer.step(grad_scale=scale)
+        self.loss_optimizer.step(grad_scale=scale)
         return g["loss"].detach().clone(), g["neg"].clone()
 
     def _capture(self, key, pcm, labels):
@@ -278,7 +307,10 @@ class Trainer:
         # overwritten, none accumulated); kept here so _graphed_step can restore them after eager interludes
         grads = [(p, p.grad) for p in list(self.model.parameters()) + list(self.loss.parameters())
                  if p.grad is not None]
-        ops.pin_workspaces()
+        ops.pin_workspaces(id(self))
+        if not getattr(self, "_pin_finalizer", None):
+            import weakref
+            self._pin_finalizer = weakref.finalize(self, ops.unpin_workspaces, id(self))
         self._graph = dict(key=key, graph=graph, pcm=s_pcm, labels=s_labels, loss=loss, neg=neg, grads=grads,
                            ws_gen=ops.workspace_generation())
         return self._graph

@@ -44,6 +44,57 @@ PMC_FAMILY = {"wino4_conv_kernel": "wino4_conv_kernel", "wino_conv_kernel": "win
               "c1b_tap_kernel": "c1b_tap"}
 
 
+def smi_sample(device_index=0):
+    """One clock / power / temperature sample of the GPU (amd-smi, else rocm-smi), so that a slow headline can be
+    attributed from the record.  Never raises; {"error": ...} when no tool answers."""
+    import shutil
+    import subprocess
+    out = {"t": round(time.time(), 1)}
+    tool = shutil.which("amd-smi")
+    try:
+        if tool:
+            r = subprocess.run([tool, "metric", "-g", str(device_index), "--clock", "--power", "--temperature", "--json"],
+                               capture_output=True, text=True, timeout=20)
+            if r.returncode == 0 and r.stdout.strip():
+                j = json.loads(r.stdout)
+                g = j[0] if isinstance(j, list) else (j.get("gpu_data", [j])[0] if isinstance(j, dict) else {})
+                clk = g.get("clock", {})
+                pick = {}
+                for name in ("gfx_0", "mem_0"):
+                    c = clk.get(name, {})
+                    if isinstance(c, dict) and "clk" in c:
+                        v = c["clk"]
+                        pick[name + "_mhz"] = v.get("value") if isinstance(v, dict) else v
+                pw = g.get("power", {})
+                for name in ("socket_power", "current_socket_power", "average_socket_power"):
+                    if name in pw:
+                        v = pw[name]
+                        pick["socket_power_w"] = v.get("value") if isinstance(v, dict) else v
+                        break
+                tp = g.get("temperature", {})
+                for name in ("hotspot", "edge"):
+                    if name in tp:
+                        v = tp[name]
+                        pick[name + "_c"] = v.get("value") if isinstance(v, dict) else v
+                if pick:
+                    out.update(pick, tool="amd-smi")
+                    return out
+        tool = shutil.which("rocm-smi")
+        if tool:
+            r = subprocess.run([tool, "-d", str(device_index), "-c", "-P", "-t", "--json"], capture_output=True, text=True,
+                               timeout=20)
+            if r.returncode == 0 and r.stdout.strip():
+                j = json.loads(r.stdout)
+                card = next(iter(j.values())) if isinstance(j, dict) and j else {}
+                keep = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "power", "temperature (sensor junction)", "fclk"))}
+                out.update(keep, tool="rocm-smi")
+                return out
+        out["error"] = "neither amd-smi nor rocm-smi answered"
+    except Exception as exc:  # noqa: BLE001
+        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+    return out
+
+
 def synth_batch(step, rank, device):
     g = torch.Generator(device=device).manual_seed(688 + rank * 1000 + step)
     pcm = 0.1 * torch.randn(BATCH, LENGTH, generator=g, device=device, dtype=torch.float32)
@@ -145,12 +196,20 @@ def roofline_leg(trainer, batches):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / nrep
+        # 4 L + 4 T 60 = 352,240 B per 4 s utterance (PCM in, the T = 401 feature frames out) is THE
+        # algorithmic figure; the launch also writes the repeat-padded frames 401..feat_len-1 (what the library counts)
         per_launch_bytes = lf[0]["work"] / lf[0]["launches"]
-        gbs = per_launch_bytes / (ms * 1e-3) / 1e9
+        nutt = pcm.shape[0]
+        survey_bytes = nutt * (4 * pcm.shape[1] + 4 * (1 + pcm.shape[1] // 160) * 60)
+        gbs = survey_bytes / (ms * 1e-3) / 1e9
+        gbs_padded = per_launch_bytes / (ms * 1e-3) / 1e9
         out["lfcc_kernel"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_ms": round(ms, 4),
                               "timing": "%d back-to-back launches in one event bracket" % nrep,
-                              "algorithmic_bytes": round(per_launch_bytes),
+                              "algorithmic_bytes": round(survey_bytes),
+                              "bytes_per_utt": round(survey_bytes / nutt),
+                              "with_padded_output": {"bytes": round(per_launch_bytes), "achieved": round(gbs_padded, 1),
+                                                     "frac": round(gbs_padded / PEAK_HBM_GBS, 4)},
                               "single_bracket_launch_ms": round(lf[0]["total_ms"] / lf[0]["launches"], 4)}
     out["per_kernel"] = [{"kernel": r["kernel"], "launches_per_step": r["launches"] // 2,
                           "ms_per_step": round(r["total_ms"] / 2, 3),
@@ -179,7 +238,7 @@ def pmc_traffic_leg(model_name, family, argv_extra, timeout_s=170):
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
             cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--model", model_name, "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-pmc"] + argv_extra
+                   "--no-cpu-baseline", "--no-roofline", "--no-extra-configs", "--no-pmc", "--plain-timing"] + argv_extra
             env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -202,7 +261,19 @@ def pmc_traffic_leg(model_name, family, argv_extra, timeout_s=170):
             if k.startswith(prefix):
                 tot += v
                 n += 1
-        whole[counter] = everything / 3.0  # the child ran 1 warm-up + 2 timed steps
+        # whole-step bytes: everything the child's kernels moved / the train steps the child actually ran, which it
+        # reports itself (1 warm-up + 2 timed, plus the 2 eager steps and the capture pass in front of a hipGraph
+        # replay: round 4 divided ECAPA's 6 steps by 3)
+        nsteps = 3.0
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                try:
+                    nsteps = float(json.loads(ln).get("steps_run_total") or 3.0)
+                except ValueError:
+                    pass
+                break
+        whole[counter] = everything / nsteps
+        whole["steps"] = nsteps
         if n == 0:
             return {"traffic": None, "traffic_source": "no %s launch in the %s pass" % (prefix, counter)}
         per[counter] = tot / n
@@ -210,7 +281,8 @@ def pmc_traffic_leg(model_name, family, argv_extra, timeout_s=170):
     return {"traffic": round((2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0),
             "traffic_detail": {"fetch_kb_per_launch": round(per["FETCH_SIZE"], 1), "write_kb_per_launch": round(per["WRITE_SIZE"], 1),
                                "launches_sampled": launches,
-                               "whole_step_bytes_all_kernels": round((2.0 * whole["FETCH_SIZE"] + whole["WRITE_SIZE"]) * 1024.0)},
+                               "whole_step_bytes_all_kernels": round((2.0 * whole["FETCH_SIZE"] + whole["WRITE_SIZE"]) * 1024.0),
+                               "whole_step_divisor_steps": whole["steps"]},
             "traffic_source": "measured in this run: child passes of this command under rocprofv3 --kernel-trace --pmc "
                               "FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB per "
                               "launch, launch average over every %s* instance" % prefix}
@@ -223,12 +295,16 @@ def cpu_baseline_leg():
     import numpy as np
     from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
     from oracle.filler import fill_state, fill_value, synth_pcm
-    # PyTorch-CPU's conv backward collapses when oversubscribed (256 threads on a batch-8 problem ran 100x
-    # slower than 8 threads), so "all cores" is not its best: sweep {8, 16, 32, 64} threads with two steps
-    # each, then run BASELINE.md 5's 3 warm-up + 10 timed steps at the fastest count and report the sweep
+    # 3 warm-up + 10 timed steps, plain MEDIAN, at a STATED thread count.  PyTorch-CPU's conv backward
+    # collapses when oversubscribed (256 threads on a batch-8 problem ran 100x slower than 8), so "all cores" is not a
+    # baseline anyone would run: the count is fixed at min(16, host threads) - the fastest of {8, 16, 32, 64} on every
+    # box seen so far.  A 2-step sweep over those counts is reported beside it as `sweep` / `best` (VERDICT r4 item 12:
+    # `value` is the plain median at the stated count, never a best-of).
     ncpu = os.cpu_count() or 1
+    cores = min(16, ncpu)
     pcm = synth_pcm(64, LENGTH, seed=688)
     fb, dct = o_lfcc.linear_filterbank(), o_lfcc.dct2_ortho_matrix()
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     feats = [o_lfcc.lfcc_forward(pcm[i:i + 1].numpy().copy(), fb=fb, dct=dct) for i in range(64)]
     t_lfcc = time.perf_counter() - t0
@@ -236,6 +312,16 @@ def cpu_baseline_leg():
     x = o_pad.to_model_input(x).contiguous()
     labels = torch.tensor([0, 1, 1, 1, 0, 1, 1, 1])
     tr = o_train.OracleTrainer("resnet", fill_state(o_resnet.resnet18_shapes()), fill_value("center", (1, 256)))
+    times = []
+    t_start = time.perf_counter()
+    for it in range(13):
+        t0 = time.perf_counter()
+        tr.step(x, labels, None)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 25.0 and len(times) >= 5:  # bounded sample
+            break
+    warm = min(3, len(times) - 2)
+    step = float(np.median(times[warm:]))
     sweep = {}
     for nt in (8, 16, 32, 64):
         if nt > ncpu and sweep:
@@ -245,35 +331,22 @@ def cpu_baseline_leg():
         t0 = time.perf_counter()
         tr.step(x, labels, None)
         sweep[min(nt, ncpu)] = round(8.0 / (time.perf_counter() - t0), 2)
-    cores = max(sweep, key=sweep.get)
-    torch.set_num_threads(cores)
-    # 3 warm-up + 10 timed steps, median - taken THREE times, the best median reported (the figure
-    # wandered 35 - 58 utt/s across boxes on identical code: a host that is busy during one window is not the baseline)
-    medians, times = [], []
-    t_start = time.perf_counter()
-    for rnd in range(3):
-        times = []
-        for it in range(13 if rnd == 0 else 10):
-            t0 = time.perf_counter()
-            tr.step(x, labels, None)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > 30.0 and len(times) >= 4:  # bounded sample
-                break
-        warm = min(3, len(times) - 1) if rnd == 0 else 0
-        medians.append(float(np.median(times[warm:])))
-        if time.perf_counter() - t_start > 30.0:
+        if time.perf_counter() - t_start > 45.0:
             break
-    warm = 0
-    step = min(medians)
+    torch.set_num_threads(cores)
     per_utt = t_lfcc / 64 + step / 8
-    return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": torch.get_num_threads(),
+    best_threads = max(sweep, key=sweep.get)
+    return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": cores,
             "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
-                      "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, 3 warm-up + "
-                      "10 timed, best of %d medians %.3f s/step (medians %s) at the fastest of the swept thread counts "
-                      "(%d of %d host threads; PyTorch-CPU conv backward collapses when oversubscribed)" % (
-                          1e3 * t_lfcc / 64, len(medians), step, [round(m, 3) for m in medians], cores, ncpu),
-            "sweep": {"unit": "train-step utt/s after one warm-up step", "threads": sweep},
+                      "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, %d warm-up + "
+                      "%d timed steps, plain median %.3f s/step at %d of %d host threads (PyTorch-CPU conv backward "
+                      "collapses when oversubscribed: see sweep)" % (
+                          1e3 * t_lfcc / 64, warm, len(times) - warm, step, cores, ncpu),
+            "step_times_s": [round(t, 3) for t in times[warm:]],
+            "sweep": {"unit": "train-step utt/s, one step after one warm-up step", "threads": sweep},
+            "best": {"threads": best_threads, "train_step_utt_per_s": sweep[best_threads],
+                     "note": "single-step figure from the sweep; not the reported value"},
             "lfcc_utt_per_s": round(64 / t_lfcc, 1), "train_step_utt_per_s": round(8 / step, 2)}
 
 
@@ -298,6 +371,10 @@ def main():
     ap.add_argument("--sync-each-step", action="store_true",
                     help="read the loss back on the host after every timed step, as the reference's loop does "
                          "(main_train.py:479-481 writes loss.item() to train_loss.log per iteration)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of the headline configuration (median reported)")
+    ap.add_argument("--plain-timing", action="store_true",
+                    help="the contract's literal protocol: W warm-up steps and ONE window of exactly K steps, no stability "
+                         "warm-up (what the rocprofv3 --pmc child passes and the tests run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
@@ -331,9 +408,10 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    def run_config(model_name, dtype, batch, steps, warmup, augment, want_roofline):
-        """W untimed + K timed train steps of one configuration (barrier + synchronize fences, MAX over ranks),
-        then the instrumented roofline steps.  Returns (model, dict)."""
+    def run_config(model_name, dtype, batch, steps, warmup, augment, want_roofline, nwin=3):
+        """One configuration: W warm-up steps, the stability warm-up, `nwin` timed windows (barrier + synchronize
+        fences, MAX over ranks), then the instrumented roofline steps.  Returns (model, dict, retime) - retime(nwin)
+        times the same trainer again later in the process (the A-B-A repeat of the headline)."""
         global BATCH
         torch.manual_seed(688)
         if model_name == "resnet":
@@ -348,41 +426,97 @@ def main():
         # (Trainer broadcasts rank 0's weights, loss centre and BatchNorm buffers when world > 1)
         trainer = Trainer(model, enc_dim=256, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
                           feat_len=FEAT_LEN, device=device, ecapa=(model_name == "ecapa"))
-        # hipGraph replay of front-end + forward + backward (train.py): bit-identical to the eager launches
-        # (tests/test_ecapa_gpu.py).  Round 4: captured as ONE chain (no side-stream fork / join nodes, which made the
-        # replay slower than eager in round 3: tools/exp_ecapa_graph.sh) it needs 0.2 ms of host time per step
-        # instead of 6 and is 1 % faster than eager on the GPU-bound step: default for ECAPA at N = 1 (AIR_GRAPH=0:
-        # eager).  The ResNet draws its attention noise on the host side of the step and stays eager.
-        if model_name == "ecapa" and world == 1 and not augment and os.environ.get("AIR_GRAPH", "1") == "1":
+        # hipGraph replay of front-end + forward + backward (train.py): bit-identical to the eager launches of the same
+        # chain (tests/test_ecapa_gpu.py, tests/test_resnet_gpu.py).  Captured as ONE chain it needs ~0.2 ms of host
+        # time per step instead of 4 - 7.  Round 5: the ResNet too (its attention noise comes from a device-side
+        # Philox offset), and with world > 1 the gradient all-reduce runs behind the replay.  Defaults: ECAPA always;
+        # ResNet at N = 1 - with N > 1 it stays eager with the all-reduce in buckets from inside backward (BASELINE
+        # configs[3]: "overlapped with backward").  AIR_GRAPH=0 / 1 forces eager / replay everywhere.
+        want_graph = os.environ.get("AIR_GRAPH", "")
+        if not augment and (want_graph == "1" or (want_graph != "0" and (model_name == "ecapa" or world == 1))):
             trainer.enable_graph()
         if augment:
             from asvspoof2021_air_amd.augment import ChannelAugment
             trainer.augment = ChannelAugment(p=1.0, seed=688 + rank, device=device)
         nb = max(2, min(4, steps + warmup))
         batches = [synth_batch(i, rank, device) for i in range(nb)]  # inputs resident in HBM
-        if trainer.use_graph:  # two eager steps + the capture happen before the W warm-up steps, never inside the timed ones
-            for i in range(3):
-                trainer.step(*batches[i % nb])
-        for i in range(warmup):
-            trainer.step(*batches[i % nb])
-        fence()
-        t0 = time.perf_counter()
-        last = None
-        for i in range(steps):
-            last, _ = trainer.step(*batches[i % nb])
-            if args.sync_each_step:
-                last.item()
-        t_host = time.perf_counter() - t0  # all launches issued (the host side of the step; the GPU is behind)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            dt = float(t.item())
-        res = {"value": round(world * BATCH * steps / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
-               "ms_per_step": round(1e3 * dt / steps, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
-               "final_loss": round(float(last.item()), 5), "host_issue_ms_per_step": round(1e3 * t_host / steps, 3),
-               "launch": "hipGraph replay (one chain) + optimiser launches" if trainer.use_graph else "eager"}
+        nrun = [0]
+
+        def window(n):
+            """n steps between barrier + synchronize fences; (seconds, host-issue seconds, last loss), MAX over ranks."""
+            fence()
+            t0 = time.perf_counter()
+            last = None
+            for i in range(n):
+                last, _ = trainer.step(*batches[i % nb])
+                if args.sync_each_step:
+                    last.item()
+            t_host = time.perf_counter() - t0  # all launches issued (the host side of the step; the GPU is behind)
+            fence()
+            dt = time.perf_counter() - t0
+            nrun[0] += n
+            if world > 1:
+                t = torch.tensor([dt], device=device, dtype=torch.float64)
+                td.all_reduce(t, op=td.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt, t_host, last
+
+        def measure(nwin, first=True):
+            """The timed part: (result dict, seconds of one median step)."""
+            if first:
+                if trainer.use_graph:  # two eager steps + the capture happen before the W warm-up steps, never inside the timed ones
+                    for i in range(3):
+                        trainer.step(*batches[i % nb])
+                    nrun[0] += 3
+                for i in range(warmup):
+                    trainer.step(*batches[i % nb])
+                nrun[0] += warmup
+            smi0 = smi_sample(local) if (rank == 0 and not args.plain_timing) else None
+            timing = {"protocol": "plain"}
+            if args.plain_timing:
+                # the contract's literal protocol: W warm-up steps, ONE window of exactly K steps (PMC child passes, tests)
+                wsteps = steps
+                wins = [window(steps)]
+            else:
+                # Round 5 (VERDICT r4 item 9: the round-4 headline was taken 0.1 s after start on a cold box and read 11 %
+                # low).  Warm-up by TIME and STABILITY behind the W steps: 10-step windows until >= 2 s have been run and
+                # three consecutive windows agree within 1 % (capped at 12 s; the decision uses the all-reduced MAX, so
+                # every rank leaves the loop together).  Then `nwin` windows of max(K, 50) steps; value = the MEDIAN window.
+                settle, t_settle = [], 0.0
+                while True:
+                    dt, _, _ = window(10)
+                    settle.append(1e3 * dt / 10)
+                    t_settle += dt
+                    last3 = settle[-3:]
+                    stable = len(last3) == 3 and (max(last3) - min(last3)) <= 0.01 * min(last3)
+                    if (t_settle >= 2.0 and stable) or t_settle >= 12.0:
+                        break
+                wsteps = max(steps, 50)
+                wins = [window(wsteps) for _ in range(nwin)]
+                timing = {"protocol": "W warm-up steps, then 10-step windows until >= 2 s and three consecutive windows within "
+                                      "1 % (cap 12 s), then %d windows of max(K, 50) = %d steps between barrier + synchronize "
+                                      "fences; value and ms_per_step are the MEDIAN window" % (nwin, wsteps),
+                          "settle_windows_ms_per_step": [round(v, 3) for v in settle], "settle_s": round(t_settle, 2),
+                          "settled": bool(stable)}
+            per = sorted(1e3 * w[0] / wsteps for w in wins)
+            med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+            dt = med * 1e-3 * wsteps
+            t_host = sorted(w[1] for w in wins)[len(wins) // 2]
+            last = wins[-1][2]
+            timing.update({"steps_per_window": wsteps, "windows_ms_per_step": [round(1e3 * w[0] / wsteps, 3) for w in wins],
+                           "min_ms_per_step": round(per[0], 3), "max_ms_per_step": round(per[-1], 3),
+                           "spread": round((per[-1] - per[0]) / med, 4)})
+            if smi0 is not None:
+                timing["smi_before"], timing["smi_after"] = smi0, smi_sample(local)
+            steps_timed = wsteps
+            res = {"value": round(world * BATCH * steps_timed / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
+                   "ms_per_step": round(1e3 * dt / steps_timed, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
+                   "final_loss": round(float(last.item()), 5), "host_issue_ms_per_step": round(1e3 * t_host / steps_timed, 3),
+                   "launch": "hipGraph replay (one chain) + optimiser launches" if trainer.use_graph else "eager",
+                   "timing": timing, "steps_run_total": nrun[0]}
+            return res, dt / steps_timed
+
+        res, step_s = measure(nwin)
         comm = None
         if world > 1:
             # exposed communication: the same steps without the gradient exchange (no buckets from inside
@@ -403,7 +537,7 @@ def main():
             trainer.world, model._bucketer = saved
             trainer.sync_from_rank0()
             comm = {"allreduce_bytes_per_step": ar_bytes, "step_ms_without_exchange": round(1e3 * float(d2.item()), 3),
-                    "exposed_ms": round(1e3 * (dt / steps - float(d2.item())), 3),
+                    "exposed_ms": round(1e3 * (step_s - float(d2.item())), 3),
                     "overlap": os.environ.get("AIR_DDP_OVERLAP", "1") == "1"}
         # The instrumented roofline steps are ordinary train steps: with world > 1 they contain the gradient
         # all-reduce, so EVERY rank runs them (rank 0 alone would wait for its peers forever); only rank 0 reports.
@@ -412,25 +546,30 @@ def main():
         bucketer = getattr(model, "_bucketer", None)
         res["ddp"] = {"device": "cuda:%d" % local, "world": world,
                       "buckets_in_backward": (bucketer.total_launched if bucketer is not None else 0)}
+        if world > 1:
+            # self-documenting first multi-GPU run: what the process group actually is
+            res["ddp"].update(backend=td.get_backend(), ranks_seen=td.get_world_size(),
+                              nccl_version=(".".join(str(v) for v in torch.cuda.nccl.version())
+                                            if td.get_backend() == "nccl" else None),
+                              devices_visible=torch.cuda.device_count())
         if comm is not None:
             res["ddp"]["communication"] = comm
-        return model, res
+        res["steps_run_total"] = nrun[0]
+        return model, res, (lambda n: measure(n, first=False)[0])
 
-    model, main_res = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup, args.augment,
-                                 not args.no_roofline)
-    dt_unused = None
+    model, main_res, retime_main = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup, args.augment,
+                                              not args.no_roofline, nwin=args.windows)
     roofline = main_res.pop("roofline", None)
     main_batch = BATCH
     # BASELINE configs[2] (ECAPA-TDNN-512, bf16 compute, batch 128 per GPU) rides along in the default run so
     # that the driver's bench line carries a measured number for it too
     extra = {}
     if args.model == "resnet" and not args.no_extra_configs and args.batch == 0 and not args.augment:
-        del model
-        torch.cuda.empty_cache()
+        # (the headline's model and trainer stay alive for the A-B-A repeat at the end: 288 GB of HBM)
         # (a failure of this additional leg must not cost the headline line; with world > 1 every rank takes the
         # same path through its collectives, so an exception there is not caught - it would desynchronise the ranks)
         try:
-            _, e = run_config("ecapa", "bf16", 0, args.steps, args.warmup, False, not args.no_roofline)
+            _, e, _ = run_config("ecapa", "bf16", 0, args.steps, args.warmup, False, not args.no_roofline)
             e["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
             e["dtype"] = "bf16"
             e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16-resident "
@@ -449,7 +588,7 @@ def main():
                 try:
                     FEAT_LEN = 401
                     torch.cuda.empty_cache()
-                    _, e = run_config(mname, mdt, 0, args.steps, args.warmup, False, False)
+                    _, e, _ = run_config(mname, mdt, 0, args.steps, args.warmup, False, False)
                     e["dtype"] = "bf16" if mdt else "f32"
                     e["workload"] = "the same train step at the native T = 401 frames (no repeat-padding)"
                     extra[key] = e
@@ -475,6 +614,14 @@ def main():
         if e is not None and "roofline" in e:
             e["roofline"].update(pmc_traffic_leg("ecapa", e["roofline"]["kernel"], ["--feat-len", str(args.feat_len)]))
 
+    # A-B-A: the headline configuration once more at the END of the process (same trainer, no warm-up beyond the
+    # stability windows), so that a drift between the first and the last leg of the process shows in the record
+    repeat = None
+    if not args.plain_timing and extra:
+        BATCH = main_batch
+        r2 = retime_main(3)
+        repeat = {k: r2[k] for k in ("value", "ms_per_step", "host_issue_ms_per_step", "timing")}
+        repeat["vs_first"] = round(r2["value"] / main_res["value"], 4)
     if rank == 0:
         line = {
             "metric": "utterances/sec (LFCC+ResNet-OCSoftmax train step, 4 s@16 kHz)",
@@ -489,6 +636,7 @@ def main():
                        "parallelism": "dp%d" % world},
             "final_loss": main_res["final_loss"],
             "host_issue_ms_per_step": main_res["host_issue_ms_per_step"],
+            "launch": main_res["launch"], "timing": main_res["timing"], "steps_run_total": main_res["steps_run_total"],
             "sync_each_step": bool(args.sync_each_step),
             "ddp": main_res["ddp"],
         }
@@ -509,6 +657,8 @@ def main():
             line["roofline"] = roofline
         if extra:
             line["configs"] = extra
+        if repeat is not None:
+            line["headline_repeat_at_end"] = repeat
         if world == 1 and not args.no_cpu_baseline and args.model == "resnet":
             try:
                 line["cpu_baseline"] = cpu_baseline_leg()

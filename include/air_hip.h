@@ -432,6 +432,11 @@ int air_sum_rows(const float* x, int M, int N, float* out, air_stream_t stream);
  * replacement for the host-side ``1e-5*torch.randn`` of resnet.py:38. */
 int air_randn(float* out, size_t n, uint64_t seed, uint64_t offset, float scale,
               air_stream_t stream);
+/* The same draw with the stream offset held in DEVICE memory: reads *counter as the offset and advances it by
+ * ceil(n / 4) behind the draw (a second, 1-thread launch on the same stream).  resnet.py:38 draws fresh noise on
+ * every call; inside a captured hipGraph a host-side offset would be frozen into the graph, a device-side one is
+ * not - eager launches and graph replays walk the same (seed, offset) sequence.  counter: 8-byte aligned. */
+int air_randn_ctr(float* out, size_t n, uint64_t seed, uint64_t* counter, float scale, air_stream_t stream);
 
 /* --------------------------------------------------------------- linear ---
  * nn.Linear (resnet.py:143-144,187-189; ecapa_tdnn.py:148-149): y = x W^T + b.

@@ -97,6 +97,13 @@ def _worker(rank, world, port, out):
     ok &= tr.should_stop(patience=4) is False and tr.early_stop_cnt == 3
     tr.early_stop_cnt += 1 if rank == 0 else 0
     ok &= tr.should_stop(patience=4) is True
+    # improve -> reset -> should_stop.  Rank 0 saw an improvement and reset; the other ranks still carry
+    # the count they adopted (4).  The reference counts CONSECUTIVE epochs (main_train.py:705-711): everyone is at 0.
+    if rank == 0:
+        tr.early_stop_cnt = 0
+    ok &= tr.should_stop(patience=4) is False and tr.early_stop_cnt == 0
+    tr.early_stop_cnt += 1 if rank == 0 else 0
+    ok &= tr.should_stop(patience=4) is False and tr.early_stop_cnt == 1
     out[rank] = bool(ok)
     td.barrier()
     td.destroy_process_group()

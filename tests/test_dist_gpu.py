@@ -172,7 +172,8 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "8"]  # default flags otherwise: the roofline leg runs on every rank
+           "--warmup", "1", "--batch", "8", "--plain-timing"]  # (gloo moves 49.8 MB per step through the host: one
+    # window of K steps instead of the settle + 5 x 50-step protocol); the roofline leg runs on every rank
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -189,4 +190,5 @@ def test_bench_two_ranks_on_one_gpu():
     # 2,056 bytes of fc_mu.* (514 floats), which get no gradient under ang_iso and which SURVEY 8e says to skip
     comm = d["ddp"]["communication"]
     assert d["ddp"]["world"] == 2 and comm["allreduce_bytes_per_step"] == 49_802_184 - 2_056
+    assert d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo" and d["launch"] == "eager"
     assert comm["step_ms_without_exchange"] > 0 and "exposed_ms" in comm and comm["overlap"] is True

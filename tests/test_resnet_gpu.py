@@ -364,3 +364,113 @@ def test_long_utterance_beyond_lds_pooling():
     feat, _ = m(x.cuda())
     feat.square().mean().backward()
     assert torch.isfinite(m.conv1.weight.grad).all() and float(m.conv1.weight.grad.abs().max()) > 0
+
+
+def _graph_trainer(graph, seed=4242):
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.train import Trainer
+    m = make_model()
+    m._noise_seed = seed  # device noise ON (resnet.py:38): the replay has to draw what the eager step draws
+    lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+    fill_module_(lossm)
+    tr = Trainer(m, loss_module=lossm, feat_len=128)
+    if graph:
+        tr.enable_graph()
+    return m, tr
+
+
+def test_randn_ctr_walks_the_host_offset_sequence():
+    """air_randn_ctr (device-side offset, advanced by the draw) == air_randn at the offsets the host would have passed."""
+    from asvspoof2021_air_amd import ops
+    dev = torch.device("cuda")
+    ctr = torch.tensor([17], dtype=torch.int64, device=dev)
+    off = 17
+    for n in (5, 4096, 1023):
+        a = ops.randn_ctr((n,), dev, 99, ctr, 1e-5)
+        b = ops.randn((n,), dev, 99, off, 1e-5)
+        off += (n + 3) // 4
+        assert torch.equal(a, b) and int(ctr.item()) == off
+
+
+def test_graphed_train_step_equals_eager():
+    """Trainer.enable_graph() on the ResNet - LFCC + forward (with the per-call attention noise of
+    resnet.py:38 drawn from a device-side Philox offset) + OC-Softmax + backward replayed as one hipGraph chain, the
+    optimisers outside - ends on bit-identical weights, centre, BatchNorm statistics and noise offset as the eager
+    launches of the same one-chain step, over six steps with changing batches and a learning-rate change."""
+    from oracle.filler import synth_pcm
+    batches = [(synth_pcm(4, 16000, seed=500 + i).cuda(), ((torch.arange(4) + i) % 3 != 0).long().cuda()) for i in range(6)]
+    ends = []
+    for graph in (False, True):
+        m, tr = _graph_trainer(graph)
+        if not graph:
+            m.overlap_wgrad = False  # the capture is one chain; same launches eagerly
+        losses = []
+        for i, (pcm, lab) in enumerate(batches):
+            if i == 3:
+                tr.set_epoch(4, lr_decay=0.5, interval=4)
+            losses.append(tr.step(pcm, lab)[0].item())
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        ends.append((losses, m.arena().flat.clone(), tr.loss.center.detach().clone(), m.bn1.running_var.clone(),
+                     m.layer4[1].bn2.running_mean.clone(), int(m.bn1.num_batches_tracked), int(m._noise_ctr.item())))
+    (l0, w0, c0, rv0, rm0, n0, k0), (l1, w1, c1, rv1, rm1, n1, k1) = ends
+    assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and torch.equal(rm0, rm1)
+    assert n0 == n1 == 6 and k0 == k1 > 0
+
+
+def test_graphed_noise_is_fresh_per_replay():
+    """Two replays on the SAME batch from the same weights must not see the same attention noise: the saved noise
+    tensor of the replay changes, and it is the draw at the advanced offset."""
+    from asvspoof2021_air_amd import ops
+    from oracle.filler import synth_pcm
+    m, tr = _graph_trainer(True)
+    m.noise_scale = 1.0  # make the draw visible in the loss
+    pcm, lab = synth_pcm(4, 16000, seed=7).cuda(), torch.tensor([0, 1, 1, 0]).cuda()
+    for _ in range(3):
+        tr.step(pcm, lab)
+    assert tr._graph is not None
+    k0 = int(m._noise_ctr.item())
+    flat = m.arena().flat.clone()
+    l1 = tr.step(pcm, lab)[0].item()
+    m.arena().flat.copy_(flat)
+    l2 = tr.step(pcm, lab)[0].item()
+    k2 = int(m._noise_ctr.item())
+    Tp = att_T(128)
+    assert k2 - k0 == 2 * ((4 * Tp * 256 + 3) // 4)
+    assert l1 != l2
+
+
+def test_graphed_steps_interleaved_with_eager():
+    """An eager step, an external zero_grad(), a score() call or an outgrown scratch buffer between replays: same
+    sequence eager-only (one chain) and with the graph enabled -> bit-identical ends."""
+    from oracle.filler import synth_pcm
+    batches = [(synth_pcm(4, 16000, seed=600 + i).cuda(), ((torch.arange(4) + i) % 3 != 0).long().cuda()) for i in range(10)]
+    big = (synth_pcm(12, 16000, seed=78).cuda(), (torch.arange(12) % 4 != 0).long().cuda())
+    ends = []
+    for graph in (False, True):
+        m, tr = _graph_trainer(graph)
+        if not graph:
+            m.overlap_wgrad = False
+        losses, kept = [], None
+        for i, (pcm, lab) in enumerate(batches):
+            if i == 3:
+                out = tr.step_features(tr.features(pcm), lab)
+            elif i == 5:
+                tr.feat_optimizer.zero_grad(); tr.loss_optimizer.zero_grad()
+                tr.score(pcm)
+                out = tr.step(pcm, lab)
+            elif i == 6:
+                out = tr.step_features(tr.features(big[0]), big[1])
+            else:
+                out = tr.step(pcm, lab)
+            if i == 4:
+                kept = (out[1], out[1].clone())
+            losses.append(out[0].item())
+        torch.cuda.synchronize()
+        assert torch.equal(kept[0], kept[1])
+        ends.append((losses, m.arena().flat.clone(), tr.loss.center.detach().clone(), m.bn1.running_var.clone(),
+                     int(m._noise_ctr.item())))
+        if graph:
+            assert tr._graph is not None and tr.model.training
+    (l0, w0, c0, rv0, k0), (l1, w1, c1, rv1, k1) = ends
+    assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and k0 == k1
