@@ -494,7 +494,7 @@ def main():
                 wsteps = max(steps, 50)
                 wins = [window(wsteps) for _ in range(nwin)]
                 timing = {"protocol": "W warm-up steps, then 10-step windows until >= 2 s and three consecutive windows within "
-                                      "1 % (cap 12 s), then %d windows of max(K, 50) = %d steps between barrier + synchronize "
+                                      "1 %% (cap 12 s), then %d windows of max(K, 50) = %d steps between barrier + synchronize "
                                       "fences; value and ms_per_step are the MEDIAN window" % (nwin, wsteps),
                           "settle_windows_ms_per_step": [round(v, 3) for v in settle], "settle_s": round(t_settle, 2),
                           "settled": bool(stable)}
