@@ -141,7 +141,7 @@ def test_training_loop_body_runs_from_a_dataloader():
     # (train-mode BatchNorm on 5 utterances amplifies the 3e-5 feature differences; the golden-vector tests hold the
     # model itself to 1e-5 on identical inputs)
     np.testing.assert_allclose(feats.detach().cpu().numpy(), o_feats.numpy(), atol=2e-3 * float(o_feats.abs().max()))
-    np.testing.assert_allclose(float(ang_isoloss), float(o_loss), rtol=2e-3)
+    np.testing.assert_allclose(float(ang_isoloss.detach()), float(o_loss), rtol=2e-3)
     ang_isoloss.backward()  # main_train.py:406
     assert feat_model.conv1.weight.grad is not None and torch.isfinite(feat_model.conv1.weight.grad).all()
 
@@ -168,10 +168,13 @@ def test_generate_score_from_the_dataset(tmp_path):
     dl5 = DataLoader(fast, batch_size=5, shuffle=False, num_workers=0, collate_fn=fast.collate_fn)
     test_on_dataset(model, dl5, str(fb), lossm, "ocsoftmax", task="19eval", keep_dataset_labels=True)
     la, lb = fa.read_text().splitlines(), fb.read_text().splitlines()
-    assert len(la) == 5 and la == lb
+    assert len(la) == len(lb) == 5
+    for x, y in zip(la, lb):  # batch 1 and batch 5 pick different conv tilings: same names and keys, scores to 1e-6
+        assert x.split()[0] == y.split()[0] and x.split()[2] == y.split()[2]
+        assert abs(float(x.split()[1]) - float(y.split()[1])) <= 1e-6
     pcm = torch.stack([src.pcm(i) for i in range(5)]).cuda()
     want = score_pcm(model, lossm, pcm, feat_len=128).cpu().tolist()
-    for i, ln in enumerate(la):
+    for i, ln in enumerate(lb):
         name, val, key = ln.split()
         assert name == "LA_E_%07d" % (1000000 + i) and key == ("spoof" if src._utt(i, label_only=True)[1] else "bonafide")
         assert float(val) == want[i]
