@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "air_common.h"
+#include "air_hip.h"
 
 namespace {
 struct Rec {
@@ -24,6 +25,19 @@ const char* const kNames[AIR_K_COUNT] = {
     "conv_wgrad_kernel<conv1d>", "lfcc_kernel", "wino_conv_kernel", "wino_wgrad_kernel",
     "c1b_fwd_kernel", "c1b_gemm_kernel", "c1b_tap_kernel", "wino4_conv_kernel",
     "c1b_tapw_kernel", "wino4_conv_kernel+bn", "conv_s2_dgrad_kernel"};
+
+// Test instrumentation (tests/test_cu_mask_gpu.py): a kernel that holds `nblocks` compute units for a while - each
+// workgroup takes `lds_bytes` of LDS (so that a 144 KB persistent Winograd workgroup cannot share its CU) and spins on
+// the 100 MHz wall clock - standing in for the RCCL kernels that are resident while the backward pass runs.
+__global__ void cu_hog_kernel(unsigned long long ticks, unsigned* sink) {
+  extern __shared__ unsigned hog_lds[];
+  hog_lds[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = wall_clock64();
+  unsigned acc = hog_lds[(threadIdx.x * 7) & 63];
+  while (wall_clock64() - t0 < ticks) acc = acc * 1664525u + 1013904223u;
+  if (acc == 0x12345u && sink) *sink = acc;  // (keeps the loop)
+}
 }  // namespace
 
 bool air_prof_on() { return g_on; }
@@ -44,6 +58,18 @@ void air_prof_end(hipStream_t st) {
 }
 
 extern "C" {
+
+int air_debug_cu_hog(int nblocks, int lds_bytes, double milliseconds, air_stream_t stream) {
+  if (nblocks <= 0 || lds_bytes < 256 || lds_bytes > 160 * 1024 || milliseconds <= 0.0 || milliseconds > 200.0)
+    return AIR_EINVAL;
+  static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(cu_hog_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  if (!attr_ok) return AIR_ELAUNCH;
+  hipLaunchKernelGGL(cu_hog_kernel, dim3(nblocks), dim3(64), (size_t)lds_bytes, air_stream(stream),
+                     (unsigned long long)(milliseconds * 1e5), (unsigned*)nullptr);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
 
 int air_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);

@@ -674,6 +674,12 @@ int air_adam_step(float* p, const float* g, float* m, float* v, size_t n, int st
 int air_sgd_step(float* p, const float* g, size_t n, float lr, float grad_scale,
                  air_stream_t stream);
 
+/* Test instrumentation: occupy `nblocks` compute units for `milliseconds` (<= 200) on `stream` - one 64-thread
+ * workgroup per block holding `lds_bytes` of LDS and spinning on the wall clock.  Stands in for collective (RCCL)
+ * kernels that are resident on some CUs while the persistent convolution kernels are dispatched
+ * (tests/test_cu_mask_gpu.py); the reference has no counterpart (main_train.py:174 is a commented-out DataParallel). */
+int air_debug_cu_hog(int nblocks, int lds_bytes, double milliseconds, air_stream_t stream);
+
 /* ------------------------------------------------- bench instrumentation ---
  * Opt-in HIP-event timing of the dominant kernels on their launch stream, used
  * by bench.py's roofline leg only (off by default).  kid indexes the kernel

@@ -116,3 +116,86 @@ def test_resnet_train_step_on_masked_stream(masked_stream):
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     rel = float((g0 - g1).norm() / g0.norm())
     assert rel <= 5e-3, rel
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a REAL kernel occupying CUs on another stream while full-grid persistent launches with cut
+# items are dispatched (the masked stream above only shrinks the grid).  air_debug_cu_hog holds N compute units
+# (N workgroups x 64 KB of LDS: a 144 KB wino4 workgroup cannot share the CU) for a few milliseconds - the position
+# RCCL's all-reduce kernels are in during BASELINE configs[3]'s backward pass.  The grid is still one workgroup per CU
+# of the device, so N of them cannot be resident until the hog leaves or an earlier workgroup finishes: the
+# publisher / owner protocol of the cut items (conv_wino4.hip) must not depend on all workgroups running at once.
+def _hog(stream, nblocks, ms):
+    _hip.check(_hip.lib().air_debug_cu_hog(ctypes.c_int(nblocks), ctypes.c_int(64 * 1024), ctypes.c_double(ms),
+                                           ctypes.c_void_p(stream.cuda_stream)), "air_debug_cu_hog")
+
+
+@pytest.mark.parametrize("nhog", [16, 64])
+@pytest.mark.parametrize("shape", [(64, 18, 750, 64), (256, 5, 188, 256), (512, 3, 94, 512)])
+def test_wino4_with_resident_hog_kernel(shape, nhog):
+    Cin, H, W, Cout = shape
+    B = 20
+    g = torch.Generator().manual_seed(Cin + H + 1)
+    x = torch.randn((B, Cin, H, W), generator=g).cuda()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / (3.0 * Cin ** 0.5)).cuda()
+    res = torch.randn((B, Cout, H, W), generator=g).cuda()
+    dy = torch.randn((B, Cout, H, W), generator=g).cuda()
+    main = torch.cuda.current_stream()
+    hog_stream = torch.cuda.Stream()
+
+    def run(n):
+        outs = []
+        for _ in range(n):
+            outs.append((ops.conv2d_fwd(x, w, 1, 1, residual=res, stats=True), ops.conv2d_dgrad(dy, w, x.shape, 1, 1)))
+        return outs
+
+    run(2)  # warm: lazy attributes, the flag ring
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(main)
+    want = run(4)
+    e1.record(main)
+    torch.cuda.synchronize()
+    free_ms = e0.elapsed_time(e1)
+    hog_ms = 6.0
+    _hog(hog_stream, nhog, hog_ms)       # resident first ...
+    e1.record(main)
+    got = run(4)                         # ... then the full-grid launches, dispatched while it holds its CUs
+    e2.record(main)
+    torch.cuda.synchronize()             # a hang (owner spinning on a never-dispatched publisher) would time out here
+    hogged_ms = e1.elapsed_time(e2)
+    for ((yf, rec), dx), ((yf0, rec0), dx0) in zip(got, want):
+        assert torch.equal(yf, yf0) and torch.equal(dx, dx0)          # same dealing, same summation order: bit-equal
+        assert (rec is None) == (rec0 is None) and (rec is None or torch.equal(rec, rec0))
+    # bounded slowdown: at worst the launches wait for the hog to leave (its 6 ms) and then run as usual
+    assert hogged_ms <= free_ms * 1.5 + hog_ms + 1.0, (free_ms, hogged_ms)
+
+
+def test_resnet_train_step_with_resident_hog_kernel():
+    """The whole ResNet step (side-stream weight gradients included) while 32 CUs are held by another kernel for most
+    of it: bit-identical loss and gradients."""
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    from oracle.filler import fill_module_, synth_pcm
+    pcm = synth_pcm(12, 32000, seed=5).cuda()
+    labels = (torch.arange(12) % 3 != 0).long().cuda()
+    hog_stream = torch.cuda.Stream()
+    outs = []
+    for hog in (False, True):
+        m = ResNet(3, 256, resnet_type="18", nclasses=2)
+        fill_module_(m)
+        m.set_attention_noise(None)
+        lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+        fill_module_(lossm)
+        tr = Trainer(m, loss_module=lossm, feat_len=201)
+        tr.step(pcm, labels)  # warm-up step (also gives the second step its prepacked weights)
+        torch.cuda.synchronize()
+        if hog:
+            for _ in range(3):
+                _hog(hog_stream, 32, 8.0)
+        loss, _ = tr.step(pcm, labels)
+        torch.cuda.synchronize()
+        outs.append((float(loss), m.arena().grad.clone(), m.arena().flat.clone()))
+    (l0, g0, w0), (l1, g1, w1) = outs
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(w0, w1)
