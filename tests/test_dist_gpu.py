@@ -130,6 +130,51 @@ def test_two_rank_step_equals_averaged_gradients(kind):
     np.testing.assert_array_equal(tr.loss.center.detach().cpu().numpy(), c0)
 
 
+def _worker_steps(rank, world, port, out, kind, graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from asvspoof2021_air_amd import dist as air_dist
+    from oracle.filler import synth_pcm
+    torch.cuda.set_device(0)
+    air_dist.init_from_env("gloo")
+    tr = _make(kind)
+    if kind == "resnet":
+        tr.model.noise_mode, tr.model._noise_seed = "device", 77 + rank  # per-rank attention noise, device-side offset
+    if graph:
+        tr.enable_graph()
+        assert tr.model._bucketer is None and tr.model.overlap_wgrad is False
+    losses = []
+    for i in range(5):
+        pcm = synth_pcm(4, 16000, seed=900 + 10 * i + rank).cuda()
+        labels = ((torch.arange(4) + i + rank) % 3 != 0).long().cuda()
+        losses.append(tr.step(pcm, labels)[0].item())
+    torch.cuda.synchronize()
+    assert (tr._graph is not None) == graph
+    out[rank] = (losses, tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["ecapa", "resnet"])
+def test_two_rank_graph_replay_equals_two_rank_eager(kind):
+    """with world > 1 the step is still replayed from the hipGraph (front-end + forward + backward as
+    one chain, no collective inside) and the gradient arena + loss centre are all-reduced BEHIND the replay; five steps
+    end on the weights of the eager two-rank run (buckets from inside backward), bit for bit, and the ranks agree."""
+    world = 2
+    mgr = mp.Manager()
+    ends = []
+    for graph in (False, True):
+        out = mgr.dict()
+        mp.spawn(_worker_steps, args=(world, _free_port(), out, kind, graph), nprocs=world, join=True)
+        (l0, w0, c0), (l1, w1, c1) = out[0], out[1]
+        assert np.array_equal(w0, w1) and np.array_equal(c0, c1)
+        ends.append((l0, l1, w0, c0))
+    (a0, a1, wa, ca), (b0, b1, wb, cb) = ends
+    assert a0 == b0 and a1 == b1
+    np.testing.assert_array_equal(wa, wb)
+    np.testing.assert_array_equal(ca, cb)
+
+
 def _worker_nccl(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
