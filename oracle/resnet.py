@@ -83,15 +83,19 @@ class ReluProbe:
     below.  ``masks`` = None: records the sign decision of every ReLU in execution order.  ``masks`` = a list of
     boolean tensors (the decisions ANOTHER evaluation of the same net took, e.g. the HIP path's): applies those
     instead of its own - y = x * mask, so the backward pass gates with them too - and counts per ReLU where its
-    own sign would have differed (``flips``) together with the largest |pre-activation| among them."""
+    own sign would have differed (``flips``) together with the largest |pre-activation| among them (``flip_mag``);
+    ``scale`` / ``count``: the largest |pre-activation| and the number of units of every ReLU."""
 
     def __init__(self, masks=None):
         self.masks, self.own, self.flips, self.flip_mag = masks, [], [], []
+        self.scale, self.count = [], []  # per ReLU: max |pre-activation|, number of units
 
     def __call__(self, x):
         own = x.detach() > 0
         i = len(self.own)
         self.own.append(own)
+        self.scale.append(float(x.detach().abs().max()))
+        self.count.append(int(x.numel()))
         if self.masks is None:
             return F.relu(x)
         m = self.masks[i].to(device=x.device).reshape(x.shape)

@@ -152,6 +152,60 @@ def wino_conv_bound():
     return MARGIN * max(max(r["wino44"], r["wino34"]) for r in conv_budget())
 
 
+# ---- the ReLU-flip budget (VERDICT r4 item 9b / ADVICE r4): WHICH pre-activations may take the other branch of a ReLU
+# is tied to the emulated rounding of the convolutions in front of it, per ReLU, instead of one flat constant.
+FLIP_K = 4.0        # a flipped pre-activation lies within FLIP_K x (accumulated emulated conv error x the ReLU input's scale)
+FLIP_COUNT_K = 1.0  # flips of a ReLU <= FLIP_COUNT_K x units x 0.8 x that error (0.8 d = P(|N(0,1)| < d), the emulated
+                    # error being a MAXIMUM over a layer where the typical unit sees a fraction of it) + FLIP_COUNT_FLOOR
+FLIP_COUNT_FLOOR = 4
+
+
+@functools.lru_cache(maxsize=None)
+def relu_flip_eps(path="default"):
+    """Per ReLU of the ResNet-18 in execution order (stem, (bn1, bn2) of the 8 blocks, bn5): the emulated rounding error
+    of the convolutions in front of it, relative to their output scale, accumulated root-sum-square along the network
+    (BatchNorm renormalises every layer's output, so relative errors carry over at O(1) gain).  3x3 stride-1 layers:
+    the Winograd error of the layer under ``default`` (tile rows as the library picks them), the direct kernel's under
+    ``strict``; stem, stride-2 and 1x1 convolutions: the direct kernel's."""
+    b = conv_budget()
+    layer_of_block = [0, 0, 1, 1, 2, 2, 3, 3]
+    acc2 = b[0]["direct"] ** 2  # the stem convolution
+    out = [acc2 ** 0.5]
+    for blk, li in enumerate(layer_of_block):
+        r, mh = b[li], LAYERS[li][4]
+        wino = r["wino44" if mh == 4 else "wino34"] if path == "default" else r["direct"]
+        first_of_strided = blk % 2 == 0 and li > 0
+        out.append(acc2 ** 0.5)                                   # bn1: the block's input
+        acc2 += (r["direct"] if first_of_strided else wino) ** 2  # conv1
+        out.append(acc2 ** 0.5)                                   # bn2: conv1's output
+        acc2 += wino ** 2 + (r["direct"] ** 2 if first_of_strided or blk == 0 else 0.0)  # conv2 (+ the 1x1 shortcut)
+    acc2 += b[3]["direct"] ** 2  # conv5
+    out.append(acc2 ** 0.5)
+    return out
+
+
+def check_relu_flips(probe, path, label=""):
+    """Every ReLU of the run under test: a unit whose decision differs from the fp64 oracle's had a pre-activation
+    within FLIP_K x eps_i x scale_i of 0, and there are at most FLIP_COUNT_K x units_i x 0.8 x eps_i x scale_i (+ floor)
+    of them - eps_i from relu_flip_eps(), scale_i = the largest |pre-activation| of that ReLU in the oracle's run.
+    Returns the per-ReLU table (also printed) for the record."""
+    eps = relu_flip_eps("default" if path == "default" else "strict")
+    assert len(probe.flips) == len(eps) == 18
+    rows = []
+    for i, (nf, mag, sc, n) in enumerate(zip(probe.flips, probe.flip_mag, probe.scale, probe.count)):
+        mag_bound = FLIP_K * eps[i] * sc
+        cnt_bound = FLIP_COUNT_K * n * 0.8 * eps[i] * sc + FLIP_COUNT_FLOOR
+        rows.append({"relu": i, "flips": nf, "units": n, "max_abs_preact": mag, "scale": sc, "eps": eps[i],
+                     "mag_bound": mag_bound, "count_bound": cnt_bound})
+    print("ReLU-flip budget %s[%s]: relu flips/bound  |preact|/bound" % (label, path))
+    for r in rows:
+        print("  %2d  %6d / %8.1f   %.2e / %.2e" % (r["relu"], r["flips"], r["count_bound"], r["max_abs_preact"], r["mag_bound"]))
+    for r in rows:
+        assert r["max_abs_preact"] <= r["mag_bound"], r
+        assert r["flips"] <= r["count_bound"], r
+    return rows
+
+
 def tol(key, path):
     """Tolerance of a model-level assertion under ``path`` = 'strict' | 'default'."""
     if path == "strict":
@@ -178,14 +232,15 @@ def check_bf16_band(errs, band):
     """bf16 gradients of a HIP run against the fp64 evaluation of the bf16 oracle (oracle/train.py::bf16_gradient_band).
     The band (the oracle's own fp32-vs-fp64 distances) is a SAMPLE of a chaotic process over ~150 tensors and so is
     the run under test: every tensor within 2.5x the oracle's own worst, cosine >= 0.85 (or the oracle's own worst
-    cosine less 0.1) - except at most 2 % of the tensors, which may reach 4x with cosine >= 0.6; the median within
-    2.5x the oracle's median."""
+    cosine less 0.1) - except at most 2 % of the tensors, which may reach 4x with cosine >= 0.8 (round 5: 0.6 until the
+    train-mode forward got its sharp pin, tests/test_ecapa_bf16_gpu.py::test_train_mode_every_stored_tensor_teacher_forced);
+    the median within 2.5x the oracle's median."""
     cos_floor = min(0.85, band["min_cos"] - 0.1)
     out = [k for k, (err, cos) in errs.items() if err > 2.5 * band["max"] or cos < cos_floor]
     print("outside the band:", [(k, round(errs[k][0], 3), round(errs[k][1], 3)) for k in out])
     assert len(out) <= max(1, len(errs) // 50), (out, band)
     for k in out:
-        assert errs[k][0] <= 4.0 * band["max"] and errs[k][1] >= 0.6, (k, errs[k], band)
+        assert errs[k][0] <= 4.0 * band["max"] and errs[k][1] >= 0.8, (k, errs[k], band)
     assert np.median([e for e, _ in errs.values()]) <= 2.5 * band["median"], (np.median([e for e, _ in errs.values()]), band)
 
 

@@ -363,3 +363,127 @@ def test_tap_conv_wgrad_all_branches(oh, cfg):
     again = [torch.empty((W, W, 3), device="cuda") for _ in range(nb)]
     oh.conv_tap_wgrad(xs, dys, T, d, again)
     assert all(torch.equal(a, b) for a, b in zip(outs, again))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the TRAIN-mode analogue of the eval-mode pin.  Model-level bf16 parity in train mode has been a
+# statistical band (batch statistics amplify one rounding ~100x through the filler-initialised net).  Teacher forcing
+# removes the amplification without leaving train mode: ONE whole train-mode forward of the bf16-resident model keeps
+# every tensor it stores (they are what backward reads); each stored tensor is then re-derived in fp64 from the stored
+# tensors it was computed FROM - the model's own inputs to that layer, bit for bit - with the layer's BatchNorm
+# statistics re-derived in fp64 from the stored BatchNorm input.  Required: every stored value within half a bf16 ulp
+# of that evaluation (the kernel tests' slack: + the fp32 sums' order noise), every batch statistic the kernels took
+# (from the convolution epilogues) within fp32 rounding of the fp64 statistic of the stored tensor.
+def _stats64(r):
+    mean = r.mean((0, 2))
+    var = r.var((0, 2), unbiased=False)
+    return mean, 1.0 / torch.sqrt(var + 1e-5)
+
+
+def _bn64(r, bn, st, name):
+    """fp64 BatchNorm(train) of the stored input r; checks the kernel's (mean, invstd) against the fp64 statistics."""
+    mean, invstd = _stats64(r)
+    rms = float(torch.sqrt((r * r).mean()))
+    got_m, got_i = st[0].cpu().double(), st[1].cpu().double()
+    assert float((got_m - mean).abs().max()) <= 2e-6 * rms, "%s: batch mean %.3g of rms" % (name, float((got_m - mean).abs().max()) / rms)
+    assert float((got_i / invstd - 1).abs().max()) <= 1e-5, "%s: invstd rel %.3g" % (name, float((got_i / invstd - 1).abs().max()))
+    g, b = bn.weight.detach().cpu().double(), bn.bias.detach().cpu().double()
+    return (r - mean[None, :, None]) * (invstd * g)[None, :, None] + b[None, :, None]
+
+
+@pytest.mark.parametrize("B,T", [(8, 200), (3, 401)])
+def test_train_mode_every_stored_tensor_teacher_forced(oh, B, T):
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from oracle.filler import fill_module_
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+    fill_module_(m)
+    m = m.cuda().train().set_compute_dtype("bf16")
+    x = synth_feat((B, 60, T), seed=900 + T)
+    with torch.no_grad():
+        feat, out, S = m._forward_impl(x.cuda(), save=True)
+    torch.cuda.synchronize()
+    assert S["resident"] and S["T"] == T
+    d = lambda p: p.detach().cpu().double()
+    rb = lambda t: t.to(torch.bfloat16).double()  # bf16 rounding of operands (weights)
+    V = lambda r: val(r.contiguous(), T)
+    checked = [0]
+
+    def stored(got_rows, exact, name, slack=0.56, floor_frac=4e-3):
+        ulp_ok(V(got_rows), exact, name, slack=slack, floor=float(exact.abs().max()) * floor_frac)
+        checked[0] += 1
+
+    def pw(xs, conv_w, bias, relu=True, bias_bc=None):
+        y = F.conv1d(xs, rb(d(conv_w)).view(conv_w.shape[0], -1, 1)) + d(bias)[None, :, None]
+        if bias_bc is not None:
+            y = y + bias_bc[:, :, None]
+        return F.relu(y) if relu else y
+
+    # conv1 (K = 5): bf16 operands, fp32 accumulate + fp32 bias -> ReLU -> stored; BatchNorm -> stored
+    c1 = F.conv1d(rb(x.double()), rb(d(m.conv1.weight)), None, 1, 2) + d(m.conv1.bias)[None, :, None]
+    stored(S["r0"], F.relu(c1), "conv1 -> relu")
+    stored(S["h"], _bn64(V(S["r0"]), m.bn1, S["st0"], "bn1"), "bn1", slack=0.53, floor_frac=1e-5)
+    inp = S["h"]
+    for k, (blk, SB) in enumerate(zip((m.layer1, m.layer2, m.layer3), S["blocks"])):
+        nm = "layer%d." % (k + 1)
+        w, dil, nums = blk.width, blk.dilation, blk.nums
+        assert SB["inp"].data_ptr() == inp.data_ptr()
+        xin = V(SB["inp"])
+        stored(SB["r1"], pw(xin, blk.conv1.weight, blk.conv1.bias), nm + "conv1 -> relu")
+        o1 = _bn64(V(SB["r1"]), blk.bn1, SB["st1"], nm + "bn1")  # (slices 0 .. nums-1 are overwritten in S['cat'] later)
+        cat = V(SB["cat"])
+        stored(SB["t"][0], o1[:, :w], nm + "bn1 slice 0 (branch 0 input)", slack=0.53, floor_frac=1e-5)
+        ulp_ok(cat[:, nums * w:], o1[:, nums * w:], nm + "bn1 pass-through slice", slack=0.53)
+        for i in range(nums):
+            ti = V(SB["t"][i])
+            wi = rb(d(blk.convs[i].weight))
+            ri = F.relu(F.conv1d(ti, wi, None, 1, dil, dil) + d(blk.convs[i].bias)[None, :, None])
+            stored(SB["r"][i], ri, nm + "convs.%d -> relu" % i)
+            yi = _bn64(V(SB["r"][i]), blk.bns[i], SB["st"][i], nm + "bns.%d" % i)
+            ulp_ok(cat[:, i * w:(i + 1) * w], yi, nm + "bns.%d (concat slice)" % i, slack=0.53)
+            checked[0] += 1
+            if i + 1 < nums:
+                # next branch input = bf16(stored y_i + stored o1 slice): o1's slice is not kept, so the exact slice
+                # stands in for it - one more half ulp of ITS rounding
+                tn = cat[:, i * w:(i + 1) * w] + o1[:, (i + 1) * w:(i + 2) * w]
+                stored(SB["t"][i + 1], tn, nm + "branch %d input" % (i + 1), slack=1.06, floor_frac=2e-3)
+        stored(SB["r3"], pw(cat, blk.conv3.weight, blk.conv3.bias), nm + "conv3 -> relu")
+        o3x = _bn64(V(SB["r3"]), blk.bn3, SB["st3"], nm + "bn3")
+        stored(SB["o3"], o3x, nm + "bn3", slack=0.53, floor_frac=1e-5)
+        o3 = V(SB["o3"])
+        close32(SB["m"], o3.mean(2), nm + "SE squeeze")
+        se = blk.se.se
+        z1 = F.relu(F.linear(SB["m"].cpu().double(), d(se[1].weight).view(se[1].out_channels, -1), d(se[1].bias)))
+        close32(SB["z1"], z1, nm + "se.1")
+        z1n = _bn64(SB["z1"].cpu().double().unsqueeze(2), se[3], SB["stS"], nm + "se.3").squeeze(2)
+        close32(SB["z1n"], z1n, nm + "se.3 apply", rtol=1e-4)
+        z2 = F.linear(SB["z1n"].cpu().double(), d(se[4].weight).view(se[4].out_channels, -1), d(se[4].bias))
+        close32(SB["z2"], z2, nm + "se.4")
+        outk = S["cat123"][:, k * 512:(k + 1) * 512]
+        stored(outk, o3 * torch.sigmoid(SB["z2"].cpu().double())[:, :, None] + xin, nm + "gate * o3 + x", slack=0.53, floor_frac=1e-5)
+        inp = outk
+    cat123 = V(S["cat123"])
+    stored(S["x4"], pw(cat123, m.layer4.weight, m.layer4.bias), "layer4 -> relu")
+    x4 = V(S["x4"])
+    close32(S["mean"], x4.mean(2), "context mean")
+    close32(S["std"], torch.sqrt(x4.var(2).clamp(min=1e-4)), "context std", rtol=1e-4)
+    w0 = d(m.attention[0].weight).view(128, -1)
+    ctxb = F.linear(torch.cat((S["mean"], S["std"]), 1).cpu().double(), w0[:, 1536:])
+    a1 = F.relu(F.conv1d(x4, rb(w0[:, :1536]).unsqueeze(2)) + ctxb[:, :, None] + d(m.attention[0].bias)[None, :, None])
+    stored(S["a1"], a1, "attention.0 -> relu")
+    stored(S["a1n"], _bn64(V(S["a1"]), m.attention[2], S["stA"], "attention.2"), "attention.2", slack=0.53, floor_frac=1e-5)
+    logits = pw(V(S["a1n"]), m.attention[3].weight, m.attention[3].bias, relu=False)
+    # the kernel stores the logits as bf16 and asp_fwd overwrites them with bf16(softmax over T of the STORED logits)
+    wts64 = torch.softmax(rb(logits), dim=2)
+    got_w = V(S["wts"])
+    # a logit within rounding of a bf16 tie moves its weight by a whole ulp of the LOGIT (e^(ulp) - 1 = 0.8 % of the
+    # weight = one weight ulp): weights within 1.6 ulp, and their sum over T within 1 % of 1
+    ulp_ok(got_w, wts64, "asp softmax weights", slack=1.6, floor=float(wts64.max()) * 1e-3)
+    assert float((got_w.sum(2) - 1).abs().max()) <= 1e-2
+    mu = (x4 * got_w).sum(2)
+    sg = torch.sqrt((((x4 * x4) * got_w).sum(2) - mu * mu).clamp(min=1e-4))
+    close32(S["pooled"], torch.cat((mu, sg), 1), "attentive statistics (mu | sg)", rtol=1e-4)
+    p5 = _bn64(S["pooled"].cpu().double().unsqueeze(2), m.bn5, S["st5"], "bn5").squeeze(2)
+    close32(S["p5"], p5, "bn5", rtol=1e-4)
+    close32(feat, F.linear(S["p5"].cpu().double(), d(m.fc6.weight), d(m.fc6.bias)), "fc6", rtol=1e-4)
+    print("teacher-forced train-mode pin: %d stored tensors within half a bf16 ulp, 34 BatchNorm statistics within fp32 rounding" % checked[0])
+    assert checked[0] == 3 * (2 + 2 * 7 + 6 + 3) + 5  # 80 stored (B, C, T) tensors

@@ -10,7 +10,7 @@ from oracle import ecapa as o_ecapa
 from oracle import lfcc as o_lfcc, pad as o_pad, resnet as o_resnet, train as o_train
 from oracle.filler import fill_module_, fill_state, fill_value, synth_feat, synth_pcm
 
-from _budget import check_bf16_band, conv_path, record, tol  # noqa: E402
+from _budget import check_bf16_band, check_relu_flips, conv_path, record, tol  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -83,8 +83,10 @@ def test_resnet_full_size_step_vs_oracle(path):
         nrm = np.linalg.norm(ref) + 1e-30
         e_hip = np.linalg.norm(gh.ravel().astype(np.float64) - ref) / nrm
         e_cpu = np.linalg.norm(go[k].numpy().ravel().astype(np.float64) - ref) / nrm
-        if path == "strict":
-            assert e_hip <= 3.0 * e_cpu + slack, (path, k, e_hip, e_cpu, slack)
+        # per tensor against the PLAIN fp64 oracle, both paths (the default path kept this bound for its worst
+        # tensor only): strict at the slack, default at twice the derived slack - the binding check for default is the
+        # masked oracle below, this one keeps a single bad tensor from hiding behind it
+        assert e_hip <= 3.0 * e_cpu + (slack if path == "strict" else 2.0 * slack), (path, k, e_hip, e_cpu, slack)
         if e_hip > worst[1]:
             worst = (k, e_hip, e_cpu)
     print("worst relative L2 gradient error vs fp64: %s hip %.2e (fp32 CPU oracle: %.2e)" % worst)
@@ -122,9 +124,13 @@ def test_resnet_full_size_step_vs_oracle(path):
               "run's decisions the worst tensor is %s at %.2e" % (n_flip, n_act, max(probe.flip_mag), worst_m[0], worst_m[1]))
         record("resnet_full_size_relu_flips[default]", {"flips": n_flip, "of": n_act, "max_abs_preact": max(probe.flip_mag),
                                                         "masked_worst": list(worst_m)})
-        # measured: 557 of 450,289,664 ReLU inputs, the largest |BatchNorm output| among them 4.7e-5
-        assert n_flip <= 2500 and max(probe.flip_mag) <= 2e-4, (n_flip, max(probe.flip_mag))
-        assert worst[1] <= 3.0 * worst[2] + 2.0 * slack, worst
+        # measured: 557 of 450,289,664 ReLU inputs, the largest |BatchNorm output| among them 4.7e-5.  Round 5: WHICH units
+        # may flip is tied to the emulated rounding per ReLU (tests/_budget.py::check_relu_flips: |pre-activation| <=
+        # FLIP_K x accumulated emulated conv error x the ReLU input's scale, count <= units x 0.8 x that error) instead of
+        # the flat 2500 / 2e-4 of round 4
+        rows = check_relu_flips(probe, path, "full size")
+        record("resnet_full_size_relu_flip_table[default]", rows)
+        assert n_flip <= 1200 and max(probe.flip_mag) <= 1e-4, (n_flip, max(probe.flip_mag))
     # the updated weights (Adam, lr 5e-4: every element moves by ~lr in step 1) agree to a fraction of a step
     w = tr.model.state_dict()["layer4.1.conv2.weight"].cpu().numpy()
     assert np.abs(w - otr.params["layer4.1.conv2.weight"].numpy()).max() <= 2 * 5e-4 + 1e-6

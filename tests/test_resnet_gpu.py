@@ -8,7 +8,7 @@ from oracle import resnet as o_resnet
 from oracle import train as o_train
 from oracle.filler import fill_module_, fill_state, fill_value, synth_feat
 
-from _budget import conv_path, record, tol  # noqa: E402
+from _budget import check_relu_flips, conv_path, record, tol  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -169,6 +169,8 @@ def _grads_vs_oracle_small(golden, path):
     print("ReLU flips %d of %d, masked worst rel L2 %.3g entry %.3g" % (n_flip, n_act, worst_m, worst_e))
     # normalised pre-activations are O(1): a flipped one was within rounding of 0, and there are few of them
     assert max(probe.flip_mag) <= FLIP_MAX_PREACT and n_flip <= FLIP_MAX_COUNT[path], (n_flip, probe.flip_mag)
+    # ... and per ReLU within the emulated rounding of the convolutions in front of it (tests/_budget.py)
+    record("resnet_small_relu_flip_table[%s]" % path, check_relu_flips(probe, path, "(2, 96)"))
     record("resnet_small_g_center_abs[%s]" % path, float(np.abs(lossm.center.grad.cpu().numpy() - g["g_center"]).max()))
     record("resnet_small_worst_grad_relL2[%s]" % path, float(worst))
     # (rtol = 0: the constant IS the bound - with round 1's rtol 1e-3 on entries of magnitude 1.75 it bound nothing)
