@@ -182,14 +182,18 @@ struct LfccArgs {
 constexpr int FLAG_EMPH = AIR_LFCC_EMPHASIS;
 constexpr int FLAG_DELTA = AIR_LFCC_DELTA;
 constexpr int FLAG_PADDED = 1 << 8;  // internal: (B, D, feat_len) output
+#ifndef LFCC_EXACT_NORM
+#define LFCC_EXACT_NORM 0
+#endif
 
-__global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_pcm[NSAMP];
-  __shared__ __attribute__((aligned(16))) float s_xch[NW * XCH_FLOATS];
-  __shared__ float s_c[FCOMP * MAXF];
-  __shared__ float s_fbwT[MAXW * MAXF];
-  __shared__ float s_dctT[MAXF * MAXF];
-
+// NF_C / MW_C > 0: the filter count and the widest filter are compile-time (the reference's LFCC(320, 160, 512, 16000,
+// 20): 20 filters, 26 bins) - the filterbank and DCT loops unroll onto immediate LDS offsets with no index arithmetic
+// (round 5: the kernel is VALU-issue bound - SQ_ACTIVE_INST_VALU 59 % of its cycles, 1314 VALU instructions per wave,
+// profiles/r05_lfcc.md - and ~40 % of them were address arithmetic, clamps and the correctly rounded sqrt).  0: any plan.
+template <int NF_C, int MW_C>
+__device__ __forceinline__ void lfcc_body(const LfccArgs& a, float* __restrict__ s_pcm, float* __restrict__ s_xch,
+                                          float* __restrict__ s_c, float* __restrict__ s_fbwT,
+                                          float* __restrict__ s_dctT) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
   const int tile = blockIdx.x - b * a.tiles;
   const int t0 = tile * FOUT;
   const LfccPlan* __restrict__ plan = a.plan;
-  const int nfilt = plan->nfilt;
-  const int maxw = plan->maxw;
+  const int nfilt = NF_C ? NF_C : plan->nfilt;
+  const int maxw = MW_C ? MW_C : plan->maxw;
   const int L = a.L, T = a.T;
   const float* __restrict__ row = a.pcm + (size_t)b * L;
   const short* __restrict__ row16 = a.pcm16 ? a.pcm16 + (size_t)b * L : nullptr;
@@ -326,23 +330,43 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
       const cf X = X1 - LFCC_HI(cs) * O;                     // - (s ore, s oim)
       const cf X2 = X * X;
       const float xr2 = X2.x, xi2 = X2.y;
-      // reference: norm(.,2,-1).pow(2)  (feature_extraction.py:113)
+      // reference: norm(.,2,-1).pow(2) (feature_extraction.py:113), i.e. fl(fl(sqrt(s))^2) - within 1.5 ulp of s itself.
+      // Round 5: the power is taken directly (X holds 2 x the bin: the factor 0.25 is exact); LFCC_EXACT_NORM = 1
+      // keeps the square root and the square (+ ~160 VALU instructions per wave for the correctly rounded sqrtf).
+#if LFCC_EXACT_NORM
       const float mag = 0.5f * sqrtf(xr2 + xi2);
       xch[f * PROW + g + 16 * p] = mag * mag;
+#else
+      xch[f * PROW + g + 16 * p] = 0.25f * (xr2 + xi2);
+#endif
       if (p == 0) {
         const float ny = x[0].x - x[0].y;  // X[256] = Re Z0 - Im Z0 (real)
         pnyq = ny * ny;
       }
     }
     if (g == 0) xch[f * PROW + 256] = pnyq;
+    if (MW_C && g >= 1 && g < PROW - 256) xch[f * PROW + 256 + g] = 0.0f;  // zeros behind the Nyquist bin (below)
     air_wave_lds_fence();
 
     // sparse triangular filterbank + log10 (feature_extraction.py:116-117)
     float acc0 = 0.0f, acc1 = 0.0f;
-    for (int w = 0; w < maxw; ++w) {
-      const int k0 = min(lo0 + w, NBIN - 1), k1 = min(lo1 + w, NBIN - 1);
-      acc0 = fmaf(xch[f * PROW + k0], s_fbwT[w * MAXF + j0], acc0);
-      acc1 = fmaf(xch[f * PROW + k1], s_fbwT[w * MAXF + j1], acc1);
+    if (MW_C) {
+      // filter j reads bins lo[j] .. lo[j] + MW_C - 1 <= PROW - 1 (checked where the plan is built): past its own
+      // support the weights are zero, past the Nyquist bin the row is zero - no clamp, immediate offsets
+      const float* __restrict__ pr0 = xch + f * PROW + lo0;
+      const float* __restrict__ pr1 = xch + f * PROW + lo1;
+      const float* __restrict__ wr = s_fbwT + j0;
+#pragma unroll
+      for (int w = 0; w < MW_C; ++w) {
+        acc0 = fmaf(pr0[w], wr[w * MAXF], acc0);
+        acc1 = fmaf(pr1[w], wr[w * MAXF + 16], acc1);
+      }
+    } else {
+      for (int w = 0; w < maxw; ++w) {
+        const int k0 = min(lo0 + w, NBIN - 1), k1 = min(lo1 + w, NBIN - 1);
+        acc0 = fmaf(xch[f * PROW + k0], s_fbwT[w * MAXF + j0], acc0);
+        acc1 = fmaf(xch[f * PROW + k1], s_fbwT[w * MAXF + j1], acc1);
+      }
     }
     xch[FBUF_OFF + f * MAXF + j0] = log10f(acc0 + 1.1920928955078125e-07f);
     xch[FBUF_OFF + f * MAXF + j1] = log10f(acc1 + 1.1920928955078125e-07f);
@@ -350,10 +374,21 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
 
     // DCT-II as a 20x20 product (feature_extraction.py:120)
     float c0 = 0.0f, c1 = 0.0f;
-    for (int j = 0; j < nfilt; ++j) {
-      const float fj = xch[FBUF_OFF + f * MAXF + j];
-      c0 = fmaf(fj, s_dctT[j * MAXF + j0], c0);
-      c1 = fmaf(fj, s_dctT[j * MAXF + j1], c1);
+    if (NF_C) {
+      const float* __restrict__ fr = xch + FBUF_OFF + f * MAXF;
+      const float* __restrict__ dr = s_dctT + j0;
+#pragma unroll
+      for (int j = 0; j < NF_C; ++j) {
+        const float fj = fr[j];
+        c0 = fmaf(fj, dr[j * MAXF], c0);
+        c1 = fmaf(fj, dr[j * MAXF + 16], c1);
+      }
+    } else {
+      for (int j = 0; j < nfilt; ++j) {
+        const float fj = xch[FBUF_OFF + f * MAXF + j];
+        c0 = fmaf(fj, s_dctT[j * MAXF + j0], c0);
+        c1 = fmaf(fj, s_dctT[j * MAXF + j1], c1);
+      }
     }
     s_c[i * MAXF + j0] = c0;
     s_c[i * MAXF + j1] = c1;
@@ -361,27 +396,60 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
   }
   __syncthreads();
 
-  // ---- deltas + coalesced store -------------------------------------------
+  // ---- deltas into an LDS tile, then coalesced stores -----------------------
+  // Round 5: a thread takes one coefficient of TWO neighbouring frames - six clamped cepstra c(t-2) .. c(t+3) give the
+  // static value, the delta and the delta-delta of both (same subtractions in the same order as value() of rounds 1-4) -
+  // and writes them into the exchange tile (dead by now); the copy out is then index arithmetic only.
   const bool with_delta = (a.flags & FLAG_DELTA) != 0;
   const int D = with_delta ? 3 * nfilt : nfilt;
   const int base = t0 - HALO;  // global frame of local row 0
-  auto cep = [&](int t, int c) -> float {  // clamped (replicate) access
-    t = min(max(t, 0), T - 1);
-    return s_c[(t - base) * MAXF + c];
-  };
-  auto value = [&](int t, int c) -> float {
-    if (c < nfilt) return cep(t, c);
-    if (c < 2 * nfilt) return cep(t + 1, c - nfilt) - cep(t - 1, c - nfilt);
-    const int cc = c - 2 * nfilt;
-    const int tp = min(t + 1, T - 1), tm = max(t - 1, 0);
-    return (cep(tp + 1, cc) - cep(tp - 1, cc)) - (cep(tm + 1, cc) - cep(tm - 1, cc));
-  };
-  if (!(a.flags & FLAG_PADDED)) {
+  const bool padded = (a.flags & FLAG_PADDED) != 0;
+  constexpr int OSTR = FOUT + 1;  // padded layout: s_out[c][fo], odd stride (conflict-free along fo)
+  float* __restrict__ s_out = s_xch;
+  {
+    const int npair = FOUT / 2;
+    for (int e = tid; e < nfilt * npair; e += NTHREADS) {
+      const int c = e / npair, pr = e - c * npair;
+      const int fo = 2 * pr, t = t0 + fo;
+      float v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v[k] = s_c[(min(max(t - 2 + k, 0), T - 1) - base) * MAXF + c];
+      // d[k] = delta at frame t - 1 + k:  c(cl(u + 1)) - c(cl(u - 1))
+      const float d0 = v[2] - v[0], d1 = v[3] - v[1], d2 = v[4] - v[2], d3 = v[5] - v[3];
+      // delta-delta(u) = delta(min(u + 1, T - 1)) - delta(max(u - 1, 0))   (feature_extraction.py:41-58 applied twice)
+      const float dd0 = (t + 1 <= T - 1 ? d2 : d1) - (t - 1 >= 0 ? d0 : d1);
+      const float dd1 = (t + 2 <= T - 1 ? d3 : d2) - d1;  // (t >= 0)
+      if (!padded) {
+        s_out[fo * D + c] = v[2];
+        s_out[(fo + 1) * D + c] = v[3];
+        if (with_delta) {
+          s_out[fo * D + nfilt + c] = d1;
+          s_out[(fo + 1) * D + nfilt + c] = d2;
+          s_out[fo * D + 2 * nfilt + c] = dd0;
+          s_out[(fo + 1) * D + 2 * nfilt + c] = dd1;
+        }
+      } else {
+        s_out[c * OSTR + fo] = v[2];
+        s_out[c * OSTR + fo + 1] = v[3];
+        if (with_delta) {
+          s_out[(nfilt + c) * OSTR + fo] = d1;
+          s_out[(nfilt + c) * OSTR + fo + 1] = d2;
+          s_out[(2 * nfilt + c) * OSTR + fo] = dd0;
+          s_out[(2 * nfilt + c) * OSTR + fo + 1] = dd1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!padded) {
     float* __restrict__ orow = a.out + ((size_t)b * T + t0) * D;
     const int nvalid = min(FOUT, T - t0);
-    for (int e = tid; e < nvalid * D; e += NTHREADS) {
-      const int fo = e / D, c = e - fo * D;
-      orow[e] = value(t0 + fo, c);
+    const int n = nvalid * D;
+    if ((D & 3) == 0 && ((reinterpret_cast<size_t>(orow) & 15) == 0)) {
+      for (int e = tid; e < n / 4; e += NTHREADS)
+        reinterpret_cast<float4*>(orow)[e] = reinterpret_cast<const float4*>(s_out)[e];
+    } else {
+      for (int e = tid; e < n; e += NTHREADS) orow[e] = s_out[e];
     }
   } else {
     // (B, D, feat_len): frame t lands on t' = t - start (+ k T when repeating)
@@ -395,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
       const int c = e / FOUT, fo = e - c * FOUT;
       const int t = t0 + fo;
       if (t >= T) continue;
-      const float v = value(t, c);
+      const float v = s_out[c * OSTR + fo];
       if (T >= flen) {
         const int tp = t - start;
         if (tp >= 0 && tp < flen) obase[(size_t)c * flen + tp] = v;
@@ -415,6 +483,19 @@ __global__ __launch_bounds__(NTHREADS) void lfcc_kernel(LfccArgs a) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void lfcc_kernel(LfccArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_pcm[NSAMP];
+  __shared__ __attribute__((aligned(16))) float s_xch[NW * XCH_FLOATS];
+  __shared__ float s_c[FCOMP * MAXF];
+  __shared__ float s_fbwT[MAXW * MAXF];
+  __shared__ float s_dctT[MAXF * MAXF];
+  // (pad0 = 1: the plan is the reference's geometry - 20 filters of at most 26 bins that end inside the padded power row)
+  if (a.plan->pad0 == 1)
+    lfcc_body<20, 26>(a, s_pcm, s_xch, s_c, s_fbwT, s_dctT);
+  else
+    lfcc_body<0, 0>(a, s_pcm, s_xch, s_c, s_fbwT, s_dctT);
 }
 
 // ---- in-place pre-emphasis (the reference mutates its input, :106) ----------
@@ -554,6 +635,11 @@ int air_lfcc_plan_build(const float* fb_host, int nbin, int nfilt, const float* 
     for (int i = 0; i < cnt; ++i) p->fbwT[i * MAXF + j] = fb_host[(size_t)(first + i) * nfilt + j];
   }
   p->maxw = maxw;
+  // the specialised instance of lfcc_kernel (20 filters, <= 26 bins each, every filter's 26-bin window inside the padded
+  // power row - PROW floats, zeros behind the Nyquist bin): the reference's LFCC(320, 160, 512, 16000, 20)
+  bool fast = nfilt == 20 && maxw <= 26;
+  for (int j = 0; j < MAXF; ++j) fast = fast && p->lo[j] + 26 <= PROW;
+  p->pad0 = fast ? 1 : 0;
   for (int i = 0; i < nfilt; ++i)
     for (int j = 0; j < nfilt; ++j) p->dctT[j * MAXF + i] = dct_host[(size_t)i * nfilt + j];
   return AIR_OK;
