@@ -21,6 +21,7 @@ enum AirOption {
   AIR_OPT_SKINNY_WGRAD,        // 1: streaming 16x16x4-MFMA weight gradient for the 16 -> 64 1x1 layer (0: the 64-channel-tile kernel)
   AIR_OPT_CONV_S2,             // bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (3 resident workgroups per CU, not 1);
                                // bit 2: stride-2 3x3 data gradient as one pass over dy (conv_s2_dgrad_kernel), not four class launches
+                               // bit 4: stride-2 3x3 forward as six bf16 products per fp32 product (conv_bf3.hip)
   AIR_OPT_COUNT
 };
 

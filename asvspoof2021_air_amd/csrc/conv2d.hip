@@ -34,6 +34,7 @@
 #include "air_prof.h"
 #include "air_lds_dma.h"
 #include "conv_wino.h"
+#include "conv_bf3.h"
 
 namespace {
 
@@ -1721,6 +1722,12 @@ static int skinny_wgrad_chunk_px(const AirConv2d* p, int nchunk) {
   return ((hw + nchunk - 1) / nchunk + 63) / 64 * 64;
 }
 
+// the split-bf16 forward of a 3x3 / stride 2 / pad 1 layer (conv_bf3.hip; option CONV_S2 bit 4)
+static bool bf3_fwd_ok(const AirConv2d* p) {
+  return p->KH == 3 && p->KW == 3 && p->sh == 2 && p->sw == 2 && p->ph == 1 && p->pw == 1 && generic_ok(p) && !direct_ok(p) &&
+         air_bf3_s2_ok(p->B, p->Cin, p->H, p->W, p->Cout);
+}
+
 size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   if (!p || !shape_ok(p)) return 0;
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
@@ -1732,6 +1739,10 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
     const int ntiles = p->B * p->Ho * ((p->Wo + PXT - 1) / PXT);
     if (((ntiles + NWAVE - 1) / NWAVE) * ((p->Cout + 31) / 32) <= 1536)
       fwd = slab + 4 * (size_t)p->B * p->Cout * p->Ho * p->Wo;
+  }
+  if (bf3_fwd_ok(p)) {  // bf16 planes: 6 bytes per weight
+    const size_t pl = (air_bf3_s2_packed_bytes(p->Cout, p->Cin) + 3) / 4;
+    if (pl > fwd) fwd = pl;
   }
   size_t dgrad = packed_dgrad_elems(p);
   if (wino_shape(p)) {  // transformed weights are 16/9 the size
@@ -1975,6 +1986,7 @@ size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
   const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
   if (kind == 4) return air_wino4_packed_elems(M, Kc) * sizeof(float);
   if (kind == 2) return air_wino_packed_elems(M, Kc) * sizeof(float);
+  if (pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_packed_bytes(p->Cout, p->Cin);
   if (!generic_pack_ok(p, pass)) return 0;
   PackScope size(PK_SIZE, nullptr);
   float* none = nullptr;
@@ -1991,6 +2003,7 @@ int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, 
   const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
   float* up = reinterpret_cast<float*>(out);
   const int kind = wino_kind(p, pass);
+  if (kind == 0 && pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_weights(w, out, p->Cout, p->Cin, air_stream(stream));
   if (kind == 0) {  // the direct kernels' slabs, in the order fwd_generic / dgrad_generic consume them
     PackScope collect(PK_COLLECT, up);
     float* none = nullptr;
@@ -2049,6 +2062,15 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
                            const_cast<float*>(reinterpret_cast<const float*>(w_packed)), conv_flops(p), st);
     return air_wino_conv(x, w, y, residual, p->B, p->Cin, p->H, p->W, p->Cout, 0, wp,
                          conv_flops(p), st);
+  }
+  if (in_scale == nullptr && residual == nullptr && bf3_fwd_ok(p)) {
+    const size_t need = air_bf3_s2_packed_bytes(p->Cout, p->Cin);
+    if (w_packed == nullptr) {
+      if (ws_bytes < need) return AIR_EWORKSPACE;
+      const int rc = air_bf3_s2_weights(w, ws, p->Cout, p->Cin, st);
+      if (rc != AIR_OK) return rc;
+    }
+    return air_bf3_s2_fwd(x, w_packed ? w_packed : ws, y, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo, conv_flops(p), st);
   }
   if (w_packed != nullptr && wino_kind(p, 0) == 0) {  // slabs from air_conv2d_prepack (a Winograd-shaped layer's
     PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));  // buffer is not ours)

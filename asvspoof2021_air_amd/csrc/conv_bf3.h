@@ -1,0 +1,10 @@
+// Split-bf16 ("bf16 x 3", six products on v_mfma_f32_32x32x16_bf16) stride-2 3x3 forward convolution (conv_bf3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+bool air_bf3_s2_ok(int B, int Cin, int H, int W, int Cout);   // option CONV_S2 bit 4 and the shape constraints
+size_t air_bf3_s2_packed_bytes(int Cout, int Cin);            // weight planes in fragment order
+int air_bf3_s2_weights(const float* w, void* packed, int Cout, int Cin, hipStream_t st);
+int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo,
+                   double flops, hipStream_t st);

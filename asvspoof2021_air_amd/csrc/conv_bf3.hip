@@ -1,0 +1,440 @@
+// Stride-2 3x3 convolution forward on the bf16 matrix cores with fp32-EQUIVALENT arithmetic ("bf16 x 3").
+//
+// Replaces, for the three stride-2 conv1 layers of the ResNet (resnet.py:59: layer2.0 / layer3.0 / layer4.0 .conv1, 3.2 %
+// + 3.5 % + 4.2 % of the forward FLOPs), the direct kernel on v_mfma_f32_32x32x2_f32 (conv2d.hip, ~90 TF of a
+// 157 TF peak).  Every fp32 operand is split EXACTLY into three bf16 planes, x = hi + mid + lo (8 + 8 + 8 mantissa bits,
+// round to nearest even at each step), and the product is taken as the six terms
+//     hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the dropped terms (mid.lo, lo.mid, lo.lo) are below 2^-24 of the
+// product.  Emulated against fp64 the six-product form sits BELOW the fp32 fma chain it replaces (1.6e-7 .. 5.7e-7 of
+// the output scale for K = 576 .. 4608 against 6.6e-7 .. 1.4e-6: profiles/r05_split_bf16.md), an order of magnitude
+// inside the direct kernels' parity bound (tests/_budget.py: conv_rtol 1e-5).  Ceiling 2500 / 6 = 417 TF.
+//
+// Mapping (wave64, one 4-wave workgroup per CU):
+//   * a wave owns 64 output channels x NT x 32 consecutive output pixels of one output row; the four waves of a
+//     workgroup take four neighbouring pixel groups and SHARE the weights;
+//   * weights: split into planes once per optimiser step by bf3_pack_kernel (air_conv2d_prepack), laid out in MFMA
+//     fragment order; a 54 KB slab = 16 input channels x 9 taps x 64 channels x 3 planes is staged per K chunk by
+//     LDS-DMA, double buffered (108 KB);
+//   * activations: NO LDS - a lane loads the 8 channels x 3 columns of its pixel straight from global memory (the rows of
+//     one channel plane are contiguous: 128-byte segments per 32 lanes), splits them in registers (11 VALU per pair of
+//     values: v_cvt_pk_bf16_f32 + shifts + subtractions) and keeps the nine fragments of a kernel row; the loads of
+//     the NEXT row are issued right behind the split, under that row's 3 x 24 MFMAs;
+//   * one K step = one tap x 16 channels: 6 products x 2 channel tiles x NT pixel tiles MFMAs.
+#include "air_common.h"
+#include "air_lds_dma.h"
+#include "air_options.h"
+#include "air_prof.h"
+#include "conv_bf3.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef BF3_EXP
+#define BF3_EXP 0
+#endif
+#ifndef BF3_SCHED
+#define BF3_SCHED 1
+#endif
+constexpr int NWAVE = 4;
+constexpr int CK = 16;                                  // input channels per K chunk = the MFMA's K
+constexpr int TAPS = 9;
+constexpr int SLAB_U4 = TAPS * 2 * 3 * 64;              // 16-byte words per (channel tile, chunk) slab
+constexpr int SLAB_BYTES = SLAB_U4 * 16;                // 55,296
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32: round to nearest even
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// x = hi + mid + lo, each a bf16 (exact: 24 significant bits over three 8-bit pieces)
+__device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = v[2 * q], b = v[2 * q + 1];
+    const unsigned h = pack2(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack2(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    hi[q] = h;
+    mid[q] = m;
+    lo[q] = pack2(sa, sb);
+  }
+}
+
+// fp32 weights (Cout, Cin, 3, 3) -> planes in fragment order:
+//   word(((cot * nchunk + chunk) * 9 + tap) * 2 + mt) * 3 + plane) * 64 + lane) = 8 bf16: channel co = cot * 64 + mt * 32
+//   + (lane & 31), input channels chunk * 16 + 8 * (lane >> 5) + 0 .. 7
+__global__ __launch_bounds__(256) void bf3_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Cout,
+                                                       int Cin, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63;
+  int blk = e >> 6;
+  const int mt = blk & 1;
+  blk >>= 1;
+  const int tap = blk % TAPS;
+  blk /= TAPS;
+  const int nchunk = Cin / CK;
+  const int chunk = blk % nchunk, cot = blk / nchunk;
+  const int co = cot * 64 + mt * 32 + (lane & 31);
+  const int ci0 = chunk * CK + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = w[((size_t)co * Cin + ci0 + i) * TAPS + tap];
+  u32x4 hi, mid, lo;
+  split3(v, hi, mid, lo);
+  u32x4* dst = wp + ((size_t)(e >> 6) * 3) * 64 + lane;
+  dst[0] = hi;
+  dst[64] = mid;
+  dst[128] = lo;
+}
+
+struct Bf3Args {
+  const float* x;
+  const u32x4* wp;
+  float* y;
+  int B, Cin, H, W, Cout, Ho, Wo;
+  int WT;       // pixel groups (NT x 32 pixels) per output row
+  int ngroups;  // B * Ho * WT
+  int ncot;     // Cout / 64
+};
+
+template <int NT>
+__global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Args a) {
+  __shared__ __attribute__((aligned(16))) u32x4 slab[2 * SLAB_U4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lb % a.ncot;
+  const int pxg = lb / a.ncot;
+  const int grp = pxg * NWAVE + wave;
+  const bool grp_ok = grp < a.ngroups;
+  const int grpc = min(grp, a.ngroups - 1);  // (a surplus wave recomputes the last group and stores nothing)
+  const int wt = grpc % a.WT;
+  const int rowid = grpc / a.WT;
+  const int ho = rowid % a.Ho, b = rowid / a.Ho;
+  const int wo0 = wt * (32 * NT);
+  const int hi0 = 2 * ho - 1;
+  const int H = a.H, W = a.W;
+  const int HW = H * W;
+  const int nchunk = a.Cin / CK;
+
+  // Columns of this lane's pixel wo in tile j: 2 wo - 1, 2 wo, 2 wo + 1.  The lane loads (2 wo, 2 wo + 1) as ONE 8-byte
+  // word (16 loads per kernel row instead of 48; 4-byte aligned when W is odd - global memory takes that) and gets
+  // 2 wo - 1 from its left neighbour's second element (ds_bpermute); lane 0 of tile j > 0 takes it from lane 31 of tile
+  // j - 1, lane 0 of tile 0 from one extra load.  Indices are clamped into the row; what a clamp changed is masked:
+  //   * left edge (wo0 == 0): column -1 is padding -> the extra value is 0;
+  //   * odd W: the last pixel's 2 wo = W - 1 -> its pair is loaded one column early: c1 = second element, c2 = padding.
+  unsigned off2[NT];   // float offset of the pair inside a channel plane row, + this half's 8 channels
+  bool fix_last[NT];   // this lane's 2 wo == W - 1 (odd W only)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c1 = 2 * (wo0 + 32 * j + l31);
+    fix_last[j] = c1 == W - 1;
+    off2[j] = (unsigned)(8 * half * HW + min(c1, W - 2));
+  }
+  const unsigned offl = (unsigned)(8 * half * HW + max(2 * wo0 - 1, 0));
+  const bool left_pad = wo0 == 0;         // wave-uniform
+  const bool odd_w = (W & 1) != 0;        // uniform
+  const int src_lane4 = 4 * (l31 > 0 ? lane - 1 : lane + 31);
+  bool rowok[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) rowok[kh] = hi0 + kh >= 0 && hi0 + kh < H;
+
+  // buffer loads: one descriptor per wave over its utterance's (Cin, H, W) block; the per-lane byte offset (this half's
+  // 8 channels + the column pair) never changes, the (chunk, channel, row) part travels in the SCALAR offset operand -
+  // no vector arithmetic per load
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (size_t)b * a.Cin * HW), (short)0, (int)((unsigned)a.Cin * (unsigned)HW * 4u), 0x00020000);
+  unsigned voff2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) voff2[j] = 4u * off2[j];
+  const unsigned voffl = 4u * offl;
+  f32x2 ld2[NT][8];  // the loads in flight: [tile][channel] = columns (2 wo, 2 wo + 1)
+  float ldl[8];      // column 2 wo0 - 1 (used by lane 0 of tile 0)
+  auto load_row = [&](int chunk, int kh) {
+    const unsigned s0 = 4u * (unsigned)((chunk * CK) * HW + (hi0 + kh) * W);  // uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned so = s0 + 4u * (unsigned)(i * HW);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        ld2[j][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff2[j], so, 0));
+      ldl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voffl, so, 0));  // (masked in gather_row)
+    }
+  };
+  // raw[tile][kernel column][channel] from the landed loads
+  float raw[NT][3][8];
+  auto gather_row = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float prev = left_pad ? 0.0f : ldl[i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float c1 = ld2[j][i].x, c2 = ld2[j][i].y;
+        if (odd_w) {
+          c1 = fix_last[j] ? c2 : c1;
+          c2 = fix_last[j] ? 0.0f : c2;
+        }
+        const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, c2)));
+        raw[j][0][i] = l31 > 0 ? t : prev;
+        raw[j][1][i] = c1;
+        raw[j][2][i] = c2;
+        prev = t;  // (for lane 0: lane 31's second element of this tile)
+      }
+    }
+  };
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(slab)));
+  const u32x4* __restrict__ wsrc = a.wp + (size_t)cot * nchunk * SLAB_U4;
+  auto dma = [&](int chunk, int buf) {
+    const u32x4* __restrict__ src = wsrc + (size_t)chunk * SLAB_U4;
+#pragma unroll
+    for (int i = 0; i < (SLAB_U4 / 64 + NWAVE - 1) / NWAVE; ++i) {
+      const int blk = wave + NWAVE * i;  // 1 KB block (wave-uniform)
+      if (blk < SLAB_U4 / 64)
+        dma16(reinterpret_cast<const float*>(src + blk * 64 + lane), lds0 + (unsigned)(buf * SLAB_BYTES + blk * 1024));
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.0f;
+
+  // The K loop walks the VALID kernel rows (a padding row contributes nothing and is skipped: wave-uniform) of every
+  // chunk as one flat sequence, software-pipelined two rows deep:
+  //   row it + 2: loads in flight | row it + 1: gathered and split into planes (VALU) | row it: 3 x 24 MFMAs
+  // so that the split of the next row can be issued in the shadow of this row's MFMAs.
+  const int kh0 = rowok[0] ? 0 : 1;                                         // valid rows are contiguous
+  const int nv = (rowok[0] ? 1 : 0) + (rowok[1] ? 1 : 0) + (rowok[2] ? 1 : 0);
+  const int total = nchunk * nv;
+  auto split_row = [&](u32x4 (&bp)[3][NT][3]) {
+    gather_row();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#if BF3_EXP & 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bp[c][j][0][q] = __builtin_bit_cast(unsigned, raw[j][c][q]);
+          bp[c][j][1][q] = __builtin_bit_cast(unsigned, raw[j][c][q + 4]);
+          bp[c][j][2][q] = __builtin_bit_cast(unsigned, raw[j][c][(q + 2) & 7]);
+        }
+#else
+        split3(raw[j][c], bp[c][j][0], bp[c][j][1], bp[c][j][2]);
+#endif
+      }
+  };
+  u32x4 bpA[3][NT][3], bpB[3][NT][3];  // [kernel column][tile][plane] of two consecutive rows
+  // (chunk, r) of the row being computed, one and two rows ahead
+  int c0 = 0, r0 = 0, c1, r1, c2, r2;
+  auto advance = [&](int c, int r, int& cn, int& rn) {
+    rn = r + 1;
+    cn = c;
+    if (rn == nv) { rn = 0; cn = c + 1; }
+  };
+  advance(c0, r0, c1, r1);
+  advance(c1, r1, c2, r2);
+
+  dma(0, 0);
+  load_row(0, kh0);
+  split_row(bpA);                              // row 0
+  load_row(total > 1 ? c1 : 0, kh0 + (total > 1 ? r1 : 0));  // row 1 in flight
+  dma_wait();
+  __syncthreads();
+  if (nchunk > 1) dma(1, 1);
+
+  // Per row: 3 x 6 x 2 x NT MFMAs, and between them - pinned by sched_barrier, one item behind every second MFMA so
+  // that each runs in the shadow of the matrix pipe - the work that prepares row it + 1 and fetches row it + 2:
+  //   items 0 .. 8     channel i: bpermute issue (item i) / selects into raw + the loads of row it + 2 (item i + 1)
+  //   items 9 ..       the pair splits, (pair q, column c, tile j): 11 VALU each
+  float tperm[NT];  // bpermute results in flight (channel i, consumed one item later)
+  float pc1[NT], pc2[NT];
+  auto body = [&](u32x4 (&cur)[3][NT][3], u32x4 (&nxt)[3][NT][3], int it) {
+    const u32x4* __restrict__ sl = slab + (c0 & 1) * SLAB_U4 + (kh0 + r0) * (3 * 2 * 3 * 64) + lane;
+    const bool more = it + 2 < total;  // (past the end the loads redo the last row: harmless)
+    const unsigned s_next = 4u * (unsigned)(((more ? c2 : c1) * CK) * HW + (hi0 + kh0 + (more ? r2 : r1)) * W);
+    auto perm_issue = [&](int i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float c1v = ld2[j][i].x, c2v = ld2[j][i].y;
+        if (odd_w) {
+          c1v = fix_last[j] ? c2v : c1v;
+          c2v = fix_last[j] ? 0.0f : c2v;
+        }
+        pc1[j] = c1v;
+        pc2[j] = c2v;
+        tperm[j] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane4, __builtin_bit_cast(int, c2v)));
+      }
+    };
+    auto perm_take = [&](int i) {
+      float prev = left_pad ? 0.0f : ldl[i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        raw[j][0][i] = l31 > 0 ? tperm[j] : prev;
+        raw[j][1][i] = pc1[j];
+        raw[j][2][i] = pc2[j];
+        prev = tperm[j];
+      }
+#if !(BF3_EXP & 1)
+      const unsigned so = s_next + 4u * (unsigned)(i * HW);  // the loads of row it + 2, channel i
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        ld2[j][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff2[j], so, 0));
+      ldl[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voffl, so, 0));
+#endif
+    };
+    auto pair_split = [&](int k) {  // k = (q * 3 + c) * NT + j: pair q needs channels 2 q, 2 q + 1 (taken by item 2 q + 2)
+      const int j = k % NT, c = (k / NT) % 3, q = k / (3 * NT);
+      const float av = raw[j][c][2 * q], bv = raw[j][c][2 * q + 1];
+#if BF3_EXP & 2
+      nxt[c][j][0][q] = __builtin_bit_cast(unsigned, av);
+      nxt[c][j][1][q] = __builtin_bit_cast(unsigned, bv);
+      nxt[c][j][2][q] = __builtin_bit_cast(unsigned, av) ^ __builtin_bit_cast(unsigned, bv);
+#else
+      const unsigned h = pack2(av, bv);
+      const float ra = av - __builtin_bit_cast(float, h << 16), rb = bv - __builtin_bit_cast(float, h & 0xffff0000u);
+      const unsigned m = pack2(ra, rb);
+      const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+      unsigned hh = h, mm = m, ll = pack2(sa, sb);
+      // (pins the split HERE: without it the compiler sinks the whole computation to its first use, the next row's
+      // MFMAs, i.e. out of the shadow of this row's)
+      asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));
+      nxt[c][j][0][q] = hh;
+      nxt[c][j][1][q] = mm;
+      nxt[c][j][2][q] = ll;
+#endif
+    };
+    constexpr int NITEM = 9 + 4 * 3 * NT;
+    auto item = [&](int k) {
+      if (k < 9) {
+        if (k >= 1) perm_take(k - 1);
+        if (k < 8) perm_issue(k);
+      } else {
+        pair_split(k - 9);
+      }
+    };
+    u32x4 ap[2][3], apn[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) ap[m][pl] = sl[(m * 3 + pl) * 64];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // six products, small terms first
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      if (kw < 2) {  // the next tap's weight fragments, read under this tap's MFMAs
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) apn[m][pl] = sl[(((kw + 1) * 2 + m) * 3 + pl) * 64];
+      }
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {  // (consecutive MFMAs go to different accumulators)
+            const int n = ((kw * 6 + p) * 2 + m) * NT + j;
+            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[m][PA[p]]),
+                                                                __builtin_bit_cast(bf16x8, cur[kw][j][PB[p]]), acc[m][j],
+                                                                0, 0, 0);
+#if BF3_SCHED
+            if ((n & 1) == 0 && n / 2 < NITEM) item(n / 2);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ap[m][pl] = apn[m][pl];
+    }
+#if !BF3_SCHED
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) item(k);
+#endif
+    if (r0 == nv - 1) {  // last row of a chunk: the next chunk's slab has landed; this one's buffer is free for the one after
+      dma_wait();
+      __syncthreads();
+      if (c0 + 2 < nchunk) dma(c0 + 2, c0 & 1);
+    }
+    c0 = c1; r0 = r1; c1 = c2; r1 = r2;
+    advance(c1, r1, c2, r2);
+  };
+  for (int it = 0; it < total; it += 2) {
+    body(bpA, bpB, it);
+    if (it + 1 < total) body(bpB, bpA, it + 1);
+  }
+
+  // epilogue: D row i = (r & 3) + 8 (r >> 2) + 4 half -> output channel, column l31 -> pixel
+  if (!grp_ok) return;
+  const size_t plane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int wo = wo0 + 32 * j + l31;
+      if (wo >= a.Wo) continue;
+      float* __restrict__ yo = a.y + ((size_t)b * a.Cout + cot * 64 + m * 32 + 4 * half) * plane + (size_t)ho * a.Wo + wo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yo[(size_t)((r & 3) + 8 * (r >> 2)) * plane] = acc[m][j][r];
+    }
+}
+
+int pick_nt(int Wo) {
+  // pixel tiles of 32 per wave: the split that wastes the fewest pixel columns (Wo = 375: 6 x 64 = 384; 188: 3 x 64 = 192;
+  // 94: 1 x 96)
+  const int w2 = (Wo + 63) / 64 * 64, w3 = (Wo + 95) / 96 * 96;
+  return w3 < w2 ? 3 : 2;
+}
+
+}  // namespace
+
+bool air_bf3_s2_ok(int B, int Cin, int H, int W, int Cout) {
+  return (air_opt(AIR_OPT_CONV_S2) & 4) != 0 && B > 0 && Cin % CK == 0 && Cout % 64 == 0 && H >= 2 && W >= 2;
+}
+
+size_t air_bf3_s2_packed_bytes(int Cout, int Cin) { return (size_t)(Cout / 64) * (Cin / CK) * SLAB_BYTES; }
+
+int air_bf3_s2_weights(const float* w, void* packed, int Cout, int Cin, hipStream_t st) {
+  const int total = (Cout / 64) * (Cin / CK) * TAPS * 2 * 64;
+  hipLaunchKernelGGL(bf3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<u32x4*>(packed), Cout,
+                     Cin, total);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo,
+                   double flops, hipStream_t st) {
+  Bf3Args a;
+  a.x = x; a.wp = reinterpret_cast<const u32x4*>(packed); a.y = y;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
+  const int nt = pick_nt(Wo);
+  a.WT = (Wo + 32 * nt - 1) / (32 * nt);
+  a.ngroups = B * Ho * a.WT;
+  a.ncot = Cout / 64;
+  const int nblk = ((a.ngroups + NWAVE - 1) / NWAVE) * a.ncot;
+  // MFMA FLOPs issued: 6 products per algorithmic multiply-add
+  AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
+  if (nt == 3)
+    hipLaunchKernelGGL(conv_s2_bf3_kernel<3>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv_s2_bf3_kernel<2>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}

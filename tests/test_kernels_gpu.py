@@ -85,12 +85,14 @@ S2 = [
 ]
 
 
-@pytest.mark.parametrize("s2", [0, 1])
+@pytest.mark.parametrize("s2", [0, 1, 7])
 @pytest.mark.parametrize("cfg", S2)
 @pytest.mark.parametrize("fused", [False, True])
 def test_conv2d_stride2_options(ops, cfg, fused, s2):
     """Option CONV_S2: the stride-2 3x3 forward in 4- or 8-channel K chunks - either an fmaf chain held to the direct
-    kernels' constant (1e-5 of the output scale); the weight gradient of the same layers beside it."""
+    kernels' constant (1e-5 of the output scale) - or (bit 4, plain input only) as six bf16 products per fp32 product on
+    operands split exactly into three bf16 planes (conv_bf3.hip), held to the SAME constant; the weight gradient of the
+    same layers beside it."""
     from asvspoof2021_air_amd import _hip
     B, Cin, H, W, Cout = cfg
     x = synth_feat((B, Cin, H, W), 1)
@@ -110,6 +112,38 @@ def test_conv2d_stride2_options(ops, cfg, fused, s2):
         gw = ops.conv2d_wgrad(x.cuda(), dy.cuda(), tuple(w.shape), 2, 1, sc, sh, relu=fused)
     close(got, y.detach(), rtol=1e-5, name="conv2d_fwd stride 2")
     close(gw, w.grad, rtol=1e-5, name="conv2d_wgrad stride 2")
+
+
+@pytest.mark.parametrize("cfg", S2 + [(2, 16, 2, 2, 64), (1, 32, 7, 61, 64), (5, 48, 11, 200, 192), (64, 256, 5, 188, 512)])
+def test_conv2d_stride2_split_bf16(ops, cfg):
+    """conv_bf3.hip (built): 3x3 / stride 2 forward as hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid
+    on v_mfma_f32_32x32x16_bf16 with x = hi + mid + lo exact.  fp32-EQUIVALENT arithmetic or it does not ship: held to
+    the direct f32 kernels' constant (STRICT conv_rtol = 1e-5 of the output scale; measured 8e-7 .. 1.5e-6, the f32 chain
+    4e-7 .. 5e-7) against fp64; the layer takes this path (the prepacked planes are 6 bytes per weight); prepacked ==
+    packed in place, bit for bit; shapes: every ResNet geometry, the smallest image, odd widths, 3-tile rows, B = 64 at
+    layer4's size."""
+    import ctypes
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = torch.relu(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    nref = min(B, 3)
+    want = F.conv2d(x[:nref].double(), w.double(), None, 2, 1)
+    with _hip.options(CONV_S2=7):
+        d = ops._conv_desc(x.shape, w.shape, 2, 1)
+        assert int(_hip.lib().air_conv2d_prepack_bytes(ctypes.byref(d), 0)) == (Cout // 64) * (Cin // 16) * 9 * 2 * 3 * 1024
+        got = ops.conv2d_fwd(x.cuda(), w.cuda(), 2, 1)
+        pk = ops.conv2d_prepack(w.cuda(), x.shape, 2, 1, 0)
+        got2 = ops.conv2d_fwd(x.cuda(), torch.full_like(w, float("nan")).cuda(), 2, 1, w_packed=pk)
+    assert torch.equal(got, got2)
+    close(got[:nref], want, rtol=STRICT["conv_rtol"], name="split-bf16 stride-2 forward")
+    with _hip.options(CONV_S2=3):
+        f32 = ops.conv2d_fwd(x.cuda(), w.cuda(), 2, 1)
+    # against the f32 kernel on the whole batch (both within 1e-5 of the truth)
+    assert float((got - f32).abs().max()) <= 2e-5 * float(f32.abs().max())
+    e = float((got[:nref].cpu().double() - want).abs().max() / want.abs().max())
+    record("conv_s2_bf3_err[%s]" % (cfg,), e)
 
 
 @pytest.mark.parametrize("cfg", S2 + [(2, 40, 7, 66, 64), (1, 24, 5, 9, 64)])  # + input-channel counts that fill no 32-channel tile
