@@ -2152,8 +2152,14 @@ static size_t s2d_pack_elems(const AirConv2d* p, int taps) {
   return (size_t)((p->Cin + bm - 1) / bm * bm) * p->Cout * taps;
 }
 
+// the split-bf16 form of the paired data gradient (conv_bf3.hip; option CONV_S2 bit 8)
+static bool bf3_s2d_ok(const AirConv2d* p) {
+  return s2d_ok(p) && generic_ok(p) && air_bf3_s2d_ok(p->B, p->Cin, p->H, p->W, p->Cout);
+}
+
 size_t air_conv2d_dgrad_s2_pair_prepack_bytes(const AirConv2d* p) {
   if (!p || !shape_ok(p) || !generic_ok(p) || !s2d_ok(p)) return 0;
+  if (bf3_s2d_ok(p)) return air_bf3_s2d_packed_bytes(p->Cout, p->Cin);
   return (s2d_pack_elems(p, 9) + s2d_pack_elems(p, 1)) * sizeof(float);
 }
 
@@ -2164,6 +2170,7 @@ int air_conv2d_dgrad_s2_pair_prepack(const AirConv2d* p, const float* w, const f
   if (need == 0) return AIR_EUNSUPPORTED;
   if (out_bytes < need) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
+  if (bf3_s2d_ok(p)) return air_bf3_s2d_weights(w, w_sc, out, p->Cout, p->Cin, st);
   const int mt = s2d_mt(p);
   float* w9 = reinterpret_cast<float*>(out);
   float* w1 = w9 + s2d_pack_elems(p, 9);
@@ -2202,6 +2209,16 @@ int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w
   const size_t need = air_conv2d_dgrad_s2_pair_prepack_bytes(p);
   if (need == 0) return AIR_EUNSUPPORTED;
   const float* w9 = reinterpret_cast<const float*>(packed);
+  if (bf3_s2d_ok(p)) {
+    if (packed == nullptr) {
+      if (!ws || ws_bytes < need) return AIR_EWORKSPACE;
+      const int rc = air_bf3_s2d_weights(w, w_sc, ws, p->Cout, p->Cin, air_stream(stream));
+      if (rc != AIR_OK) return rc;
+      packed = ws;
+    }
+    return air_bf3_s2d_dgrad(dy, dy_sc, packed, dx, accumulate, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo,
+                             conv_flops(p) * 10.0 / 9.0, air_stream(stream));
+  }
   if (w9 == nullptr) {
     if (g_pk_defer) return AIR_EINVAL;  // between air_conv2d_prepack_begin and _flush nothing is packed yet
     if (!ws || ws_bytes < need) return AIR_EWORKSPACE;

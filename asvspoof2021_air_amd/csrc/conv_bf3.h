@@ -8,3 +8,11 @@ size_t air_bf3_s2_packed_bytes(int Cout, int Cin);            // weight planes i
 int air_bf3_s2_weights(const float* w, void* packed, int Cout, int Cin, hipStream_t st);
 int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo,
                    double flops, hipStream_t st);
+
+// the data gradient of the same layer (+ the block's 1x1 / stride 2 shortcut's: dy_sc / w_sc, may be null) in one pass;
+// option CONV_S2 bit 8
+bool air_bf3_s2d_ok(int B, int Cin, int H, int W, int Cout);
+size_t air_bf3_s2d_packed_bytes(int Cout, int Cin);
+int air_bf3_s2d_weights(const float* w, const float* w_sc, void* packed, int Cout, int Cin, hipStream_t st);
+int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, float* dx, const float* accumulate, int B,
+                      int Cin, int H, int W, int Cout, int Ho, int Wo, double flops, hipStream_t st);

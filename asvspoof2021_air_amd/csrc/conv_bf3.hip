@@ -396,6 +396,287 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Data gradient of the same layer, joined with the data gradient of the block's 1x1 / stride 2 shortcut
+// (resnet.py:56-66), in one pass over dy - conv_s2_dgrad_kernel's formulation (conv2d.hip) on the six-product MFMAs:
+// a wave owns 32 consecutive columns j of one dy row i and keeps the four parity classes of dx rows 2 i, 2 i + 1 /
+// columns 2 j, 2 j + 1 as 64-channel x 32-column tiles (8 accumulators).  Input pixel (2 i + a, 2 j + b) sees the taps
+// kh = 1 (a = 0, dy row i) or kh = 2, 0 (a = 1, dy rows i, i + 1), the same along w.  K = the layer's OUTPUT channels, 16
+// per chunk; per chunk a lane loads dy at (i, j .. j + 1), (i + 1, j .. j + 1) and the shortcut's dy at (i, j) for its
+// 8 channels (five B fragments, split in registers), the slab holds 10 taps (3 x 3 + the shortcut) x 64 dx channels.
+constexpr int DTAPS = 10;
+constexpr int DSLAB_U4 = DTAPS * 2 * 3 * 64;
+constexpr int DSLAB_BYTES = DSLAB_U4 * 16;  // 61,440
+
+// weights (Cout, Cin, 3, 3) [+ (Cout, Cin, 1, 1)] -> planes, roles swapped: rows = dx channels ci, K = co
+//   word((((cot * nchunk + chunk) * 10 + tap) * 2 + mt) * 3 + plane) * 64 + lane): ci = cot * 64 + mt * 32 + (lane & 31),
+//   co = chunk * 16 + 8 * (lane >> 5) + 0 .. 7; tap 9 = the shortcut (zeros without one)
+__global__ __launch_bounds__(256) void bf3_pack_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ wsc,
+                                                             u32x4* __restrict__ wp, int Cout, int Cin, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63;
+  int blk = e >> 6;
+  const int mt = blk & 1;
+  blk >>= 1;
+  const int tap = blk % DTAPS;
+  blk /= DTAPS;
+  const int nchunk = Cout / CK;
+  const int chunk = blk % nchunk, cot = blk / nchunk;
+  const int ci = cot * 64 + mt * 32 + (lane & 31);
+  const int co0 = chunk * CK + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    v[i] = tap < 9 ? w[((size_t)(co0 + i) * Cin + ci) * 9 + tap] : (wsc ? wsc[(size_t)(co0 + i) * Cin + ci] : 0.0f);
+  u32x4 hi, mid, lo;
+  split3(v, hi, mid, lo);
+  u32x4* dst = wp + ((size_t)(e >> 6) * 3) * 64 + lane;
+  dst[0] = hi;
+  dst[64] = mid;
+  dst[128] = lo;
+}
+
+struct Bf3dArgs {
+  const float* dy;          // (B, K, Ho, Wo)
+  const float* dysc;        // (B, K, Ho, Wo) gradient of the shortcut's output (SC)
+  const u32x4* wp;
+  float* dx;                // (B, M, H, W)
+  const float* accumulate;  // like dx, may alias it (may be null)
+  int B, K, M, H, W, Ho, Wo;
+  int WT, ntiles, ncot;
+  int pair;                 // W even and dx / accumulate 8-byte aligned: classes (a, 0), (a, 1) leave as one float2
+};
+
+template <bool SC>
+__global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2d_bf3_kernel(const Bf3dArgs a) {
+  __shared__ __attribute__((aligned(16))) u32x4 slab[2 * DSLAB_U4];
+  constexpr int NPOS = SC ? 5 : 4;   // B fragments per chunk: dy at (i, j), (i, j + 1), (i + 1, j), (i + 1, j + 1), shortcut dy
+  constexpr int NTAP = SC ? 10 : 9;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = lb % a.ncot;
+  const int pxg = lb / a.ncot;
+  const int nt = pxg * NWAVE + wave;
+  const bool tile_ok = nt < a.ntiles;
+  const int ntc = min(nt, a.ntiles - 1);
+  const int wt = ntc % a.WT;
+  const int rowid = ntc / a.WT;
+  const int i = rowid % a.Ho, b = rowid / a.Ho;
+  const int j0 = wt * 32;
+  const int j = j0 + l31;
+  const int Wo = a.Wo;
+  const int HWo = a.Ho * Wo;
+  const int nchunk = a.K / CK;
+
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned nrec = (unsigned)a.K * (unsigned)HWo * 4u;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy + (size_t)b * a.K * HWo), (short)0, (int)nrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>((SC ? a.dysc : a.dy) + (size_t)b * a.K * HWo), (short)0, (int)nrec, 0x00020000);
+  // the lane's column pair (j, j + 1), clamped into the row; what the clamp changed is fixed when the values are taken
+  const bool shifted = Wo >= 2 && j == Wo - 1;   // pair loaded one column early: element 1 is column j
+  const bool ok_c1 = j + 1 < Wo;
+  const unsigned voff2 = 4u * (unsigned)(8 * half * HWo + max(min(j, Wo - 2), 0));
+  const unsigned voff1 = 4u * (unsigned)(8 * half * HWo + min(j, Wo - 1));
+  const bool ok_r1 = i + 1 < a.Ho;  // wave-uniform: dy row i + 1 exists (else its loads are sent out of range: zeros)
+
+  f32x2 ld0[8], ld1[8];  // loads in flight: rows i, i + 1, columns (j, j + 1)
+  float lds_[8];         // the shortcut's dy at (i, j)
+  auto load_chunk = [&](int chunk) {
+    const unsigned s0 = 4u * (unsigned)((chunk * CK) * HWo + i * Wo);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const unsigned so = s0 + 4u * (unsigned)(c * HWo);
+      ld0[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, voff2, so, 0));
+      ld1[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, voff2, ok_r1 ? so + 4u * (unsigned)Wo : nrec, 0));
+      if (SC) lds_[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, voff1, so, 0));
+    }
+  };
+  float raw[NPOS][8];
+  auto take = [&](int c) {
+    const float x0 = ld0[c].x, y0 = ld0[c].y, x1 = ld1[c].x, y1 = ld1[c].y;
+    raw[0][c] = shifted ? y0 : x0;
+    raw[1][c] = ok_c1 ? y0 : 0.0f;
+    raw[2][c] = shifted ? y1 : x1;
+    raw[3][c] = ok_c1 ? y1 : 0.0f;
+    if (SC) raw[4][c] = lds_[c];
+  };
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(reinterpret_cast<const float*>(slab)));
+  const u32x4* __restrict__ wsrc = a.wp + (size_t)cot * nchunk * DSLAB_U4;
+  auto dma = [&](int chunk, int buf) {
+    const u32x4* __restrict__ src = wsrc + (size_t)chunk * DSLAB_U4;
+#pragma unroll
+    for (int n = 0; n < (DSLAB_U4 / 64 + NWAVE - 1) / NWAVE; ++n) {
+      const int blk = wave + NWAVE * n;
+      if (blk < NTAP * 6)
+        dma16(reinterpret_cast<const float*>(src + blk * 64 + lane), lds0 + (unsigned)(buf * DSLAB_BYTES + blk * 1024));
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][m][r] = 0.0f;
+
+  auto pair_split = [&](u32x4 (&dst)[NPOS][3], int k) {  // k = q * NPOS + pos
+    const int pos = k % NPOS, q = k / NPOS;
+    const float av = raw[pos][2 * q], bv = raw[pos][2 * q + 1];
+    const unsigned h = pack2(av, bv);
+    const float ra = av - __builtin_bit_cast(float, h << 16), rb = bv - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack2(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+    unsigned hh = h, mm = m, ll = pack2(sa, sb);
+    asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));  // (pins the split here: see conv_s2_bf3_kernel)
+    dst[pos][0][q] = hh;
+    dst[pos][1][q] = mm;
+    dst[pos][2][q] = ll;
+  };
+  u32x4 bpA[NPOS][3], bpB[NPOS][3];
+
+  dma(0, 0);
+  load_chunk(0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) take(c);
+#pragma unroll
+  for (int k = 0; k < 4 * NPOS; ++k) pair_split(bpA, k);
+  load_chunk(nchunk > 1 ? 1 : 0);
+  dma_wait();
+  __syncthreads();
+  if (nchunk > 1) dma(1, 1);
+
+  // tap t < 9 = (kh, kw) = (t / 3, t % 3): kh = 0 reads dy row i + 1, kw = 0 column j + 1; tap 9 = the shortcut's dy
+  constexpr int POS[10] = {3, 2, 2, 1, 0, 0, 1, 0, 0, 4};
+  constexpr int CLS[10] = {3, 2, 3, 1, 0, 1, 3, 2, 3, 0};
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // six products, small terms first
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int NITEM = 8 + 4 * NPOS;
+  auto body = [&](u32x4 (&cur)[NPOS][3], u32x4 (&nxt)[NPOS][3], int chunk) {
+    const u32x4* __restrict__ sl = slab + (chunk & 1) * DSLAB_U4 + lane;
+    const int cn = min(chunk + 2, nchunk - 1);  // (past the end the loads redo the last chunk: harmless)
+    const unsigned s_next = 4u * (unsigned)((cn * CK) * HWo + i * Wo);
+    auto item = [&](int k) {
+      if (k < 8) {
+        take(k);  // chunk + 1, channel k; then its registers take the loads of chunk + 2
+        const unsigned so = s_next + 4u * (unsigned)(k * HWo);
+        ld0[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, voff2, so, 0));
+        ld1[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(yrs, voff2, ok_r1 ? so + 4u * (unsigned)Wo : nrec, 0));
+        if (SC) lds_[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, voff1, so, 0));
+      } else {
+        pair_split(nxt, k - 8);
+      }
+    };
+    // taps two at a time (their classes differ, so consecutive MFMAs never share an accumulator)
+    u32x4 ap[2][2][3], apn[2][2][3];
+    auto rd = [&](u32x4 (&d)[2][2][3], int tp) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const int tap = 2 * tp + t;
+            if (tap < NTAP) d[t][m][pl] = sl[((tap * 2 + m) * 3 + pl) * 64];
+          }
+    };
+    rd(ap, 0);
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) {
+      if (tp < 4) rd(apn, tp + 1);
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int tap = 2 * tp + t;
+            const int n = ((tp * 6 + p) * 2 + t) * 2 + m;
+            if (tap < NTAP)
+              acc[CLS[tap]][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  __builtin_bit_cast(bf16x8, ap[t][m][PA[p]]), __builtin_bit_cast(bf16x8, cur[POS[tap]][PB[p]]),
+                  acc[CLS[tap]][m], 0, 0, 0);
+            if ((n & 1) == 0 && n / 2 < NITEM) item(n / 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ap[t][m][pl] = apn[t][m][pl];
+    }
+    dma_wait();
+    __syncthreads();
+    if (chunk + 2 < nchunk) dma(chunk + 2, chunk & 1);
+  };
+  for (int chunk = 0; chunk < nchunk; chunk += 2) {
+    body(bpA, bpB, chunk);
+    if (chunk + 1 < nchunk) body(bpB, bpA, chunk + 1);
+  }
+
+  // epilogue (conv_s2_dgrad_kernel's): D row (r & 3) + 8 (r >> 2) + 4 half -> dx channel, column l31 -> dy column j;
+  // classes (a, 0) and (a, 1) of a lane are neighbours in dx row 2 i + a
+  if (!tile_ok || j >= Wo) return;
+  const size_t plane = (size_t)a.H * a.W;
+  const bool ok_b1 = 2 * j + 1 < a.W;
+  const bool pair = a.pair != 0;
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa) {
+    const int h = 2 * i + pa;
+    if (h >= a.H) continue;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int cb = cot * 64 + 32 * m + 4 * half;
+      const size_t o0 = ((size_t)b * a.M + cb) * plane + (size_t)h * a.W + 2 * j;
+      float v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] = acc[2 * pa][m][r];
+        v1[r] = acc[2 * pa + 1][m][r];
+      }
+      if (a.accumulate != nullptr) {  // every load of the tile before its first store
+        float t0[16], t1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane;
+          if (pair) {
+            const float2 t = *reinterpret_cast<const float2*>(a.accumulate + o);
+            t0[r] = t.x;
+            t1[r] = t.y;
+          } else {
+            t0[r] = a.accumulate[o];
+            t1[r] = ok_b1 ? a.accumulate[o + 1] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v0[r] += t0[r];
+          v1[r] += t1[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* __restrict__ o = a.dx + o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane;
+        if (pair) {
+          *reinterpret_cast<float2*>(o) = make_float2(v0[r], v1[r]);
+        } else {
+          o[0] = v0[r];
+          if (ok_b1) o[1] = v1[r];
+        }
+      }
+    }
+  }
+}
+
 int pick_nt(int Wo) {
   // pixel tiles of 32 per wave: the split that wastes the fewest pixel columns (Wo = 375: 6 x 64 = 384; 188: 3 x 64 = 192;
   // 94: 1 x 96)
@@ -435,6 +716,39 @@ int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin,
     hipLaunchKernelGGL(conv_s2_bf3_kernel<3>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
     hipLaunchKernelGGL(conv_s2_bf3_kernel<2>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+bool air_bf3_s2d_ok(int B, int Cin, int H, int W, int Cout) {
+  return (air_opt(AIR_OPT_CONV_S2) & 8) != 0 && B > 0 && Cout % CK == 0 && Cin % 64 == 0 && H >= 2 && W >= 2;
+}
+
+size_t air_bf3_s2d_packed_bytes(int Cout, int Cin) { return (size_t)(Cin / 64) * (Cout / CK) * DSLAB_BYTES; }
+
+int air_bf3_s2d_weights(const float* w, const float* w_sc, void* packed, int Cout, int Cin, hipStream_t st) {
+  const int total = (Cin / 64) * (Cout / CK) * DTAPS * 2 * 64;
+  hipLaunchKernelGGL(bf3_pack_dgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, w_sc,
+                     reinterpret_cast<u32x4*>(packed), Cout, Cin, total);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, float* dx, const float* accumulate, int B,
+                      int Cin, int H, int W, int Cout, int Ho, int Wo, double flops, hipStream_t st) {
+  Bf3dArgs a;
+  a.dy = dy; a.dysc = dy_sc; a.wp = reinterpret_cast<const u32x4*>(packed); a.dx = dx; a.accumulate = accumulate;
+  a.B = B; a.K = Cout; a.M = Cin; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.WT = (Wo + 31) / 32;
+  a.ntiles = B * Ho * a.WT;
+  a.ncot = Cin / 64;
+  a.pair = (W % 2 == 0) && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(accumulate)) & 7) == 0;
+  const int nblk = ((a.ntiles + NWAVE - 1) / NWAVE) * a.ncot;
+  AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
+  if (dy_sc)
+    hipLaunchKernelGGL(conv_s2d_bf3_kernel<true>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv_s2d_bf3_kernel<false>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

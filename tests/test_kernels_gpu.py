@@ -147,7 +147,7 @@ def test_conv2d_stride2_split_bf16(ops, cfg):
 
 
 @pytest.mark.parametrize("cfg", S2 + [(2, 40, 7, 66, 64), (1, 24, 5, 9, 64)])  # + input-channel counts that fill no 32-channel tile
-@pytest.mark.parametrize("one_pass", [True, False])
+@pytest.mark.parametrize("one_pass", [True, False, "bf3"])
 def test_conv2d_stride2_dgrad_one_pass(ops, cfg, one_pass):
     """Option CONV_S2 bit 2: the 3x3 / stride 2 data gradient with all four parity classes in one pass over dy
     (conv_s2_dgrad_kernel) or as four class launches; alone, with `accumulate`, and joined with the 1x1 / stride 2
@@ -166,8 +166,14 @@ def test_conv2d_stride2_dgrad_one_pass(ops, cfg, one_pass):
     gsc, = torch.autograd.grad(ysc, x, dysc.double())
     acc = synth_feat((B, Cin, H, W), 7)
     xs = (B, Cin, H, W)
-    with _hip.options(CONV_S2=3 if one_pass else 1):
-        assert ops.conv2d_dgrad_s2_pair_ok(w.shape, xs) == one_pass
+    # "bf3": option bit 8 - the paired data gradient as six bf16 products per fp32 product (conv_bf3.hip) where the layer
+    # fits it (Cin % 64 == 0, Cout % 16 == 0; the one-pass f32 kernel otherwise), held to the SAME 1e-5
+    with _hip.options(CONV_S2=15 if one_pass == "bf3" else (3 if one_pass else 1)):
+        assert ops.conv2d_dgrad_s2_pair_ok(w.shape, xs) == bool(one_pass)
+        if one_pass == "bf3" and Cin % 64 == 0 and Cout % 16 == 0:
+            import ctypes
+            d = ops._conv_desc(xs, w.shape, 2, 1)
+            assert int(_hip.lib().air_conv2d_dgrad_s2_pair_prepack_bytes(ctypes.byref(d))) == (Cin // 64) * (Cout // 16) * 10 * 6 * 1024
         got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), xs, 2, 1)
         close(got, g3, rtol=1e-5, name="stride-2 dgrad")
         got = ops.conv2d_dgrad(dy.cuda(), w.cuda(), xs, 2, 1, accumulate=acc.cuda())
