@@ -2211,6 +2211,7 @@ int air_conv2d_dgrad_s2_pair(const AirConv2d* p, const float* dy, const float* w
   const float* w9 = reinterpret_cast<const float*>(packed);
   if (bf3_s2d_ok(p)) {
     if (packed == nullptr) {
+      if (g_pk_defer) return AIR_EINVAL;  // (one rule for every pair launch: nothing packs in place inside a prepack block)
       if (!ws || ws_bytes < need) return AIR_EWORKSPACE;
       const int rc = air_bf3_s2d_weights(w, w_sc, ws, p->Cout, p->Cin, air_stream(stream));
       if (rc != AIR_OK) return rc;
