@@ -52,8 +52,9 @@ class GraphedScorer:
     generate_score.py scores with ``DataLoader(batch_size=1)`` (:73): ~150 kernel launches of a few
     microseconds each per utterance, i.e. launch-bound.  When the caller keeps that batch size, capture the
     whole forward (model + loss score) once for the feature shape and replay it per utterance: one graph
-    launch instead of ~150 kernel launches.  The attention noise of resnet.py:38 is drawn ONCE at capture and
-    replayed (it is 1e-5-scale by construction); use ``model.set_attention_noise(None)`` for none."""
+    launch instead of ~150 kernel launches.  The attention noise of resnet.py:38 comes from a device-side Philox offset
+    that the captured draw advances (ops.randn_ctr): every replay draws fresh noise, like the reference's per-call
+    ``torch.randn``; ``model.set_attention_noise(None)`` for none."""
 
     def __init__(self, model, example, loss_model=None, add_loss=None):
         if not example.is_cuda:
