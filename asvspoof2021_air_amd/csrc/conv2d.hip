@@ -1741,7 +1741,7 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
       fwd = slab + 4 * (size_t)p->B * p->Cout * p->Ho * p->Wo;
   }
   if (bf3_fwd_ok(p)) {  // bf16 planes: 6 bytes per weight
-    const size_t pl = (air_bf3_s2_packed_bytes(p->Cout, p->Cin) + 3) / 4;
+    const size_t pl = (air_bf3_s2_packed_bytes(p->Cout, p->Cin, true) + 3) / 4;
     if (pl > fwd) fwd = pl;
   }
   size_t dgrad = packed_dgrad_elems(p);
@@ -1986,7 +1986,7 @@ size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
   const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
   if (kind == 4) return air_wino4_packed_elems(M, Kc) * sizeof(float);
   if (kind == 2) return air_wino_packed_elems(M, Kc) * sizeof(float);
-  if (pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_packed_bytes(p->Cout, p->Cin);
+  if (pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_packed_bytes(p->Cout, p->Cin, false);
   if (!generic_pack_ok(p, pass)) return 0;
   PackScope size(PK_SIZE, nullptr);
   float* none = nullptr;
@@ -2003,7 +2003,7 @@ int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, 
   const int M = pass ? p->Cin : p->Cout, Kc = pass ? p->Cout : p->Cin;
   float* up = reinterpret_cast<float*>(out);
   const int kind = wino_kind(p, pass);
-  if (kind == 0 && pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_weights(w, out, p->Cout, p->Cin, air_stream(stream));
+  if (kind == 0 && pass == 0 && bf3_fwd_ok(p)) return air_bf3_s2_weights(w, nullptr, out, p->Cout, p->Cin, air_stream(stream));
   if (kind == 0) {  // the direct kernels' slabs, in the order fwd_generic / dgrad_generic consume them
     PackScope collect(PK_COLLECT, up);
     float* none = nullptr;
@@ -2064,19 +2064,52 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
                          conv_flops(p), st);
   }
   if (in_scale == nullptr && residual == nullptr && bf3_fwd_ok(p)) {
-    const size_t need = air_bf3_s2_packed_bytes(p->Cout, p->Cin);
+    const size_t need = air_bf3_s2_packed_bytes(p->Cout, p->Cin, false);
     if (w_packed == nullptr) {
       if (ws_bytes < need) return AIR_EWORKSPACE;
-      const int rc = air_bf3_s2_weights(w, ws, p->Cout, p->Cin, st);
+      const int rc = air_bf3_s2_weights(w, nullptr, ws, p->Cout, p->Cin, st);
       if (rc != AIR_OK) return rc;
     }
-    return air_bf3_s2_fwd(x, w_packed ? w_packed : ws, y, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo, conv_flops(p), st);
+    return air_bf3_s2_fwd(x, w_packed ? w_packed : ws, y, nullptr, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo,
+                          conv_flops(p), st);
   }
   if (w_packed != nullptr && wino_kind(p, 0) == 0) {  // slabs from air_conv2d_prepack (a Winograd-shaped layer's
     PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));  // buffer is not ours)
     return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));
   }
   return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));
+}
+
+// ---- forward of a stride-2 PreActBlock's two convolutions on the same input (resnet.py:56-66) in one launch
+size_t air_conv2d_fwd_s2_pair_prepack_bytes(const AirConv2d* p) {
+  if (!p || !shape_ok(p) || !bf3_fwd_ok(p)) return 0;
+  return air_bf3_s2_packed_bytes(p->Cout, p->Cin, true);
+}
+
+int air_conv2d_fwd_s2_pair_prepack(const AirConv2d* p, const float* w, const float* w_sc, void* out, size_t out_bytes,
+                                   air_stream_t stream) {
+  if (!p || !w || !w_sc || !out || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_fwd_s2_pair_prepack_bytes(p);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  if (out_bytes < need) return AIR_EWORKSPACE;
+  return air_bf3_s2_weights(w, w_sc, out, p->Cout, p->Cin, air_stream(stream));
+}
+
+int air_conv2d_fwd_s2_pair(const AirConv2d* p, const float* x, const float* w, const float* w_sc, const void* packed,
+                           float* y, float* y_sc, void* ws, size_t ws_bytes, air_stream_t stream) {
+  if (!p || !x || !w || !w_sc || !y || !y_sc || !shape_ok(p)) return AIR_EINVAL;
+  const size_t need = air_conv2d_fwd_s2_pair_prepack_bytes(p);
+  if (need == 0) return AIR_EUNSUPPORTED;
+  hipStream_t st = air_stream(stream);
+  if (packed == nullptr) {
+    if (g_pk_defer) return AIR_EINVAL;  // (nothing packs in place inside a prepack block)
+    if (!ws || ws_bytes < need) return AIR_EWORKSPACE;
+    const int rc = air_bf3_s2_weights(w, w_sc, ws, p->Cout, p->Cin, st);
+    if (rc != AIR_OK) return rc;
+    packed = ws;
+  }
+  // (3x3 + 1x1: 10 / 9 of the 3x3 layer's multiply-adds)
+  return air_bf3_s2_fwd(x, packed, y, y_sc, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo, conv_flops(p) * 10.0 / 9.0, st);
 }
 
 int air_conv2d_fwd(const AirConv2d* p, const float* x, const float* w, float* y,

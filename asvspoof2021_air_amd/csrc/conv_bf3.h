@@ -4,10 +4,12 @@
 #include <stddef.h>
 
 bool air_bf3_s2_ok(int B, int Cin, int H, int W, int Cout);   // option CONV_S2 bit 4 and the shape constraints
-size_t air_bf3_s2_packed_bytes(int Cout, int Cin);            // weight planes in fragment order
-int air_bf3_s2_weights(const float* w, void* packed, int Cout, int Cin, hipStream_t st);
-int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo,
-                   double flops, hipStream_t st);
+// weight planes in fragment order; with_shortcut / w_sc / y_sc: the block's 1x1 / stride 2 shortcut rides along as a tenth
+// tap and a second output of the same launch
+size_t air_bf3_s2_packed_bytes(int Cout, int Cin, bool with_shortcut);
+int air_bf3_s2_weights(const float* w, const float* w_sc, void* packed, int Cout, int Cin, hipStream_t st);
+int air_bf3_s2_fwd(const float* x, const void* packed, float* y, float* y_sc, int B, int Cin, int H, int W, int Cout, int Ho,
+                   int Wo, double flops, hipStream_t st);
 
 // the data gradient of the same layer (+ the block's 1x1 / stride 2 shortcut's: dy_sc / w_sc, may be null) in one pass;
 // option CONV_S2 bit 8

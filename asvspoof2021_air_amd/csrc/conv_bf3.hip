@@ -44,8 +44,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NWAVE = 4;
 constexpr int CK = 16;                                  // input channels per K chunk = the MFMA's K
 constexpr int TAPS = 9;
-constexpr int SLAB_U4 = TAPS * 2 * 3 * 64;              // 16-byte words per (channel tile, chunk) slab
-constexpr int SLAB_BYTES = SLAB_U4 * 16;                // 55,296
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
   f32x2 v = {a, b};
@@ -71,23 +69,24 @@ __device__ __forceinline__ void split3(const float (&v)[8], u32x4& hi, u32x4& mi
 // fp32 weights (Cout, Cin, 3, 3) -> planes in fragment order:
 //   word(((cot * nchunk + chunk) * 9 + tap) * 2 + mt) * 3 + plane) * 64 + lane) = 8 bf16: channel co = cot * 64 + mt * 32
 //   + (lane & 31), input channels chunk * 16 + 8 * (lane >> 5) + 0 .. 7
-__global__ __launch_bounds__(256) void bf3_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Cout,
-                                                       int Cin, int total) {
+// ntaps = 10: tap 9 = the block's 1x1 / stride 2 shortcut (wsc, (Cout, Cin)), computed by the same launch
+__global__ __launch_bounds__(256) void bf3_pack_kernel(const float* __restrict__ w, const float* __restrict__ wsc,
+                                                       u32x4* __restrict__ wp, int Cout, int Cin, int ntaps, int total) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int lane = e & 63;
   int blk = e >> 6;
   const int mt = blk & 1;
   blk >>= 1;
-  const int tap = blk % TAPS;
-  blk /= TAPS;
+  const int tap = blk % ntaps;
+  blk /= ntaps;
   const int nchunk = Cin / CK;
   const int chunk = blk % nchunk, cot = blk / nchunk;
   const int co = cot * 64 + mt * 32 + (lane & 31);
   const int ci0 = chunk * CK + 8 * (lane >> 5);
   float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = w[((size_t)co * Cin + ci0 + i) * TAPS + tap];
+  for (int i = 0; i < 8; ++i) v[i] = tap < TAPS ? w[((size_t)co * Cin + ci0 + i) * TAPS + tap] : wsc[(size_t)co * Cin + ci0 + i];
   u32x4 hi, mid, lo;
   split3(v, hi, mid, lo);
   u32x4* dst = wp + ((size_t)(e >> 6) * 3) * 64 + lane;
@@ -100,14 +99,21 @@ struct Bf3Args {
   const float* x;
   const u32x4* wp;
   float* y;
+  float* ysc;   // SC: the shortcut's output (B, Cout, Ho, Wo)
   int B, Cin, H, W, Cout, Ho, Wo;
   int WT;       // pixel groups (NT x 32 pixels) per output row
   int ngroups;  // B * Ho * WT
   int ncot;     // Cout / 64
 };
 
-template <int NT>
+// SC: also the block's 1x1 / stride 2 shortcut on the same input (resnet.py:61-66) - its operand is the centre tap's B
+// fragment, which this kernel has split already: 6 x 2 x NT more MFMAs per chunk against a tenth weight tap, a second
+// set of accumulators, no second pass over x
+template <int NT, bool SC>
 __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Args a) {
+  constexpr int NTAPS = SC ? 10 : TAPS;
+  constexpr int SLAB_U4 = NTAPS * 2 * 3 * 64;  // 16-byte words per (channel tile, chunk) slab
+  constexpr int SLAB_BYTES = SLAB_U4 * 16;     // 55,296 (61,440 with the shortcut)
   __shared__ __attribute__((aligned(16))) u32x4 slab[2 * SLAB_U4];
 
   const int tid = threadIdx.x;
@@ -207,13 +213,16 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
     }
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[2][NT], accs[SC ? 2 : 1][SC ? NT : 1];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) {
+        acc[m][j][r] = 0.0f;
+        if (SC) accs[m][j][r] = 0.0f;
+      }
 
   // The K loop walks the VALID kernel rows (a padding row contributes nothing and is skipped: wave-uniform) of every
   // chunk as one flat sequence, software-pipelined two rows deep:
@@ -266,7 +275,8 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
   float tperm[NT];  // bpermute results in flight (channel i, consumed one item later)
   float pc1[NT], pc2[NT];
   auto body = [&](u32x4 (&cur)[3][NT][3], u32x4 (&nxt)[3][NT][3], int it) {
-    const u32x4* __restrict__ sl = slab + (c0 & 1) * SLAB_U4 + (kh0 + r0) * (3 * 2 * 3 * 64) + lane;
+    const u32x4* __restrict__ sl0 = slab + (c0 & 1) * SLAB_U4 + lane;
+    const u32x4* __restrict__ sl = sl0 + (kh0 + r0) * (3 * 2 * 3 * 64);
     const bool more = it + 2 < total;  // (past the end the loads redo the last row: harmless)
     const unsigned s_next = 4u * (unsigned)(((more ? c2 : c1) * CK) * HW + (hi0 + kh0 + (more ? r2 : r1)) * W);
     auto perm_issue = [&](int i) {
@@ -368,6 +378,22 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
 #pragma unroll
     for (int k = 0; k < NITEM; ++k) item(k);
 #endif
+    if (SC && kh0 + r0 == 1) {  // the centre row (never padding): its middle column is the shortcut's input pixel
+      u32x4 as[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) as[m][pl] = sl0[((9 * 2 + m) * 3 + pl) * 64];
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            accs[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as[m][PA[p]]),
+                                                                 __builtin_bit_cast(bf16x8, cur[1][j][PB[p]]), accs[m][j],
+                                                                 0, 0, 0);
+    }
     if (r0 == nv - 1) {  // last row of a chunk: the next chunk's slab has landed; this one's buffer is free for the one after
       dma_wait();
       __syncthreads();
@@ -390,9 +416,13 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
     for (int j = 0; j < NT; ++j) {
       const int wo = wo0 + 32 * j + l31;
       if (wo >= a.Wo) continue;
-      float* __restrict__ yo = a.y + ((size_t)b * a.Cout + cot * 64 + m * 32 + 4 * half) * plane + (size_t)ho * a.Wo + wo;
+      const size_t o0 = ((size_t)b * a.Cout + cot * 64 + m * 32 + 4 * half) * plane + (size_t)ho * a.Wo + wo;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yo[(size_t)((r & 3) + 8 * (r >> 2)) * plane] = acc[m][j][r];
+      for (int r = 0; r < 16; ++r) a.y[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = acc[m][j][r];
+      if (SC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.ysc[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * plane] = accs[m][j][r];
+      }
     }
 }
 
@@ -690,32 +720,37 @@ bool air_bf3_s2_ok(int B, int Cin, int H, int W, int Cout) {
   return (air_opt(AIR_OPT_CONV_S2) & 4) != 0 && B > 0 && Cin % CK == 0 && Cout % 64 == 0 && H >= 2 && W >= 2;
 }
 
-size_t air_bf3_s2_packed_bytes(int Cout, int Cin) { return (size_t)(Cout / 64) * (Cin / CK) * SLAB_BYTES; }
+size_t air_bf3_s2_packed_bytes(int Cout, int Cin, bool with_shortcut) {
+  return (size_t)(Cout / 64) * (Cin / CK) * (with_shortcut ? 10 : TAPS) * 2 * 3 * 1024;
+}
 
-int air_bf3_s2_weights(const float* w, void* packed, int Cout, int Cin, hipStream_t st) {
-  const int total = (Cout / 64) * (Cin / CK) * TAPS * 2 * 64;
-  hipLaunchKernelGGL(bf3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, reinterpret_cast<u32x4*>(packed), Cout,
-                     Cin, total);
+int air_bf3_s2_weights(const float* w, const float* w_sc, void* packed, int Cout, int Cin, hipStream_t st) {
+  const int ntaps = w_sc ? 10 : TAPS;
+  const int total = (Cout / 64) * (Cin / CK) * ntaps * 2 * 64;
+  hipLaunchKernelGGL(bf3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, w_sc, reinterpret_cast<u32x4*>(packed),
+                     Cout, Cin, ntaps, total);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }
 
-int air_bf3_s2_fwd(const float* x, const void* packed, float* y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo,
-                   double flops, hipStream_t st) {
+int air_bf3_s2_fwd(const float* x, const void* packed, float* y, float* y_sc, int B, int Cin, int H, int W, int Cout, int Ho,
+                   int Wo, double flops, hipStream_t st) {
   Bf3Args a;
-  a.x = x; a.wp = reinterpret_cast<const u32x4*>(packed); a.y = y;
+  a.x = x; a.wp = reinterpret_cast<const u32x4*>(packed); a.y = y; a.ysc = y_sc;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
-  const int nt = pick_nt(Wo);
+  const int nt = y_sc ? 2 : pick_nt(Wo);  // (three pixel tiles + the shortcut's accumulators do not fit the register file)
   a.WT = (Wo + 32 * nt - 1) / (32 * nt);
   a.ngroups = B * Ho * a.WT;
   a.ncot = Cout / 64;
   const int nblk = ((a.ngroups + NWAVE - 1) / NWAVE) * a.ncot;
   // MFMA FLOPs issued: 6 products per algorithmic multiply-add
   AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
-  if (nt == 3)
-    hipLaunchKernelGGL(conv_s2_bf3_kernel<3>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  if (y_sc)
+    hipLaunchKernelGGL((conv_s2_bf3_kernel<2, true>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  else if (nt == 3)
+    hipLaunchKernelGGL((conv_s2_bf3_kernel<3, false>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
-    hipLaunchKernelGGL(conv_s2_bf3_kernel<2>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_s2_bf3_kernel<2, false>), dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -204,6 +204,48 @@ def conv2d_dgrad_s2_pair(dy, w, dy_sc, w_sc, x_shape, accumulate=None, out=None,
     return dx
 
 
+def conv2d_fwd_s2_pair_ok(w_shape, x_shape):
+    """Whether a 3x3 / stride 2 / pad 1 convolution and the 1x1 / stride 2 shortcut on the same input have the one-launch
+    forward under the current dispatch options."""
+    d = _conv_desc(x_shape, w_shape, 2, 1)
+    return int(_hip.lib().air_conv2d_fwd_s2_pair_prepack_bytes(ctypes.byref(d))) > 0
+
+
+def conv2d_fwd_s2_pair_prepack(w, w_sc, x_shape, out=None):
+    """Both weights of a PreActBlock's stride-2 pair in the layout conv2d_fwd_s2_pair consumes; None when the pair has
+    no one-launch forward under the current dispatch options."""
+    d = _conv_desc(x_shape, w.shape, 2, 1)
+    n = int(_hip.lib().air_conv2d_fwd_s2_pair_prepack_bytes(ctypes.byref(d)))
+    if n == 0:
+        return None
+    if out is None or out.numel() < n:
+        out = torch.empty(n, dtype=torch.uint8, device=w.device)
+    _hip.check(_hip.lib().air_conv2d_fwd_s2_pair_prepack(ctypes.byref(d), dptr(w), dptr(w_sc), dptr(out, torch.uint8),
+                                                         csz(n), stream()), "air_conv2d_fwd_s2_pair_prepack")
+    return out
+
+
+def conv2d_fwd_s2_pair(x, w, w_sc, packed=None):
+    """(conv2d(x, w, stride 2, pad 1), conv2d(x, w_sc, stride 2)) in one launch (resnet.py:56-66: both read the block's
+    activated input); None when the pair has no such form under the current dispatch options."""
+    d = _conv_desc(x.shape, w.shape, 2, 1)
+    if tuple(w_sc.shape) != (w.shape[0], w.shape[1], 1, 1):
+        raise _hip.AirError("conv2d_fwd_s2_pair: the shortcut must be the 1x1 / stride 2 convolution beside the 3x3 one")
+    n = int(_hip.lib().air_conv2d_fwd_s2_pair_prepack_bytes(ctypes.byref(d)))
+    if n == 0:
+        return None
+    if packed is not None and packed.numel() * packed.element_size() < n:
+        raise _hip.AirError("conv2d_fwd_s2_pair: packed holds %d bytes, the pair consumes %d under the current dispatch "
+                            "options" % (packed.numel() * packed.element_size(), n))
+    y = torch.empty((d.B, d.Cout, d.Ho, d.Wo), device=x.device, dtype=torch.float32)
+    ysc = torch.empty_like(y)
+    ws = workspace(n, x.device) if packed is None else None
+    _hip.check(_hip.lib().air_conv2d_fwd_s2_pair(
+        ctypes.byref(d), dptr(x), dptr(w), dptr(w_sc), dptr(packed, torch.uint8, allow_none=True), dptr(y), dptr(ysc),
+        dptr(ws, torch.uint8, allow_none=True), csz(n if packed is None else 0), stream()), "air_conv2d_fwd_s2_pair")
+    return y, ysc
+
+
 def conv2d_wgrad(x, dy, w_shape, stride=1, padding=0, in_scale=None, in_shift=None, relu=False,
                  out=None):
     d = _conv_desc(x.shape, w_shape, stride, padding)

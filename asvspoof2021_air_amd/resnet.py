@@ -314,6 +314,19 @@ class ResNet(nn.Module):
                         # (bi, 1 | 2): a block's 3x3 convs; (bi, 0): its 1x1 shortcut; (-1, 5): conv5
                         conv = self.conv5 if bi < 0 else (blocks[bi].shortcut[0] if ci == 0 else
                                                           blocks[bi].conv1 if ci == 1 else blocks[bi].conv2)
+                        if which == 0 and bi >= 0 and s == 2 and ci in (0, 1) and hasattr(blocks[bi], "shortcut") and \
+                                ops.conv2d_fwd_s2_pair_ok(blocks[bi].conv1.weight.shape, shape):
+                            # a stride-2 block's conv1 and shortcut share ONE forward launch (round 5): their weights
+                            # travel together under (bi, 1); the shortcut has no buffer of its own then
+                            if ci == 0:
+                                continue
+                            buf = ops.conv2d_fwd_s2_pair_prepack(conv.weight.detach(), blocks[bi].shortcut[0].weight.detach(),
+                                                                 shape, out=self._packs.get(((bi, ci), "fpair")))
+                            if buf is not None:
+                                self._packs[((bi, ci), "fpair")] = buf
+                                live[((bi, ci), which)] = buf
+                                self._geo_live[(bi, ci)] = shape
+                                continue
                         if which == 1 and bi >= 0 and s == 2 and ci in (0, 1) and hasattr(blocks[bi], "shortcut"):
                             # a stride-2 block's conv1 and shortcut share ONE data-gradient launch (round 4): their
                             # weights travel together under (bi, 1); the shortcut has no buffer of its own then
@@ -386,11 +399,18 @@ class ResNet(nn.Module):
                 actA, pA = cur, dict(in_scale=stA[2], in_shift=stA[3], relu=True)
             else:     # activated tensor written once (HBM-bound pass), convs run their plain loop
                 actA, pA = ops.bn_apply(cur, stA[2], stA[3], relu=True), {}
-            if hasattr(blk, "shortcut"):
-                sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, w_packed=packed((bi, 0), 0, actA.shape), **pA)
+            fpair = hasattr(blk, "shortcut") and s == 2 and not fuse and ops.conv2d_fwd_s2_pair_ok(blk.conv1.weight.shape, actA.shape)
+            if fpair:  # conv1 and the 1x1 shortcut of a stride-2 block in one launch over actA (round 5)
+                if prepack:
+                    self._geo[(bi, 0)] = (tuple(actA.shape), s, 0)
+                h, sc = ops.conv2d_fwd_s2_pair(actA, w(blk.conv1), w(blk.shortcut[0]), packed=packed((bi, 1), 0, actA.shape))
+                h_rec = None
             else:
-                sc = cur
-            h, h_rec = conv_st(want_stats, actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
+                if hasattr(blk, "shortcut"):
+                    sc = ops.conv2d_fwd(actA, w(blk.shortcut[0]), s, 0, w_packed=packed((bi, 0), 0, actA.shape), **pA)
+                else:
+                    sc = cur
+                h, h_rec = conv_st(want_stats, actA, w(blk.conv1), s, 1, w_packed=packed((bi, 1), 0, actA.shape), **pA)
             stB = _bn_train_coeffs(h, blk.bn2, training, h_rec)
             if fuse:
                 actB, pB = h, dict(in_scale=stB[2], in_shift=stB[3], relu=True)

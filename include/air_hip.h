@@ -208,6 +208,18 @@ int air_conv2d_dgrad_bn(const AirConv2d* p, const float* dy, const float* w, con
                         const float* accumulate, const float* bn_x, const float* bn_mean, const float* bn_invstd,
                         const float* bn_gamma, const float* bn_beta, void* sums, void* ws, size_t ws_bytes,
                         air_stream_t stream);
+/* Forward of the two convolutions a stride-2 PreActBlock applies to the SAME activated input (resnet.py:56 conv1 3x3 /
+ * stride 2 / pad 1 and :61-66 the 1x1 / stride 2 shortcut, both reading `out` of :64) in one launch (round 5, split-bf16
+ * kernel of csrc/conv_bf3.hip: the shortcut's operand is the centre tap's fragment, already loaded and split): y =
+ * conv1(x), y_sc = shortcut(x).  p describes the 3x3 layer.  _prepack_bytes 0 / AIR_EUNSUPPORTED: not this shape, or
+ * option CONV_S2 bit 4 off - a binding then makes the two air_conv2d_fwd calls.  packed: the buffer _prepack wrote under
+ * the same options, or NULL (then ws, >= _prepack_bytes, receives the planes in front of the launch). */
+size_t air_conv2d_fwd_s2_pair_prepack_bytes(const AirConv2d* p);
+int air_conv2d_fwd_s2_pair_prepack(const AirConv2d* p, const float* w, const float* w_sc, void* out, size_t out_bytes,
+                                   air_stream_t stream);
+int air_conv2d_fwd_s2_pair(const AirConv2d* p, const float* x, const float* w, const float* w_sc, const void* packed,
+                           float* y, float* y_sc, void* ws, size_t ws_bytes, air_stream_t stream);
+
 /* The data gradient of a PreActBlock's stride-2 pair in one pass (resnet.py:56-66: conv1 3x3 / stride 2 / pad 1 and
  * the 1x1 / stride 2 shortcut read the same activated tensor): dx = conv_transpose(dy, w) + conv_transpose(dy_sc, w_sc)
  * [+ accumulate].  p describes the 3x3 convolution; the shortcut has its Cin, Cout, input and output shape.  A wave

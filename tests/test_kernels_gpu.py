@@ -144,6 +144,21 @@ def test_conv2d_stride2_split_bf16(ops, cfg):
     assert float((got - f32).abs().max()) <= 2e-5 * float(f32.abs().max())
     e = float((got[:nref].cpu().double() - want).abs().max() / want.abs().max())
     record("conv_s2_bf3_err[%s]" % (cfg,), e)
+    # the block's 1x1 / stride 2 shortcut in the same launch (air_conv2d_fwd_s2_pair): both outputs against fp64, the
+    # 3x3 output bit-identical to the launch without the shortcut where the tiling is the same (two pixel tiles per wave)
+    wsc = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+    want_sc = F.conv2d(x[:nref].double(), wsc.double(), None, 2, 0)
+    with _hip.options(CONV_S2=7):
+        assert ops.conv2d_fwd_s2_pair_ok(w.shape, x.shape)
+        y2, ysc = ops.conv2d_fwd_s2_pair(x.cuda(), w.cuda(), wsc.cuda())
+        pkp = ops.conv2d_fwd_s2_pair_prepack(w.cuda(), wsc.cuda(), x.shape)
+        nan = torch.full_like(w, float("nan")).cuda()
+        y3, ysc3 = ops.conv2d_fwd_s2_pair(x.cuda(), nan, nan[:, :, :1, :1].contiguous(), packed=pkp)
+    assert torch.equal(y2, y3) and torch.equal(ysc, ysc3)
+    close(y2[:nref], want, rtol=STRICT["conv_rtol"], name="pair forward: 3x3")
+    close(ysc[:nref], want_sc, rtol=STRICT["conv_rtol"], name="pair forward: shortcut")
+    with _hip.options(CONV_S2=3):
+        assert not ops.conv2d_fwd_s2_pair_ok(w.shape, x.shape) and ops.conv2d_fwd_s2_pair(x.cuda(), w.cuda(), wsc.cuda()) is None
 
 
 @pytest.mark.parametrize("cfg", S2 + [(2, 40, 7, 66, 64), (1, 24, 5, 9, 64)])  # + input-channel counts that fill no 32-channel tile
