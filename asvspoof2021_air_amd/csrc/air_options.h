@@ -22,7 +22,7 @@ enum AirOption {
   AIR_OPT_CONV_S2,             // bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (3 resident workgroups per CU, not 1);
                                // bit 2: stride-2 3x3 data gradient as one pass over dy (conv_s2_dgrad_kernel), not four class launches
                                // bit 4: stride-2 3x3 forward as six bf16 products per fp32 product (conv_bf3.hip)
-                               // bit 8: the paired stride-2 data gradient likewise
+                               // bit 8: the paired stride-2 data gradient likewise; bit 16: the stride-2 3x3 weight gradient
   AIR_OPT_COUNT
 };
 

@@ -1728,6 +1728,11 @@ static bool bf3_fwd_ok(const AirConv2d* p) {
          air_bf3_s2_ok(p->B, p->Cin, p->H, p->W, p->Cout);
 }
 
+static bool bf3_wgrad_ok(const AirConv2d* p) {
+  return p->KH == 3 && p->KW == 3 && p->sh == 2 && p->sw == 2 && p->ph == 1 && p->pw == 1 && generic_ok(p) && !direct_ok(p) &&
+         air_bf3_s2w_ok(p->B, p->Cin, p->H, p->W, p->Cout);
+}
+
 size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   if (!p || !shape_ok(p)) return 0;
   const size_t wsz = (size_t)p->Cout * p->Cin * p->KH * p->KW;
@@ -1765,6 +1770,10 @@ size_t air_conv2d_ws_bytes(const AirConv2d* p) {
   }
   if (const int nch = skinny_wgrad_chunks(p)) {
     const size_t sk = (size_t)p->B * nch * wsz;
+    if (sk > wgrad) wgrad = sk;
+  }
+  if (bf3_wgrad_ok(p)) {
+    const size_t sk = (size_t)air_bf3_s2w_nseg(p->B, p->Cin, p->Ho, p->Wo, p->Cout) * wsz;
     if (sk > wgrad) wgrad = sk;
   }
   if (skinny3_wgrad_ok(p)) {
@@ -2311,6 +2320,17 @@ int air_conv2d_wgrad(const AirConv2d* p, const float* x, const float* dy, float*
     if (rc != AIR_OK) return rc;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nsplit)), dim3(256), 0, st,
                        reinterpret_cast<const float*>(ws), dw, wsz, nsplit, 9);
+    AIR_CHECK_LAUNCH();
+    return AIR_OK;
+  }
+  if (in_scale == nullptr && bf3_wgrad_ok(p)) {  // split-bf16 stride-2 weight gradient (conv_bf3.hip)
+    const int nseg = air_bf3_s2w_nseg(p->B, p->Cin, p->Ho, p->Wo, p->Cout);
+    if (!ws || ws_bytes < (size_t)nseg * wsz * sizeof(float)) return AIR_EWORKSPACE;
+    int rc = air_bf3_s2w_partials(x, dy, reinterpret_cast<float*>(ws), p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo,
+                                  conv_flops(p), st);
+    if (rc != AIR_OK) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_grid(wsz, nseg)), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(ws), dw, wsz, nseg, 9);
     AIR_CHECK_LAUNCH();
     return AIR_OK;
   }

@@ -18,3 +18,10 @@ size_t air_bf3_s2d_packed_bytes(int Cout, int Cin);
 int air_bf3_s2d_weights(const float* w, const float* w_sc, void* packed, int Cout, int Cin, hipStream_t st);
 int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, float* dx, const float* accumulate, int B,
                       int Cin, int H, int W, int Cout, int Ho, int Wo, double flops, hipStream_t st);
+
+// the weight gradient of the same layer: partial sums per segment of output rows, [nseg][9][Cout][Cin] floats, to be added
+// in order (reduce_partials_kernel); option CONV_S2 bit 16
+bool air_bf3_s2w_ok(int B, int Cin, int H, int W, int Cout);
+int air_bf3_s2w_nseg(int B, int Cin, int Ho, int Wo, int Cout);
+int air_bf3_s2w_partials(const float* x, const float* dy, float* partial, int B, int Cin, int H, int W, int Cout, int Ho,
+                         int Wo, double flops, hipStream_t st);

@@ -21,6 +21,8 @@
 //     values: v_cvt_pk_bf16_f32 + shifts + subtractions) and keeps the nine fragments of a kernel row; the loads of
 //     the NEXT row are issued right behind the split, under that row's 3 x 24 MFMAs;
 //   * one K step = one tap x 16 channels: 6 products x 2 channel tiles x NT pixel tiles MFMAs.
+#include <type_traits>
+
 #include "air_common.h"
 #include "air_lds_dma.h"
 #include "air_options.h"
@@ -707,6 +709,249 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2d_bf3_kernel(const Bf3dA
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer: dW[co][ci][kh][kw] = sum over (b, ho, wo) of dy[b][co][ho][wo] x[b][ci][2 ho + kh - 1]
+// [2 wo + kw - 1].  K = pixels, 16 per MFMA (a run of 16 consecutive wo of one output row), BOTH operands are activations:
+// A = dy (a lane = one output channel, 8 consecutive wo = 32 contiguous bytes), B = x (a lane = one input channel, the 17
+// consecutive columns 2 wo0 - 1 .. 2 wo0 + 15 behind its 8 pixels: the even / odd / shifted-even elements are the three
+// kw fragments).  No LDS, no barriers: a wave is on its own - it owns ONE kernel row kh, 128 output channels x 32 input
+// channels x 3 kw (12 accumulators) and a segment of the output rows, splits 4 + 3 fragments per 72 MFMAs, and writes
+// its sums into the slice of its segment; reduce_partials_kernel (conv2d.hip) adds the slices in order.
+struct Bf3wArgs {
+  const float* x;    // (B, Cin, H, W)
+  const float* dy;   // (B, Cout, Ho, Wo)
+  float* partial;    // [nseg][9][Cout][Cin]
+  int B, Cin, H, W, Cout, Ho, Wo;
+  int ncog, ncit;    // Cout / 128, Cin / 32
+  int nseg, rps;     // segments of rps output rows (b, ho)
+  int KS;            // 16-pixel K steps per output row
+};
+
+__global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2w_bf3_kernel(const Bf3wArgs a) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  // work unit = (segment, kh, channel-group pair); the pair index is fastest so that the waves of a workgroup and
+  // neighbouring workgroups stream the same rows (L2)
+  int u = blockIdx.x * NWAVE + wave;  // (an XCD-contiguous order measured no better: l2s same, l4s 0.29 -> 0.36 ms)
+  const int npair = a.ncog * a.ncit;
+  const int nunit = a.nseg * 3 * npair;
+  if (u >= nunit) return;
+  const int pr = u % npair;
+  u /= npair;
+  const int kh = u % 3, seg = u / 3;
+  const int cog = pr / a.ncit, cit = pr % a.ncit;
+  const int H = a.H, W = a.W, Wo = a.Wo, Ho = a.Ho;
+  const int HW = H * W, HWo = Ho * Wo;
+  const int KS = a.KS;
+  const int nrows = a.B * Ho;
+  const int row0 = seg * a.rps, row1 = min(row0 + a.rps, nrows);
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), (short)0, (int)((unsigned)a.B * (unsigned)a.Cin * (unsigned)HW * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy), (short)0, (int)((unsigned)a.B * (unsigned)a.Cout * (unsigned)HWo * 4u), 0x00020000);
+  unsigned voffA[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) voffA[m] = 4u * (unsigned)((cog * 128 + m * 32 + l31) * HWo + 8 * half);
+  const unsigned voffB = 4u * (unsigned)((cit * 32 + l31) * HW + 16 * half);
+
+  typedef float f32x4u __attribute__((ext_vector_type(4)));
+  // step = (row, ks) over the rows of the segment whose input row 2 ho + kh - 1 exists
+  auto row_ok = [&](int rid) { const int hi = 2 * (rid % Ho) + kh - 1; return hi >= 0 && hi < H; };
+  auto next_step = [&](int& rid, int& ks) {  // advance to the next valid step (rid == row1: past the end)
+    if (++ks < KS) return;
+    ks = 0;
+    ++rid;
+    while (rid < row1 && !row_ok(rid)) ++rid;
+  };
+  int rid0 = row0, ks0 = 0;
+  while (rid0 < row1 && !row_ok(rid0)) ++rid0;
+
+  f32x4u la[4][2];   // loads in flight / landed: dy, 8 pixels per channel tile
+  f32x4u lb[4];      // x: columns 2 wo0' .. 2 wo0' + 15 of this lane's 8 pixels (wo0' = 16 ks + 8 half)
+  float xm1 = 0.0f;  //    column 2 wo0' - 1: the left neighbour's last column (below)
+  float carry = 0.0f;
+  auto offs = [&](int rid, int ks, unsigned& sa, unsigned& sb) {
+    const int ridc = min(rid, row1 - 1);  // (past the end: redo the last row - harmless)
+    const int b = ridc / Ho, ho = ridc - b * Ho;
+    const int wo0 = 16 * ks;
+    sa = 4u * (unsigned)(b * a.Cout * HWo + ho * Wo + wo0);
+    sb = 4u * (unsigned)(b * a.Cin * HW + (2 * ho + kh - 1) * W + 2 * wo0);
+  };
+  auto issue_a = [&](int m, unsigned sa) {
+    la[m][0] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(yrs, voffA[m], sa, 0));
+    la[m][1] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(yrs, voffA[m] + 16u, sa, 0));
+  };
+  auto issue_b = [&](unsigned sb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lb[q] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(xrs, voffB + 16u * q, sb, 0));
+  };
+  // Column 2 wo0' - 1 is never loaded (for the first step of the first row it would lie in front of the tensor): for the
+  // upper half-wave it is the last column of the lower half's span (lane - 32), for the lower half the last column the
+  // upper half held one step ago (the previous 16 pixels of the row).  One ds_bpermute per step: the upper half sends what
+  // it kept from the previous step, the lower half its current last column; at the first step of a row the lower half's
+  // value is column -1 = padding (masked in xval).
+  auto left_col = [&]() {
+    const float last = lb[3][3];
+    const float send = half ? carry : last;
+    xm1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __builtin_bit_cast(int, send)));
+    carry = last;
+  };
+
+  f32x16 acc[4][3];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][kw][r] = 0.0f;
+
+  // What lies outside the image / the row must enter the sums as zero.  dy of pixels wo >= Wo (the ragged last step of
+  // a row) is selected to zero - then whatever x holds behind the row's end meets a zero; x itself needs only column -1
+  // (first step) and, for odd W, the kw = 2 column of the last valid pixel.  The per-lane conditions are the same for
+  // every row (launch constants, kept as lane masks); a step ORs in "this is not the first / last step" (scalar), so the
+  // price is one v_cndmask per dy value and nine per x fragment set, no compares - selecting in place under a uniform
+  // branch, or branching between a masked and an unmasked copy of the step, spilled ~500 registers.
+  bool mkA[8], mkB2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int wo = 16 * (KS - 1) + 8 * half + i;
+    mkA[i] = wo < Wo;
+    mkB2[i] = 2 * wo + 1 < W;
+  }
+  const bool mkB0 = half != 0;
+  auto aval = [&](int m, int i, int ks) -> float {  // dy of tile m, pixel i of this lane
+    const float v = la[m][i >> 2][i & 3];
+    return (ks != KS - 1 || mkA[i]) ? v : 0.0f;
+  };
+  auto xval = [&](int i, int ks) -> float {         // x at column 2 (16 ks + 8 half) - 1 + i
+    const float v = i == 0 ? xm1 : lb[(i - 1) >> 2][(i - 1) & 3];
+    if (i == 0) return (ks != 0 || mkB0) ? v : 0.0f;
+    if (i >= 2 && (i & 1) == 0) return (ks != KS - 1 || mkB2[i / 2 - 1]) ? v : 0.0f;  // element 2 p + 2 = pixel p's kw = 2
+    return v;
+  };
+  auto pair_split = [&](float av, float bv, u32x4 (&dst)[3], int q) {
+#if BF3_EXP & 2
+    dst[0][q] = __builtin_bit_cast(unsigned, av);
+    dst[1][q] = __builtin_bit_cast(unsigned, bv);
+    dst[2][q] = __builtin_bit_cast(unsigned, av) ^ __builtin_bit_cast(unsigned, bv);
+    return;
+#endif
+    const unsigned h = pack2(av, bv);
+    const float r0 = av - __builtin_bit_cast(float, h << 16), r1 = bv - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack2(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    unsigned hh = h, mm = m, ll = pack2(s0, s1);
+    asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));  // (pins the split here: see conv_s2_bf3_kernel)
+    dst[0][q] = hh;
+    dst[1][q] = mm;
+    dst[2][q] = ll;
+  };
+  // Register budget: VALU operands live in 256 VGPRs (the 12 accumulators take 192 AGPRs), so only the x planes are
+  // double buffered; the dy planes ROLL: the MFMAs run tile-major (18 per dy tile m), tile m's planes are dead behind its
+  // block and take the NEXT step's tile m at once, and tile 3 - alive to the end of the step - is split at the start of
+  // the step that consumes it.  Per step s (every item behind every second MFMA):
+  //   block m = 0:  dy tile 3 of step s (4 pair splits; its loads for step s + 1 behind them), x of step s + 1 (5 of 12)
+  //   block m = 1:  dy tile 0 of step s + 1 (4; its loads for step s + 2 behind them),        x of step s + 1 (4)
+  //   block m = 2:  dy tile 1 of step s + 1 (4; loads),                                        x of step s + 1 (3; x loads)
+  //   block m = 3:  dy tile 2 of step s + 1 (4; loads)
+  u32x4 ap[4][3], bpA[3][3], bpB[3][3];
+
+  if (rid0 < row1) {
+    int r1 = rid0, k1 = ks0;   // step s + 1 while step s computes (here: step 0)
+    int kc;                    // ks of the step being computed (the masks of its tile 3)
+    unsigned sa, sb;
+    offs(r1, k1, sa, sb);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) issue_a(m, sa);
+    issue_b(sb);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pair_split(aval(m, 2 * q, k1), aval(m, 2 * q + 1, k1), ap[m], q);
+    left_col();
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pair_split(xval(4 * q + kw, k1), xval(4 * q + 2 + kw, k1), bpA[kw], q);
+    kc = k1;
+    next_step(r1, k1);   // (r1, k1) = step 1: tiles 0 .. 2 and x go out now; la[3] still holds step 0's tile 3
+    offs(r1, k1, sa, sb);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) issue_a(m, sa);
+    issue_b(sb);
+
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};  // six products, small terms first
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    auto body = [&](u32x4 (&bcur)[3][3], u32x4 (&bnxt)[3][3]) {
+      // offsets of step s + 1 (tile 3's reload) and of step s + 2 (everything else)
+      unsigned sa1, sb1, sa2, sb2;
+      offs(r1, k1, sa1, sb1);
+      int r2 = r1, k2 = k1;
+      if (r2 < row1) next_step(r2, k2);
+      offs(r2, k2, sa2, sb2);
+      auto item = [&](int k) {  // slot k of 36
+        if (k < 4) {            // dy tile 3 of THIS step
+          pair_split(aval(3, 2 * k, kc), aval(3, 2 * k + 1, kc), ap[3], k);
+          if (k == 3 && !(BF3_EXP & 1)) issue_a(3, sa1);
+          if (k == 2) left_col();  // (x of step s + 1 has landed; the bpermute is consumed two slots later)
+        } else if (k < 9) {     // x of step s + 1, pairs 0 .. 4
+          const int e = k - 4;
+          pair_split(xval(4 * (e & 3) + (e >> 2), k1), xval(4 * (e & 3) + 2 + (e >> 2), k1), bnxt[e >> 2], e & 3);
+        } else if (k < 13 || (k >= 18 && k < 22) || (k >= 27 && k < 31)) {  // dy tile 0 / 1 / 2 of step s + 1
+          const int m = k < 13 ? 0 : (k < 22 ? 1 : 2), q = k - (k < 13 ? 9 : (k < 22 ? 18 : 27));
+          pair_split(aval(m, 2 * q, k1), aval(m, 2 * q + 1, k1), ap[m], q);
+          if (q == 3 && !(BF3_EXP & 1)) issue_a(m, sa2);
+        } else if ((k >= 13 && k < 17) || (k >= 22 && k < 25)) {            // x of step s + 1, pairs 5 .. 11
+          const int e = k < 17 ? k - 13 + 5 : k - 22 + 9;
+          pair_split(xval(4 * (e & 3) + (e >> 2), k1), xval(4 * (e & 3) + 2 + (e >> 2), k1), bnxt[e >> 2], e & 3);
+          if (e == 11 && !(BF3_EXP & 1)) issue_b(sb2);
+        }
+      };
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {  // (consecutive MFMAs cycle through the tile's three accumulators)
+            const int n = (m * 6 + p) * 3 + kw;
+            if (m == 3 && p == 0 && kw == 0) __builtin_amdgcn_sched_barrier(0);
+            acc[m][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[m][PA[p]]),
+                                                                 __builtin_bit_cast(bf16x8, bcur[kw][PB[p]]), acc[m][kw],
+                                                                 0, 0, 0);
+            if ((n & 1) == 0) item(n / 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      kc = k1;
+      r1 = r2; k1 = k2;
+    };
+    // (r1 is the step AFTER the one being computed; the loop ends when the computed step was the last valid one)
+    for (;;) {
+      const bool more = r1 < row1;
+      body(bpA, bpB);
+      if (!more) break;
+      const bool more2 = r1 < row1;
+      body(bpB, bpA);
+      if (!more2) break;
+    }
+  }
+
+  // sums -> this segment's slice, [tap][co][ci]: D row (r & 3) + 8 (r >> 2) + 4 half -> co, column l31 -> ci
+  float* __restrict__ out = a.partial + (size_t)seg * 9 * a.Cout * a.Cin;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cog * 128 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[((size_t)(kh * 3 + kw) * a.Cout + co) * a.Cin + cit * 32 + l31] = acc[m][kw][r];
+      }
+}
+
 int pick_nt(int Wo) {
   // pixel tiles of 32 per wave: the split that wastes the fewest pixel columns (Wo = 375: 6 x 64 = 384; 188: 3 x 64 = 192;
   // 94: 1 x 96)
@@ -784,6 +1029,38 @@ int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, f
     hipLaunchKernelGGL(conv_s2d_bf3_kernel<true>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
     hipLaunchKernelGGL(conv_s2d_bf3_kernel<false>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+bool air_bf3_s2w_ok(int B, int Cin, int H, int W, int Cout) {
+  return (air_opt(AIR_OPT_CONV_S2) & 16) != 0 && B > 0 && Cout % 128 == 0 && Cin % 32 == 0 && H >= 2 && W >= 2;
+}
+
+// segments of output rows: enough waves for ~2 per SIMD-slot of the chip, at least 8 K steps each
+int air_bf3_s2w_nseg(int B, int Cin, int Ho, int Wo, int Cout) {
+  const int per_seg = 3 * (Cout / 128) * (Cin / 32);
+  const int nrows = B * Ho, KS = (Wo + 15) / 16;
+  int nseg = (2048 + per_seg - 1) / per_seg;
+  int rps = (nrows + nseg - 1) / nseg;
+  while (rps * KS < 8 && rps < nrows) ++rps;
+  if (rps < 1) rps = 1;
+  return (nrows + rps - 1) / rps;
+}
+
+int air_bf3_s2w_partials(const float* x, const float* dy, float* partial, int B, int Cin, int H, int W, int Cout, int Ho,
+                         int Wo, double flops, hipStream_t st) {
+  Bf3wArgs a;
+  a.x = x; a.dy = dy; a.partial = partial;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = Ho; a.Wo = Wo;
+  a.ncog = Cout / 128; a.ncit = Cin / 32;
+  a.nseg = air_bf3_s2w_nseg(B, Cin, Ho, Wo, Cout);
+  const int nrows = B * Ho;
+  a.rps = (nrows + a.nseg - 1) / a.nseg;
+  a.KS = (Wo + 15) / 16;
+  const int nunit = a.nseg * 3 * a.ncog * a.ncit;
+  AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
+  hipLaunchKernelGGL(conv_s2w_bf3_kernel, dim3((nunit + NWAVE - 1) / NWAVE), dim3(NWAVE * 64), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -59,12 +59,12 @@ int air_abi_version(void);
  *   C1B_PS (7)            bit mask of the persistent bf16 pointwise kernels
  *   C1B_GEMM_PS (1)       256x256 persistent bf16 GEMM
  *   SKINNY_WGRAD (1)      streaming weight gradient of the 16 -> 64 1x1 layer (0: generic 64-channel tiles)
- *   CONV_S2 (15)          bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (three resident
+ *   CONV_S2 (31)          bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (three resident
  *                         workgroups per CU instead of one; same arithmetic, chunk boundaries only); bit 2: stride-2
  *                         3x3 data gradient in one pass; bit 4: stride-2 3x3 forward on the bf16 matrix cores as six
  *                         bf16 products per fp32 product (operands split exactly into three bf16 planes: fp32-
  *                         equivalent arithmetic, csrc/conv_bf3.hip); bit 8: the same for the paired stride-2 data
- *                         gradient (air_conv2d_dgrad_s2_pair)
+ *                         gradient (air_conv2d_dgrad_s2_pair); bit 16: the stride-2 3x3 weight gradient likewise
  */
 int air_set_option(const char* name, int value);
 int air_get_option(const char* name, int* value_out);

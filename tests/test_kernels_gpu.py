@@ -85,14 +85,14 @@ S2 = [
 ]
 
 
-@pytest.mark.parametrize("s2", [0, 1, 7])
+@pytest.mark.parametrize("s2", [0, 1, 7, 31])
 @pytest.mark.parametrize("cfg", S2)
 @pytest.mark.parametrize("fused", [False, True])
 def test_conv2d_stride2_options(ops, cfg, fused, s2):
     """Option CONV_S2: the stride-2 3x3 forward in 4- or 8-channel K chunks - either an fmaf chain held to the direct
     kernels' constant (1e-5 of the output scale) - or (bit 4, plain input only) as six bf16 products per fp32 product on
     operands split exactly into three bf16 planes (conv_bf3.hip), held to the SAME constant; the weight gradient of the
-    same layers beside it."""
+    same layers beside it (bit 16: on the split-bf16 kernel too, where Cout % 128 == 0 and Cin % 32 == 0)."""
     from asvspoof2021_air_amd import _hip
     B, Cin, H, W, Cout = cfg
     x = synth_feat((B, Cin, H, W), 1)
