@@ -154,7 +154,13 @@ def _check(g, epoch_loss, scores, eer, lab_ho, name, curve_rtol, spread=None, mo
     # MEDIAN of their floors is what must match the reference's
     floors = [float(epoch_loss[-1])] + [float(v) for v in getattr(more, "final_loss", ())]
     np.testing.assert_allclose(np.median(floors), g["epoch_loss"][-1], rtol=0.40)
-    assert epoch_loss[-1] < 0.15 and epoch_loss[-1] <= 1.05 * epoch_loss[-4:].min()  # ... and it IS a floor
+    # Round 5 (profiles/r05_eer_chaos.md): 20 runs each of the all-f32 and the split-bf16 configuration at the 4 s shape
+    # (one initial weight moved by 1e-7) end at a median of 0.0797 / 0.0802 (reference 0.0786) with 2 / 1 of 20 runs
+    # still on a transient at the last epoch (0.17, 0.21 / 0.16): a single run above 0.15 is a 5 - 10 % event of EITHER
+    # arithmetic, so the gate is on the samples - at most one of them above 0.15, none above 0.30 - and the unperturbed
+    # run's last epoch must still be its floor
+    assert sum(f >= 0.15 for f in floors) <= (1 if len(floors) >= 3 else 0) and max(floors) < 0.30, floors
+    assert epoch_loss[-1] <= 1.05 * epoch_loss[-4:].min()  # ... and it IS a floor
     # first epoch (24 steps, Adam's first updates are lr * sign(g)): builds of this round that differ only in the
     # summation order of one weight-gradient kernel gave 3.57 and 4.1 against the reference's 4.32
     np.testing.assert_allclose(epoch_loss[0], g["epoch_loss"][0], rtol=curve_rtol[0])
