@@ -246,6 +246,7 @@ struct W4Args {
   unsigned* flags;        // split: one word per cut item, raised to `epoch` when its upper-half sums are in y
   unsigned epoch;
   long long* trace;       // debug: cycle totals of workgroup 0 (null in production)
+  int dephase;            // option WINO4_DEPHASE: every second workgroup of a dealing group starts this many x 4096 cycles late
   // BatchNorm statistics of y from the epilogue (forward only; null = none): a header {G, Cout, 0, 0} and then one
   // record {n, K, sum(y - K), sum((y - K)^2)} per (channel c, tile group g) at [c * G + g], G = 4 * nquad: the
   // (n, mean, M2) of the group's valid outputs in shifted form, merged in fp64 by bn_finalize_records_kernel
@@ -408,6 +409,11 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(W4Args a) {
 #define W4_ROLE 0  // A/B: 1 = round 3 (index from the front), 2 = index from the front with the two roles swapped
 #endif
   const int j = W4_ROLE == 0 ? Wx - 1 - (int)blockIdx.x / a.nxg : (int)blockIdx.x / a.nxg;
+  // VERDICT r4 item 6a (de-phasing): all workgroups walk items of equal length in lockstep, so their store sections
+  // collide; started late by a fraction of an item, every second workgroup stores while its neighbours compute
+  if (a.dephase > 0 && (j & 1)) {
+    for (int d = 0; d < a.dephase; ++d) __builtin_amdgcn_s_sleep(64);
+  }
   // xmode 1: group xg owns the contiguous id range [R0, R0 + nx); xmode 2: the quads congruent to xg mod nxg
   // (nqx of them, every channel slab), numbered locally the same way.  Items below are LOCAL ids 0 .. nx - 1.
   const int nqx = (a.nquad - xg + a.nxg - 1) / a.nxg;
@@ -1453,6 +1459,7 @@ int air_wino4_conv(const float* x, const float* w, float* y, const float* residu
   while (a.ncot % a.cotb != 0) --a.cotb;  // (channel counts here are powers of two times 32: a no-op)
   a.nitems = a.nquad * a.ncot;
   a.trace = g_wino4_trace;
+  a.dephase = air_opt(AIR_OPT_WINO4_DEPHASE);
   // one persistent workgroup per CU the stream can use (144 KB of LDS and 4 x 512 registers: one fits)
   const int ncu = air_stream_cus(st);
   const int nblk = a.nitems < ncu ? a.nitems : ncu;

@@ -59,6 +59,8 @@ int air_abi_version(void);
  *   C1B_PS (7)            bit mask of the persistent bf16 pointwise kernels
  *   C1B_GEMM_PS (1)       256x256 persistent bf16 GEMM
  *   SKINNY_WGRAD (1)      streaming weight gradient of the 16 -> 64 1x1 layer (0: generic 64-channel tiles)
+ *   WINO4_DEPHASE (0)     every second persistent Winograd workgroup starts N x 4096 cycles late, so that the store
+ *                         sections of neighbouring workgroups do not coincide (measured: profiles/r05_wino4_dephase.md)
  *   CONV_S2 (31)          bit 1: stride-2 forward in 4-channel (3x3) / 16-channel (1x1) K chunks (three resident
  *                         workgroups per CU instead of one; same arithmetic, chunk boundaries only); bit 2: stride-2
  *                         3x3 data gradient in one pass; bit 4: stride-2 3x3 forward on the bf16 matrix cores as six
