@@ -25,7 +25,9 @@ enum AirKernelId {
   AIR_K_C1B_TAPW,          // c1b_tapw_kernel: bf16 weight gradient of the dilated K=3 Res2 convs, all branches of a block (ECAPA)
   AIR_K_CONV_WINO4_BN,     // wino4_conv_kernel launches whose epilogue also takes BatchNorm statistics / backward sums (round 4)
   AIR_K_CONV_S2_DGRAD,     // conv_s2_dgrad_kernel: 3x3 stride-2 data gradient (+ the 1x1 shortcut's), all parity classes in one pass
-  AIR_K_CONV_S2_BF3,       // conv_s2_bf3_kernel: 3x3 stride-2 forward as six bf16 products per fp32 product (round 5)
+  AIR_K_CONV_S2_BF3,       // conv_s2_bf3_kernel: 3x3 stride-2 forward (+ 1x1 shortcut) as six bf16 products per fp32 product (round 5)
+  AIR_K_CONV_S2D_BF3,      // conv_s2d_bf3_kernel: the paired stride-2 data gradient likewise
+  AIR_K_CONV_S2W_BF3,      // conv_s2w_bf3_kernel: the stride-2 weight gradient likewise
   AIR_K_COUNT
 };
 

@@ -38,18 +38,7 @@ int find_opt(const char* name) {
 }
 }  // namespace
 
-int air_stream_cus(hipStream_t st) {
-  struct Entry { int dev; hipStream_t st; int cus; };
-  static std::mutex mu;
-  static Entry cache[64];
-  static int n = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < n; ++i)
-      if (cache[i].dev == dev && cache[i].st == st) return cache[i].cus;
-  }
+static int query_stream_cus(int dev, hipStream_t st) {
   int total = 0;
   if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || total <= 0) total = 256;
   int cus = total;
@@ -61,8 +50,40 @@ int air_stream_cus(hipStream_t st) {
   } else {
     (void)hipGetLastError();  // a stream type without the query: the device's count stands
   }
+  return cus;
+}
+
+// CUs a launch on `st` can occupy.  Cached per (device, stream handle) - the query costs microseconds of host time per
+// launch - but a handle can be destroyed and handed out again with another CU mask: every entry is re-queried
+// after 64 hits (never during a stream capture, where the query is not allowed), and when the table is full the oldest
+// entry is replaced instead of every later stream paying the query per launch.  A stale count can only be wrong for
+// 64 launches; the persistent kernels additionally never cut items unless the occupancy query says a workgroup fits.
+int air_stream_cus(hipStream_t st) {
+  struct Entry { int dev; hipStream_t st; int cus; int hits; };
+  static std::mutex mu;
+  static Entry cache[64];
+  static int n = 0, next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n; ++i)
+      if (cache[i].dev == dev && cache[i].st == st) {
+        if (++cache[i].hits < 64) return cache[i].cus;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+          (void)hipGetLastError();
+          return cache[i].cus;
+        }
+        cache[i].hits = 0;
+        cache[i].cus = query_stream_cus(dev, st);
+        return cache[i].cus;
+      }
+  }
+  const int cus = query_stream_cus(dev, st);
   std::lock_guard<std::mutex> lk(mu);
-  if (n < 64) cache[n++] = Entry{dev, st, cus};
+  const int slot = n < 64 ? n++ : (next++ & 63);
+  cache[slot] = Entry{dev, st, cus, 0};
   return cus;
 }
 

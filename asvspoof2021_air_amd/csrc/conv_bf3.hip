@@ -1024,7 +1024,7 @@ int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, f
   a.ncot = Cin / 64;
   a.pair = (W % 2 == 0) && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(accumulate)) & 7) == 0;
   const int nblk = ((a.ntiles + NWAVE - 1) / NWAVE) * a.ncot;
-  AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
+  AirProfScope ps(AIR_K_CONV_S2D_BF3, flops, st, 6.0 * flops);
   if (dy_sc)
     hipLaunchKernelGGL(conv_s2d_bf3_kernel<true>, dim3(nblk), dim3(NWAVE * 64), 0, st, a);
   else
@@ -1059,7 +1059,7 @@ int air_bf3_s2w_partials(const float* x, const float* dy, float* partial, int B,
   a.rps = (nrows + a.nseg - 1) / a.nseg;
   a.KS = (Wo + 15) / 16;
   const int nunit = a.nseg * 3 * a.ncog * a.ncit;
-  AirProfScope ps(AIR_K_CONV_S2_BF3, flops, st, 6.0 * flops);
+  AirProfScope ps(AIR_K_CONV_S2W_BF3, flops, st, 6.0 * flops);
   hipLaunchKernelGGL(conv_s2w_bf3_kernel, dim3((nunit + NWAVE - 1) / NWAVE), dim3(NWAVE * 64), 0, st, a);
   AIR_CHECK_LAUNCH();
   return AIR_OK;

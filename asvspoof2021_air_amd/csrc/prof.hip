@@ -24,7 +24,8 @@ const char* const kNames[AIR_K_COUNT] = {
     "conv_fwd_kernel<parity class>", "conv_fwd_kernel<conv1d>",
     "conv_wgrad_kernel<conv1d>", "lfcc_kernel", "wino_conv_kernel", "wino_wgrad_kernel",
     "c1b_fwd_kernel", "c1b_gemm_kernel", "c1b_tap_kernel", "wino4_conv_kernel",
-    "c1b_tapw_kernel", "wino4_conv_kernel+bn", "conv_s2_dgrad_kernel", "conv_s2_bf3_kernel"};
+    "c1b_tapw_kernel", "wino4_conv_kernel+bn", "conv_s2_dgrad_kernel", "conv_s2_bf3_kernel", "conv_s2d_bf3_kernel",
+    "conv_s2w_bf3_kernel"};
 
 // Test instrumentation (tests/test_cu_mask_gpu.py): a kernel that holds `nblocks` compute units for a while - each
 // workgroup takes `lds_bytes` of LDS (so that a 144 KB persistent Winograd workgroup cannot share its CU) and spins on
