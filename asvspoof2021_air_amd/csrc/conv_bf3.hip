@@ -9,6 +9,9 @@
 // product.  Emulated against fp64 the six-product form sits BELOW the fp32 fma chain it replaces (1.6e-7 .. 5.7e-7 of
 // the output scale for K = 576 .. 4608 against 6.6e-7 .. 1.4e-6: profiles/r05_split_bf16.md), an order of magnitude
 // inside the direct kernels' parity bound (tests/_budget.py: conv_rtol 1e-5).  Ceiling 2500 / 6 = 417 TF.
+// Domain of the exact split (tests/test_split_bf16_cpu.py): 2^-100 <= |x| <= 3.38e38 and 0.  A value within 2^-8 of FLT_MAX
+// rounds its hi plane to infinity (the fp32 kernels would carry it), the low planes of values below ~2^-110 are bf16
+// denormals - activations and weights of this network are O(1e-4 .. 1e2).
 //
 // Mapping (wave64, one 4-wave workgroup per CU):
 //   * a wave owns 64 output channels x NT x 32 consecutive output pixels of one output row; the four waves of a
