@@ -439,7 +439,9 @@ def main():
         # ResNet at N = 1 - with N > 1 it stays eager with the all-reduce in buckets from inside backward (BASELINE
         # configs[3]: "overlapped with backward").  AIR_GRAPH=0 / 1 forces eager / replay everywhere.
         want_graph = os.environ.get("AIR_GRAPH", "")
-        if not augment and (want_graph == "1" or (want_graph != "0" and (model_name == "ecapa" or world == 1))):
+        # (the IR augmentation runs in front of the captured region - its per-utterance draw is host state - and hands
+        # its output to the replay like any other batch)
+        if want_graph == "1" or (want_graph != "0" and (model_name == "ecapa" or world == 1)):
             trainer.enable_graph()
         if augment:
             from asvspoof2021_air_amd.augment import ChannelAugment
