@@ -1081,19 +1081,37 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
   const unsigned arow8 = (unsigned)(8 * p.a_rs * 2), brow8 = (unsigned)((BKM ? 2 : 8) * p.b_rs * 2);
   int it_i = 0, iseg = 0, ik = 0, islot = 0;  // next stage to issue
   G2Tile ti = g2_tile(p, first);
-  auto issue = [&]() {
-    const unsigned base = lds0 + islot * G2_SB + wave * 4096;
+  // One stage = 64 DMA instructions (1 KB each: 32 of A, 32 of B), ALL issued by waves 0 - 3 - one "loader" per
+  // SIMD, 16 instructions each - right behind the stage barrier, while waves 4 - 7 (their SIMD partners, raised to
+  // priority 1) start the stage's MFMAs at once.  An LDS-DMA instruction holds the issuing wave for ~60 cycles
+  // (16 = ~1000 cycles, s_memtime trace): with every wave issuing its eighth of the stage, as rounds 3 - 4 had it,
+  // no wave of the workgroup had an MFMA to offer for the first ~600 cycles of a 3400-cycle stage.  Spreading the
+  // instructions between the MFMAs instead costs their lead time (layer4: 496 us against 438).
+  // profiles/r05_gemm_kloop.md has the stage traces and the clock the kernel really runs at.
+  unsigned d_base = 0, d_ao = 0, d_bo = 0;
+  constexpr int G2_NP = 8, G2_WR = 64;  // pieces of A (and of B) per loader wave and stage; tile rows per loader wave
+  auto issue_setup = [&]() {
+    d_base = lds0 + islot * G2_SB + wave * (G2_NP * 1024);
     const size_t koff = (size_t)iseg * p.a_ss + (size_t)ik * GK, koffb = (size_t)iseg * p.b_ss + (size_t)ik * GK;
-    const unsigned ao = (unsigned)(((size_t)ti.batch * p.a_bs + (size_t)(ti.m0 + 32 * wave) * p.a_rs + koff) * 2);
-    const unsigned bo = BKM ? (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)iseg * p.b_ss +
-                                          ((size_t)ik * GK + 8 * wave) * p.b_rs + ti.n0) * 2)
-                            : (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + 32 * wave) * p.b_rs + koffb) * 2);
+    d_ao = (unsigned)(((size_t)ti.batch * p.a_bs + (size_t)(ti.m0 + G2_WR * wave) * p.a_rs + koff) * 2);
+    d_bo = BKM ? (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)iseg * p.b_ss +
+                             ((size_t)ik * GK + (G2_WR / 4) * wave) * p.b_rs + ti.n0) * 2)
+               : (unsigned)(((size_t)ti.batch * p.b_bs + (size_t)(ti.n0 + G2_WR * wave) * p.b_rs + koffb) * 2);
+  };
+  auto issue_piece = [&](const int q) {
 #ifndef G2_X_NODMA
-#pragma unroll
-    for (int q = 0; q < 4; ++q) fd_dma16(ars, ao + q * arow8, base + q * 1024, (q & 1) ? av1 : av0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) fd_dma16(brs, bo + q * brow8, base + G2_AB + q * 1024, (q & 1) ? bv1 : bv0);
+    if (q < G2_NP) {
+#ifndef G2_X_NOA
+      fd_dma16(ars, d_ao + q * arow8, d_base + q * 1024, (q & 1) ? av1 : av0);
 #endif
+    } else {
+#ifndef G2_X_NOB
+      fd_dma16(brs, d_bo + (q - G2_NP) * brow8, d_base + G2_AB + (q - G2_NP) * 1024, (q & 1) ? bv1 : bv0);
+#endif
+    }
+#endif
+  };
+  auto issue_advance = [&]() {
     islot ^= 1;
     if (++ik == kst) {
       ik = 0;
@@ -1103,6 +1121,17 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
         if (it_i < nmy) ti = g2_tile(p, first + it_i * nwg);
       }
     }
+  };
+  auto issue_all = [&]() {
+    if (wave < 4) {  // one loader wave per SIMD: its partner starts the stage's MFMAs while it feeds the DMA queue
+      issue_setup();
+#pragma unroll
+      for (int q = 0; q < 2 * G2_NP; ++q) issue_piece(q);
+    }
+  };
+  auto issue = [&]() {
+    issue_all();
+    issue_advance();
   };
 
   const int wm = wave & 1, wn = wave >> 1;
@@ -1126,27 +1155,53 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
   }
 #endif
   issue();
+  // the partner of a loader wave issues its MFMAs while the loader feeds the DMA queue; the loader is the OLDER wave of
+  // the SIMD and would otherwise take the matrix pipe back as soon as it gets there, leaving the partner - and with it
+  // the barrier - 1000 cycles behind (stage trace in profiles/r05_gemm_kloop.md)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   int slot = 0;
+#ifdef G2_X_TRACE
+  int trace_n = 0;
+  unsigned long long trace_sum[3] = {0, 0, 0}, trace_last = 0;  // per workgroup and wave: total wait / dma issue / mfma clocks
+  const unsigned long long trace_t0 = __builtin_readcyclecounter(), trace_w0 = wall_clock64();
+#endif
   for (int it = 0; it < nmy; ++it) {
     const G2Tile tl = g2_tile(p, first + it * nwg);
     const int ng = tl.nseg * kst;
     for (int g = 0; g < ng; ++g) {
+#ifdef G2_X_TRACE
+      // timing build: s_memtime at four points of the first 128 stages of workgroup 0, waves 0 and 4, into the
+      // (oversized) bias buffer: tools/kbench_h_gemm.py KB_TRACE=1 prints the per-stage deltas
+      unsigned long long* trc = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + 1024 + (wave >> 2) * 512;
+      const bool tron = blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && trace_n < 128;
+#define G2_TR(j) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); \
+                      if (tron) trc[trace_n * 4 + j] = now_; if (j > 0) trace_sum[j - 1] += now_ - trace_last; trace_last = now_; \
+                      __builtin_amdgcn_sched_barrier(0); } while (0)
+      G2_TR(0);
+#else
+#define G2_TR(j)
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef G2_X_NOBAR
       __syncthreads();  // this stage has landed everywhere; everyone is done with the previous one
-      if (g + 1 < ng || it + 1 < nmy) issue();
+#endif
       const unsigned short* sA = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB);
       const unsigned short* sB = reinterpret_cast<const unsigned short*>(g2_lds + slot * G2_SB + G2_AB);
 #ifdef G2_X_NOMFMA
+      if (g + 1 < ng || it + 1 < nmy) issue();
       if (p.kseg < 0)
 #endif
-#pragma unroll
-      for (int kk = 0; kk < GK / 16; ++kk) {
-        const int cpos = ((kk * 2 + kg) ^ sw) * 8;
-        bf16x8 fa[4], fb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 32 + r) * GK + cpos);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      {
+        // Fragments of k-step kk + 1 are requested while the MFMAs of k-step kk issue (two register sets), one LDS
+        // instruction (pair, for the transposed B reads) behind each of the first six MFMAs.  (Left to the compiler
+        // every pair of MFMAs waited for its own just-issued ds_reads.  tools/ubench/g2_loop.hip, the loop alone:
+        // 1690 TF with the reads as a burst per k-step, 1830 one by one; in the kernel the two are equal.)
+        bf16x8 fa[2][4], fb[2][2];
+        auto rdA = [&](bf16x8& q, const int kk, const int i) {
+          const int cpos = ((kk * 2 + kg) ^ sw) * 8;
+          q = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 32 + r) * GK + cpos);
+        };
+        auto rdB = [&](bf16x8& q, const int kk, const int j) {
           if (BKM) {
             const int i16 = lane & 15, gsel = (lane >> 4) & 1;
             const int nl = wn * 64 + j * 32 + gsel * 16 + 4 * (i16 & 3);  // first of this lane's 4 columns
@@ -1160,16 +1215,53 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
             }
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             const s16x8 both = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-            fb[j] = __builtin_bit_cast(bf16x8, both);
+            q = __builtin_bit_cast(bf16x8, both);
           } else {
-            fb[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+            const int cpos = ((kk * 2 + kg) ^ sw) * 8;
+            q = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + j * 32 + r) * GK + cpos);
+          }
+        };
+#ifdef G2_X_NOLDS
+#define rdA(q, kk, i) do { for (int e_ = 0; e_ < 8; ++e_) q[e_] = (__bf16)(float)(lane + kk); } while (0)
+#define rdB(q, kk, j) do { for (int e_ = 0; e_ < 8; ++e_) q[e_] = (__bf16)(float)(r + kk); } while (0)
+#endif
+        rdA(fa[0][0], 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rdB(fb[0][j], 0, j);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) rdA(fa[0][i], 0, i);
+        const bool more = g + 1 < ng || it + 1 < nmy;
+#ifndef G2_X_NOMFMA
+        __builtin_amdgcn_sched_barrier(0);
+        G2_TR(1);
+        if (more) issue_all();
+        G2_TR(2);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < GK / 16; ++kk) {
+          const int cb = kk & 1, nb = cb ^ 1;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const int i = n >> 1, j = n & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < GK / 16) {
+              // (in the order the next k-step's MFMAs want them: A0, B0, B1, A1, A2, A3)
+              if (n == 0) rdA(fa[nb][0], kk + 1, 0);
+              else if (n < 3) rdB(fb[nb][n - 1], kk + 1, n - 1);
+              else if (n < 6) rdA(fa[nb][n - 2], kk + 1, n - 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#ifndef G2_X_NOMFMA
+        if (more) issue_advance();
+#endif
+        G2_TR(3);
+#ifdef G2_X_TRACE
+        ++trace_n;
+#endif
       }
       slot ^= 1;
     }
@@ -1264,6 +1356,14 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
     }
     zero();
   }
+#ifdef G2_X_TRACE
+  if ((wave & 3) == 0 && lane == 0) {
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias)) + 4096 +
+                              (blockIdx.x * 2 + (wave >> 2)) * 4;
+    tot[0] = trace_sum[0]; tot[1] = wall_clock64() - trace_w0; tot[2] = trace_sum[2];  // ([1]: 100 MHz ticks)
+    tot[3] = __builtin_readcyclecounter() - trace_t0;
+  }
+#endif
 }
 
 // ===================================================================================

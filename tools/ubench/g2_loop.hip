@@ -1,0 +1,158 @@
+// The k-loop of c1b_gemm_ps_kernel without its DMA and epilogue: per stage (64 k) a barrier, then 4 k-steps of
+// LDS fragment reads (A: ds_read_b128 from [256 m][64 k] swizzled rows; B: ds_read_b64_tr_b16 from [64 k][256 n])
+// and v_mfma_f32_32x32x16_bf16.  What is measured: MFMA rate against how the reads are placed and how the 256 x 256
+// tile is cut into waves.  hipcc --offload-arch=gfx950 -O3 -o g2_loop g2_loop.hip
+//   MODE bits 0-1: 0 = next k-step's reads as one burst before this k-step's MFMAs (the product), 1 = one read
+//                  behind every MFMA, 2 = reads of a k-step right before its own MFMAs (no prefetch), 3 = no reads
+//   MODE bit 2: no barrier;  bit 3: s_setprio 1 on the second half of the waves
+//   NWAVE 8: wave tile 128 x 64 (2 waves per SIMD);  NWAVE 4: wave tile 128 x 128 (1 wave per SIMD, 256 accumulators)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int GK = 64;
+
+template <int MODE, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void k(float* out, int stages) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  constexpr int NJ = NWAVE == 8 ? 2 : 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 2 * 65536 / 4; i += 64 * NWAVE) reinterpret_cast<unsigned*>(lds)[i] = 0x3c003c00u + (i & 0xff);
+  __syncthreads();
+  const int wm = wave & 1, wn = wave >> 1;
+  const int r = lane & 31, kg = lane >> 5, sw = (r >> 1) & 7;
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  if ((MODE & 8) && wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+  int slot = 0;
+  for (int g = 0; g < stages; ++g) {
+    if (!(MODE & 4)) __syncthreads();
+    const unsigned short* sA = reinterpret_cast<const unsigned short*>(lds + slot * 65536);
+    const unsigned short* sB = sA + 16384;
+    auto rdA = [&](bf16x8& q, const int kk, const int i) {
+      const int cpos = ((kk * 2 + kg) ^ sw) * 8;
+      q = *reinterpret_cast<const bf16x8*>(sA + (wm * 128 + i * 32 + r) * GK + cpos);
+    };
+    auto rdB = [&](bf16x8& q, const int kk, const int j) {
+      const int i16 = lane & 15, gsel = (lane >> 4) & 1;
+      const int nl = wn * (32 * NJ) + j * 32 + gsel * 16 + 4 * (i16 & 3);
+      s16x4 h[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int row = kk * 16 + kg * 8 + 4 * hh + (i16 >> 2);
+        const unsigned short* src = sB + row * 256 + (((nl >> 3) ^ ((i16 >> 2) << 2)) << 3) + (nl & 4);
+        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)src);
+      }
+      const s16x8 both = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+      q = __builtin_bit_cast(bf16x8, both);
+    };
+    bf16x8 fa[2][4], fb[2][NJ];
+    auto ldall = [&](const int b, const int kk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rdA(fa[b][i], kk, i);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) rdB(fb[b][j], kk, j);
+    };
+    constexpr int RD = MODE & 3;
+    if (RD == 3) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fa[b][i][e] = (__bf16)1.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fb[b][j][e] = (__bf16)1.0f;
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(fa[b][i]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(fb[b][j]));
+      }
+    }
+    if (RD == 0 || RD == 1) ldall(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < GK / 16; ++kk) {
+      const int cb = kk & 1, nb = cb ^ 1;
+      if (RD == 2) ldall(cb, kk);
+      if (RD == 0 && kk + 1 < GK / 16) ldall(nb, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][i], fb[cb][j], acc[i][j], 0, 0, 0);
+          if (RD == 1 && kk + 1 < GK / 16) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int n = i * NJ + j;
+            if (n < 4) rdA(fa[nb][n], kk + 1, n);
+            else if (n - 4 < NJ) rdB(fb[nb][n - 4], kk + 1, n - 4);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot ^= 1;
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int MODE, int NWAVE>
+static void run(const char* name, float* d) {
+  const int stages = 24 * 9, nb = 256;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, NWAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  float best = 1e9f;
+  for (int rep = 0; rep < 6; ++rep) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<MODE, NWAVE>), dim3(nb), dim3(64 * NWAVE), 131072, 0, d, stages);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep >= 2 && ms < best) best = ms;
+  }
+  const double mfma = (double)stages * 4 * 64 * nb;  // 64 MFMAs per k-step per workgroup either way
+  printf("%-64s %8.1f us  %7.1f TF\n", name, best * 1e3, mfma * 32768.0 / (best * 1e9));
+}
+
+int main() {
+  float* d;
+  hipMalloc(&d, 1024);
+  run<3, 8>("8 waves (128x64), no reads", d);
+  run<7, 8>("8 waves (128x64), no reads, no barrier", d);
+  run<0, 8>("8 waves, burst prefetch (product)", d);
+  run<4, 8>("8 waves, burst prefetch, no barrier", d);
+  run<8, 8>("8 waves, burst prefetch, setprio on waves 4-7", d);
+  run<1, 8>("8 waves, one read behind every MFMA", d);
+  run<9, 8>("8 waves, one read behind every MFMA, setprio", d);
+  run<2, 8>("8 waves, just-in-time reads", d);
+  run<3, 4>("4 waves (128x128), no reads", d);
+  run<0, 4>("4 waves, burst prefetch", d);
+  run<1, 4>("4 waves, one read behind every MFMA", d);
+  run<5, 4>("4 waves, one read behind every MFMA, no barrier", d);
+  run<2, 4>("4 waves, just-in-time reads", d);
+  return 0;
+}
