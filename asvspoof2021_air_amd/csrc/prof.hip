@@ -39,6 +39,22 @@ __global__ void cu_hog_kernel(unsigned long long ticks, unsigned* sink) {
   while (wall_clock64() - t0 < ticks) acc = acc * 1664525u + 1013904223u;
   if (acc == 0x12345u && sink) *sink = acc;  // (keeps the loop)
 }
+
+// Measurement instrumentation (bench.py "core_clock"): ONE wave that samples {100 MHz wall clock, s_memtime core clock
+// counter} every `interval` wall ticks while other kernels run beside it on another stream - the clock the compute
+// units really run at under a given kernel mix (amd-smi answers with a slow average; the MFMA-dense kernels are
+// power-capped well below the 2.4 GHz the peaks are quoted at).  out[2 i] = wall ticks, out[2 i + 1] = core clocks.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int n, unsigned long long interval) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = wall_clock64();
+  for (int i = 0; i < n; ++i) {
+    unsigned long long w;
+    while ((w = wall_clock64()) < next) __builtin_amdgcn_s_sleep(32);
+    out[2 * i] = w;
+    out[2 * i + 1] = __builtin_readcyclecounter();
+    next += interval;
+  }
+}
 }  // namespace
 
 bool air_prof_on() { return g_on; }
@@ -68,6 +84,14 @@ int air_debug_cu_hog(int nblocks, int lds_bytes, double milliseconds, air_stream
   if (!attr_ok) return AIR_ELAUNCH;
   hipLaunchKernelGGL(cu_hog_kernel, dim3(nblocks), dim3(64), (size_t)lds_bytes, air_stream(stream),
                      (unsigned long long)(milliseconds * 1e5), (unsigned*)nullptr);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_debug_clock_probe(unsigned long long* out, int n_samples, double interval_us, air_stream_t stream) {
+  if (!out || n_samples < 2 || n_samples > (1 << 20) || interval_us < 1.0 || interval_us * n_samples > 5e6) return AIR_EINVAL;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, air_stream(stream), out, n_samples,
+                     (unsigned long long)(interval_us * 100.0));
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

@@ -817,3 +817,47 @@ def bn_flush():
     if _TICKS:
         torch._foreach_add_(_TICKS, 1)
         del _TICKS[:]
+
+
+class ClockProbe:
+    """Core clock of the GPU WHILE other kernels run (air_debug_clock_probe): one wave on a side stream samples
+    {wall clock, core-clock counter} every ``interval_us``; ``mhz()`` after the measured work has been synchronised.
+    Measurement instrumentation (bench.py "core_clock"), not part of the training path."""
+
+    def __init__(self, device, n_samples=2000, interval_us=50.0):
+        self.n = int(n_samples)
+        self.buf = torch.zeros(2 * self.n, dtype=torch.int64, device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.interval_us = float(interval_us)
+
+    def start(self):
+        self.buf.zero_()
+        torch.cuda.current_stream(self.buf.device).synchronize()
+        _hip.check(_hip.lib().air_debug_clock_probe(ctypes.c_void_p(self.buf.data_ptr()), ci(self.n),
+                                                    ctypes.c_double(self.interval_us),
+                                                    ctypes.c_void_p(self.side.cuda_stream)), "air_debug_clock_probe")
+
+    def samples(self):
+        """(t_us, mhz) per sampling interval, after the probe has finished."""
+        self.side.synchronize()
+        raw = self.buf.cpu().numpy().reshape(self.n, 2)
+        ok = raw[:, 0] > 0
+        raw = raw[ok]
+        dw = (raw[1:, 0] - raw[:-1, 0]).astype("float64")
+        dc = (raw[1:, 1] - raw[:-1, 1]).astype("float64")
+        keep = dw > 0
+        t = (raw[1:, 0] - raw[0, 0])[keep] / 100.0
+        return t, dc[keep] / dw[keep] * 100.0
+
+    def mhz(self, t_lo_us=None, t_hi_us=None):
+        """Median / min / max core clock over the samples whose time since the probe's start lies in [t_lo, t_hi]."""
+        import numpy as np
+        t, f = self.samples()
+        if t_lo_us is not None:
+            sel = (t >= t_lo_us) & (t <= t_hi_us)
+            f = f[sel]
+        if f.size == 0:
+            return None
+        return {"median": round(float(np.median(f)), 1), "min": round(float(f.min()), 1), "max": round(float(f.max()), 1),
+                "samples": int(f.size), "interval_us": self.interval_us}
+

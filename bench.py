@@ -516,6 +516,32 @@ def main():
                            "spread": round((per[-1] - per[0]) / med, 4)})
             if smi0 is not None:
                 timing["smi_before"], timing["smi_after"] = smi0, smi_sample(local)
+                # The clock the compute units run at DURING the steps (amd-smi above is sampled with the GPU idle): one
+                # probe wave on a side stream (air_debug_clock_probe) beside 20 further, untimed steps.  The MFMA-dense
+                # kernels are power-capped well below the 2.4 GHz that the peaks in `roofline` are quoted at.
+                try:
+                    if world > 1:
+                        raise RuntimeError("single-process runs only (the extra steps would need every rank)")
+                    from asvspoof2021_air_amd.ops import ClockProbe
+                    import numpy as np
+                    n_probe = 20
+                    probe = ClockProbe(device, n_samples=int(min(60000, n_probe * med * 1e3 / 100.0 * 1.5 + 200)), interval_us=100.0)
+                    probe.start()
+                    time.sleep(0.002)
+                    for i in range(n_probe):  # (no fence: a device-wide synchronize would wait for the probe itself)
+                        trainer.step(*batches[i % nb])
+                    nrun[0] += n_probe
+                    torch.cuda.current_stream(device).synchronize()
+                    t, f = probe.samples()
+                    sel = f[(t > 1000.0) & (t < n_probe * med * 1e3)]
+                    if sel.size:
+                        timing["core_clock_mhz_during_steps"] = {
+                            "median": round(float(np.median(sel)), 1), "p10": round(float(np.percentile(sel, 10)), 1),
+                            "p90": round(float(np.percentile(sel, 90)), 1), "min": round(float(sel.min()), 1),
+                            "max": round(float(sel.max()), 1), "samples": int(sel.size), "interval_us": 100.0,
+                            "how": "s_memtime / 100 MHz wall clock sampled by one wave on a side stream beside %d untimed steps" % n_probe}
+                except Exception as e:  # instrumentation only
+                    timing["core_clock_mhz_during_steps"] = {"error": repr(e)[:200]}
             steps_timed = wsteps
             res = {"value": round(world * BATCH * steps_timed / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
                    "ms_per_step": round(1e3 * dt / steps_timed, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,

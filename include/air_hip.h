@@ -698,6 +698,13 @@ int air_sgd_step(float* p, const float* g, size_t n, float lr, float grad_scale,
  * (tests/test_cu_mask_gpu.py); the reference has no counterpart (main_train.py:174 is a commented-out DataParallel). */
 int air_debug_cu_hog(int nblocks, int lds_bytes, double milliseconds, air_stream_t stream);
 
+/* Measurement instrumentation: one wave on `stream` that writes n_samples pairs {wall-clock ticks (100 MHz), core-clock
+ * counter (s_memtime)} into out[2 * n_samples], one pair every interval_us (>= 1; n_samples * interval_us <= 5 s).
+ * Launched on a side stream next to the training step it gives the clock the compute units run at under that kernel
+ * mix (bench.py "core_clock"): the MFMA-dense kernels are power-capped below the 2.4 GHz the peak figures assume.
+ * No reference counterpart. */
+int air_debug_clock_probe(unsigned long long* out, int n_samples, double interval_us, air_stream_t stream);
+
 /* ------------------------------------------------- bench instrumentation ---
  * Opt-in HIP-event timing of the dominant kernels on their launch stream, used
  * by bench.py's roofline leg only (off by default).  kid indexes the kernel

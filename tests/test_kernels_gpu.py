@@ -433,6 +433,22 @@ def test_ocsoftmax(ops, golden, mode):
     np.testing.assert_allclose(dx.cpu().numpy(), gx, atol=2e-7, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,D", [(1, 256), (7, 100), (130, 256), (64, 300), (33, 1100), (4096, 64)])
+def test_ocsoftmax_shapes(ops, B, D):
+    """Ragged row / dimension counts through the 16-wave kernels (rows in groups of 4 per wave, dimension chunks of a
+    power of two, row groups per dimension) against the fp64 closed form."""
+    x = synth_feat((B, D), 11)
+    c = synth_feat((1, D), 12)
+    lab = (torch.arange(B) % 3 == 0).long()
+    l64, n64, gx, gc = o_loss.ocsoftmax_grads_f64(x.numpy(), c.numpy(), lab.numpy(), 0.9, 0.2, 20.0)
+    loss, neg = ops.ocsoftmax_fwd(x.cuda(), c.cuda(), lab.cuda(), 0.9, 0.2, 20.0)
+    np.testing.assert_allclose(loss.item(), l64, rtol=5e-6)
+    np.testing.assert_allclose(neg.cpu().numpy(), n64, atol=2e-6)
+    dx, dc = ops.ocsoftmax_bwd(x.cuda(), c.cuda(), lab.cuda(), 0.9, 0.2, 20.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, atol=2e-7 + 1e-6 / B, rtol=2e-4)
+    np.testing.assert_allclose(dc.cpu().numpy().reshape(-1), np.asarray(gc).reshape(-1), atol=5e-6, rtol=2e-4)
+
+
 def test_adam_sgd(ops):
     n = 100003
     p = synth_feat((n,), 1)
