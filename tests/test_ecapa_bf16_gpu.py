@@ -270,6 +270,31 @@ def test_pointwise_conv_statistics_from_the_epilogue(oh, cfg):
         oh.conv_pointwise(x, w.transpose(0, 1).contiguous(), T, dgrad=True, stats=True)
 
 
+def test_pointwise_conv_statistics_large_mean(oh):
+    """The epilogue records are UNSHIFTED fp32 {sum, sum of squares} of 64 stored values each, merged in fp64
+    (h_bn_finalize_records_kernel): the variance s2 / N - mean^2 loses ~6e-8 (1 + mean^2 / var) relative.  A channel
+    whose mean is 30 - 60 standard deviations (mean^2 / var ~ 1e3 - 4e3; ECAPA's post-ReLU channels sit at 0.5 - 2)
+    still gets its mean to 3e-6 and its inverse deviation to 5e-4 of an fp64 evaluation of the stored values, and
+    agrees with the two-pass statistics (shifted sums) to the same bound."""
+    B, Cin, Cout, T = 4, 64, 512, 300
+    x, _ = res(oh, synth_feat((B, Cin, T), 81))
+    w = synth_feat((Cout, Cin, 1), 82, scale=0.05).cuda()
+    bias = (30.0 + 0.1 * synth_feat((Cout,), 83)).cuda()
+    gamma, beta = (1.0 + 0.2 * synth_feat((Cout,), 85)).cuda(), (0.3 * synth_feat((Cout,), 86)).cuda()
+    y1, rec = oh.conv_pointwise(x, w, T, bias=bias, relu=True, stats=True)
+    st0 = oh.bn_stats(y1, T, gamma, beta)
+    st1 = oh.bn_stats(y1, T, gamma, beta, stats_in=rec)
+    yd = val(y1, T).double()
+    mean, var = yd.mean((0, 2)), yd.var((0, 2), unbiased=False)
+    ratio = float((mean * mean / var).max())
+    assert 500.0 < ratio < 2e4, ratio  # the test is about THIS regime
+    want = [mean, 1.0 / torch.sqrt(var + 1e-5)]
+    for k, (name, tol) in enumerate((("mean", 3e-6), ("invstd", 5e-4))):
+        for st in (st0, st1):
+            got = st[k].double().cpu()
+            assert float(((got - want[k]).abs() / want[k].abs()).max()) <= tol, name
+
+
 @pytest.mark.parametrize("cfg", [(3, 64, 96, 2), (2, 64, 750, 3), (5, 128, 401, 4), (130, 64, 200, 2)])
 def test_tap_conv_statistics_from_the_epilogue(oh, cfg):
     """air_h_conv1d_tap_ex: the Res2 branch conv (ecapa_tdnn.py:46-48, conv -> ReLU -> BatchNorm1d) leaves the BatchNorm
