@@ -9,6 +9,8 @@ trap), and the results must be the unmasked launch's up to the summation order o
 """
 import ctypes
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -199,3 +201,24 @@ def test_resnet_train_step_with_resident_hog_kernel():
         outs.append((float(loss), m.arena().grad.clone(), m.arena().flat.clone()))
     (l0, g0, w0), (l1, g1, w1) = outs
     assert l0 == l1 and torch.equal(g0, g1) and torch.equal(w0, w1)
+
+
+@pytest.mark.gpu
+def test_clock_probe_beside_a_kernel():
+    """air_debug_clock_probe (bench.py timing.core_clock_mhz_during_steps): one wave on a side stream samples {wall clock,
+    core-clock counter} while another kernel runs; the samples are monotonic, evenly spaced and give a plausible clock."""
+    from asvspoof2021_air_amd.ops import ClockProbe
+    dev = torch.device("cuda")
+    probe = ClockProbe(dev, n_samples=200, interval_us=50.0)
+    probe.start()
+    a = torch.randn(4096, 4096, device=dev)
+    for _ in range(10):
+        a = a * 1.0001 + 0.5
+    torch.cuda.current_stream().synchronize()
+    t, f = probe.samples()
+    assert len(t) >= 150 and bool((np.diff(t) > 0).all())
+    assert abs(float(np.median(np.diff(t))) - 50.0) < 10.0
+    r = probe.mhz()
+    assert 300.0 < r["min"] <= r["median"] <= r["max"] < 3500.0
+    with pytest.raises(Exception):
+        ClockProbe(dev, n_samples=1).start()
