@@ -211,6 +211,13 @@ class Res2Net2(nn.Module):
         self.fuse_tap_stats = os.environ.get("AIR_TAP_STATS", "1") == "1"  # Res2 branch statistics from the conv epilogue
         self.fuse_pw_stats = os.environ.get("AIR_PW_STATS", "1") == "1"    # K = 1 convs: statistics from the GEMM epilogue
         self._side_stream = None
+        # Under hipGraph capture (train.Trainer.enable_graph) a fork per weight gradient makes a graph with ~14 cross-stream
+        # edges, which ROCm replays slower than one chain (round 4).  "batched" (experiment, AIR_WGRAD_BATCHED=1): the
+        # bf16-resident backward queues its weight-gradient launches and hands them to the side stream at FOUR points
+        # only - in front of each block's Res2 chain (21 short dependent launches that leave most of the chip idle) and
+        # at the end: 4 forks and 1 join.  Measured (round 5): still 5 ms of host time per replay and a slower step than
+        # one chain; left off.
+        self.wgrad_batched = False
 
     def enable_ddp_overlap(self, bucket_bytes=8 << 20):
         """Launch the gradient all-reduce from inside backward (one process per GPU, world size > 1):
@@ -753,8 +760,9 @@ class Res2Net2(nn.Module):
         ops.bn_flush()
         return feat, out, S
 
-    def _block_bwd_h(self, S, dout, T, G, pre, add2, on_side):
-        """dout: gradient w.r.t. the block output (resident rows or a channel slice).  Returns d(inp) + dout + add2."""
+    def _block_bwd_h(self, S, dout, T, G, pre, add2, on_side, flush_side=None):
+        """dout: gradient w.r.t. the block output (resident rows or a channel slice).  Returns d(inp) + dout + add2.
+        flush_side (batched weight gradients): called in front of the Res2 chain - what has been queued runs beside it."""
         blk = S["blk"]
         det = lambda p: p.detach()
         B, C, Tp = S["o3"].shape
@@ -778,6 +786,8 @@ class Res2Net2(nn.Module):
         din_next = sums_next = None
         dcs = [None] * nums
         fuse = getattr(self, "fuse_tap_stats", True)
+        if flush_side is not None:
+            flush_side()
         for i in reversed(range(nums)):
             st_i = S["st"][i]
             dc_i = oh.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], T, st_i[0], st_i[1], det(blk.bns[i].weight),
@@ -819,18 +829,34 @@ class Res2Net2(nn.Module):
         if use_side and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=main.device)
         side = self._side_stream if use_side else main
-        keep = []
+        batched = use_side and self.wgrad_batched
+        keep, pending = [], []
 
         def on_side(fn, *reads):
             if not use_side:
                 fn()
                 return
             keep.extend(reads)
+            if batched:
+                pending.append(fn)
+                return
             ready = torch.cuda.Event()
             ready.record(main)
             side.wait_event(ready)
             with torch.cuda.stream(side):
                 fn()
+
+        def flush_side():
+            """batched mode: everything queued so far goes to the side stream behind ONE event of the main stream"""
+            if not pending:
+                return
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                for fn in pending:
+                    fn()
+            del pending[:]
 
         if dfeat is None:
             dfeat = torch.zeros_like(S["feat"])
@@ -882,6 +908,7 @@ class Res2Net2(nn.Module):
 
         def grads_final_from(first_param):
             if bucketer is not None:
+                flush_side()
                 evs = [torch.cuda.Event()]
                 evs[0].record(main)
                 if use_side:
@@ -899,7 +926,7 @@ class Res2Net2(nn.Module):
             # already added this block's slice (add2); block 3 reads its slice in place
             dblk = dcat123[:, k * C:(k + 1) * C] if dnext is None else dnext
             add2 = dcat123[:, (k - 1) * C:k * C] if k > 0 else None
-            dnext = self._block_bwd_h(S["blocks"][k], dblk, T, G, "layer%d." % (k + 1), add2, on_side)
+            dnext = self._block_bwd_h(S["blocks"][k], dblk, T, G, "layer%d." % (k + 1), add2, on_side, flush_side)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
         st0 = S["st0"]
         dc0 = oh.bn_bwd(S["r0"], dnext, T, st0[0], st0[1], det(self.bn1.weight), G["bn1.weight"], G["bn1.bias"], dx=dnext,
@@ -911,6 +938,7 @@ class Res2Net2(nn.Module):
             ops.add_strided(G["conv1.weight"].view(C, 1, nk), dwm.view(C, 1, R0)[:, :, :nk])  # drop the zero columns
 
         on_side(conv1_wgrad, dc0)
+        flush_side()
         if use_side:
             main.wait_stream(side)
         del keep[:]

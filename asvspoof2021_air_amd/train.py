@@ -226,13 +226,23 @@ class Trainer:
             # through several internal streams with a signal per edge - hipGraphLaunch itself took 5.4 ms of host time
             # per replay and the step 8.41 ms against eager's 8.16.  Captured as ONE chain (no side stream) the replay
             # costs 0.22 ms of host time and the step 8.08 ms (6.19 ms at T = 401, eager 6.24).
+            # Round 5 re-test with FOUR forks and one join (Res2Net2.wgrad_batched: the weight gradients queued and handed
+            # to the side stream in front of each block's Res2 chain; AIR_WGRAD_BATCHED=1): hipGraphLaunch 5.1 ms of host
+            # time again, step 7.58 ms against 7.40 as one chain (5.60 / 5.42 at T = 401) - ANY fork makes the replay
+            # multi-stream.  Off by default.
             if self._overlap_saved is None:  # (a second enable_graph() must not save the already-forced False)
                 self._overlap_saved = (getattr(self.model, "overlap_wgrad", None), getattr(self.model, "_bucketer", None))
-            self.model.overlap_wgrad = False
+            batched = (isinstance(self.model, Res2Net2) and getattr(self.model, "compute_dtype", "fp32") == "bf16"
+                       and os.environ.get("AIR_WGRAD_BATCHED", "0") == "1")
+            self.model.overlap_wgrad = batched
+            if isinstance(self.model, Res2Net2):
+                self.model.wgrad_batched = batched
             if hasattr(self.model, "_bucketer"):
                 self.model._bucketer = None
         elif self._overlap_saved is not None:
             self.model.overlap_wgrad, bucketer = self._overlap_saved
+            if hasattr(self.model, "wgrad_batched"):
+                self.model.wgrad_batched = False
             if hasattr(self.model, "_bucketer"):
                 self.model._bucketer = bucketer
             self._overlap_saved = None
