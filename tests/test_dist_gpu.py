@@ -237,3 +237,51 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["ddp"]["world"] == 2 and comm["allreduce_bytes_per_step"] == 49_802_184 - 2_056
     assert d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo" and d["launch"] == "eager"
     assert comm["step_ms_without_exchange"] > 0 and "exposed_ms" in comm and comm["overlap"] is True
+
+
+@pytest.mark.parametrize("kind", ["resnet_b64", "ecapa_bf16_b128_aug"])
+def test_bench_two_ranks_at_the_stated_per_gpu_size(kind):
+    """BASELINE configs[3] / configs[4] at their STATED per-GPU size (ResNet fp32 B = 64, ECAPA bf16 B = 128 + the IR
+    augmentation; 4 s, feat_len 750) - two of the eight ranks, on one GPU, over gloo: the path the driver's 8-GPU run
+    takes (torch.distributed.run, one process per rank, bucketed all-reduce / all-reduce behind the graph replay),
+    at the tensor sizes it takes it with.  Finite loss, the whole-job batch, the exchange's byte count."""
+    env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    extra = [] if kind == "resnet_b64" else ["--model", "ecapa", "--augment"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--plain-timing", "--no-roofline", "--no-extra-configs"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    per = 64 if kind == "resnet_b64" else 128
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 2 * per and d["config"]["parallelism"] == "dp2"
+    assert np.isfinite(d["final_loss"]) and d["final_loss"] > 0
+    assert d["ddp"]["world"] == 2 and d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo"
+    assert d["ddp"]["communication"]["allreduce_bytes_per_step"] > 20_000_000
+    if kind == "resnet_b64":
+        assert d["dtype"] in ("f32", "fp32") and d["launch"] == "eager"
+    else:
+        assert d["dtype"] == "bf16" and d["launch"].startswith("hipGraph")
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8` exactly as the driver launches it (eight processes, LOCAL_RANK 0 - 7), configs[3]'s per-GPU
+    shape, all eight ranks time-slicing the one GPU of this box over gloo: rendezvous, bucketed all-reduce from inside
+    backward across EIGHT ranks, the barrier + max-over-ranks timing and the single JSON line.  (What RCCL over xGMI
+    adds on a real node is the transport; the call pattern is this one.)"""
+    env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1",
+           "--warmup", "1", "--plain-timing", "--no-roofline", "--no-extra-configs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
+    assert d["ddp"]["world"] == 8 and d["ddp"]["ranks_seen"] == 8
+    assert np.isfinite(d["final_loss"]) and d["value"] > 0
+
