@@ -705,7 +705,15 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_leg()
             except Exception as exc:  # noqa: BLE001  (the headline line still goes out)
                 line["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
-        print(json.dumps(line), flush=True)
+        text = json.dumps(line)
+        # ONE write of the whole line (print() may split a line longer than the pipe buffer into several writes, between
+        # which another rank's output can land when N processes share the launcher's stdout)
+        sys.stdout.flush()
+        os.write(sys.stdout.fileno(), (text + "\n").encode())
+        out_path = os.environ.get("AIR_BENCH_JSON_OUT")  # tests: the same line into a file as well
+        if out_path:
+            with open(out_path, "w") as f:
+                f.write(text + "\n")
     if world > 1:
         td.barrier()
         td.destroy_process_group()
