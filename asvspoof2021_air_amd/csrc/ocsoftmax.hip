@@ -160,6 +160,7 @@ int air_ocsoftmax_fwd(const float* x, const float* center, const int64_t* labels
                       float r_real, float r_fake, float alpha, float* loss, float* neg_scores,
                       air_stream_t stream) {
   if (!x || !center || !labels || !loss || !neg_scores || B <= 0 || D <= 0) return AIR_EINVAL;
+  if (B > MAXB) return AIR_EUNSUPPORTED;  // (the per-row loss terms go through LDS)
   hipLaunchKernelGGL(ocs_fwd_kernel, dim3(1), dim3(NT), 0, air_stream(stream), x, center, labels,
                      B, D, r_real, r_fake, alpha, loss, neg_scores);
   AIR_CHECK_LAUNCH();

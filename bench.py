@@ -531,7 +531,7 @@ def main():
                     from asvspoof2021_air_amd.ops import ClockProbe
                     import numpy as np
                     n_probe = 20
-                    probe = ClockProbe(device, n_samples=int(min(60000, n_probe * med * 1e3 / 100.0 * 1.5 + 200)), interval_us=100.0)
+                    probe = ClockProbe(device, n_samples=int(min(45000, n_probe * med * 1e3 / 100.0 * 1.5 + 200)), interval_us=100.0)
                     probe.start()
                     time.sleep(0.002)
                     for i in range(n_probe):  # (no fence: a device-wide synchronize would wait for the probe itself)

@@ -673,6 +673,7 @@ int air_h_unfold(const float* x, size_t x_bs, int B, int Cin, int T, int Tp, int
  * AngularIsoLoss.forward == OCSoftmax.forward (loss.py:73-97, :187-206).
  * x (B,D), center (1,D), labels (B,) int64.  loss: scalar; neg_scores (B,).
  * bwd: dx (B,D), dcenter (1,D) for d(loss*gscale).
+ * One workgroup each (the loss is summed in a fixed order): B <= 4096, else AIR_EUNSUPPORTED.
  */
 int air_ocsoftmax_fwd(const float* x, const float* center, const int64_t* labels, int B, int D,
                       float r_real, float r_fake, float alpha, float* loss, float* neg_scores,

@@ -449,6 +449,16 @@ def test_ocsoftmax_shapes(ops, B, D):
     np.testing.assert_allclose(dc.cpu().numpy().reshape(-1), np.asarray(gc).reshape(-1), atol=5e-6, rtol=2e-4)
 
 
+def test_ocsoftmax_refuses_more_rows_than_its_workgroup_holds(ops):
+    x = synth_feat((4097, 8), 13).cuda()
+    c = synth_feat((1, 8), 14).cuda()
+    lab = torch.zeros(4097, dtype=torch.long, device="cuda")
+    with pytest.raises(Exception):
+        ops.ocsoftmax_fwd(x, c, lab, 0.9, 0.2, 20.0)
+    with pytest.raises(Exception):
+        ops.ocsoftmax_bwd(x, c, lab, 0.9, 0.2, 20.0)
+
+
 def test_adam_sgd(ops):
     n = 100003
     p = synth_feat((n,), 1)
