@@ -965,7 +965,9 @@ int pick_nt(int Wo) {
 }  // namespace
 
 bool air_bf3_s2_ok(int B, int Cin, int H, int W, int Cout) {
-  return (air_opt(AIR_OPT_CONV_S2) & 4) != 0 && B > 0 && Cin % CK == 0 && Cout % 64 == 0 && H >= 2 && W >= 2;
+  // (a buffer descriptor per utterance: one utterance's (Cin, H, W) block below 4 GB)
+  return (air_opt(AIR_OPT_CONV_S2) & 4) != 0 && B > 0 && Cin % CK == 0 && Cout % 64 == 0 && H >= 2 && W >= 2 &&
+         4ull * (unsigned long long)Cin * H * W < (1ull << 32);
 }
 
 size_t air_bf3_s2_packed_bytes(int Cout, int Cin, bool with_shortcut) {
@@ -1004,7 +1006,8 @@ int air_bf3_s2_fwd(const float* x, const void* packed, float* y, float* y_sc, in
 }
 
 bool air_bf3_s2d_ok(int B, int Cin, int H, int W, int Cout) {
-  return (air_opt(AIR_OPT_CONV_S2) & 8) != 0 && B > 0 && Cout % CK == 0 && Cin % 64 == 0 && H >= 2 && W >= 2;
+  return (air_opt(AIR_OPT_CONV_S2) & 8) != 0 && B > 0 && Cout % CK == 0 && Cin % 64 == 0 && H >= 2 && W >= 2 &&
+         4ull * (unsigned long long)Cout * H * W < (1ull << 32);  // (dy block of one utterance, generously)
 }
 
 size_t air_bf3_s2d_packed_bytes(int Cout, int Cin) { return (size_t)(Cin / 64) * (Cout / CK) * DSLAB_BYTES; }
@@ -1037,7 +1040,12 @@ int air_bf3_s2d_dgrad(const float* dy, const float* dy_sc, const void* packed, f
 }
 
 bool air_bf3_s2w_ok(int B, int Cin, int H, int W, int Cout) {
-  return (air_opt(AIR_OPT_CONV_S2) & 16) != 0 && B > 0 && Cout % 128 == 0 && Cin % 32 == 0 && H >= 2 && W >= 2;
+  // (one buffer descriptor over the WHOLE x and dy tensors, 32-bit byte offsets: both must stay below 4 GB - B = 64 at
+  // the bench shape is 0.7 GB; beyond that the f32 kernel, which addresses with 64 bits, takes the layer)
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const unsigned long long xb = 4ull * (unsigned long long)B * Cin * H * W, yb = 4ull * (unsigned long long)B * Cout * Ho * Wo;
+  return (air_opt(AIR_OPT_CONV_S2) & 16) != 0 && B > 0 && Cout % 128 == 0 && Cin % 32 == 0 && H >= 2 && W >= 2 &&
+         xb < (1ull << 32) && yb < (1ull << 32);
 }
 
 // segments of output rows: enough waves for ~2 per SIMD-slot of the chip, at least 8 K steps each
