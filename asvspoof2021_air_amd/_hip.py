@@ -52,7 +52,7 @@ def lib():
         _lib.air_lfcc_plan_bytes.restype = ctypes.c_size_t
         _lib.air_preemph_ws_bytes.restype = ctypes.c_size_t
         for name in ("air_conv2d_ws_bytes", "air_bn_ws_bytes", "air_conv1d_ws_bytes", "air_conv1d_bf16_ws_bytes",
-                     "air_channel_sum_ws_bytes", "air_ir_convolve_ws_bytes", "air_conv2d_prepack_bytes",
+                     "air_channel_sum_ws_bytes", "air_ir_convolve_ws_bytes", "air_ir_convolve_ws_bytes_ex", "air_conv2d_prepack_bytes",
                      "air_conv1d_tap_pack_elems", "air_h_bn_ws_bytes", "air_h_conv1d_ws_bytes", "air_conv2d_fwd_stats_bytes", "air_conv2d_dgrad_bn_sums_bytes", "air_conv2d_dgrad_s2_pair_prepack_bytes", "air_h_conv1d_tap_stats_bytes", "air_h_conv1d_tap_bwd_sums_bytes", "air_h_conv1d_pointwise_stats_bytes",
                      "air_h_conv1d_tap_wgrad_ws_bytes"):
             if hasattr(_lib, name):

@@ -55,7 +55,7 @@ def ir_convolve(pcm, irs, idx=None, normalize=True, out=None):
     n_ir, H = irs.shape
     y = out if out is not None else torch.empty_like(pcm)
     lib = _hip.lib()
-    n = lib.air_ir_convolve_ws_bytes(_hip.ci(B))
+    n = lib.air_ir_convolve_ws_bytes_ex(_hip.ci(B), _hip.ci(n_ir), _hip.ci(H))  # (+ the FFT tables when H qualifies)
     ws = ops.workspace(n, pcm.device)
     _hip.check(lib.air_ir_convolve(_hip.dptr(pcm), _hip.ci(B), _hip.ci(L), _hip.dptr(irs), _hip.ci(n_ir),
                                    _hip.ci(H), _hip.dptr(idx, torch.int32, True), _hip.ci(1 if normalize else 0),

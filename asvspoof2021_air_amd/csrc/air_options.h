@@ -24,6 +24,7 @@ enum AirOption {
                                // bit 4: stride-2 3x3 forward as six bf16 products per fp32 product (conv_bf3.hip)
                                // bit 8: the paired stride-2 data gradient likewise; bit 16: the stride-2 3x3 weight gradient
   AIR_OPT_WINO4_DEPHASE,       // every second persistent Winograd workgroup starts N x 4096 cycles late (0 = in phase)
+  AIR_OPT_IR_FFT,              // 1: impulse responses of 128 .. 1025 taps are convolved by overlap-save FFT (augment.hip); 0: direct FIR
   AIR_OPT_COUNT
 };
 

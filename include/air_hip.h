@@ -271,6 +271,10 @@ int air_softmax_ce_bwd(const float* probs, const long long* labels, int B, int C
  * uses IR 0 for all.  normalize != 0 rescales each augmented utterance to its input peak
  * (max|y| = max|x|).  irs is (n_ir, H) fp32, rows zero-padded to H taps.  x and y must not alias. */
 size_t air_ir_convolve_ws_bytes(int B);
+/* Round 5: with a workspace of air_ir_convolve_ws_bytes_ex(B, n_ir, H) bytes (>= the above), impulse responses of
+ * 128 .. 1025 taps are convolved by overlap-save FFT (option IR_FFT, default 1; same result to fp32 FFT rounding, ~10 x
+ * faster at 1024 taps); with the smaller workspace, or any other H, the direct FIR runs. */
+size_t air_ir_convolve_ws_bytes_ex(int B, int n_ir, int H);
 int air_ir_convolve(const float* x, int B, int L, const float* irs, int n_ir, int H, const int* ir_idx,
                     int normalize, float* y, void* ws, size_t ws_bytes, air_stream_t stream);
 

@@ -29,7 +29,10 @@ def test_synthetic_bank_is_deterministic_and_unit_energy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,L,H", [(3, 64000, 1024), (2, 5000, 37), (2, 2049, 1), (2, 777, 2500), (1, 4096, 1025)])
+@pytest.mark.parametrize("B,L,H", [(3, 64000, 1024), (2, 5000, 37), (2, 2049, 1), (2, 777, 2500), (1, 4096, 1025),
+                                   # the overlap-save FFT form (128 <= H <= 1025): shortest / longest response, one block,
+                                   # one sample into the second block of a pair, one sample into the second pair
+                                   (2, 6149, 128), (3, 9300, 700), (2, 3072, 1024), (2, 3073, 1024), (2, 6145, 1025)])
 def test_fir_kernel_vs_oracle(B, L, H):
     from asvspoof2021_air_amd.augment import ir_convolve
     rng = np.random.default_rng(L + H)
@@ -48,6 +51,31 @@ def test_fir_kernel_vs_oracle(B, L, H):
     one[0, 0] = 1.0
     same = ir_convolve(x.cuda(), one.cuda(), None, False).cpu()
     assert torch.equal(same, x)  # h = delta: identity, bit-exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,H", [(64000, 1024), (10000, 300)])
+def test_fft_form_equals_direct_form(L, H):
+    """Option IR_FFT: the overlap-save FFT kernel and the direct FIR kernel on the same input - equal to fp32 FFT rounding
+    (4e-6 of the output scale), pass-through utterances bit-identical in both, the rescaled peaks equal to 1e-6."""
+    from asvspoof2021_air_amd import _hip
+    from asvspoof2021_air_amd.augment import ir_convolve
+    rng = np.random.default_rng(L)
+    x = synth_pcm(5, L, seed=3).cuda()
+    irs = torch.from_numpy((rng.standard_normal((3, H)) * np.exp(-np.arange(H) / (H / 6.0))).astype(np.float32)).cuda()
+    idx = torch.tensor([0, 2, -1, 1, 2], dtype=torch.int32).cuda()
+    out = {}
+    for mode in (1, 0):
+        old = _hip.set_option("IR_FFT", mode)
+        try:
+            out[mode] = [ir_convolve(x, irs, idx, nz).cpu() for nz in (False, True)]
+        finally:
+            _hip.set_option("IR_FFT", old)
+    for a, b in zip(out[1], out[0]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 4e-6 * scale
+        assert torch.equal(a[2], x[2].cpu()) and torch.equal(b[2], x[2].cpu())
+    assert float((out[1][1].abs().amax(1) - out[0][1].abs().amax(1)).abs().max()) <= 1e-6
 
 
 @pytest.mark.gpu
