@@ -30,6 +30,8 @@
 #include "air_lds_dma.h"
 #include "air_options.h"
 #include "air_prof.h"
+#include <utility>
+
 #include "conv_bf3.h"
 
 namespace {
@@ -42,6 +44,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef BF3_EXP
 #define BF3_EXP 0
+#endif
+#ifndef BF3W_ASM_MFMA
+#define BF3W_ASM_MFMA 1
 #endif
 #ifndef BF3_SCHED
 #define BF3_SCHED 1
@@ -730,6 +735,38 @@ struct Bf3wArgs {
   int KS;            // 16-pixel K steps per output row
 };
 
+template <class F, int... Ns>
+__device__ __forceinline__ void bf3_seq(F&& f, std::integer_sequence<int, Ns...>) {
+  (f(std::integral_constant<int, Ns>{}), ...);
+}
+
+// acc[N / 3][N % 3] += A B as ONE v_mfma_f32_32x32x16_bf16 in place on the fixed AGPR tuple a[16 N : 16 N + 15].
+// Through the builtin (and through a plain "+a" constraint alike) the register allocator moves whole accumulator tuples
+// between AGPR ranges over the weight-gradient kernel's two-step loop body and copies them back at the loop header:
+// 452 v_accvgpr moves per 144 MFMAs, which made that loop VALU-bound (9 VALU instructions per MFMA; 6 without them).
+// hipcc pads no hazards for an asm statement: the s_nop covers an operand the allocator brings back with a
+// v_accvgpr_read right in front of the MFMA (conv_wino4.hip, round 3).
+#if BF3W_ASM_MFMA
+#define BF3W_PIN(N, LO, HI)                                                              \
+  if constexpr (NI == N)                                                                  \
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                     \
+                 : "+{a[" #LO ":" #HI "]}"(acc[N / 3][N % 3])                             \
+                 : "v"(a), "v"(b));
+template <int NI>
+__device__ __forceinline__ void bf3w_mfma(f32x16 (&acc)[4][3], const u32x4& a, const u32x4& b) {
+  BF3W_PIN(0, 0, 15) BF3W_PIN(1, 16, 31) BF3W_PIN(2, 32, 47) BF3W_PIN(3, 48, 63) BF3W_PIN(4, 64, 79) BF3W_PIN(5, 80, 95)
+  BF3W_PIN(6, 96, 111) BF3W_PIN(7, 112, 127) BF3W_PIN(8, 128, 143) BF3W_PIN(9, 144, 159) BF3W_PIN(10, 160, 175)
+  BF3W_PIN(11, 176, 191)
+}
+#undef BF3W_PIN
+#else
+template <int NI>
+__device__ __forceinline__ void bf3w_mfma(f32x16 (&acc)[4][3], const u32x4& a, const u32x4& b) {
+  acc[NI / 3][NI % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                acc[NI / 3][NI % 3], 0, 0, 0);
+}
+#endif
+
 __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2w_bf3_kernel(const Bf3wArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -914,20 +951,16 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2w_bf3_kernel(const Bf3wA
           if (e == 11 && !(BF3_EXP & 1)) issue_b(sb2);
         }
       };
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {  // (consecutive MFMAs cycle through the tile's three accumulators)
-            const int n = (m * 6 + p) * 3 + kw;
-            if (m == 3 && p == 0 && kw == 0) __builtin_amdgcn_sched_barrier(0);
-            acc[m][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[m][PA[p]]),
-                                                                 __builtin_bit_cast(bf16x8, bcur[kw][PB[p]]), acc[m][kw],
-                                                                 0, 0, 0);
-            if ((n & 1) == 0) item(n / 2);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+      // 72 MFMAs, tile-major: n = (6 m + p) 3 + kw - consecutive MFMAs cycle through the tile's three accumulators.  The
+      // indices are compile-time (integer sequence): every MFMA names the fixed AGPR tuple of its accumulator.
+      auto one = [&](auto nc) {
+        constexpr int n = decltype(nc)::value, m = n / 18, p = (n / 3) % 6, kw = n % 3;
+        if (m == 3 && p == 0 && kw == 0) __builtin_amdgcn_sched_barrier(0);
+        bf3w_mfma<m * 3 + kw>(acc, ap[m][PA[p]], bcur[kw][PB[p]]);
+        if ((n & 1) == 0) item(n / 2);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      bf3_seq(one, std::make_integer_sequence<int, 72>{});
       kc = k1;
       r1 = r2; k1 = k2;
     };
