@@ -64,15 +64,31 @@ def build(verbose=True, force=False):
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
+    _prune(objs)
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
+
+
+def _prune(objs, keep_variants=False):
+    """Objects of A/B variants (build_variant: <src>.<tag>.o, libair_hip.<tag>.so) travel to every GPU lease with the
+    snapshot: a default build removes them unless AIR_KEEP_VARIANTS=1."""
+    if keep_variants or os.environ.get("AIR_KEEP_VARIANTS", "0") == "1":
+        return
+    want = set(os.path.basename(o) for o in objs)
+    for f in os.listdir(OBJ):
+        if f.endswith(".o") and f not in want:
+            os.remove(os.path.join(OBJ, f))
+    for f in os.listdir(LIBDIR):
+        if f.startswith("libair_hip.") and f.endswith(".so") and f != os.path.basename(LIB):
+            os.remove(os.path.join(LIBDIR, f))
 
 
 def build_variant(tag, src, defines):
     """A/B tooling: libair_hip.<tag>.so = the current objects with `src` recompiled under extra -D flags
     (``python -m asvspoof2021_air_amd.build --variant v1 conv_wino4.hip -DW4_X=1``); load it with
     AIR_HIP_LIB=<path> (see _hip.py).  The default library is untouched."""
+    os.environ["AIR_KEEP_VARIANTS"] = "1"  # an A/B session holds several variants side by side
     build(verbose=False)
     s = os.path.join(CSRC, src)
     o = os.path.join(OBJ, "%s.%s.o" % (src[:-4], tag))

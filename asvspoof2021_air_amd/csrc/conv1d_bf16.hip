@@ -1777,8 +1777,10 @@ bool gemm_ps_ok(int M) {
 
 // *bf_done (optional): set when the kernel that ran wrote g.out_bf itself
 int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_bytes, int kid, double flops,
-                hipStream_t st, bool* bf_done = nullptr, bool b_kmajor = false) {
+                hipStream_t st, bool* bf_done = nullptr, bool b_kmajor = false, double alg_bytes = -1.0) {
   if (bf_done) *bf_done = false;
+  // algorithmic HBM bytes for the profiler (operands once + result once); callers with strided operands state them
+  if (alg_bytes < 0) alg_bytes = (double)a_bytes + (double)b_bytes + 4.0 * g.M * (double)n_padded * nbatch;
   if (b_kmajor && !(gemm_ps_ok(g.M) && n_padded % G2_BN == 0 && a_bytes < ((size_t)1 << 32) && b_bytes < ((size_t)1 << 32) &&
                     ((size_t)g.out & 7) == 0 && g.o_bs % 2 == 0 && g.b_rs % 8 == 0))
     return AIR_EUNSUPPORTED;  // only the 256 x 256 kernel reads a K-major B
@@ -1794,7 +1796,7 @@ int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_by
     g.tiles_n = n_padded / G2_BN;
     g.total = g.tiles_m * g.tiles_n * nbatch;
     g.per_xcd = (g.total + NXCD - 1) / NXCD;
-    AirProfScope prof(kid, flops, st);
+    AirProfScope prof(kid, flops, st, -1.0, alg_bytes);
     if (b_kmajor)
       hipLaunchKernelGGL(c1b_gemm_ps_kernel<true>, dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
     else
@@ -1807,7 +1809,7 @@ int launch_gemm(NtGemm& g, int nbatch, int n_padded, size_t a_bytes, size_t b_by
   g.tiles_n = n_padded / BN;
   g.total = g.tiles_m * g.tiles_n * nbatch;
   g.per_xcd = (g.total + NXCD - 1) / NXCD;
-  AirProfScope prof(kid, flops, st);
+  AirProfScope prof(kid, flops, st, -1.0, alg_bytes);
   hipLaunchKernelGGL(c1b_gemm_kernel, dim3(g.per_xcd * NXCD), dim3(256), 0, st, g);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
@@ -2244,7 +2246,9 @@ int air_h_conv1d_pointwise_ex(int B, int Cin, int Cout, int T, int Tp, const uns
   g.tiles_n = Tp / G2_BN;
   g.total = g.tiles_m * g.tiles_n * B;
   g.per_xcd = (g.total + NXCD - 1) / NXCD;
-  AirProfScope prof(AIR_K_C1B_GEMM, 2.0 * B * T * (double)Cout * Cin, st);
+  // algorithmic HBM bytes: packed weights + x rows read once, y rows written once, the accumulate operands read once
+  const double alg_bytes = (double)a_bytes + 2.0 * B * (double)T * (K + M) + 2.0 * B * (double)T * M * ((acc ? 1 : 0) + (acc2 ? 1 : 0));
+  AirProfScope prof(AIR_K_C1B_GEMM, 2.0 * B * T * (double)Cout * Cin, st, -1.0, alg_bytes);
   hipLaunchKernelGGL((c1b_gemm_ps_kernel<true, true>), dim3(256), dim3(512), G2_LDS, st, g, (unsigned)a_bytes,
                      (unsigned)b_bytes);
   AIR_CHECK_LAUNCH();
@@ -2382,7 +2386,8 @@ int air_conv1d_wgrad_bf16_pre(const AirConv1d* p, const float* x, const float* d
   g.o_rs = N; g.o_bs = (size_t)M * N;
   g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
   int rc = launch_gemm(g, nsplit, N, ((size_t)(B - 1) * a_ss + (size_t)M * Tp) * 2, ((size_t)(B - 1) * b_ss + (size_t)N * Tp) * 2,
-                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
+                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st, nullptr, false,
+                       2.0 * B * (double)T * (M + N) + 4.0 * M * (double)N);
   if (rc != AIR_OK) return rc;
   if (nsplit > 1) {
     const size_t n = (size_t)M * N;
@@ -2415,7 +2420,8 @@ int air_h_conv1d_wgrad(int B, int Cin, int Cout, int T, int Tp, const unsigned s
   g.o_rs = N; g.o_bs = (size_t)M * N;
   g.M = M; g.n_valid = N; g.kseg = Tp; g.nseg_per_batch = per; g.nseg_total = B; g.relu = 0;
   int rc = launch_gemm(g, nsplit, N, ((size_t)(B - 1) * a_ss + (size_t)M * Tp) * 2, ((size_t)(B - 1) * b_ss + (size_t)N * Tp) * 2,
-                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st);
+                       AIR_K_C1B_GEMM, 2.0 * B * T * (double)M * N, st, nullptr, false,
+                       2.0 * B * (double)T * (M + N) + 4.0 * M * (double)N);
   if (rc != AIR_OK) return rc;
   if (nsplit > 1) {
     const size_t n = (size_t)M * N;

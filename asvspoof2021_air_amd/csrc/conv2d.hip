@@ -2004,6 +2004,17 @@ size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass) {
   return rc == AIR_OK ? g_pk.used * sizeof(float) : 0;
 }
 
+// Which layout air_conv2d_prepack(p, ., pass) writes under the CURRENT dispatch options (a buffer packed under
+// other options - or the split-bf16 planes handed to a call that takes the f32 slabs - must be refused, not walked).
+int air_conv2d_prepack_layout(const AirConv2d* p, int pass) {
+  if (!p || !shape_ok(p)) return AIR_PACK_NONE;
+  const int kind = wino_kind(p, pass);
+  if (kind == 4) return AIR_PACK_WINO4;
+  if (kind == 2) return AIR_PACK_WINO2;
+  if (pass == 0 && bf3_fwd_ok(p)) return AIR_PACK_BF3;
+  return generic_pack_ok(p, pass) ? AIR_PACK_F32_SLABS : AIR_PACK_NONE;
+}
+
 int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes, air_stream_t stream) {
   if (!p || !w || !out || !shape_ok(p)) return AIR_EINVAL;
   const size_t need = air_conv2d_prepack_bytes(p, pass);
@@ -2082,8 +2093,10 @@ int air_conv2d_fwd_pre(const AirConv2d* p, const float* x, const float* w, const
     return air_bf3_s2_fwd(x, w_packed ? w_packed : ws, y, nullptr, p->B, p->Cin, p->H, p->W, p->Cout, p->Ho, p->Wo,
                           conv_flops(p), st);
   }
-  if (w_packed != nullptr && wino_kind(p, 0) == 0) {  // slabs from air_conv2d_prepack (a Winograd-shaped layer's
-    PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));  // buffer is not ours)
+  // slabs from air_conv2d_prepack (a Winograd-shaped layer's buffer is not ours; neither are the split-bf16 planes that
+  // prepack writes for a bf3-eligible layer - a call with a prologue or a residual lands here and packs from w instead)
+  if (w_packed != nullptr && wino_kind(p, 0) == 0 && !bf3_fwd_ok(p)) {
+    PackScope use(PK_USE, const_cast<float*>(reinterpret_cast<const float*>(w_packed)));
     return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));
   }
   return fwd_generic(p, x, w, y, in_scale, in_shift, relu, residual, wp, st, ws_bytes / sizeof(float));

@@ -95,6 +95,12 @@ def find_files(directory, ext="pt"):
     return sorted(out)
 
 
+def _bad_fork():
+    """True in a process forked from one that had already initialised the GPU runtime (it cannot use the GPU)."""
+    f = getattr(torch.cuda, "_is_in_bad_fork", None)
+    return bool(f()) if f is not None else False
+
+
 # ---------------------------------------------------------------------------- backends
 class FileSource:
     """``.pt`` feature files of one folder, in the reference's order."""
@@ -138,10 +144,60 @@ class PCMSource:
         w = self.items[i][1]
         return w if torch.is_tensor(w) else torch.from_numpy(np.ascontiguousarray(w))
 
+    def _need_gpu_here(self, what):
+        """The reference's Dataset is pure CPU and forks DataLoader workers freely (--num_workers); this source launches
+        HIP kernels, which a FORKED worker cannot (CUDA / HIP cannot be re-initialised in a forked child).  Fail with
+        the remedy instead of torch's 'Cannot re-initialize CUDA in forked subprocess' (ADVICE r5)."""
+        if self.device.type == "cuda" and torch.utils.data.get_worker_info() is not None and _bad_fork():
+            raise RuntimeError("%s runs the HIP LFCC on %s and cannot run inside a DataLoader worker forked from a process "
+                               "that already uses the GPU: use num_workers=0 (the reference's default, "
+                               "main_train.py:63) or DataLoader(..., multiprocessing_context='spawn')" % (what, self.device))
+
+    def feature(self, i, ds):
+        return torch.load(self.files[i])  # (1, T, 60) as preprocess.py saved it
+
+
+class PCMSource:
+    """Waveforms instead of feature files.  ``items``: sequence of ``(name, pcm)`` with ``name`` in the file-name
+    scheme of the corpus the Dataset class reads (``00012_LA_T_1000137_A04_spoof`` ...; ``.pt`` optional) and ``pcm``
+    a 1-D float32 array / tensor (or int16 PCM).  Features are computed by the HIP LFCC on ``device``."""
+
+    def __init__(self, items, device="cuda"):
+        self.items = list(items)
+        self.device = torch.device(device)
+
+    def __len__(self):
+        return len(self.items)
+
+    def path(self, i):
+        n = self.items[i][0]
+        return n if n.endswith(".pt") else n + ".pt"
+
+    def take(self, keep):
+        self.items = [self.items[i] for i in keep]
+
+    def pcm(self, i):
+        w = self.items[i][1]
+        return w if torch.is_tensor(w) else torch.from_numpy(np.ascontiguousarray(w))
+
+    def _need_gpu_here(self, what):
+        """The reference's Dataset is pure CPU and forks DataLoader workers freely (--num_workers); this source launches
+        HIP kernels, which a FORKED worker cannot (CUDA / HIP cannot be re-initialised in a forked child).  Fail with
+        the remedy instead of torch's 'Cannot re-initialize CUDA in forked subprocess' (ADVICE r5)."""
+        if self.device.type == "cuda" and torch.utils.data.get_worker_info() is not None:
+            import multiprocessing as mp
+            if (mp.get_start_method(allow_none=True) or "fork") == "fork" and torch.cuda.is_initialized() is False:
+                return  # a spawned / fresh worker that owns its own context would have initialised lazily: let it try
+            if (mp.get_start_method(allow_none=True) or "fork") == "fork":
+                raise RuntimeError("%s runs the HIP LFCC on %s and cannot run inside a forked DataLoader worker: use "
+                                   "num_workers=0 (the reference's default, main_train.py:63) or "
+                                   "DataLoader(..., multiprocessing_context='spawn')" % (what, self.device))
+
     def feature(self, i, ds):
         """Features of one utterance on the GPU (preprocess.py:239-244 runs batch 1 too): with ``ds.pad_chop`` the
         fused LFCC -> pad / chop kernel's (1, 60, feat_len) output viewed as (1, feat_len, 60), the crop offset drawn
         like dataset.py:69; otherwise the plain (1, T, 60) LFCC."""
+        self._need_gpu_here("PCMSource.feature")
         pcm = self.pcm(i).to(self.device, non_blocking=True).unsqueeze(0)
         if not ds.pad_chop:
             return ds.lfcc(pcm)
@@ -159,10 +215,14 @@ class SyntheticSource(PCMSource):
 
     PART = {"train": "T", "dev": "D", "eval": "E"}
 
-    def __init__(self, seed, n, length=64000, part="train", channels=None, devices=None, device="cuda", first=0):
+    def __init__(self, seed, n, length=64000, part="train", channels=None, devices=None, device="cuda", first=0,
+                 cache_items=256):
         from . import synth
+        from collections import OrderedDict
         self._synth, self.seed, self.length = synth, seed, length
-        self._cache = {}
+        # generated utterances, least recently used first out (an epoch over a large set kept every
+        # utterance - ~0.25 MB each at 4 s - forever); cache_items=None keeps everything
+        self._cache, self._cache_items = OrderedDict(), cache_items
         names = []
         for i in range(n):
             idx = first + i
@@ -181,9 +241,15 @@ class SyntheticSource(PCMSource):
         if label_only:  # the label is the generator's first draw
             rng = np.random.Generator(np.random.PCG64(self.seed * 1000003 + idx))
             return None, int(rng.random() < 0.5)
-        if idx not in self._cache:
-            self._cache[idx] = self._synth.utterance(self.seed, idx, self.length)
-        return self._cache[idx]
+        if idx in self._cache:
+            self._cache.move_to_end(idx)
+            return self._cache[idx]
+        u = self._synth.utterance(self.seed, idx, self.length)
+        self._cache[idx] = u
+        if self._cache_items is not None:
+            while len(self._cache) > max(1, self._cache_items):
+                self._cache.popitem(last=False)
+        return u
 
     def take(self, keep):
         super().take(keep)
@@ -206,6 +272,9 @@ class _SpoofDataset(Dataset):
         self.label = dict(LABEL)
         self.return_pcm = bool(return_pcm)
         self._lfcc = None
+        self._silence_cpu = None
+        if padding == "silence" and pad_chop and torch.cuda.is_available():
+            self.prepare()
 
     @property
     def lfcc(self):
@@ -239,7 +308,25 @@ class _SpoofDataset(Dataset):
         return info
 
     def _silence_row(self, like):
-        return self.lfcc.silence_row(like.device if like.is_cuda else torch.device("cuda")).to(like.device)
+        """The LFCC frame of silence (dataset.py:13-16 computes it at import, on the CPU).  Here the HIP front-end makes
+        it ONCE per dataset, in the process that first needs it, and keeps it on the host: ``padding='silence'`` sets
+        compute it at construction - in the parent, so forked DataLoader workers inherit the row instead of touching
+        the GPU."""
+        row = getattr(self, "_silence_cpu", None)
+        if row is None:
+            if torch.utils.data.get_worker_info() is not None and _bad_fork():
+                raise RuntimeError("padding='silence': the silence frame comes from the HIP LFCC and was not computed "
+                                   "before the DataLoader forked its workers - construct the dataset with "
+                                   "padding='silence' (it is then computed at construction) or call "
+                                   "dataset.prepare() in the parent process first")
+            row = self.lfcc.silence_row(like.device if like.is_cuda else torch.device("cuda")).cpu()
+            self._silence_cpu = row
+        return row.to(like.device)
+
+    def prepare(self):
+        """Everything that needs the GPU once, done in the calling (parent) process: the silence frame."""
+        self._silence_row(torch.empty(0))
+        return self
 
     def _pad_chop(self, feat):
         """dataset.py:66-79 on a (1, T, D) tensor of either device (pure data movement)."""
@@ -289,6 +376,7 @@ class _SpoofDataset(Dataset):
             return default_collate(samples)
         if not self.pad_chop:
             raise ValueError("return_pcm needs pad_chop=True (one feat_len per batch)")
+        next(s for s in self._sources() if isinstance(s, PCMSource))._need_gpu_here("collate_fn(return_pcm=True)")
         dev = next(s.device for s in self._sources() if isinstance(s, PCMSource))
         B = len(samples)
         out = torch.empty((B, self.lfcc.out_dim, self.feat_len), device=dev, dtype=torch.float32)

@@ -269,7 +269,7 @@ class Res2Net2(nn.Module):
         B, C, T = inp.shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16c"
+        bf = getattr(self, "_bf16c_now", self.compute_dtype == "bf16c")
         r1 = ops.conv1d_fwd(inp, det(blk.conv1.weight), det(blk.conv1.bias), relu=True, bf16=bf)
         st1 = _bn(r1, blk.bn1, training)
         o1 = ops.bn_apply(r1, st1[2], st1[3])
@@ -313,16 +313,28 @@ class Res2Net2(nn.Module):
         z2 = ops.linear_fwd(z1n, det(se[4].weight).view(se[4].out_channels, -1), det(se[4].bias))
         ops.se_scale_fwd(o3, z2, inp, out, out_bf=out_bf)
         if save:
-            return dict(blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat, cat_bf=cat_bf,
+            return dict(bf16c=bf, blk=blk, inp=inp, r1=r1, st1=st1, o1=o1, t=t_list, r=r_list, st=st_list, cat=cat, cat_bf=cat_bf,
                         r3=r3, st3=st3, o3=o3, m=m, z1=z1, stS=stS, z1n=z1n, z2=z2)
         return None
 
     def _forward_impl(self, x, save):
+        bf = self.compute_dtype == "bf16c"
         if self.compute_dtype == "bf16":
-            return self._forward_h(x, save)
+            if oh.tp(x.shape[2]) <= oh.max_tp():
+                return self._forward_h(x, save)
+            #  longer than the bf16-resident kernels' register-resident rows: THIS call runs as bf16
+            # compute on fp32 tensors (any length, like the reference) instead of raising; the backward follows the
+            # saved tensors' kind, so nothing else has to switch
+            if not getattr(self, "_warned_long", False):
+                import warnings
+                warnings.warn("bf16-resident ECAPA takes utterances of at most %d frames (got T = %d): this and later "
+                              "longer inputs run as compute_dtype 'bf16c' (bf16 matrix cores on fp32 tensors)"
+                              % (oh.max_tp(), x.shape[2]))
+                self._warned_long = True
+            bf = True
+        self._bf16c_now = bf  # what _block_fwd sees for THIS call; the backward reads it from the saved state
         training = self.training
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16c"
         B, _, T = x.shape
         C = self.C
         r0 = ops.conv1d_fwd(x, det(self.conv1.weight), det(self.conv1.bias), relu=True, pad=2)  # :159-160
@@ -381,7 +393,7 @@ class Res2Net2(nn.Module):
         if save:
             if not training:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
-            S = dict(x=x, r0=r0, st0=st0, h=h, h_bf=h_bf, a1n_bf=a1n_bf, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
+            S = dict(bf16c=bf, x=x, r0=r0, st0=st0, h=h, h_bf=h_bf, a1n_bf=a1n_bf, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
                      std=std,
                      ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
@@ -398,7 +410,7 @@ class Res2Net2(nn.Module):
             on_side = lambda fn, *reads: fn()
         blk = S["blk"]
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16c"
+        bf = S.get("bf16c", self.compute_dtype == "bf16c")
         B, C, T = S["o3"].shape
         w, d, nums = blk.width, blk.dilation, blk.nums
         se = blk.se.se
@@ -468,7 +480,7 @@ class Res2Net2(nn.Module):
                            for n, p, _, _ in arena.entries)
         old = arena.grad.clone() if accumulating else None
         det = lambda p: p.detach()
-        bf = self.compute_dtype == "bf16c"
+        bf = S.get("bf16c", self.compute_dtype == "bf16c")
         B, _, T = S["x"].shape
         C = self.C
         tail = ("fc7.weight", "fc7.bias", "bn7.weight", "bn7.bias")

@@ -83,6 +83,7 @@ def conv2d_prepack(w, x_shape, stride, padding, which, out=None):
         out = torch.empty(n, dtype=torch.uint8, device=w.device)
     _hip.check(_hip.lib().air_conv2d_prepack(ctypes.byref(d), dptr(w), ci(which), dptr(out, torch.uint8), csz(n),
                                              stream()), "air_conv2d_prepack")
+    out._air_pack_layout = int(_hip.lib().air_conv2d_prepack_layout(ctypes.byref(d), ci(which)))
     return out
 
 
@@ -104,6 +105,13 @@ def _check_packed(d, w_packed, which):
     """A prepacked weight buffer must be at least what the layer consumes under the CURRENT dispatch options
     (options can change between prepack and use; the library walks the buffer without a size)."""
     if w_packed is not None:
+        # (ADVICE r5) the layouts differ in element type, not only in size: the tag conv2d_prepack left on the buffer
+        # must be what the layer consumes now (f32 slabs / Winograd F2 / split-bf16 planes / Winograd F4)
+        have = getattr(w_packed, "_air_pack_layout", None)
+        now = int(_hip.lib().air_conv2d_prepack_layout(ctypes.byref(d), ci(which)))
+        if have is not None and have != now:
+            raise _hip.AirError("conv2d: w_packed was written in layout %d, the layer consumes layout %d under the current "
+                                "dispatch options (prepack again after air_set_option)" % (have, now))
         need = int(_hip.lib().air_conv2d_prepack_bytes(ctypes.byref(d), ci(which)))
         if w_packed.numel() * w_packed.element_size() < need:
             raise _hip.AirError("conv2d: w_packed holds %d bytes, the layer consumes %d under the current dispatch "

@@ -192,6 +192,7 @@ class ResNet(nn.Module):
         if st.get("_noise_ctr") is not None:  # the device-side counter travels as its value
             st["_noise_offset"] = int(st["_noise_ctr"].item())
         st["_noise_ctr"] = None
+        st["_noise_ctrs"] = None
         st.pop("_last_saved_for_test", None)
         st.pop("keep_saved_for_test", None)
         if st.get("noise_mode") == "tensor":
@@ -253,9 +254,24 @@ class ResNet(nn.Module):
         # (seed, offset) of the Philox stream: the offset lives on the device and the draw advances it there, so
         # that a step captured in a hipGraph draws fresh noise on every replay (resnet.py:38 draws per call) and
         # eager launches and replays walk one sequence
-        ctr = getattr(self, "_noise_ctr", None)
-        if ctr is None or ctr.device != device:
-            ctr = self._noise_ctr = torch.tensor([self._noise_offset], dtype=torch.int64, device=device)
+        # ONE counter per device, never replaced once made: a captured hipGraph (train.Trainer, GraphedScorer) holds
+        # its address.  Moving to another device first folds the live count back into the host field, so that the
+        # Philox sequence goes on instead of restarting (it restarted from the stale host value).
+        ctrs = getattr(self, "_noise_ctrs", None)
+        if ctrs is None:
+            ctrs = self._noise_ctrs = {}
+        ctr = ctrs.get(device)
+        if ctr is None:
+            live = getattr(self, "_noise_ctr", None)
+            if live is not None:
+                self._noise_offset = int(live.item())
+            ctr = ctrs[device] = torch.tensor([self._noise_offset], dtype=torch.int64, device=device)
+        elif getattr(self, "_noise_ctr", None) is not ctr:
+            # back on a device used before: carry the count of the counter used in between over (device-side copy)
+            live = getattr(self, "_noise_ctr", None)
+            if live is not None:
+                ctr.copy_(live)
+        self._noise_ctr = ctr
         return ops.randn_ctr((B, T, 256), device, self._noise_seed, ctr, self.noise_scale)
 
     def forward(self, x):

@@ -351,7 +351,8 @@ def cpu_baseline_leg():
     return {"value": round(1.0 / per_utt, 2), "unit": "utt/s", "cores": cores,
             "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle (PyTorch-CPU port pinned to the reference by tests/golden): per-utterance LFCC over "
-                      "64 seeded 4 s wavs (%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, %d warm-up + "
+                      "64 seeded 4 s wavs (numpy rfft LFCC - not the reference's torch.stft route -, single un-warmed pass, "
+                      "%.1f ms/utt) + ResNet-18/ang_iso train step batch 8, T=750, %d warm-up + "
                       "%d timed steps, plain median %.3f s/step at %d of %d host threads (PyTorch-CPU conv backward "
                       "collapses when oversubscribed: see sweep)" % (
                           1e3 * t_lfcc / 64, warm, len(times) - warm, step, cores, ncpu),
@@ -553,6 +554,7 @@ def main():
                    "ms_per_step": round(1e3 * dt / steps_timed, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
                    "final_loss": round(float(last.item()), 5), "host_issue_ms_per_step": round(1e3 * t_host / steps_timed, 3),
                    "launch": "hipGraph replay (one chain) + optimiser launches" if trainer.use_graph else "eager",
+                   "steps_timed_per_window": steps_timed, "windows": len(wins),
                    "timing": timing, "steps_run_total": nrun[0]}
             return res, dt / steps_timed
 
@@ -677,7 +679,11 @@ def main():
                        "parallelism": "dp%d" % world},
             "final_loss": main_res["final_loss"],
             "host_issue_ms_per_step": main_res["host_issue_ms_per_step"],
-            "launch": main_res["launch"], "timing": main_res["timing"], "steps_run_total": main_res["steps_run_total"],
+            "launch": main_res["launch"],
+            # `steps` echoes --steps (the contract); the timed region is `windows` windows of `steps_timed_per_window` steps
+            # (= max(K, 50) unless --plain-timing), value / ms_per_step = the median window
+            "steps_timed_per_window": main_res["steps_timed_per_window"], "windows": main_res["windows"],
+            "timing": main_res["timing"], "steps_run_total": main_res["steps_run_total"],
             "sync_each_step": bool(args.sync_each_step),
             "ddp": main_res["ddp"],
         }

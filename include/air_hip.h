@@ -185,6 +185,10 @@ int air_conv2d_dgrad(const AirConv2d* p, const float* dy, const float* w, float*
  * consumes, in consumption order (one code path walks them for sizing, packing and use).  A buffer must be consumed
  * under the dispatch options it was produced under. */
 size_t air_conv2d_prepack_bytes(const AirConv2d* p, int pass);
+/* The layout air_conv2d_prepack writes for (p, pass) under the current dispatch options: a binding records it beside the
+ * buffer and compares at use (options can change in between; the layouts differ in element type, not only in size). */
+enum { AIR_PACK_NONE = 0, AIR_PACK_F32_SLABS = 1, AIR_PACK_WINO2 = 2, AIR_PACK_BF3 = 3, AIR_PACK_WINO4 = 4 };
+int air_conv2d_prepack_layout(const AirConv2d* p, int pass);
 int air_conv2d_prepack(const AirConv2d* p, const float* w, int pass, void* out, size_t out_bytes,
                        air_stream_t stream);
 /* Between _begin and _flush the air_conv2d_prepack / air_conv2d_dgrad_s2_pair_prepack calls of the calling thread only

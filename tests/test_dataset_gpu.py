@@ -178,3 +178,41 @@ def test_generate_score_from_the_dataset(tmp_path):
         name, val, key = ln.split()
         assert name == "LA_E_%07d" % (1000000 + i) and key == ("spoof" if src._utt(i, label_only=True)[1] else "bonafide")
         assert float(val) == want[i]
+
+
+def test_forked_dataloader_workers(golden, tmp_path):
+    """the reference's Dataset is pure CPU and exposes --num_workers; this port touches the GPU.
+    (a) ``.pt`` feature files with padding='silence' work under FORKED workers: the silence frame is computed once at
+    construction in the parent and inherited (it used to launch the HIP LFCC inside the worker: 'Cannot re-initialize
+    CUDA in forked subprocess'); items equal the in-process ones.  (b) a PCM source inside a forked worker fails with
+    the remedy in the message, not with torch's."""
+    from torch.utils.data import DataLoader
+    root = fx.build(str(tmp_path))
+    torch.zeros(1, device="cuda")  # the parent owns a GPU context before the fork
+    ds = air_ds.ASVspoof2019("LA", os.path.join(root, "la19"), "train", "LFCC", feat_len=fx.FEAT_LEN, padding="silence")
+    assert ds._silence_cpu is not None and not ds._silence_cpu.is_cuda
+    want = [ds[i][0] for i in range(len(ds))]
+    dl = DataLoader(ds, batch_size=1, shuffle=False, num_workers=2, multiprocessing_context="fork")
+    got = [b[0][0] for b in dl]
+    assert len(got) == len(want)
+    for a in got:
+        assert a.shape[-2:] == (fx.FEAT_LEN, 60)
+    # (items longer than feat_len are cropped at random offsets: the padded ones are compared)
+    short = [i for i in range(len(ds)) if torch.load(ds.source.path(i)).shape[1] < fx.FEAT_LEN]
+    assert short
+    for i in short:
+        np.testing.assert_array_equal(got[i].numpy(), want[i].numpy())
+    names = ["%05d_LA_T_%07d_-_bonafide" % (i, 1000 + i) for i in range(4)]
+    pds = air_ds.ASVspoof2019("LA", None, "train", feat_len=60, padding="repeat",
+                              source=air_ds.PCMSource(list(zip(names, _pcm_corpus([9600] * 4, 3)))))
+    with pytest.raises(RuntimeError, match="num_workers=0"):
+        list(DataLoader(pds, batch_size=2, num_workers=1, multiprocessing_context="fork"))
+
+
+def test_synthetic_source_cache_is_bounded():
+    src = air_ds.SyntheticSource(688, 40, length=4000, cache_items=8)
+    for i in range(40):
+        src.pcm(i)
+    assert len(src._cache) == 8 and list(src._cache)[-1] == 39
+    a = src.pcm(3).clone()
+    assert torch.equal(a, air_ds.SyntheticSource(688, 40, length=4000, cache_items=None).pcm(3))  # regenerated identically

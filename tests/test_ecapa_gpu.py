@@ -415,3 +415,33 @@ def test_other_widths():
         m(x)
     with pytest.raises(_hip.AirError):
         m.set_compute_dtype("fp32")(x)
+
+
+def test_bf16_resident_long_input_falls_back_to_bf16c():
+    """beyond the bf16-resident kernels' row length (oh.max_tp() frames) a 'bf16' model used to
+    RAISE and the caller had to switch dtype by hand; now that call runs as 'bf16c' (bf16 matrix cores on fp32 tensors,
+    any length like the reference) behind a one-time warning, forward and backward, bit-identical to a model that was
+    set to 'bf16c' explicitly - and a short input afterwards takes the resident path again."""
+    import warnings
+    from asvspoof2021_air_amd import ops_h as oh
+    T = oh.max_tp() + 40
+    x = synth_feat((2, 60, T), seed=31).cuda()
+    outs = {}
+    for dt in ("bf16", "bf16c"):
+        m = make_model().train().set_compute_dtype(dt)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            feat, _ = m(x)
+            feat.square().mean().backward()
+            feat2, _ = m(x)  # the warning is issued once
+        assert (len([r for r in w if "bf16c" in str(r.message)]) == (1 if dt == "bf16" else 0)), [str(r.message) for r in w]
+        outs[dt] = (feat.detach().clone(), m.layer2.conv1.weight.grad.detach().clone())
+        if dt == "bf16":
+            assert m.compute_dtype == "bf16"
+            short = synth_feat((2, 60, 96), seed=32).cuda()
+            f_short, _ = m(short)
+            m2 = make_model().train().set_compute_dtype("bf16")
+            f_want, _ = m2(short)
+            # (the first model's BatchNorm buffers moved on; train-mode outputs do not read them)
+            assert torch.equal(f_short, f_want)
+    assert torch.equal(outs["bf16"][0], outs["bf16c"][0]) and torch.equal(outs["bf16"][1], outs["bf16c"][1])

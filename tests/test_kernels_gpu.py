@@ -236,6 +236,41 @@ def test_conv2d_prepack(ops, cfg):
         ops.conv2d_fwd(x, w, s, p, w_packed=pf[:pf.numel() // 2].clone())
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 18, 75, 128), (3, 128, 9, 94, 256)])
+def test_conv2d_prepack_layout_mismatch(ops, cfg):
+    """air_conv2d_prepack(pass 0) writes split-bf16 planes (6 bytes per weight) for a bf3-eligible
+    3x3 / stride 2 layer, but a forward WITH a BatchNorm + ReLU prologue or a residual takes the f32 kernel: it must not
+    read those planes as f32 slabs.  (a) such calls with the prepacked buffer equal the calls without it bit for bit;
+    (b) a buffer packed under other dispatch options (CONV_S2 bit 4 flipped in between) is refused by layout, not size."""
+    from asvspoof2021_air_amd import _hip
+    B, Cin, H, W, Cout = cfg
+    x = synth_feat((B, Cin, H, W), 1).cuda()
+    w = synth_feat((Cout, Cin, 3, 3), 2, scale=0.1).cuda()
+    scale = (1.0 + 0.2 * synth_feat((Cin,), 3)).cuda()
+    shift = (0.3 * synth_feat((Cin,), 4)).cuda()
+    with _hip.options(CONV_S2=31):
+        pk = ops.conv2d_prepack(w, x.shape, 2, 1, 0)
+        assert pk._air_pack_layout == 3  # AIR_PACK_BF3
+        y0 = ops.conv2d_fwd(x, w, 2, 1, scale, shift, relu=True)
+        y1 = ops.conv2d_fwd(x, w, 2, 1, scale, shift, relu=True, w_packed=pk)
+        assert torch.equal(y0, y1)
+        res = synth_feat(tuple(y0.shape), 8).cuda()
+        r0 = ops.conv2d_fwd(x, w, 2, 1, residual=res)
+        r1 = ops.conv2d_fwd(x, w, 2, 1, residual=res, w_packed=pk)
+        assert torch.equal(r0, r1)
+        want = F.conv2d(F.relu(x.double().cpu() * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)),
+                        w.double().cpu(), None, 2, 1)
+        close(y1, want, rtol=1e-5, name="prologue forward beside a bf3 prepack buffer")
+    with _hip.options(CONV_S2=3):  # bit 4 off: the layer now consumes f32 slabs
+        with pytest.raises(_hip.AirError):
+            ops.conv2d_fwd(x, w, 2, 1, w_packed=pk)
+        pk32 = ops.conv2d_prepack(w, x.shape, 2, 1, 0)
+        assert pk32._air_pack_layout == 1
+    with _hip.options(CONV_S2=31):
+        with pytest.raises(_hip.AirError):
+            ops.conv2d_fwd(x, w, 2, 1, w_packed=pk32)
+
+
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv2d_dgrad(ops, cfg):
     B, Cin, H, W, Cout, k, s, p = cfg
