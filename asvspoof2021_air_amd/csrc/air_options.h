@@ -25,6 +25,7 @@ enum AirOption {
                                // bit 8: the paired stride-2 data gradient likewise; bit 16: the stride-2 3x3 weight gradient
   AIR_OPT_WINO4_DEPHASE,       // every second persistent Winograd workgroup starts N x 4096 cycles late (0 = in phase)
   AIR_OPT_IR_FFT,              // 1: impulse responses of 128 .. 1025 taps are convolved by overlap-save FFT (augment.hip); 0: direct FIR
+  AIR_OPT_TAP_ROWS,            // 1: the 64 -> 64 Res2 convs on bf16-resident rows stage 16-byte row pieces (round 6) also without a prologue (measured slower: default 0)
   AIR_OPT_COUNT
 };
 

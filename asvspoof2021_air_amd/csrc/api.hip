@@ -17,7 +17,7 @@ const OptDef kOpts[AIR_OPT_COUNT] = {
     {"NO_WINO4", 0},   {"NO_WINOGRAD", 0},       {"WINO4_SPLIT", 1},       {"WINO4_TH3", 2},
     {"WINO4_XCD", 2},  {"CONV_MT", 0},           {"WGRAD_WGS", 256},       {"WINO_WGRAD_WGS", 256},
     {"DIRECT_WGRAD_ROWS", 1}, {"C1B_PS", 7},     {"C1B_GEMM_PS", 1}, {"SKINNY_WGRAD", 1},
-    {"CONV_S2", 31}, {"WINO4_DEPHASE", 0}, {"IR_FFT", 1},
+    {"CONV_S2", 31}, {"WINO4_DEPHASE", 0}, {"IR_FFT", 1}, {"TAP_ROWS", 0},
 };
 std::atomic<int> g_val[AIR_OPT_COUNT];
 std::once_flag g_once;

@@ -1399,6 +1399,22 @@ struct C1bTap {
   const float* bn_mean;
   const float* bn_invstd;
   float* bsums;
+  // c1b_tap_kernel<true, PRO> (round 6): the operand is COMPUTED while it is staged - the elementwise pass that used to
+  // produce it (h_res2_kernel forward, h_bn_bwd_apply_kernel backward: 42 launches per ECAPA step) is gone; its stored
+  // results leave this launch as side outputs (the centre 128 frames of the staged tile, 16-byte row pieces).
+  //   PRO 1 (forward, branch i >= 1): x = r of branch i - 1; y1 = bf16(x * pa[c] + pb[c]) -> its slice of the concat
+  //     (side1), operand t = bf16(y1 + g0) (g0 = this branch's slice of o1) -> side0 (the weight gradient's input)
+  //   PRO 2 (data gradient of branch i): x = r of branch i (its BatchNorm's input), g = g0 + g1 (the concat gradient's
+  //     slice + the next branch's input gradient; g1 optional), operand dc = bf16(pc (g - k1 - xhat k2)) or 0 where
+  //     x <= 0, xhat = (x - pa) pb, pc = gamma pb, k1 = pd invN, k2 = pe invN -> side0 (the weight gradient's dy)
+  const unsigned short* g0;
+  const unsigned short* g1;
+  size_t g0_bs, g1_bs;
+  const float *pa, *pb, *pc, *pd, *pe;
+  float invN;
+  unsigned short* side0;
+  unsigned short* side1;
+  size_t side0_bs, side1_bs;
 };
 
 // fp32 (Cout, Cin, 3) -> bf16 A[tap][m][k].  transpose = 0: m = co, k = ci, tap as is (forward);
@@ -1423,8 +1439,9 @@ __global__ __launch_bounds__(256) void c1b_pack3_kernel(const float* __restrict_
 
 // HIO: bf16-resident tensors (ecapa_bf16.hip) - x and y are bf16 rows [b][c][Tp]: staging copies the bits, the epilogue
 // rounds once and writes zeros for the frames T .. Tp - 1 (tiles cover the whole row).
-template <bool HIO>
+template <bool HIO, int PRO = 0>
 __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
+  static_assert(PRO == 0 || HIO, "the fused prologues exist for the bf16-resident tensors only");
   __shared__ __attribute__((aligned(16))) unsigned short sA[2][3 * 64 * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short sB[2][TAP_ROWS * LDK];
   const int work = xcd_chunked(blockIdx.x, p.per_xcd);
@@ -1505,12 +1522,129 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
 
   const int r31 = lane & 31, kgl = lane >> 5;
   const int nk = p.K / BK;
-  TAP_FETCH(0);
-  TAP_STASH(0);
-  __syncthreads();
+  if (PRO) {
+    // Round 6: K = 64 (both k-steps = the two buffers) staged in ONE go from 16-byte ROW pieces - 8 frames of one channel
+    // - instead of 2-byte loads down the channels: the piece is where the elementwise prologue runs (one coefficient set
+    // per piece), its result leaves as a 16-byte side-output store when the piece lies in the tile's centre, and goes
+    // to the [frame][k] operand buffers as eight 2-byte LDS writes (the transpose).  Pieces: 18 per channel, frames
+    // t0 - 8 .. t0 + 135 (the staged window t0 - d .. t0 + 127 + d, d <= 4, lies inside); lanes run along the channels.
+    static_assert(TAP_MAXD <= 8, "the halo fits one piece on either side");
+    // weights: both k-steps
+    uint4 wa[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wa[ks][i] = *reinterpret_cast<const uint4*>(ga[i] + ks * BK);
+    const u16* __restrict__ q0 = PRO == 3 ? nullptr : p.g0 + (size_t)b * p.g0_bs;
+    const u16* __restrict__ q1 = (PRO == 2 && p.g1) ? p.g1 + (size_t)b * p.g1_bs : nullptr;
+    u16* __restrict__ o0 = PRO == 3 ? nullptr : p.side0 + (size_t)b * p.side0_bs;
+    u16* __restrict__ o1 = PRO == 1 ? p.side1 + (size_t)b * p.side1_bs : nullptr;
+    constexpr int NPC = 18, NJ = (64 * NPC + 255) / 256;  // 1152 pieces, 4.5 per thread
+    uint4 vx[NJ], v0[NJ], v1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int idx = tid + 256 * j;
+      const int c = idx & 63, pc = idx >> 6;
+      const int tp = t0 - 8 + pc * 8;  // first frame of the piece
+      const bool ok = pc < NPC && tp >= 0 && tp < p.Tp;
+      const size_t off = (size_t)c * p.Tp + (ok ? tp : 0);
+      // (`off` is a valid address either way: load, then select - a select between pointers would go through scratch)
+      vx[j] = *reinterpret_cast<const uint4*>(xh + off);
+      if (!ok) vx[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (PRO != 3) {
+        v0[j] = *reinterpret_cast<const uint4*>(q0 + off);
+        if (!ok) v0[j] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (PRO == 2) {
+        v1[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (q1) {
+          v1[j] = *reinterpret_cast<const uint4*>(q1 + off);
+          if (!ok) v1[j] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(&sA[ks][la[i]]) = wa[ks][i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int idx = tid + 256 * j;
+      const int c = idx & 63, pc = idx >> 6;
+      if (pc >= NPC) continue;
+      const int tp = t0 - 8 + pc * 8;
+      unsigned wx[4] = {vx[j].x, vx[j].y, vx[j].z, vx[j].w};
+      unsigned res[4], res1[4];
+      if (PRO == 3) {  // no prologue: the stored operand, zero outside [0, T) like the 2-byte staging
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const unsigned lo = (tp + 2 * h >= 0 && tp + 2 * h < p.T) ? (wx[h] & 0xffffu) : 0u;
+          const unsigned hi = (tp + 2 * h + 1 >= 0 && tp + 2 * h + 1 < p.T) ? (wx[h] & 0xffff0000u) : 0u;
+          res[h] = lo | hi;
+        }
+      } else {
+        const unsigned w0[4] = {v0[j].x, v0[j].y, v0[j].z, v0[j].w};
+        const unsigned w1[4] = {v1[j].x, v1[j].y, v1[j].z, v1[j].w};
+        float ca, cb, cc = 0.0f, k1 = 0.0f, k2 = 0.0f;
+        ca = p.pa[c];
+        cb = p.pb[c];
+        if (PRO == 2) {
+          cc = p.pc[c] * cb;      // (h_bn_bwd_apply_kernel: sc = gamma[c] * is)
+          k1 = p.pd[c] * p.invN;  // dbeta[c] * invN
+          k2 = p.pe[c] * p.invN;  // dgamma[c] * invN
+        }
+        float o[8], y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool live = tp + e >= 0 && tp + e < p.T;
+          const float xv = (e & 1) ? __builtin_bit_cast(float, wx[e >> 1] & 0xffff0000u) : __builtin_bit_cast(float, wx[e >> 1] << 16);
+          const float g0 = (e & 1) ? __builtin_bit_cast(float, w0[e >> 1] & 0xffff0000u) : __builtin_bit_cast(float, w0[e >> 1] << 16);
+          if (PRO == 1) {
+            y[e] = live ? fmaf(xv, ca, cb) : 0.0f;  // (h_res2_kernel: y1 = bf16(x * scale + shift), zeros behind T)
+            o[e] = g0;
+          } else {
+            float g = g0;
+            if (q1) g += (e & 1) ? __builtin_bit_cast(float, w1[e >> 1] & 0xffff0000u) : __builtin_bit_cast(float, w1[e >> 1] << 16);
+            const float xh_ = (xv - ca) * cb;
+            float r = cc * ((g + 0.0f) - k1 - xh_ * k2);  // (h_bn_bwd_apply_kernel, rowbias = 0)
+            if (!(xv > 0.0f) || !live) r = 0.0f;
+            o[e] = r;
+          }
+        }
+        if (PRO == 1) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) res1[h] = pack2(y[2 * h], y[2 * h + 1]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool live = tp + e >= 0 && tp + e < p.T;
+            const float yy = (e & 1) ? __builtin_bit_cast(float, res1[e >> 1] & 0xffff0000u) : __builtin_bit_cast(float, res1[e >> 1] << 16);
+            o[e] = live ? yy + o[e] : 0.0f;  // t = bf16(y1 + add)
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) res[h] = pack2(o[2 * h], o[2 * h + 1]);
+        if (pc >= 1 && pc <= 16) {  // the tile's own 128 frames: every (channel, frame) of the tensor is written once
+          *reinterpret_cast<uint4*>(o0 + (size_t)c * p.Tp + tp) = make_uint4(res[0], res[1], res[2], res[3]);
+          if (PRO == 1) *reinterpret_cast<uint4*>(o1 + (size_t)c * p.Tp + tp) = make_uint4(res1[0], res1[1], res1[2], res1[3]);
+        }
+      }
+      u16* dstb = &sB[c >> 5][0] + (c & 31);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = pc * 8 + e - 8 + d;  // staged frame index: frame t0 - d is row 0
+        if (row >= 0 && row < nrows)
+          dstb[row * LDK] = (u16)((e & 1) ? (res[e >> 1] >> 16) : (res[e >> 1] & 0xffffu));
+      }
+    }
+    __syncthreads();
+  } else {
+    TAP_FETCH(0);
+    TAP_STASH(0);
+    __syncthreads();
+  }
   for (int s = 0; s < nk; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nk) TAP_FETCH((s + 1) * BK);
+    if (!PRO && s + 1 < nk) TAP_FETCH((s + 1) * BK);
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap) {
 #pragma unroll
@@ -1525,8 +1659,8 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
         }
       }
     }
-    if (s + 1 < nk) TAP_STASH(cur ^ 1);
-    __syncthreads();
+    if (!PRO && s + 1 < nk) TAP_STASH(cur ^ 1);
+    if (!PRO || s + 1 == nk) __syncthreads();  // (PRO: both buffers were complete before the loop)
   }
 #undef TAP_FETCH
 #undef TAP_STASH
@@ -2124,7 +2258,7 @@ int air_h_conv1d_tap_ex2(int B, int Cin, int Cout, int T, int Tp, int dil, const
     return AIR_EINVAL;
   const int M = dgrad ? Cin : Cout, K = dgrad ? Cout : Cin;
   if (dil < 1 || dil > TAP_MAXD || M % 64 != 0 || K % BK != 0) return AIR_EUNSUPPORTED;
-  C1bTap p;
+  C1bTap p = {};
   p.x = reinterpret_cast<const float*>(x); p.a = w_packed; p.y = reinterpret_cast<float*>(y); p.bias = bias; p.acc = nullptr;
   p.x_bs = x_bs ? x_bs : (size_t)K * Tp; p.y_bs = y_bs ? y_bs : (size_t)M * Tp;
   p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu; p.Tp = Tp;
@@ -2138,7 +2272,70 @@ int air_h_conv1d_tap_ex2(int B, int Cin, int Cout, int T, int Tp, int dil, const
   p.per_xcd = (p.total + NXCD - 1) / NXCD;
   hipStream_t st = air_stream(stream);
   AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
-  hipLaunchKernelGGL(c1b_tap_kernel<true>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  if (M == 64 && K == 64 && air_opt(AIR_OPT_TAP_ROWS) && ((reinterpret_cast<size_t>(x) & 15) == 0) && p.x_bs % 8 == 0)
+    hipLaunchKernelGGL((c1b_tap_kernel<true, 3>), dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);  // (same sums, same order)
+  else
+    hipLaunchKernelGGL(c1b_tap_kernel<true>, dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  AIR_CHECK_LAUNCH();
+  return AIR_OK;
+}
+
+int air_h_conv1d_tap_pro_ok(int Cin, int Cout) { return Cin == 64 && Cout == 64 ? 1 : 0; }
+
+int air_h_conv1d_tap_pro(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                         size_t y_bs, void* stats, const unsigned short* bn_x, size_t bn_x_bs,
+                         const unsigned short* bn_dy, size_t bn_dy_bs, const float* bn_mean, const float* bn_invstd,
+                         void* bn_sums, const AirTapPrologue* pro, air_stream_t stream) {
+  if (pro == nullptr || pro->kind == 0)
+    return air_h_conv1d_tap_ex2(B, Cin, Cout, T, Tp, dil, x, x_bs, w_packed, dgrad, bias, relu, y, y_bs, stats, bn_x, bn_x_bs,
+                                bn_dy, bn_dy_bs, bn_mean, bn_invstd, bn_sums, stream);
+  if (!x || !w_packed || !y || B <= 0 || T <= 0 || Tp < T || Tp % BN != 0) return AIR_EINVAL;
+  if (!air_h_conv1d_tap_pro_ok(Cin, Cout)) return AIR_EUNSUPPORTED;  // the whole K = 64 tile lives in the two staging buffers
+  if (stats != nullptr && (reinterpret_cast<size_t>(stats) & 7)) return AIR_EINVAL;
+  if (bn_sums != nullptr && (!bn_x || !bn_dy || !bn_mean || !bn_invstd || (reinterpret_cast<size_t>(bn_sums) & 15) ||
+                             ((reinterpret_cast<size_t>(bn_x) | reinterpret_cast<size_t>(bn_dy)) & 15) ||
+                             bn_x_bs % 8 || bn_dy_bs % 8))
+    return AIR_EINVAL;
+  if (dil < 1 || dil > TAP_MAXD) return AIR_EUNSUPPORTED;
+  const int M = 64, K = 64;
+  if ((pro->kind == 1) == (dgrad != 0) || (pro->kind != 1 && pro->kind != 2)) return AIR_EINVAL;
+  if (!pro->g0 || !pro->side0 || !pro->pa || !pro->pb) return AIR_EINVAL;
+  if (pro->kind == 1 && !pro->side1) return AIR_EINVAL;
+  if (pro->kind == 2 && (!pro->pc || !pro->pd || !pro->pe)) return AIR_EINVAL;
+  if ((reinterpret_cast<size_t>(pro->side0) | reinterpret_cast<size_t>(pro->side1) | reinterpret_cast<size_t>(x) |
+       reinterpret_cast<size_t>(pro->g0) | reinterpret_cast<size_t>(pro->g1)) & 15)
+    return AIR_EINVAL;  // 16-byte row pieces
+  if (pro->side0_bs % 8 || pro->side1_bs % 8 || x_bs % 8 || pro->g0_bs % 8 || pro->g1_bs % 8) return AIR_EINVAL;
+  // a side output must not be a tensor this launch reads with a halo (neighbouring workgroups would race)
+  if (y == x || y == pro->g0 || y == pro->g1) return AIR_EINVAL;
+  if (pro->side0 == x || pro->side0 == pro->g0 || pro->side0 == pro->g1 || pro->side1 == x || pro->side1 == pro->g0 ||
+      (pro->side1 != nullptr && pro->side1 == pro->side0))
+    return AIR_EINVAL;
+  C1bTap p = {};
+  p.x = reinterpret_cast<const float*>(x); p.a = w_packed; p.y = reinterpret_cast<float*>(y); p.bias = bias; p.acc = nullptr;
+  p.x_bs = x_bs ? x_bs : (size_t)K * Tp; p.y_bs = y_bs ? y_bs : (size_t)M * Tp;
+  p.B = B; p.M = M; p.K = K; p.T = T; p.dil = dil; p.relu = relu; p.Tp = Tp;
+  p.stats = reinterpret_cast<float*>(stats);
+  p.bsums = reinterpret_cast<float*>(bn_sums);
+  p.bn_x = bn_x; p.bn_dy = bn_dy; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd;
+  p.bn_x_bs = bn_x_bs ? bn_x_bs : (size_t)M * Tp; p.bn_dy_bs = bn_dy_bs ? bn_dy_bs : (size_t)M * Tp;
+  p.g0 = pro->g0; p.g1 = pro->kind == 2 ? pro->g1 : nullptr;
+  p.g0_bs = pro->g0_bs ? pro->g0_bs : (size_t)K * Tp; p.g1_bs = pro->g1_bs ? pro->g1_bs : (size_t)K * Tp;
+  p.pa = pro->pa; p.pb = pro->pb; p.pc = pro->pc; p.pd = pro->pd; p.pe = pro->pe;
+  p.invN = (float)(1.0 / ((double)B * (double)T));  // (air_h_bn_bwd_ex: (float)invN)
+  p.side0 = pro->side0; p.side1 = pro->side1;
+  p.side0_bs = pro->side0_bs ? pro->side0_bs : (size_t)K * Tp; p.side1_bs = pro->side1_bs ? pro->side1_bs : (size_t)K * Tp;
+  p.tiles_m = 1;
+  p.tiles_t = Tp / BN;
+  p.total = B * p.tiles_t;
+  p.per_xcd = (p.total + NXCD - 1) / NXCD;
+  hipStream_t st = air_stream(stream);
+  AirProfScope prof(AIR_K_C1B_TAP, 2.0 * B * T * (double)Cout * Cin * 3, st);
+  if (pro->kind == 1)
+    hipLaunchKernelGGL((c1b_tap_kernel<true, 1>), dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((c1b_tap_kernel<true, 2>), dim3(p.per_xcd * NXCD), dim3(256), 0, st, p);
   AIR_CHECK_LAUNCH();
   return AIR_OK;
 }

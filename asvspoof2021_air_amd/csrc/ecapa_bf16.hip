@@ -826,7 +826,7 @@ int air_h_bn_bwd_ex(const unsigned short* x, size_t x_bs, const unsigned short* 
                     const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
                     size_t dx_bs, float* dgamma, float* dbeta, float* dbias, const void* sums_in, size_t sums_bytes,
                     void* ws, size_t ws_bytes, air_stream_t stream) {
-  if (!x || !dy || !mean || !invstd || !gamma || !dx || !dgamma || !dbeta || !h_shape_ok(B, C, T, Tp)) return AIR_EINVAL;
+  if (!x || !dy || !mean || !invstd || !gamma || !dgamma || !dbeta || !h_shape_ok(B, C, T, Tp)) return AIR_EINVAL;
   if (dbias && !relu_in) return AIR_EUNSUPPORTED;
   if (!ws || ws_bytes < air_h_bn_ws_bytes(B, C)) return AIR_EWORKSPACE;
   hipStream_t st = air_stream(stream);
@@ -849,6 +849,7 @@ int air_h_bn_bwd_ex(const unsigned short* x, size_t x_bs, const unsigned short* 
                        dgamma, dbeta, dbias);
     AIR_CHECK_LAUNCH();
   }
+  if (dx == nullptr) return AIR_OK;  // (round 6: the apply is the consumer's prologue, air_h_conv1d_tap_pro)
   const size_t rows = (size_t)B * C;
   hipLaunchKernelGGL(h_bn_bwd_apply_kernel, dim3(h_row_grid(rows)), dim3(NT), 0, st, x, bs_or(x_bs, C, Tp), dy,
                      bs_or(dy_bs, C, Tp), dy2, bs_or(dy2_bs, C, Tp), dy_rowbias, rowbias_scale, C, T, Tp, (float)invN, mean,

@@ -154,46 +154,6 @@ class PCMSource:
                                "main_train.py:63) or DataLoader(..., multiprocessing_context='spawn')" % (what, self.device))
 
     def feature(self, i, ds):
-        return torch.load(self.files[i])  # (1, T, 60) as preprocess.py saved it
-
-
-class PCMSource:
-    """Waveforms instead of feature files.  ``items``: sequence of ``(name, pcm)`` with ``name`` in the file-name
-    scheme of the corpus the Dataset class reads (``00012_LA_T_1000137_A04_spoof`` ...; ``.pt`` optional) and ``pcm``
-    a 1-D float32 array / tensor (or int16 PCM).  Features are computed by the HIP LFCC on ``device``."""
-
-    def __init__(self, items, device="cuda"):
-        self.items = list(items)
-        self.device = torch.device(device)
-
-    def __len__(self):
-        return len(self.items)
-
-    def path(self, i):
-        n = self.items[i][0]
-        return n if n.endswith(".pt") else n + ".pt"
-
-    def take(self, keep):
-        self.items = [self.items[i] for i in keep]
-
-    def pcm(self, i):
-        w = self.items[i][1]
-        return w if torch.is_tensor(w) else torch.from_numpy(np.ascontiguousarray(w))
-
-    def _need_gpu_here(self, what):
-        """The reference's Dataset is pure CPU and forks DataLoader workers freely (--num_workers); this source launches
-        HIP kernels, which a FORKED worker cannot (CUDA / HIP cannot be re-initialised in a forked child).  Fail with
-        the remedy instead of torch's 'Cannot re-initialize CUDA in forked subprocess' (ADVICE r5)."""
-        if self.device.type == "cuda" and torch.utils.data.get_worker_info() is not None:
-            import multiprocessing as mp
-            if (mp.get_start_method(allow_none=True) or "fork") == "fork" and torch.cuda.is_initialized() is False:
-                return  # a spawned / fresh worker that owns its own context would have initialised lazily: let it try
-            if (mp.get_start_method(allow_none=True) or "fork") == "fork":
-                raise RuntimeError("%s runs the HIP LFCC on %s and cannot run inside a forked DataLoader worker: use "
-                                   "num_workers=0 (the reference's default, main_train.py:63) or "
-                                   "DataLoader(..., multiprocessing_context='spawn')" % (what, self.device))
-
-    def feature(self, i, ds):
         """Features of one utterance on the GPU (preprocess.py:239-244 runs batch 1 too): with ``ds.pad_chop`` the
         fused LFCC -> pad / chop kernel's (1, 60, feat_len) output viewed as (1, feat_len, 60), the crop offset drawn
         like dataset.py:69; otherwise the plain (1, T, 60) LFCC."""

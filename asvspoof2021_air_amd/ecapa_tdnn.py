@@ -210,6 +210,12 @@ class Res2Net2(nn.Module):
         self.overlap_wgrad = os.environ.get("AIR_OVERLAP_WGRAD", "1") == "1"
         self.fuse_tap_stats = os.environ.get("AIR_TAP_STATS", "1") == "1"  # Res2 branch statistics from the conv epilogue
         self.fuse_pw_stats = os.environ.get("AIR_PW_STATS", "1") == "1"    # K = 1 convs: statistics from the GEMM epilogue
+        # (round 6) Res2 chain: the elementwise pass in front of a branch conv is that conv's prologue (bf16-resident path)
+        # bit 1: forward (h_res2_kernel's join), bit 2: backward (h_bn_bwd_apply_kernel).  Measured (profiles/
+        # r06_res2_chain.md): forward 16.80 k utt/s against 16.79 k unfused (18 launches and 0.45 GB per step fewer, no
+        # time: the conv's fixed ~8 us per launch hides nothing of the extra streams), backward 16.56 k (-1.3 %: the
+        # fused launch is 29.9 us where conv 14.8 + apply 9.4 were 24.2) - so forward on, backward off
+        self.fuse_tap_prologue = int(os.environ.get("AIR_TAP_PROLOGUE", "1"))
         self._side_stream = None
         # Under hipGraph capture (train.Trainer.enable_graph) a fork per weight gradient makes a graph with ~14 cross-stream
         # edges, which ROCm replays slower than one chain (round 4).  "batched" (experiment, AIR_WGRAD_BATCHED=1): the
@@ -683,18 +689,32 @@ class Res2Net2(nn.Module):
         t_i = oh.copy(cat[:, :w], oh.rows(B, w, T, dev))  # branch 0's input outlives its slice (weight gradient)
         wp = ops.conv1d_tap_pack([det(c.weight) for c in blk.convs], transpose=False)
         t_list, r_list, st_list = [], [], []
+        # (round 6) the BatchNorm-apply + join of branch i - 1 (h_res2_kernel: y1 -> its concat slice, t_i = y1 + o1's
+        # slice i) is the PROLOGUE of branch i's conv: that launch reads r_{i-1} and the slice, computes its operand while
+        # staging it and writes y1 and t_i as side outputs - same arithmetic, same rounding points, 6 launches fewer per
+        # block.  Only the last branch's BatchNorm output still takes a pass of its own.
+        fusep = bool(int(getattr(self, "fuse_tap_prologue", 1)) & 1) and oh.tap_pro_ok(w, w)
         for i in range(nums):
             # (round 4: the branch's BatchNorm statistics leave the conv's epilogue - no pass over r_i)
             fuse = training and getattr(self, "fuse_tap_stats", True)
-            r_i, rec_i = oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True, stats=True) if fuse \
-                else (oh.conv_tap(t_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True), None)
+            pro, x_i = None, t_i
+            if fusep and i > 0:
+                t_i = oh.rows(B, w, T, dev)
+                pro = oh.res2_prologue(st_list[i - 1][2], st_list[i - 1][3], add=cat[:, i * w:(i + 1) * w],
+                                       y1=cat[:, (i - 1) * w:i * w], t_out=t_i)
+                x_i = r_list[i - 1]
+            r_i, rec_i = oh.conv_tap(x_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True, stats=True, pro=pro) if fuse \
+                else (oh.conv_tap(x_i, wp[i], T, d, w, w, bias=det(blk.convs[i].bias), relu=True, pro=pro), None)
             st_i = self._bn_h(r_i, T, blk.bns[i], training, stats_in=rec_i)
-            if i + 1 < nums:
+            t_next = None
+            if fusep:
+                if i + 1 == nums:
+                    oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
+            elif i + 1 < nums:
                 t_next = oh.rows(B, w, T, dev)
                 oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w],
                                  add=cat[:, (i + 1) * w:(i + 2) * w], y2=t_next)
             else:
-                t_next = None
                 oh.res2_bn_apply(r_i, T, st_i[2], st_i[3], cat[:, i * w:(i + 1) * w])
             t_list.append(t_i)
             r_list.append(r_i)
@@ -800,7 +820,32 @@ class Res2Net2(nn.Module):
         fuse = getattr(self, "fuse_tap_stats", True)
         if flush_side is not None:
             flush_side()
-        for i in reversed(range(nums)):
+        # (round 6) the BatchNorm-backward APPLY of branch i (h_bn_bwd_apply_kernel: 21 passes per step) is the prologue
+        # of that branch's data-gradient conv, which reads r_i + the two gradient halves, computes dc_i while staging it
+        # and writes it out for the weight gradient.  Its output (d t_i) goes into a second tensor, do1, slice by slice
+        # (the launch reads dcat's slice with a halo, so it cannot overwrite it in place); do1 = d(o1) at the end.
+        fusep = bool(int(getattr(self, "fuse_tap_prologue", 1)) & 2) and oh.tap_pro_ok(w, w) and fuse
+        if fusep:
+            do1 = oh.rows(B, C, T, dcat.device)
+            oh.copy(dcat[:, nums * w:], do1[:, nums * w:])  # the pass-through group (ecapa_tdnn.py:85)
+        for i in reversed(range(nums)) if fusep else ():
+            st_i = S["st"][i]
+            dy_i = dcat[:, i * w:(i + 1) * w]
+            oh.bn_bwd(S["r"][i], dy_i, T, st_i[0], st_i[1], det(blk.bns[i].weight), gv("bns.%d.weight" % i),
+                      gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i), sums_in=sums_next, apply=False)
+            dcs[i] = oh.rows(B, w, T, dcat.device)
+            pro = oh.bn_bwd_prologue(dy_i, din_next, st_i[0], st_i[1], det(blk.bns[i].weight), gv("bns.%d.weight" % i),
+                                     gv("bns.%d.bias" % i), dcs[i])
+            out_i = do1[:, i * w:(i + 1) * w]
+            if i > 0:
+                st_p = S["st"][i - 1]
+                din_next, sums_next = oh.conv_tap(S["r"][i], wpt[i], T, d, w, w, dgrad=True, out=out_i, pro=pro,
+                                                  bn=(S["r"][i - 1], dcat[:, (i - 1) * w:i * w], st_p[0], st_p[1]))
+            else:
+                oh.conv_tap(S["r"][i], wpt[i], T, d, w, w, dgrad=True, out=out_i, pro=pro)
+        if fusep:
+            dcat = do1
+        for i in reversed(range(nums)) if not fusep else ():
             st_i = S["st"][i]
             dc_i = oh.bn_bwd(S["r"][i], dcat[:, i * w:(i + 1) * w], T, st_i[0], st_i[1], det(blk.bns[i].weight),
                              gv("bns.%d.weight" % i), gv("bns.%d.bias" % i), dy2=din_next, dbias=gv("convs.%d.bias" % i),

@@ -126,10 +126,52 @@ def conv_wgrad(x, dy, T, out):
     return out
 
 
-def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None, stats=False, bn=None):
+class AirTapPrologue(ctypes.Structure):
+    """include/air_hip.h: the elementwise pass that produces a Res2 conv's operand, folded into its staging."""
+    _fields_ = [("kind", ctypes.c_int),
+                ("g0", ctypes.c_void_p), ("g0_bs", ctypes.c_size_t), ("g1", ctypes.c_void_p), ("g1_bs", ctypes.c_size_t),
+                ("pa", ctypes.c_void_p), ("pb", ctypes.c_void_p), ("pc", ctypes.c_void_p), ("pd", ctypes.c_void_p),
+                ("pe", ctypes.c_void_p),
+                ("side0", ctypes.c_void_p), ("side0_bs", ctypes.c_size_t), ("side1", ctypes.c_void_p),
+                ("side1_bs", ctypes.c_size_t)]
+
+
+def tap_pro_ok(Cin, Cout):
+    return bool(_hip.lib().air_h_conv1d_tap_pro_ok(ci(Cin), ci(Cout)))
+
+
+def _f32p(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise _hip.AirError("prologue coefficients must be contiguous fp32 GPU tensors")
+    return t.data_ptr()
+
+
+def res2_prologue(scale, shift, add, y1, t_out):
+    """Forward: the conv's input is r of the PREVIOUS branch; operand = bf16(bf16(r * scale + shift) + add); y1 (the
+    previous branch's slice of the concat) and t_out (the operand, kept for the weight gradient) are written."""
+    g0, g0b = hv(add)
+    s0, s0b = hv(t_out)
+    s1, s1b = hv(y1)
+    return AirTapPrologue(1, g0.value, g0b, None, 0, _f32p(scale), _f32p(shift), None, None, None, s0.value, s0b, s1.value, s1b)
+
+
+def bn_bwd_prologue(dy, dy2, mean, invstd, gamma, dgamma, dbeta, dc_out):
+    """Data gradient: the conv's input is r of THIS branch (its BatchNorm's input); operand = the BatchNorm-backward
+    apply of (dy + dy2) with the ReLU mask; dc_out receives it (the weight gradient's dy)."""
+    g0, g0b = hv(dy)
+    g1, g1b = hv(dy2, True)
+    s0, s0b = hv(dc_out)
+    return AirTapPrologue(2, g0.value, g0b, g1.value, g1b, _f32p(mean), _f32p(invstd), _f32p(gamma), _f32p(dbeta),
+                          _f32p(dgamma), s0.value, s0b, None, 0)
+
+
+def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False, out=None, stats=False, bn=None, pro=None):
     """stats=True: returns (y, records) - the BatchNorm statistics of the stored y from the epilogue, for
     ``bn_stats(y, ..., stats_in=records)``.  bn = (bn_x, bn_dy, mean, invstd) on a data-gradient launch: returns
-    (y, sums) - the backward sums of the BatchNorm whose output gradient is bn_dy + y, for ``bn_bwd(..., sums_in=sums)``."""
+    (y, sums) - the backward sums of the BatchNorm whose output gradient is bn_dy + y, for ``bn_bwd(..., sums_in=sums)``.
+    pro (round 6): ``res2_prologue`` / ``bn_bwd_prologue`` - x is then the RAW tensor the operand is computed from."""
     B, K, Tp = x.shape
     M = Cin if dgrad else Cout
     if out is None:
@@ -146,12 +188,20 @@ def conv_tap(x, w_packed, T, dil, Cout, Cin, dgrad=False, bias=None, relu=False,
         sums = torch.empty(int(lib.air_h_conv1d_tap_bwd_sums_bytes(ci(B), ci(M), ci(Tp))), dtype=torch.uint8, device=x.device)
         bxp, bxb = hv(bn_x)
         bdp, bdb = hv(bn_dy)
-    _hip.check(lib.air_h_conv1d_tap_ex2(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
-                                        dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
-                                        ci(1 if relu else 0), yp, csz(yb), dptr(rec, torch.uint8, allow_none=True),
-                                        bxp, csz(bxb), bdp, csz(bdb), dptr(mean, allow_none=True),
-                                        dptr(invstd, allow_none=True), dptr(sums, torch.uint8, allow_none=True), stream()),
-               "air_h_conv1d_tap_ex2")
+    if pro is not None:
+        _hip.check(lib.air_h_conv1d_tap_pro(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
+                                            dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+                                            ci(1 if relu else 0), yp, csz(yb), dptr(rec, torch.uint8, allow_none=True),
+                                            bxp, csz(bxb), bdp, csz(bdb), dptr(mean, allow_none=True),
+                                            dptr(invstd, allow_none=True), dptr(sums, torch.uint8, allow_none=True),
+                                            ctypes.byref(pro), stream()), "air_h_conv1d_tap_pro")
+    else:
+        _hip.check(lib.air_h_conv1d_tap_ex2(ci(B), ci(Cin), ci(Cout), ci(T), ci(Tp), ci(dil), xp, csz(xb),
+                                            dptr(w_packed, torch.int16), ci(1 if dgrad else 0), dptr(bias, allow_none=True),
+                                            ci(1 if relu else 0), yp, csz(yb), dptr(rec, torch.uint8, allow_none=True),
+                                            bxp, csz(bxb), bdp, csz(bdb), dptr(mean, allow_none=True),
+                                            dptr(invstd, allow_none=True), dptr(sums, torch.uint8, allow_none=True), stream()),
+                   "air_h_conv1d_tap_ex2")
     if bn is not None:
         return out, sums
     return (out, rec) if stats else out
@@ -237,16 +287,17 @@ def bn_apply(x, T, scale, shift, out=None, rowmean=None):
 
 
 def bn_bwd(x, dy, T, mean, invstd, gamma, dgamma, dbeta, dx=None, dy2=None, rowbias=None, rowbias_scale=1.0,
-           dbias=None, relu_in=True, sums_in=None):
-    """sums_in: the records ``conv_tap(..., dgrad=True, bn=...)`` returned for THIS BatchNorm (no first pass)."""
+           dbias=None, relu_in=True, sums_in=None, apply=True):
+    """sums_in: the records ``conv_tap(..., dgrad=True, bn=...)`` returned for THIS BatchNorm (no first pass).
+    apply=False (round 6): dgamma / dbeta / dbias only - dx is computed by the consumer (``bn_bwd_prologue``)."""
     B, C, Tp = x.shape
-    if dx is None:
+    if dx is None and apply:
         dx = torch.empty((B, C, Tp), device=x.device, dtype=torch.int16)
     ws, n = _bn_ws(B, C, x.device)
     xp, xb = hv(x)
     gp, gb = hv(dy)
     g2p, g2b = hv(dy2, True)
-    dp, db = hv(dx)
+    dp, db = hv(dx if apply else None, True)
     _hip.check(_hip.lib().air_h_bn_bwd_ex(xp, csz(xb), gp, csz(gb), g2p, csz(g2b), dptr(rowbias, allow_none=True),
                                           cf(rowbias_scale), ci(B), ci(C), ci(T), ci(Tp), dptr(mean), dptr(invstd),
                                           dptr(gamma), ci(1 if relu_in else 0), dp, csz(db), dptr(dgamma), dptr(dbeta),

@@ -67,6 +67,10 @@ int air_abi_version(void);
  *                         bf16 products per fp32 product (operands split exactly into three bf16 planes: fp32-
  *                         equivalent arithmetic, csrc/conv_bf3.hip); bit 8: the same for the paired stride-2 data
  *                         gradient (air_conv2d_dgrad_s2_pair); bit 16: the stride-2 3x3 weight gradient likewise
+ *   TAP_ROWS (0)          the 64 -> 64 Res2 convs on bf16-resident rows (air_h_conv1d_tap*) stage their operand as 16-byte
+ *                         row pieces (8 frames of a channel, transposed into LDS) instead of 2-byte loads down the
+ *                         channels; same sums in the same order (air_h_conv1d_tap_pro always does; measured -0.7 % of
+ *                         the ECAPA step without a prologue: off)
  */
 int air_set_option(const char* name, int value);
 int air_get_option(const char* name, int* value_out);
@@ -603,6 +607,34 @@ int air_h_conv1d_tap_ex2(int B, int Cin, int Cout, int T, int Tp, int dil, const
                          size_t y_bs, void* stats, const unsigned short* bn_x, size_t bn_x_bs,
                          const unsigned short* bn_dy, size_t bn_dy_bs, const float* bn_mean, const float* bn_invstd,
                          void* bn_sums, air_stream_t stream);
+/* Round 6: the Res2 chain's elementwise passes folded into the staging of the conv that consumes them
+ * (ecapa_tdnn.py:78-83: `sp = sp + spx[i]; sp = convs[i](sp); sp = bns[i](relu(sp))` - the BatchNorm of branch i - 1
+ * needs batch statistics, so it cannot go into the launch that produces r_{i-1}; it goes into the NEXT launch's
+ * operand read instead).  Same arithmetic and the same rounding points as air_h_res2_bn_apply / air_h_bn_bwd followed
+ * by air_h_conv1d_tap_ex2: every stored tensor is bit-identical (tests/test_ecapa_bf16_gpu.py).  64 -> 64 channels only
+ * (air_h_conv1d_tap_pro_ok); pro NULL or kind 0 = air_h_conv1d_tap_ex2.
+ *   kind 1 (forward, dgrad = 0): x = r_{i-1} (raw ReLU output of the previous branch).  y1 = bf16(x * pa[c] + pb[c])
+ *     -> side1 (its slice of the concat); operand t = bf16(y1 + g0) (g0 = o1's slice i) -> side0 (kept for the weight
+ *     gradient).  pa / pb = the BatchNorm's scale / shift.
+ *   kind 2 (data gradient, dgrad = 1): x = r_i (the BatchNorm input of THIS branch), g = g0 (+ g1) the gradient of its
+ *     output; operand dc = bf16(pc pb (g - pd / N - xhat pe / N)), xhat = (x - pa) pb, zero where x <= 0 -> side0 (the
+ *     weight gradient's dy).  pa / pb / pc / pd / pe = mean / invstd / gamma / dbeta / dgamma (air_h_bn_bwd_ex with
+ *     dx = NULL leaves dgamma / dbeta / dbias without the apply pass).
+ * side0 / side1 must not alias x, g0 or g1 (those are read with a halo of `dil` frames by neighbouring workgroups). */
+typedef struct AirTapPrologue {
+  int kind;
+  const unsigned short* g0; size_t g0_bs;
+  const unsigned short* g1; size_t g1_bs;
+  const float* pa; const float* pb; const float* pc; const float* pd; const float* pe;
+  unsigned short* side0; size_t side0_bs;
+  unsigned short* side1; size_t side1_bs;
+} AirTapPrologue;
+int air_h_conv1d_tap_pro_ok(int Cin, int Cout);
+int air_h_conv1d_tap_pro(int B, int Cin, int Cout, int T, int Tp, int dil, const unsigned short* x, size_t x_bs,
+                         const unsigned short* w_packed, int dgrad, const float* bias, int relu, unsigned short* y,
+                         size_t y_bs, void* stats, const unsigned short* bn_x, size_t bn_x_bs,
+                         const unsigned short* bn_dy, size_t bn_dy_bs, const float* bn_mean, const float* bn_invstd,
+                         void* bn_sums, const AirTapPrologue* pro, air_stream_t stream);
 /* Weight gradients of the n_branches dilated K = 3 convs of one Res2 block (ecapa_tdnn.py:46, W -> W channels,
  * padding = dilation) in ONE launch: dw[i] (W, W, 3) fp32 = sum_{b,t} dy[i][b][co][t] x[i][b][ci][t + (k - 1) dil],
  * bf16 MFMA over the resident operands (products exact, fp32 sums, fixed-order split over the utterances) - the
@@ -636,6 +668,7 @@ int air_h_bn_bwd(const unsigned short* x, size_t x_bs, const unsigned short* dy,
                  const float* mean, const float* invstd, const float* gamma, int relu_in, unsigned short* dx,
                  size_t dx_bs, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
                  air_stream_t stream);
+/* (round 6) dx NULL: the sums / dgamma / dbeta / dbias only - the apply pass is the prologue of air_h_conv1d_tap_pro. */
 /* sums_in / sums_bytes: the records air_h_conv1d_tap_ex2 wrote for this BatchNorm (merged in fp64, a workgroup per
  * channel; the first pass over x / dy / dy2 is skipped), or NULL / 0 = air_h_bn_bwd.  Needs relu_in = 1, no row bias. */
 int air_h_bn_bwd_ex(const unsigned short* x, size_t x_bs, const unsigned short* dy, size_t dy_bs, const unsigned short* dy2,

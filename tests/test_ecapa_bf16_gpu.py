@@ -524,3 +524,146 @@ def test_train_mode_every_stored_tensor_teacher_forced(oh, B, T):
     close32(feat, F.linear(S["p5"].cpu().double(), d(m.fc6.weight), d(m.fc6.bias)), "fc6", rtol=1e-4)
     print("teacher-forced train-mode pin: %d stored tensors within half a bf16 ulp, 34 BatchNorm statistics within fp32 rounding" % checked[0])
     assert checked[0] == 3 * (2 + 2 * 7 + 6 + 3) + 5  # 80 stored (B, C, T) tensors
+
+
+@pytest.mark.parametrize("cfg", [(3, 96, 2), (2, 750, 3), (5, 401, 4), (130, 200, 2), (2, 128, 4), (1, 5, 3)])
+def test_tap_prologue_forward_is_the_unfused_sequence_bit_for_bit(oh, cfg):
+    """Round 6 (air_h_conv1d_tap_pro, kind 1): the Res2 join in front of branch i - y1 = bf16(bn(r_{i-1})) into the concat
+    slice, t_i = bf16(y1 + o1's slice) - computed while the conv stages its operand.  Against air_h_res2_bn_apply followed
+    by air_h_conv1d_tap_ex: the conv output, its statistics records, y1 and t_i are the SAME BITS (same arithmetic, same
+    rounding points; only the launch count differs), with every tensor a channel slice of a wider one, and neighbouring
+    slices untouched.  Aliasing a side output with a tensor the launch reads with a halo is refused."""
+    from asvspoof2021_air_amd import _hip, ops
+    B, T, d = cfg
+    C = 64
+    r_prev, _ = res(oh, synth_feat((B, C, T), 71).relu())
+    cat0 = oh.rows(B, 4 * C, T, "cuda", zero=True)  # [guard | slice i - 1 | slice i | guard]
+    add, _ = res(oh, synth_feat((B, C, T), 72))
+    cat0[:, 2 * C:3 * C] = add
+    scale = (1.0 + 0.2 * synth_feat((C,), 73)).cuda()
+    shift = (0.3 * synth_feat((C,), 74)).cuda()
+    w = synth_feat((C, C, 3), 75, scale=0.1)
+    bias = (0.1 * synth_feat((C,), 76)).cuda()
+    wp = ops.conv1d_tap_pack([w.cuda()], transpose=False)
+    # unfused
+    cat_a = cat0.clone()
+    t_a = oh.rows(B, C, T, "cuda")
+    oh.res2_bn_apply(r_prev, T, scale, shift, cat_a[:, C:2 * C], add=cat_a[:, 2 * C:3 * C], y2=t_a)
+    y_a, rec_a = oh.conv_tap(t_a, wp[0], T, d, C, C, bias=bias, relu=True, stats=True)
+    # fused
+    cat_b = cat0.clone()
+    t_b = oh.rows(B, C, T, "cuda")
+    t_b.fill_(0x7fc0)  # every element must be written
+    pro = oh.res2_prologue(scale, shift, add=cat_b[:, 2 * C:3 * C], y1=cat_b[:, C:2 * C], t_out=t_b)
+    y_b, rec_b = oh.conv_tap(r_prev, wp[0], T, d, C, C, bias=bias, relu=True, stats=True, pro=pro)
+    assert torch.equal(t_a, t_b), "t_i"
+    assert torch.equal(cat_a, cat_b), "y1 / the concat buffer"
+    assert torch.equal(y_a, y_b), "conv output"
+    assert torch.equal(rec_a, rec_b), "statistics records"
+    assert int(cat_b[:, :C].abs().max()) == 0 and int(cat_b[:, 3 * C:].abs().max()) == 0
+    # without statistics records (eval mode)
+    y_c = oh.conv_tap(r_prev, wp[0], T, d, C, C, bias=bias, relu=True, pro=oh.res2_prologue(
+        scale, shift, add=cat_b[:, 2 * C:3 * C], y1=cat_b[:, C:2 * C], t_out=t_b))
+    assert torch.equal(y_a, y_c)
+    with pytest.raises(_hip.AirError):  # y1 may not be the tensor read as `add` (halo race)
+        oh.conv_tap(r_prev, wp[0], T, d, C, C, pro=oh.res2_prologue(scale, shift, add=cat_b[:, 2 * C:3 * C],
+                                                                   y1=cat_b[:, 2 * C:3 * C], t_out=t_b))
+    assert not oh.tap_pro_ok(128, 128) and oh.tap_pro_ok(64, 64)
+
+
+@pytest.mark.parametrize("cfg", [(3, 96, 2, True), (2, 750, 3, True), (5, 401, 4, False), (130, 200, 2, True), (1, 5, 3, False)])
+def test_tap_prologue_backward_is_the_unfused_sequence_bit_for_bit(oh, cfg):
+    """air_h_conv1d_tap_pro, kind 2: the BatchNorm-backward apply of branch i (h_bn_bwd_apply_kernel) as the prologue of
+    that branch's data-gradient conv.  Against air_h_bn_bwd_ex followed by air_h_conv1d_tap_ex2: dc_i (side output), the
+    data gradient, the previous BatchNorm's backward sums, dgamma / dbeta / dbias - the same bits; with and without the
+    second gradient half (the last branch has none)."""
+    from asvspoof2021_air_amd import ops
+    B, T, d, two = cfg
+    C = 64
+    r_i, _ = res(oh, synth_feat((B, C, T), 81).relu())
+    r_p, _ = res(oh, synth_feat((B, C, T), 82).relu())
+    dcat = oh.rows(B, 2 * C, T, "cuda", zero=True)  # [slice i - 1 | slice i] of the concat gradient
+    dcat[:, :C] = res(oh, synth_feat((B, C, T), 83))[0]
+    dcat[:, C:] = res(oh, synth_feat((B, C, T), 84))[0]
+    dy2 = res(oh, synth_feat((B, C, T), 85))[0] if two else None
+    gamma = (1.0 + 0.2 * synth_feat((C,), 86)).cuda()
+    zeros = torch.zeros(C, device="cuda")
+    mean_i, invstd_i, _, _ = oh.bn_stats(r_i, T, gamma, zeros)
+    mean_p, invstd_p, _, _ = oh.bn_stats(r_p, T, gamma, zeros)
+    w = synth_feat((C, C, 3), 87, scale=0.1)
+    wpt = ops.conv1d_tap_pack([w.cuda()], transpose=True)
+    # unfused
+    dg_a, db_a, dbias_a = (torch.zeros(C, device="cuda") for _ in range(3))
+    dc_a = oh.bn_bwd(r_i, dcat[:, C:], T, mean_i, invstd_i, gamma, dg_a, db_a, dy2=dy2, dbias=dbias_a)
+    din_a, sums_a = oh.conv_tap(dc_a, wpt[0], T, d, C, C, dgrad=True, bn=(r_p, dcat[:, :C], mean_p, invstd_p))
+    # fused
+    dg_b, db_b, dbias_b = (torch.zeros(C, device="cuda") for _ in range(3))
+    oh.bn_bwd(r_i, dcat[:, C:], T, mean_i, invstd_i, gamma, dg_b, db_b, dy2=dy2, dbias=dbias_b, apply=False)
+    dc_b = oh.rows(B, C, T, "cuda")
+    dc_b.fill_(0x7fc0)
+    do1 = oh.rows(B, 2 * C, T, "cuda", zero=True)
+    pro = oh.bn_bwd_prologue(dcat[:, C:], dy2, mean_i, invstd_i, gamma, dg_b, db_b, dc_b)
+    din_b, sums_b = oh.conv_tap(r_i, wpt[0], T, d, C, C, dgrad=True, out=do1[:, C:], pro=pro,
+                                bn=(r_p, dcat[:, :C], mean_p, invstd_p))
+    assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b) and torch.equal(dbias_a, dbias_b)
+    assert torch.equal(dc_a, dc_b), "dc_i"
+    assert torch.equal(din_a, do1[:, C:].contiguous()), "data gradient"
+    assert torch.equal(sums_a, sums_b), "BatchNorm-backward sums of the previous branch"
+    assert int(do1[:, :C].abs().max()) == 0
+    # the first branch of the chain has no BatchNorm in front of it: no sums
+    din_c = oh.conv_tap(r_i, wpt[0], T, d, C, C, dgrad=True, pro=oh.bn_bwd_prologue(
+        dcat[:, C:], dy2, mean_i, invstd_i, gamma, dg_b, db_b, dc_b))
+    assert torch.equal(din_a, din_c)
+
+
+@pytest.mark.parametrize("B,T", [(4, 96), (3, 401)])
+def test_fused_res2_chain_train_step_equals_unfused(B, T):
+    """The whole bf16-resident model, one train-mode forward + backward with the Res2 prologues on (default) and off
+    (AIR_TAP_PROLOGUE=0's switch): outputs, every parameter gradient and the BatchNorm buffers are bit-identical."""
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from oracle.filler import fill_module_
+    x = synth_feat((B, 60, T), seed=500 + T).cuda()
+    out = {}
+    for fused in (True, False, 1, 2):
+        m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60)
+        fill_module_(m)
+        m = m.cuda().train().set_compute_dtype("bf16")
+        m.fuse_tap_prologue = {True: 3, False: 0}.get(fused, fused) if isinstance(fused, bool) else fused
+        feat, o = m(x)
+        (feat.square().mean() + o.square().mean()).backward()
+        out[fused] = (feat.detach().clone(), o.detach().clone(),
+                      {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None},
+                      {k: v.detach().clone() for k, v in m.named_buffers()})
+    for other in (True, 1, 2):
+        assert torch.equal(out[other][0], out[False][0]) and torch.equal(out[other][1], out[False][1])
+        assert out[other][2].keys() == out[False][2].keys()
+        for k in out[other][2]:
+            assert torch.equal(out[other][2][k], out[False][2][k]), (other, k)
+        for k in out[other][3]:
+            assert torch.equal(out[other][3][k], out[False][3][k]), (other, k)
+
+
+@pytest.mark.parametrize("cfg", [(3, 96, 2), (2, 750, 3), (5, 401, 4), (1, 5, 3)])
+def test_tap_row_piece_staging_equals_channel_staging(oh, cfg):
+    """Option TAP_ROWS: the 64 -> 64 convs stage 16-byte row pieces (transposed into LDS by 2-byte writes) instead of
+    2-byte loads down the channels - forward with statistics and data gradient with the BatchNorm sums are the same bits."""
+    from asvspoof2021_air_amd import _hip, ops
+    B, T, d = cfg
+    C = 64
+    wide = oh.rows(B, 3 * C, T, "cuda", zero=True)
+    wide[:, C:2 * C] = res(oh, synth_feat((B, C, T), 91))[0]
+    w = synth_feat((C, C, 3), 92, scale=0.1)
+    bias = (0.1 * synth_feat((C,), 93)).cuda()
+    wp = ops.conv1d_tap_pack([w.cuda()], transpose=False)
+    wpt = ops.conv1d_tap_pack([w.cuda()], transpose=True)
+    r_p, _ = res(oh, synth_feat((B, C, T), 94).relu())
+    dyp, _ = res(oh, synth_feat((B, C, T), 95))
+    mean_p, invstd_p, _, _ = oh.bn_stats(r_p, T, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"))
+    got = {}
+    for rows_on in (0, 1):
+        with _hip.options(TAP_ROWS=rows_on):
+            y, rec = oh.conv_tap(wide[:, C:2 * C], wp[0], T, d, C, C, bias=bias, relu=True, stats=True)
+            din, sums = oh.conv_tap(wide[:, C:2 * C], wpt[0], T, d, C, C, dgrad=True, bn=(r_p, dyp, mean_p, invstd_p))
+        got[rows_on] = (y, rec, din, sums)
+    for a, b_, name in zip(got[0], got[1], ("forward", "records", "dgrad", "sums")):
+        assert torch.equal(a, b_), name
