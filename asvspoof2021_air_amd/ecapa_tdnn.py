@@ -238,6 +238,7 @@ class Res2Net2(nn.Module):
         st = dict(self.__dict__)
         st["_arena"] = None
         st["_bucketer"] = None
+        st["_segment_cut"] = None
         st["_side_stream"] = None
         return st
 
@@ -246,6 +247,16 @@ class Res2Net2(nn.Module):
             raise ValueError("compute_dtype must be 'fp32', 'bf16' or 'bf16c', got %r" % (dtype,))
         self.compute_dtype = dtype
         return self
+
+    def forward_saved(self, x):
+        """The train-mode forward WITHOUT autograd: (feat, saved) - see ResNet.forward_saved."""
+        x = x.float().contiguous()
+        self.arena()
+        feat, _, saved = self._forward_impl(x, save=True)
+        return feat, saved
+
+    def backward_saved(self, saved, dfeat):
+        return self._backward_impl(saved, dfeat, None)
 
     # ------------------------------------------------------------------ plumbing
     def arena(self):
@@ -585,9 +596,12 @@ class Res2Net2(nn.Module):
         on_side(layer4_wgrad, dx4)
         # data parallel: everything from layer4.weight to the end of the gradient arena is final
         bucketer = None if accumulating else getattr(self, "_bucketer", None)
-        offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
+        offsets = {n: o for n, _, o, _ in arena.entries}
 
         def grads_final_from(first_param):
+            cut = getattr(self, "_segment_cut", None)
+            if cut is not None:  # train.Trainer's segmented hipGraph capture: a segment may end here
+                cut(offsets[first_param])
             if bucketer is not None:
                 evs = [torch.cuda.Event()]
                 evs[0].record(main)
@@ -961,9 +975,12 @@ class Res2Net2(nn.Module):
         ops.sum_rows(rows, out=G["layer4.bias"])
         on_side(lambda: oh.conv_wgrad(S["cat123"], dx4, T, G["layer4.weight"]), dx4)
         bucketer = None if accumulating else getattr(self, "_bucketer", None)
-        offsets = {n: o for n, _, o, _ in arena.entries} if bucketer is not None else None
+        offsets = {n: o for n, _, o, _ in arena.entries}
 
         def grads_final_from(first_param):
+            cut = getattr(self, "_segment_cut", None)
+            if cut is not None:  # train.Trainer's segmented hipGraph capture: a segment may end here
+                cut(offsets[first_param])
             if bucketer is not None:
                 flush_side()
                 evs = [torch.cuda.Event()]

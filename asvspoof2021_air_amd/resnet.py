@@ -188,6 +188,7 @@ class ResNet(nn.Module):
         st["_side_stream"] = None
         st["_geo"], st["_packs"], st["_pack_ev"] = {}, {}, [None, None]
         st["_bucketer"] = None
+        st["_segment_cut"] = None
         st["_noise_tensor"] = None
         if st.get("_noise_ctr") is not None:  # the device-side counter travels as its value
             st["_noise_offset"] = int(st["_noise_ctr"].item())
@@ -299,6 +300,19 @@ class ResNet(nn.Module):
             return _ResNetFn.apply(self, x, None, *params)
         feat, mu, _ = self._forward_impl(x, None, save=False)
         return feat, mu
+
+    def forward_saved(self, x):
+        """The train-mode forward WITHOUT autograd: (feat, saved).  With ``backward_saved`` this is what
+        ``_ResNetFn`` does, callable from one Python thread - train.Trainer captures the step as several hipGraphs cut
+        between backward's bucket boundaries (autograd would run backward on its own worker thread)."""
+        x = x.float().contiguous()
+        self.arena()
+        feat, _, saved = self._forward_impl(x, None, save=True)
+        return feat, saved
+
+    def backward_saved(self, saved, dfeat):
+        """Gradients of every arena entry (views of the gradient arena, None where there is none), in arena order."""
+        return self._backward_impl(saved, dfeat, None)
 
     def _launch_prepack(self, fuse):
         """Enqueue the weight transforms of every conv behind conv1 - Winograd for the 3x3 stride-1 layers, the direct
@@ -536,6 +550,9 @@ class ResNet(nn.Module):
 
         def grads_final_from(first_param):
             """Everything that writes arena.grad[offset(first_param):] has been enqueued."""
+            cut = getattr(self, "_segment_cut", None)
+            if cut is not None:  # train.Trainer's segmented hipGraph capture: a segment may end here
+                cut(offsets[first_param])
             if bucketer is None:
                 return
             evs = [torch.cuda.Event()]

@@ -62,6 +62,11 @@ class Trainer:
         self._graph_warm = 0
         self.use_graph = False
         self._overlap_saved = None
+        # world > 1 under hipGraph replay: the step is captured as SEGMENTS cut where backward has finished a bucket of
+        # the gradient arena; that bucket's all-reduce is launched between two replays (enable_graph)
+        self.graph_segments = False
+        self.segment_bytes = int(os.environ.get("AIR_SEGMENT_BYTES", str(air_dist.BUCKET_BYTES)))
+        self._seg_bucketer = None
 
     # ------------------------------------------------------------------ data parallel
     def sync_from_rank0(self):
@@ -203,7 +208,7 @@ class Trainer:
         return self.step_features(self.features(pcm, start), labels)
 
     # ------------------------------------------------------------------ hipGraph replay
-    def enable_graph(self, on=True):
+    def enable_graph(self, on=True, segments=None):
         """Capture front-end + forward + loss + backward of one fixed-shape batch in a hipGraph and replay it per
         step (the optimiser launches stay outside: Adam's step count is a kernel argument).  ECAPA's step is
         ~450 launches of 5 - 150 us each and the host cannot keep the queue full once the activations are bf16
@@ -213,12 +218,21 @@ class Trainer:
         draw itself advances (ops.randn_ctr), so every replay draws fresh noise and eager launches and replays walk
         the same sequence.
 
-        world > 1: the captured chain holds no collective; the gradient arena and the loss centre are all-reduced
-        behind the replay (dist.allreduce_grads) instead of in buckets from inside backward - the eager step's
-        bucketing overlaps ~0.3 ms of transfer, the replay removes 4 - 7 ms of host time per rank."""
+        world > 1: a captured chain holds no collective.  ``segments`` False: one graph, the gradient arena and the loss
+        centre are all-reduced behind the replay (dist.allreduce_grads) - the whole exchange is exposed.  ``segments``
+        True (round 6; default with world > 1, AIR_GRAPH_SEGMENTS=0 / 1 forces): the step is captured as SEVERAL graphs
+        cut inside backward where a bucket (>= segment_bytes) of the gradient arena is final - ResNet-18: behind
+        layer4.1 (24 MB), behind layer3.1 (19 MB), the rest - and each bucket's all-reduce is launched on the
+        communication stream between two replays, underneath the next segment: replay's 0.2 - 0.4 ms of host time per
+        step AND BASELINE configs[3]'s "all-reduce overlapped with backward".  Same kernels in the same order as the
+        one-chain capture and as the eager step: bit-identical (tests/test_dist_gpu.py)."""
         from .ecapa_tdnn import Res2Net2
         from .resnet import ResNet
         self.use_graph = bool(on) and isinstance(self.model, (Res2Net2, ResNet))
+        if segments is None:
+            env = os.environ.get("AIR_GRAPH_SEGMENTS", "")
+            segments = (env == "1") if env in ("0", "1") else self.world > 1
+        self.graph_segments = bool(segments) and self.use_graph
         self._drop_graph()
         if self.use_graph:
             # Round 4, root cause of "replay slower than eager" (tools/exp_ecapa_graph.sh): with the weight gradients
@@ -292,17 +306,111 @@ class Trainer:
                 p.grad = gr
         g["pcm"].copy_(pcm, non_blocking=True)
         g["labels"].copy_(labels, non_blocking=True)
-        g["graph"].replay()
         scale = 1.0
-        if self.world > 1:  # the one exchange of the step, behind the replay (no bucketer while the graph is on)
-            air_dist.allreduce_grads(self.model, self.loss)
-            scale = 1.0 / self.world
+        if g.get("segments") is None:
+            g["graph"].replay()
+            if self.world > 1:  # the one exchange of the step, behind the replay (no bucketer while the graph is on)
+                air_dist.allreduce_grads(self.model, self.loss)
+                scale = 1.0 / self.world
+        else:
+            # segment k's replay, then (world > 1) the all-reduce of the arena slice it completed - launched on the
+            # communication stream behind an event, so that the next replay is enqueued right away
+            bucketer = None
+            if self.world > 1:
+                if self._seg_bucketer is None:
+                    self._seg_bucketer = air_dist.GradBucketer(self.segment_bytes)
+                bucketer = self._seg_bucketer
+                arena = self.model.arena()
+                bucketer.reset(arena.grad, arena.head_total)
+            main = torch.cuda.current_stream()
+            for graph, lo in g["segments"]:
+                graph.replay()
+                if bucketer is not None and lo is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    bucketer.lo, bucketer.events = lo, [ev]
+                    bucketer.flush()
+            if self.world > 1:
+                self.model._bucketer = bucketer  # (allreduce_grads waits for what was sent and reduces the remaining head)
+                try:
+                    air_dist.allreduce_grads(self.model, self.loss)
+                finally:
+                    self.model._bucketer = None
+                scale = 1.0 / self.world
         self.feat_optimizer.step(grad_scale=scale)
         self.loss_optimizer.step(grad_scale=scale)
         return g["loss"].detach().clone(), g["neg"].clone()
 
+    def _fwd_bwd_direct(self, pcm, labels):
+        """front-end + forward + loss + backward as plain calls in THIS thread (what model(x) -> loss.backward() does
+        through autograd, whose backward runs on a worker thread): (loss, -scores, [(param, grad)])."""
+        model = self.model
+        feats, saved = model.forward_saved(self.features(pcm, None))
+        leaf = feats.detach().requires_grad_(True)
+        loss, neg = self.loss(leaf, labels)
+        (loss * self.weight_loss).backward()  # the OC-Softmax head only: d(loss) / d(feats) and the centre's gradient
+        grads = model.backward_saved(saved, leaf.grad)
+        pairs = []
+        for (n, p, _, _), gr in zip(model.arena().entries, grads):
+            if gr is not None:
+                p.grad = gr
+                pairs.append((p, gr))
+        pairs += [(p, p.grad) for p in self.loss.parameters() if p.grad is not None]
+        return loss, neg, pairs
+
+    def _capture_segments(self, key, pcm, labels):
+        """The step as several hipGraphs sharing one memory pool, cut at backward's bucket boundaries (enable_graph)."""
+        from . import ops
+        self.model.train()
+        s_pcm, s_labels = pcm.detach().clone(), labels.detach().clone()
+        self.feat_optimizer.zero_grad()
+        self.loss_optimizer.zero_grad()
+        arena = self.model.arena()
+        pool = torch.cuda.graph_pool_handle()
+        state = {"g": None, "hi": arena.head_total}
+        segments = []
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=pool)
+
+        def cut(lo):
+            """backward reports: everything that writes arena.grad[lo:] has been enqueued"""
+            if lo >= state["hi"] or (state["hi"] - lo) * 4 < self.segment_bytes:
+                return
+            state["g"].capture_end()
+            segments.append((state["g"], lo))
+            state["hi"] = lo
+            begin()
+
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream())
+        self.model._segment_cut = cut
+        try:
+            with torch.cuda.stream(cap):
+                begin()
+                loss, neg, grads = self._fwd_bwd_direct(s_pcm, s_labels)
+                state["g"].capture_end()
+                segments.append((state["g"], None))  # the rest of the arena goes with the final all-reduce
+        finally:
+            self.model._segment_cut = None
+        torch.cuda.current_stream().wait_stream(cap)
+        ops.pin_workspaces(id(self))
+        if not getattr(self, "_pin_finalizer", None):
+            import weakref
+            self._pin_finalizer = weakref.finalize(self, ops.unpin_workspaces, id(self))
+        self._graph = dict(key=key, graph=None, segments=segments, pool=pool, pcm=s_pcm, labels=s_labels, loss=loss, neg=neg,
+                           grads=grads, ws_gen=ops.workspace_generation())
+        return self._graph
+
     def _capture(self, key, pcm, labels):
         from . import ops
+        if self.graph_segments:
+            return self._capture_segments(key, pcm, labels)
         self.model.train()
         s_pcm, s_labels = pcm.detach().clone(), labels.detach().clone()
         self.feat_optimizer.zero_grad()

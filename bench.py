@@ -448,7 +448,11 @@ def main():
         want_graph = os.environ.get("AIR_GRAPH", "")
         # (the IR augmentation runs in front of the captured region - its per-utterance draw is host state - and hands
         # its output to the replay like any other batch)
-        if want_graph == "1" or (want_graph != "0" and (model_name == "ecapa" or world == 1)):
+        # Round 6: with world > 1 the replay is SEGMENTED (Trainer.enable_graph: several graphs cut at backward's bucket
+        # boundaries, each bucket's all-reduce launched between two replays), so both models replay at every N - the
+        # N = 1 and N = 8 legs of a scaling curve run the same launch mode.  AIR_GRAPH=0 -> eager with buckets from
+        # inside backward; AIR_GRAPH_SEGMENTS=0 -> one chain + the whole exchange behind it.
+        if want_graph != "0":
             trainer.enable_graph()
         if augment:
             from asvspoof2021_air_amd.augment import ChannelAugment
@@ -553,7 +557,10 @@ def main():
             res = {"value": round(world * BATCH * steps_timed / dt, 2), "unit": "utt/s", "steps": steps, "warmup": warmup,
                    "ms_per_step": round(1e3 * dt / steps_timed, 3), "per_gpu_batch": BATCH, "global_batch": world * BATCH,
                    "final_loss": round(float(last.item()), 5), "host_issue_ms_per_step": round(1e3 * t_host / steps_timed, 3),
-                   "launch": "hipGraph replay (one chain) + optimiser launches" if trainer.use_graph else "eager",
+                   "launch": (("hipGraph replay (%d segments, a bucket's all-reduce between two replays) + optimiser launches"
+                               % len(trainer._graph["segments"])) if (trainer.use_graph and trainer._graph is not None
+                                                                      and trainer._graph.get("segments"))
+                              else "hipGraph replay (one chain) + optimiser launches" if trainer.use_graph else "eager"),
                    "steps_timed_per_window": steps_timed, "windows": len(wins),
                    "timing": timing, "steps_run_total": nrun[0]}
             return res, dt / steps_timed
@@ -587,8 +594,10 @@ def main():
             res["roofline"] = roofline_leg(trainer, batches)
             nrun[0] += 6
         bucketer = getattr(model, "_bucketer", None)
+        seg_b = getattr(trainer, "_seg_bucketer", None)
         res["ddp"] = {"device": "cuda:%d" % local, "world": world,
-                      "buckets_in_backward": (bucketer.total_launched if bucketer is not None else 0)}
+                      "buckets_in_backward": (bucketer.total_launched if bucketer is not None else 0),
+                      "buckets_between_replays": (seg_b.total_launched if seg_b is not None else 0)}
         if world > 1:
             # self-documenting first multi-GPU run: what the process group actually is
             res["ddp"].update(backend=td.get_backend(), ranks_seen=td.get_world_size(),

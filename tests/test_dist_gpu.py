@@ -142,7 +142,9 @@ def _worker_steps(rank, world, port, out, kind, graph):
     if kind == "resnet":
         tr.model.noise_mode, tr.model._noise_seed = "device", 77 + rank  # per-rank attention noise, device-side offset
     if graph:
-        tr.enable_graph()
+        if graph == "segments":
+            tr.segment_bytes = 8 << 20
+        tr.enable_graph(segments=(graph == "segments"))
         assert tr.model._bucketer is None and tr.model.overlap_wgrad is False
     losses = []
     for i in range(5):
@@ -150,7 +152,10 @@ def _worker_steps(rank, world, port, out, kind, graph):
         labels = ((torch.arange(4) + i + rank) % 3 != 0).long().cuda()
         losses.append(tr.step(pcm, labels)[0].item())
     torch.cuda.synchronize()
-    assert (tr._graph is not None) == graph
+    assert (tr._graph is not None) == bool(graph)
+    if graph == "segments":  # several graphs, and their buckets went out between the replays
+        assert len(tr._graph["segments"]) >= 3 and tr._seg_bucketer.total_launched >= 2 * 3, (
+            len(tr._graph["segments"]), tr._seg_bucketer.total_launched)
     out[rank] = (losses, tr.model.arena().flat.detach().cpu().numpy(), tr.loss.center.detach().cpu().numpy())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -164,16 +169,19 @@ def test_two_rank_graph_replay_equals_two_rank_eager(kind):
     world = 2
     mgr = mp.Manager()
     ends = []
-    for graph in (False, True):
+    # (round 6) "segments": the step captured as several hipGraphs cut at backward's bucket boundaries, each bucket's
+    # all-reduce launched between two replays (replay's host time AND overlap) - same bits again
+    for graph in (False, "chain", "segments"):
         out = mgr.dict()
         mp.spawn(_worker_steps, args=(world, _free_port(), out, kind, graph), nprocs=world, join=True)
         (l0, w0, c0), (l1, w1, c1) = out[0], out[1]
         assert np.array_equal(w0, w1) and np.array_equal(c0, c1)
         ends.append((l0, l1, w0, c0))
-    (a0, a1, wa, ca), (b0, b1, wb, cb) = ends
-    assert a0 == b0 and a1 == b1
-    np.testing.assert_array_equal(wa, wb)
-    np.testing.assert_array_equal(ca, cb)
+    for other in ends[1:]:
+        (a0, a1, wa, ca), (b0, b1, wb, cb) = ends[0], other
+        assert a0 == b0 and a1 == b1
+        np.testing.assert_array_equal(wa, wb)
+        np.testing.assert_array_equal(ca, cb)
 
 
 def _worker_nccl(rank, world, port, out):
@@ -227,10 +235,15 @@ def _bench_line(r, path):
     return json.loads(open(path).read())
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank)."""
+@pytest.mark.parametrize("mode", ["segments", "eager"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank).  Round 6: the
+    default launch with world > 1 is the SEGMENTED hipGraph replay (buckets go out between replays); AIR_GRAPH=0 is the
+    eager step with the buckets launched from inside backward."""
     out_json = os.path.join(tempfile.mkdtemp(prefix="air_bench_"), "line.json")
     env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT, AIR_BENCH_JSON_OUT=out_json)
+    if mode == "eager":
+        env["AIR_GRAPH"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "8", "--plain-timing"]  # (gloo moves 49.8 MB per step through the host: one
@@ -249,7 +262,13 @@ def test_bench_two_ranks_on_one_gpu():
     # 2,056 bytes of fc_mu.* (514 floats), which get no gradient under ang_iso and which SURVEY 8e says to skip
     comm = d["ddp"]["communication"]
     assert d["ddp"]["world"] == 2 and comm["allreduce_bytes_per_step"] == 49_802_184 - 2_056
-    assert d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo" and d["launch"] == "eager"
+    assert d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo"
+    if mode == "eager":
+        assert d["launch"] == "eager" and d["ddp"]["buckets_in_backward"] > 0
+    else:
+        assert d["launch"].startswith("hipGraph replay (3 segments") and d["ddp"]["buckets_between_replays"] > 0, d["launch"]
+        assert d["ddp"]["buckets_in_backward"] == 0
+    assert "host_issue_ms_per_step" in d
     assert comm["step_ms_without_exchange"] > 0 and "exposed_ms" in comm and comm["overlap"] is True
 
 
@@ -275,7 +294,7 @@ def test_bench_two_ranks_at_the_stated_per_gpu_size(kind):
     assert d["ddp"]["world"] == 2 and d["ddp"]["ranks_seen"] == 2 and d["ddp"]["backend"] == "gloo"
     assert d["ddp"]["communication"]["allreduce_bytes_per_step"] > 20_000_000
     if kind == "resnet_b64":
-        assert d["dtype"] in ("f32", "fp32") and d["launch"] == "eager"
+        assert d["dtype"] in ("f32", "fp32") and d["launch"].startswith("hipGraph replay (3 segments")
     else:
         assert d["dtype"] == "bf16" and d["launch"].startswith("hipGraph")
 

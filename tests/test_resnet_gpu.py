@@ -377,7 +377,9 @@ def _graph_trainer(graph, seed=4242):
     fill_module_(lossm)
     tr = Trainer(m, loss_module=lossm, feat_len=128)
     if graph:
-        tr.enable_graph()
+        if graph == "segments":
+            tr.segment_bytes = 8 << 20
+        tr.enable_graph(segments=(graph == "segments"))
     return m, tr
 
 
@@ -402,7 +404,10 @@ def test_graphed_train_step_equals_eager():
     from oracle.filler import synth_pcm
     batches = [(synth_pcm(4, 16000, seed=500 + i).cuda(), ((torch.arange(4) + i) % 3 != 0).long().cuda()) for i in range(6)]
     ends = []
-    for graph in (False, True):
+    # (round 6) "segments": the same step captured as several hipGraphs cut at backward's bucket boundaries (the form that
+    # lets world > 1 launch each bucket's all-reduce between two replays) - forward / backward called directly instead
+    # of through autograd: the same kernels in the same order
+    for graph in (False, True, "segments"):
         m, tr = _graph_trainer(graph)
         if not graph:
             m.overlap_wgrad = False  # the capture is one chain; same launches eagerly
@@ -412,12 +417,15 @@ def test_graphed_train_step_equals_eager():
                 tr.set_epoch(4, lr_decay=0.5, interval=4)
             losses.append(tr.step(pcm, lab)[0].item())
         torch.cuda.synchronize()
-        assert (tr._graph is not None) == graph
+        assert (tr._graph is not None) == bool(graph)
+        if graph == "segments":
+            assert len(tr._graph["segments"]) >= 3
         ends.append((losses, m.arena().flat.clone(), tr.loss.center.detach().clone(), m.bn1.running_var.clone(),
                      m.layer4[1].bn2.running_mean.clone(), int(m.bn1.num_batches_tracked), int(m._noise_ctr.item())))
-    (l0, w0, c0, rv0, rm0, n0, k0), (l1, w1, c1, rv1, rm1, n1, k1) = ends
-    assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and torch.equal(rm0, rm1)
-    assert n0 == n1 == 6 and k0 == k1 > 0
+    for other in ends[1:]:
+        (l0, w0, c0, rv0, rm0, n0, k0), (l1, w1, c1, rv1, rm1, n1, k1) = ends[0], other
+        assert l0 == l1 and torch.equal(w0, w1) and torch.equal(c0, c1) and torch.equal(rv0, rv1) and torch.equal(rm0, rm1)
+        assert n0 == n1 == 6 and k0 == k1 > 0
 
 
 def test_graphed_noise_is_fresh_per_replay():
