@@ -230,7 +230,7 @@ class _SpoofDataset(Dataset):
     def _init_common(self, feature, feat_len, pad_chop, padding, return_pcm):
         self.feat_len, self.feature, self.pad_chop, self.padding = feat_len, feature, pad_chop, padding
         self.label = dict(LABEL)
-        self.return_pcm = bool(return_pcm)
+        self.return_pcm = "batch" if return_pcm == "batch" else bool(return_pcm)
         self._lfcc = None
         self._silence_cpu = None
         if padding == "silence" and pad_chop and torch.cuda.is_available():
@@ -327,6 +327,32 @@ class _SpoofDataset(Dataset):
             feat = feat.unsqueeze(0).permute(0, 2, 1).float()
         return (self._pad_chop(feat),) + self._meta(k, info)
 
+    PINNED_RING = 6
+
+    def _pinned_batch(self, B, L, dtype):
+        """A pinned (B, L) host buffer out of a ring of PINNED_RING per shape: allocating pinned memory per batch cost
+        ~20 ms of host time per 16 MB batch on the GPU box (the from-dataset bench leg was host-bound at 0.48 of the
+        resident rate).  A batch stays valid until PINNED_RING - 1 further batches have been collated; before a slot is
+        reused, the H2D copy ``DevicePrefetcher`` issued from it is waited for (normally long done)."""
+        if not torch.cuda.is_available():
+            return torch.empty((B, L), dtype=dtype)
+        ring = self.__dict__.setdefault("_pin_ring", {})
+        key = (B, L, dtype)
+        slot = ring.get(key)
+        if slot is None:
+            slot = ring[key] = {"bufs": [None] * self.PINNED_RING, "events": [None] * self.PINNED_RING, "next": 0}
+        j = slot["next"]
+        slot["next"] = (j + 1) % self.PINNED_RING
+        if slot["bufs"][j] is None:
+            slot["bufs"][j] = torch.empty((B, L), dtype=dtype, pin_memory=True)
+        ev = slot["events"][j]
+        if ev is not None:
+            ev.synchronize()
+            slot["events"][j] = None
+        buf = slot["bufs"][j]
+        buf._air_ring = (slot, j)
+        return buf
+
     def collate_fn(self, samples):
         """default_collate of the item tuples (dataset.py:87-89).  With ``return_pcm`` the waveforms become features
         here: utterances of equal length share ONE fused LFCC -> pad / chop -> transposed launch, and the batch is
@@ -334,6 +360,26 @@ class _SpoofDataset(Dataset):
         ``feat.transpose(2, 3)`` (main_train.py:338) lands on the contiguous (B, 1, 60, feat_len) tensor."""
         if not (self.return_pcm and samples and torch.is_tensor(samples[0][0]) and samples[0][0].dim() == 1):
             return default_collate(samples)
+        if self.return_pcm == "batch":
+            # (round 6) the waveforms of the batch as ONE pinned (B, L) host tensor + the collated meta: the trainer's own
+            # fused front-end makes the features (Trainer.step(pcm, labels): LFCC inside the replayed hipGraph), the
+            # loader only moves bytes - ``DevicePrefetcher`` below copies batch n + 1 to the GPU under step n
+            L = int(samples[0][0].shape[0])
+            if any(int(smp[0].shape[0]) != L for smp in samples):
+                raise ValueError("return_pcm='batch' needs utterances of one length per batch (got %s)" % sorted(
+                    set(int(smp[0].shape[0]) for smp in samples)))
+            pcm = self._pinned_batch(len(samples), L, samples[0][0].dtype)
+            # rows through numpy (one memcpy each): ``Tensor.copy_`` of a 256 KB row fans out over the intra-op thread pool,
+            # which on a 256-thread host costs 0.3 - 0.8 ms PER ROW (tools/dbg_host_collate.py: 20 - 50 ms per batch of
+            # 64 against 0.45 ms) - the loader, not the GPU, then sets the step time
+            dst = pcm.numpy()
+            for j, smp in enumerate(samples):
+                w = smp[0]
+                if w.device.type == "cpu" and w.is_contiguous():
+                    dst[j] = w.numpy()
+                else:
+                    pcm[j].copy_(w)
+            return [pcm] + default_collate([smp[1:] for smp in samples])
         if not self.pad_chop:
             raise ValueError("return_pcm needs pad_chop=True (one feat_len per batch)")
         next(s for s in self._sources() if isinstance(s, PCMSource))._need_gpu_here("collate_fn(return_pcm=True)")
@@ -484,3 +530,59 @@ class ASVspoof2021LAeval(_SpoofDataset):
 
 class ASVspoof2021DFeval(ASVspoof2021LAeval):
     """dataset.py:476-510."""
+
+
+class DevicePrefetcher:
+    """Iterates a DataLoader whose batches hold host tensors (``return_pcm='batch'``: pinned PCM + label tensors) and
+    hands them over ON THE GPU: batch n + 1 is copied on a copy stream while the caller's stream runs step n (the
+    reference's loop does ``.to(device)`` on the compute stream, main_train.py:316-317).  Tensors go to ``device``
+    (pageable ones through a pinned staging copy), everything else (file names) passes through.  ``depth`` batches are
+    in flight; a batch's device buffers are reused only after the caller's stream has passed the next ``__next__``."""
+
+    def __init__(self, loader, device="cuda", depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _to_device(self, item):
+        if torch.is_tensor(item):
+            if not item.is_pinned() and item.device.type == "cpu":
+                item = item.pin_memory()
+            return item.to(self.device, non_blocking=True), item  # (the pinned source stays alive with the batch)
+        return item, None
+
+    def __iter__(self):
+        import collections
+        queue = collections.deque()
+        it = iter(self.loader)
+        main = torch.cuda.current_stream(self.device)
+
+        def fetch():
+            try:
+                batch = next(it)
+            except StopIteration:
+                return False
+            with torch.cuda.stream(self.copy_stream):
+                moved = [self._to_device(x) for x in batch]
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            for x in batch:  # a ring-buffer batch (collate_fn, return_pcm='batch'): its slot is reusable after this copy
+                ring = getattr(x, "_air_ring", None) if torch.is_tensor(x) else None
+                if ring is not None:
+                    ring[0]["events"][ring[1]] = ev
+            queue.append(([m[0] for m in moved], [m[1] for m in moved], ev))
+            return True
+
+        for _ in range(self.depth):
+            if not fetch():
+                break
+        while queue:
+            out, keep, ev = queue.popleft()
+            main.wait_event(ev)
+            for t in out:
+                if torch.is_tensor(t):
+                    t.record_stream(main)  # allocated on the copy stream, consumed on the caller's
+            fetch()
+            yield out

@@ -388,6 +388,9 @@ def main():
     ap.add_argument("--plain-timing", action="store_true",
                     help="the contract's literal protocol: W warm-up steps and ONE window of exactly K steps, no stability "
                          "warm-up (what the rocprofv3 --pmc child passes and the tests run)")
+    ap.add_argument("--from-dataset", action="store_true",
+                    help="also time the configuration fed by DataLoader(ASVspoof2019 over a SyntheticSource) -> pinned PCM -> "
+                         "copy stream -> Trainer.step (reported under configs.*_from_dataset; part of the default run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
@@ -607,10 +610,71 @@ def main():
         if comm is not None:
             res["ddp"]["communication"] = comm
         res["steps_run_total"] = nrun[0]
-        return model, res, (lambda n: measure(n, first=False)[0])
 
-    model, main_res, retime_main = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup, args.augment,
-                                              not args.no_roofline, nwin=args.windows)
+        def from_dataset(nwin=3, wsteps=50):
+            """the same trainer fed by the drop-in Dataset surface instead of HBM-resident batches -
+            ``ASVspoof2019`` over a ``SyntheticSource`` (the separable corpus of synth.py, 4 s waveforms generated once:
+            they stand for the corpus on disk), ``return_pcm='batch'`` + ``collate_fn`` (one pinned (B, L) host tensor per
+            batch), ``DataLoader(shuffle=True, num_workers=0)`` (the reference's default, main_train.py:63),
+            ``DevicePrefetcher`` (H2D of batch n + 1 on a copy stream under step n).  main_train.py:310-348's loop
+            body with the features made by the trainer's fused front-end inside the replayed graph."""
+            from torch.utils.data import DataLoader
+            from asvspoof2021_air_amd import dataset as air_ds
+            nutt = 4 * BATCH
+            src = air_ds.SyntheticSource(688 + rank, nutt, length=LENGTH, device=device, cache_items=None)
+            ds = air_ds.ASVspoof2019("LA", None, "train", feat_len=FEAT_LEN, padding="repeat", source=src,
+                                     return_pcm="batch")
+            t0 = time.perf_counter()
+            for i in range(nutt):
+                src.pcm(i)
+            gen_s = time.perf_counter() - t0
+            dl = DataLoader(ds, batch_size=BATCH, shuffle=True, drop_last=True, collate_fn=ds.collate_fn, num_workers=0)
+            t0 = time.perf_counter()
+            nb_host = 0
+            for _ in dl:  # host side alone: __getitem__ x B + the pinned stack
+                nb_host += 1
+            host_ms = 1e3 * (time.perf_counter() - t0) / max(1, nb_host)
+
+            def batches_forever():
+                while True:
+                    for b in air_ds.DevicePrefetcher(dl, device, depth=2):
+                        yield b
+
+            it = batches_forever()
+
+            def win(n):
+                fence()
+                t0 = time.perf_counter()
+                last = None
+                for _ in range(n):
+                    b = next(it)
+                    last, _ = trainer.step(b[0], b[3])
+                fence()
+                dt = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([dt], device=device, dtype=torch.float64)
+                    td.all_reduce(t, op=td.ReduceOp.MAX)
+                    dt = float(t.item())
+                return dt, last
+
+            win(10)
+            wins = [win(wsteps) for _ in range(nwin)]
+            per = sorted(1e3 * w[0] / wsteps for w in wins)
+            med = per[len(per) // 2]
+            out = {"value": round(world * BATCH * 1e3 / med, 2), "unit": "utt/s", "ms_per_step": round(med, 3),
+                   "windows_ms_per_step": [round(1e3 * w[0] / wsteps, 3) for w in wins], "steps_timed_per_window": wsteps,
+                   "final_loss": round(float(wins[-1][1].item()), 5),
+                   "host_loader_ms_per_batch": round(host_ms, 3), "h2d_bytes_per_step": BATCH * LENGTH * 4 + BATCH * 8,
+                   "corpus": "%d synthetic 4 s utterances (synth.py), generated once in %.1f s, shuffled every epoch" % (nutt, gen_s),
+                   "pipeline": "ASVspoof2019(SyntheticSource, return_pcm='batch').collate_fn -> pinned (B, L) -> "
+                               "DevicePrefetcher (copy stream, depth 2) -> Trainer.step (fused LFCC inside the replay)",
+                   "vs_resident": round((world * BATCH * 1e3 / med) / res["value"], 4)}
+            return out
+
+        return model, res, (lambda n: measure(n, first=False)[0]), from_dataset
+
+    model, main_res, retime_main, dataset_main = run_config(args.model, args.dtype, args.batch, args.steps, args.warmup,
+                                                            args.augment, not args.no_roofline, nwin=args.windows)
     roofline = main_res.pop("roofline", None)
     main_batch = BATCH
     # BASELINE configs[2] (ECAPA-TDNN-512, bf16 compute, batch 128 per GPU) rides along in the default run so
@@ -621,7 +685,7 @@ def main():
         # (a failure of this additional leg must not cost the headline line; with world > 1 every rank takes the
         # same path through its collectives, so an exception there is not caught - it would desynchronise the ranks)
         try:
-            _, e, _ = run_config("ecapa", "bf16", 0, args.steps, args.warmup, False, not args.no_roofline)
+            _, e, _, _ = run_config("ecapa", "bf16", 0, args.steps, args.warmup, False, not args.no_roofline)
             e["metric"] = "utterances/sec (LFCC+ECAPA-TDNN-512-OCSoftmax train step, 4 s@16 kHz)"
             e["dtype"] = "bf16"
             e["workload"] = ("BASELINE configs[2]: fused HIP LFCC + ECAPA-TDNN-512 + OC-Softmax train step, bf16-resident "
@@ -640,7 +704,7 @@ def main():
                 try:
                     FEAT_LEN = 401
                     torch.cuda.empty_cache()
-                    _, e, _ = run_config(mname, mdt, 0, args.steps, args.warmup, False, False)
+                    _, e, _, _ = run_config(mname, mdt, 0, args.steps, args.warmup, False, False)
                     e["dtype"] = "bf16" if mdt else "f32"
                     e["workload"] = "the same train step at the native T = 401 frames (no repeat-padding)"
                     extra[key] = e
@@ -666,6 +730,15 @@ def main():
         if e is not None and "roofline" in e:
             e["roofline"].update(pmc_traffic_leg("ecapa", e["roofline"]["kernel"], ["--feat-len", str(args.feat_len)]))
 
+    # the headline configuration fed through the Dataset surface (DataLoader -> pinned PCM -> copy stream -> Trainer.step)
+    if (args.from_dataset or (extra and not args.plain_timing)) and not args.augment:
+        BATCH = main_batch
+        try:
+            extra["%s_from_dataset" % ("resnet_f32_b64" if args.model == "resnet" else "ecapa_b128")] = dataset_main()
+        except Exception as exc:  # noqa: BLE001
+            if world > 1:
+                raise
+            extra["from_dataset"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     # A-B-A: the headline configuration once more at the END of the process (same trainer, no warm-up beyond the
     # stability windows), so that a drift between the first and the last leg of the process shows in the record
     repeat = None

@@ -216,3 +216,46 @@ def test_synthetic_source_cache_is_bounded():
     assert len(src._cache) == 8 and list(src._cache)[-1] == 39
     a = src.pcm(3).clone()
     assert torch.equal(a, air_ds.SyntheticSource(688, 40, length=4000, cache_items=None).pcm(3))  # regenerated identically
+
+
+def test_pcm_batches_through_the_device_prefetcher_feed_the_trainer():
+    """``return_pcm='batch'`` + ``collate_fn`` hand the loader's batch over as one pinned (B, L) host
+    tensor; ``DevicePrefetcher`` copies batch n + 1 on a copy stream under step n.  The GPU batches are the dataset's
+    waveforms and labels bit for bit, in the loader's order, over two epochs; ``Trainer.step`` on them equals the step on
+    the same tensors moved by hand (fused LFCC inside the step either way); ragged lengths in one batch are refused."""
+    from torch.utils.data import DataLoader
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    from asvspoof2021_air_amd.resnet import ResNet
+    from asvspoof2021_air_amd.train import Trainer
+    from oracle.filler import fill_module_
+    src = air_ds.SyntheticSource(688, 12, length=8000, cache_items=None)
+    ds = air_ds.ASVspoof2019("LA", None, "train", feat_len=96, padding="repeat", source=src, return_pcm="batch")
+    dl = DataLoader(ds, batch_size=4, shuffle=False, collate_fn=ds.collate_fn, num_workers=0)
+    want = [(torch.stack([src.pcm(4 * b + j) for j in range(4)]), [ds[4 * b + j][3] for j in range(4)]) for b in range(3)]
+    host = next(iter(dl))
+    assert host[0].is_pinned() and host[0].shape == (4, 8000) and not host[0].is_cuda
+    for epoch in range(2):
+        got = list(air_ds.DevicePrefetcher(dl, "cuda", depth=2))
+        assert len(got) == 3
+        for (pcm, names, tags, labels), (wp, wl) in zip(got, want):
+            assert pcm.is_cuda and labels.is_cuda and torch.equal(pcm.cpu(), wp) and labels.cpu().tolist() == wl
+            assert isinstance(names, (list, tuple)) and names[0].startswith("LA_T_")
+
+    def make():
+        m = ResNet(3, 256, resnet_type="18", nclasses=2)
+        fill_module_(m)
+        m.set_attention_noise(None)
+        lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+        fill_module_(lossm)
+        return Trainer(m, loss_module=lossm, feat_len=96)
+
+    a, b = make(), make()
+    for (pcm, _, _, labels), (wp, wl) in zip(air_ds.DevicePrefetcher(dl, "cuda"), want):
+        la = a.step(pcm, labels)[0]
+        lb = b.step(wp.cuda(), torch.tensor(wl).cuda())[0]
+        assert torch.equal(la, lb)
+    assert torch.equal(a.model.arena().flat, b.model.arena().flat)
+    ragged = air_ds.ASVspoof2019("LA", None, "train", feat_len=96, return_pcm="batch", source=air_ds.PCMSource(
+        [("%05d_LA_T_%07d_-_bonafide" % (i, i), w) for i, w in enumerate(_pcm_corpus([8000, 8160], 3))]))
+    with pytest.raises(ValueError, match="one length"):
+        ragged.collate_fn([ragged[0], ragged[1]])
