@@ -31,9 +31,20 @@ constexpr int FN = 512, FL = 320, FS = 160;
 constexpr int NBIN = FN / 2 + 1;  // 257
 constexpr int MAXF = 32;          // filters supported (2 per lane of a 16-lane group)
 constexpr int MAXW = 32;          // bins per filter supported
-constexpr int NW = 8;             // waves per workgroup
+// (A/B knobs, round 6: -DLFCC_NW / -DLFCC_GPW / -DLFCC_MINB - waves per workgroup, 4-frame groups per wave, resident
+// workgroups per CU the compiler plans for; profiles/r06_lfcc.md)
+#ifndef LFCC_NW
+#define LFCC_NW 8
+#endif
+#ifndef LFCC_GPW
+#define LFCC_GPW 1
+#endif
+#ifndef LFCC_MINB
+#define LFCC_MINB 2
+#endif
+constexpr int NW = LFCC_NW;       // waves per workgroup
 constexpr int NTHREADS = NW * 64;
-constexpr int GPW = 1;                  // 4-frame groups per wave
+constexpr int GPW = LFCC_GPW;           // 4-frame groups per wave
 constexpr int FCOMP = NW * GPW * 4;     // 32 frames computed per workgroup
 constexpr int HALO = 2;                 // delta-delta reaches 2 frames each side
 constexpr int FOUT = FCOMP - 2 * HALO;  // 28 frames written per workgroup
@@ -381,7 +392,7 @@ __device__ __forceinline__ void lfcc_body(const LfccArgs& a, float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void lfcc_kernel(LfccArgs a) {
+__global__ __launch_bounds__(NTHREADS, LFCC_MINB) void lfcc_kernel(LfccArgs a) {
   __shared__ __attribute__((aligned(16))) float s_pcm[NSAMP];
   __shared__ __attribute__((aligned(16))) float s_xch[NW * XCH_FLOATS];
   __shared__ float s_c[FCOMP * MAXF];
