@@ -105,6 +105,11 @@ __global__ __launch_bounds__(256) void bf3_pack_kernel(const float* __restrict__
   dst[128] = lo;
 }
 
+// (timing-only experiment, BF3_EXP bit 4: what a BatchNorm + ReLU prologue on the lane-loaded activations would cost -
+// scale 1 / shift 0 from a table, so that results on non-negative inputs do not change: profiles/r06_bf3_prologue.md)
+__device__ float g_bf3_exp_scale[1024] = {[0 ... 1023] = 1.0f};
+__device__ float g_bf3_exp_shift[1024] = {};
+
 struct Bf3Args {
   const float* x;
   const u32x4* wp;
@@ -290,9 +295,17 @@ __global__ __launch_bounds__(NWAVE * 64, 1) void conv_s2_bf3_kernel(const Bf3Arg
     const bool more = it + 2 < total;  // (past the end the loads redo the last row: harmless)
     const unsigned s_next = 4u * (unsigned)(((more ? c2 : c1) * CK) * HW + (hi0 + kh0 + (more ? r2 : r1)) * W);
     auto perm_issue = [&](int i) {
+#if BF3_EXP & 4
+      const float esc = g_bf3_exp_scale[c1 * CK + 8 * half + i], esh = g_bf3_exp_shift[c1 * CK + 8 * half + i];
+      ldl[i] = fmaxf(fmaf(ldl[i], esc, esh), 0.0f);
+#endif
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         float c1v = ld2[j][i].x, c2v = ld2[j][i].y;
+#if BF3_EXP & 4
+        c1v = fmaxf(fmaf(c1v, esc, esh), 0.0f);
+        c2v = fmaxf(fmaf(c2v, esc, esh), 0.0f);
+#endif
         if (odd_w) {
           c1v = fix_last[j] ? c2v : c1v;
           c2v = fix_last[j] ? 0.0f : c2v;
