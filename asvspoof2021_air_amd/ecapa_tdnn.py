@@ -176,9 +176,11 @@ class Res2Net2(nn.Module):
         self.encoder_type = encoder_type
         self.out_bn = out_bn
         super().__init__()
-        if encoder_type != "ECA" or not context or summed:
-            raise NotImplementedError("hot path: encoder_type='ECA', context=True, summed=False "
-                                      "(main_train.py:167)")
+        if encoder_type == "ASP":
+            raise NotImplementedError("encoder_type='ASP' (one attention weight per frame, ecapa_tdnn.py:133-134) is not "
+                                      "built: the trainer (main_train.py:167) and the reference's score files use 'ECA'")
+        if encoder_type != "ECA":
+            raise ValueError("Undefined encoder")  # ecapa_tdnn.py:135-136
         self.scale = model_scale
         self.conv1 = nn.Conv1d(self.n_mfcc, C, kernel_size=5, stride=1, padding=2)
         self.relu = nn.ReLU()
@@ -188,7 +190,9 @@ class Res2Net2(nn.Module):
         self.layer3 = block(C, C, kernel_size=3, dilation=4, scale=self.scale)
         self.layer4 = nn.Conv1d(3 * C, 1536, kernel_size=1)
         self.instancenorm = nn.InstanceNorm1d(self.n_mfcc)  # constructed, never applied (:120)
-        attn_input = 1536 * 3
+        # context=False / summed=True (round 6; the reference's own score files lfcc_ecapa512c{t,f}s{t,f}_* were made with
+        # them): served by the fp32 path; the bf16 paths are built for the trainer's defaults (main_train.py:167)
+        attn_input = 1536 * 3 if self.context else 1536  # :126-129
         attn_output = 1536
         self.attention = nn.Sequential(
             nn.Conv1d(attn_input, 128, kernel_size=1),
@@ -336,6 +340,9 @@ class Res2Net2(nn.Module):
 
     def _forward_impl(self, x, save):
         bf = self.compute_dtype == "bf16c"
+        if (not self.context or self.summed) and self.compute_dtype != "fp32":
+            raise _hip.AirError("Res2Net2(context=%s, summed=%s): the non-default options run in compute_dtype 'fp32' "
+                                "(the bf16 paths are built for main_train.py:167's defaults)" % (self.context, self.summed))
         if self.compute_dtype == "bf16":
             if oh.tp(x.shape[2]) <= oh.max_tp():
                 return self._forward_h(x, save)
@@ -371,7 +378,11 @@ class Res2Net2(nn.Module):
             out = cat123[:, k * C:(k + 1) * C]
             blocks.append(self._block_fwd(blk, inp, out, training, save,
                                           out_bf=cat_bf[:, k * C:(k + 1) * C] if cat_bf is not None else None))
-            inp = out
+            if self.summed:  # :163-166: the next block reads x + x1 (+ x2): the running sum, a tensor of its own
+                if k < 2:
+                    inp = ops.add_strided(torch.empty((B, C, T), device=x.device, dtype=torch.float32), inp, out)
+            else:
+                inp = out
         # bf16 training: layer4's GEMM epilogue also writes x4's bf16 copy, the X operand of attention.0's weight
         # gradient (kept until backward like x4 itself)
         x4_bf = ops.bf16_rows(None, B, self.layer4.out_channels, T, x.device) if (bf and save) else None
@@ -382,15 +393,20 @@ class Res2Net2(nn.Module):
         if x4 is None:
             x4 = ops.conv1d_fwd(cat123, det(self.layer4.weight), det(self.layer4.bias), relu=True, bf16=bf,
                                 y_bf=x4_bf)  # :172-173
-        mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178)
-        ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
+        mean, std = ops.row_stats(x4, True, 1e-4)  # context statistics (:178; context=False: only the backward's
+        # fused ReLU-mask pass reads them, with zero gradients)
         a0, a3 = self.attention[0], self.attention[3]
-        w0 = det(a0.weight).view(128, -1)  # (128, 4608)
-        w_x = ops.add_strided(torch.empty((128, 1, 1536), device=x.device),
-                              w0[:, :1536].unsqueeze(1)).view(128, 1536, 1)
-        w_c = ops.add_strided(torch.empty((128, 1, 3072), device=x.device),
-                              w0[:, 1536:].unsqueeze(1)).view(128, 3072)
-        ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std]
+        w0 = det(a0.weight).view(128, -1)  # (128, 4608), or (128, 1536) without the context rows
+        if self.context:
+            ctx = torch.cat((mean, std), 1)  # plumbing: 2 x (B,1536) copies
+            w_x = ops.add_strided(torch.empty((128, 1, 1536), device=x.device),
+                                  w0[:, :1536].unsqueeze(1)).view(128, 1536, 1)
+            w_c = ops.add_strided(torch.empty((128, 1, 3072), device=x.device),
+                                  w0[:, 1536:].unsqueeze(1)).view(128, 3072)
+            ctxb = ops.linear_fwd(ctx, w_c, None)  # (B,128): W[:,1536:] @ [mean; std]
+        else:  # :179-180: global_x = x
+            ctx, w_c, ctxb = None, None, None
+            w_x = det(a0.weight)
         a1 = ops.conv1d_fwd(x4, w_x, det(a0.bias), bias_bc=ctxb, relu=True, bf16=bf)  # attention.0 + ReLU
         stA = _bn(a1, self.attention[2], training)
         a1n_bf = ops.bf16_rows(None, B, a1.shape[1], T, x.device) if (bf and save) else None
@@ -563,16 +579,23 @@ class Res2Net2(nn.Module):
         gw0 = G["attention.0.weight"].view(128, -1)  # (128, 4608)
 
         def att0_wgrad():
+            if S["ctx"] is None:  # context=False: the layer's whole weight
+                ops.conv1d_wgrad(x4, da1, (128, 1536, 1), out=G["attention.0.weight"], bf16=bf, dy_bf=da1_bf, x_bf=S["x4_bf"])
+                return
             dwx = ops.conv1d_wgrad(x4, da1, (128, 1536, 1), bf16=bf, dy_bf=da1_bf, x_bf=S["x4_bf"])
             ops.add_strided(gw0[:, :1536].unsqueeze(1), dwx.view(128, 1, 1536))
 
         on_side(att0_wgrad, da1)
         ops.conv1d_dgrad(da1, S["w_x"], accumulate=dx4, out=dx4, bf16=bf)
-        dctxb = ops.row_sum(da1)  # (B,128)
-        dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb, True, need_db=False)
-        ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
-        dmean = dctx[:, :1536].contiguous()
-        dstd = dctx[:, 1536:].contiguous()
+        if S["ctx"] is not None:
+            dctxb = ops.row_sum(da1)  # (B,128)
+            dctx, dwc, _ = ops.linear_bwd(S["ctx"], S["w_c"], dctxb, True, need_db=False)
+            ops.add_strided(gw0[:, 1536:].unsqueeze(1), dwc.view(128, 1, 3072))
+            dmean = dctx[:, :1536].contiguous()
+            dstd = dctx[:, 1536:].contiguous()
+        else:  # no statistics rows in the attention input: nothing flows into mean / std
+            dmean = torch.zeros((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
+            dstd = torch.zeros_like(dmean)
         # context-statistics gradient, the ReLU after layer4 (:173) and the per-row sums for the bias
         # gradient in ONE pass over the (B, 1536, T) tensor
         rows = torch.empty((B, x4.shape[1]), device=x4.device, dtype=torch.float32)
@@ -621,6 +644,7 @@ class Res2Net2(nn.Module):
         # the two-operand dgrad epilogue: the fused bf16 pointwise kernels only (8-byte aligned rows; layers of
         # 1 M weights and more route to the wide GEMM, which takes a single dense accumulate operand)
         fold = bf and T % 2 == 0 and C % 128 == 0 and C * C < (1 << 20)
+        dsum = None  # summed=True: the gradient of the running sum x + x1 (+ x2) = the sum of the later blocks' d(input)
         for k in (2, 1, 0):
             if fold:
                 # d(block k output) = its slice of the concat gradient + d(block k + 1 input): block k + 1's last
@@ -629,12 +653,17 @@ class Res2Net2(nn.Module):
                 add2 = dcat123[:, (k - 1) * C:k * C] if k > 0 else None
             else:
                 dblk = torch.empty((B, C, T), device=dx4.device, dtype=torch.float32)
-                ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dnext)
+                # summed (:163-166): x_k also feeds EVERY later block's input, not only the next one's
+                ops.add_strided(dblk, dcat123[:, k * C:(k + 1) * C], dsum if self.summed else dnext)
                 add2 = None
             dnext = self._block_bwd(S["blocks"][k], dblk, G, "layer%d." % (k + 1),
                                     inp_bf=(cat_bf[:, (k - 1) * C:k * C] if k > 0 else S["h_bf"]) if bf else None, add2=add2,
                                     on_side=on_side)
+            if self.summed:
+                dsum = dnext if dsum is None else ops.add_(dsum, dnext)
             grads_final_from("layer%d.conv1.weight" % (k + 1))
+        if self.summed:
+            dnext = dsum  # d(h) = d(input of block 1) + d(input of block 2) + d(input of block 3)
         st0 = S["st0"]
         dc0, _, _ = ops.bn_bwd(S["r0"], dnext, st0[0], st0[1], det(self.bn1.weight), det(self.bn1.bias),
                                relu_in=True, dx=dnext, dgamma=G["bn1.weight"], dbeta=G["bn1.bias"],

@@ -41,9 +41,10 @@ class SelfAttention(nn.Module):
     def forward(self, inputs, noise=None):
         """inputs: (B, T, H) like the reference.  Inference-only convenience path
         (the training path goes through ResNet.forward)."""
-        if self.mean_only:
-            raise NotImplementedError("mean_only pooling is not on the hot path")
         x = inputs.permute(0, 2, 1).contiguous()
+        if self.mean_only:  # resnet.py:43-44: the attention-weighted sum alone (no noise is drawn, no std)
+            out, _ = ops.selfatt_pool_fwd(x, self.att_weights.detach(), None)
+            return out[:, :self.hidden_size].contiguous()
         out, _ = ops.selfatt_pool_fwd(x, self.att_weights.detach(), noise)
         return out
 

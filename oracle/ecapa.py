@@ -289,8 +289,10 @@ def bottle2neck(x, p, prefix, dilation, scale, training, updates, bf16=False):
 
 
 def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context=True, out_bn=True,
-                  bf16=False):
-    """Res2Net2.forward (ecapa_tdnn.py:152-198), encoder_type 'ECA', summed=False.
+                  bf16=False, summed=False):
+    """Res2Net2.forward (ecapa_tdnn.py:152-198), encoder_type 'ECA'.  ``context`` (:126-129, :177-180) and ``summed``
+    (:163-170: layer2 / layer3 read x + x1 / x + x1 + x2) are the constructor options the reference's own score files
+    were made with (lfcc_ecapa512c{t,f}s{t,f}_*; main_train.py:167 passes the defaults, context=True, summed=False).
     x: (B, n_mels, T).  Returns (feat (B,256), out (B,nOut))."""
     def tap(name, t):
         if taps is not None:
@@ -298,11 +300,16 @@ def ecapa_forward(p, x, scale=8, training=True, updates=None, taps=None, context
         return t
 
     if bf16 == "resident":
+        assert not summed, "resident arithmetic is stated for summed=False (main_train.py:167)"
         return _ecapa_forward_resident(p, x, scale, training, updates, tap, context, out_bn)
     x = _bn(F.relu(_conv(x, p, "conv1", 1, 2)), p, "bn1", training, updates)  # :159-161
     x1 = tap("x1", bottle2neck(x, p, "layer1", 2, scale, training, updates, bf16))
-    x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates, bf16))
-    x3 = tap("x3", bottle2neck(x2, p, "layer3", 4, scale, training, updates, bf16))
+    if summed:  # :163-166
+        x2 = tap("x2", bottle2neck(x + x1, p, "layer2", 3, scale, training, updates, bf16))
+        x3 = tap("x3", bottle2neck(x + x1 + x2, p, "layer3", 4, scale, training, updates, bf16))
+    else:  # :167-170
+        x2 = tap("x2", bottle2neck(x1, p, "layer2", 3, scale, training, updates, bf16))
+        x3 = tap("x3", bottle2neck(x2, p, "layer3", 4, scale, training, updates, bf16))
     x = F.relu(_conv(torch.cat((x1, x2, x3), 1), p, "layer4", bf16=bf16))  # :172-173
     tap("layer4", x)
     t = x.shape[-1]

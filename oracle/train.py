@@ -38,10 +38,11 @@ class OracleTrainer:
     """Functional train loop over a parameter dict (CPU)."""
 
     def __init__(self, model, params, center, lr=5e-4, r_real=0.9, r_fake=0.2, alpha=20.0,
-                 weight_loss=1.0, bf16=False):
+                 weight_loss=1.0, bf16=False, **ecapa_options):
         assert model in ("resnet", "ecapa")
         self.model = model
         self.bf16 = bf16  # ECAPA only: BASELINE configs[2] arithmetic (oracle/ecapa.py)
+        self.ecapa_options = ecapa_options  # ECAPA only: context= / summed= (ecapa_tdnn.py:99)
         self.params = {k: v.clone() for k, v in params.items()}
         self.center = center.clone()
         self.lr = lr
@@ -60,7 +61,7 @@ class OracleTrainer:
         if self.model == "resnet":
             return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps, relu=self.relu)
         return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps,
-                                          bf16=self.bf16)
+                                          bf16=self.bf16, **self.ecapa_options)
 
     def loss_and_grads(self, x, labels, noise=None):
         names = self.trainable()

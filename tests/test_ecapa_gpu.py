@@ -445,3 +445,90 @@ def test_bf16_resident_long_input_falls_back_to_bf16c():
             # (the first model's BatchNorm buffers moved on; train-mode outputs do not read them)
             assert torch.equal(f_short, f_want)
     assert torch.equal(outs["bf16"][0], outs["bf16c"][0]) and torch.equal(outs["bf16"][1], outs["bf16c"][1])
+
+
+@pytest.mark.parametrize("context,summed", [(False, False), (True, True), (False, True)])
+def test_non_default_constructor_options_vs_the_reference(golden, context, summed):
+    """VERDICT r5 missing 3: ``Res2Net2(context=False)`` (ecapa_tdnn.py:126-129, :177-180) and ``summed=True`` (:163-166)
+    - the variants the reference's own score files were made with (lfcc_ecapa512c{t,f}s{t,f}_*) - used to raise.  fp32
+    path against tests/golden/ecapa_variants.npz (the REAL reference, make_golden_ecapa_variants.py): the state_dict
+    surface, train / eval forward, the OC-Softmax loss and every gradient - norms against the reference's, tensors
+    against the fp64 oracle at the bounds of test_grads_vs_oracle_small (B = 2 is stiff: 5e-2; B = 8: 5e-3); the bf16
+    modes refuse these options by name."""
+    from asvspoof2021_air_amd import _hip
+    from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
+    from asvspoof2021_air_amd.loss import AngularIsoLoss
+    g = golden("ecapa_variants.npz")
+    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f")
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, context=context, summed=summed)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [
+        (k, tuple(v)) for k, v in o_ecapa.ecapa_shapes(context=context).items()]
+    fill_module_(m)
+    m = m.cuda()
+    x = synth_feat((2, 60, 96), seed=400 + 96)
+    for mode in ("train", "eval"):
+        fill_module_(m)
+        m.train(mode == "train")
+        with torch.no_grad():
+            feat, out = m(x.cuda())
+        np.testing.assert_allclose(feat.cpu().numpy(), g["feat_%s_%s" % (tag, mode)], atol=2e-4)
+        np.testing.assert_allclose(out.cpu().numpy(), g["out_%s_%s" % (tag, mode)], atol=5e-4)
+    for B, T, tol in ((2, 96, 5e-2), (8, 64, 5e-3)):
+        fill_module_(m)
+        m.train()
+        m.zero_grad(set_to_none=True)
+        lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
+        fill_module_(lossm)
+        lossm = lossm.cuda()
+        xx = synth_feat((B, 60, T), seed=400 + T)
+        labels = torch.tensor([0, 1]) if B == 2 else (torch.arange(B) % 3 != 0).long()
+        feat, _ = m(xx.cuda())
+        loss, _ = lossm(feat, labels.cuda())
+        loss.backward()
+        p64 = {k: (v.double() if v.dtype.is_floating_point else v)
+               for k, v in fill_state(o_ecapa.ecapa_shapes(context=context)).items()}
+        tr = o_train.OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), context=context, summed=summed)
+        lo, _, _, go, gco, _ = tr.loss_and_grads(xx.double(), labels)
+        # The summed variants are stiffer than the default graph: the ORACLE ITSELF, fp32 against fp64, moves gradients
+        # by 3.7e-4 (context, summed) / 5.3e-3 (no context, summed) relative L2 at B = 8 where the default graph moves
+        # 5e-6 (the block inputs x + x1 + x2 grow, more pre-activations sit within rounding of a ReLU): the bound on the
+        # median tensor scales with the oracle's own fp32 distance, measured here.
+        p32 = fill_state(o_ecapa.ecapa_shapes(context=context))
+        g32 = o_train.OracleTrainer("ecapa", p32, fill_value("center", (1, 256)), context=context,
+                                    summed=summed).loss_and_grads(xx, labels)[3]
+        band = {k: float(np.linalg.norm(g32[k].double().numpy() - go[k].numpy()) / (np.linalg.norm(go[k].numpy()) + 1e-30))
+                for k in go if go[k] is not None}
+        np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
+        if B == 2:
+            np.testing.assert_allclose(loss.item(), g["loss_" + tag], rtol=1e-4)
+        noise_floor = 1e-4 * float(go["attention.2.weight"].abs().max())
+        errs = {}
+        for k, p in m.named_parameters():
+            if go[k] is None:
+                assert p.grad is None, k
+                continue
+            assert p.grad is not None, k
+            ref, got = go[k].numpy(), p.grad.cpu().double().numpy()
+            if k in ("attention.2.bias", "attention.3.bias"):  # analytically zero (softmax over T)
+                assert np.abs(got - ref).max() < noise_floor, k
+                continue
+            err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
+            errs[k] = err
+            # a pre-activation within rounding of 0 that takes the other ReLU branch moves the bias gradients behind it
+            # by a whole element (test_grads_vs_oracle_small): measured on `summed` at B = 8 - layer2.convs.5.bias
+            # 2.8e-2, five more tensors of the same branch 0.7 - 1.8e-2, everything else at the median.  So: every
+            # tensor inside the flip-tolerant 5e-2, and the MEDIAN tensor inside 10 x the oracle's own fp32 band.
+            assert err < 5e-2, "%s %s (B = %d): relative L2 grad err %.3g (oracle fp32 band %.3g)" % (tag, k, B, err, band[k])
+            if B == 2:
+                np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_%s_%s" % (tag, k)], rtol=5e-2)
+        med, med_band = float(np.median(list(errs.values()))), float(np.median([band[k] for k in errs]))
+        print("%s B = %d: median rel L2 %.3g (oracle fp32 band %.3g), worst %.3g" % (tag, B, med, med_band, max(errs.values())))
+        assert med <= max(tol / 10.0, 10.0 * med_band), (tag, B, med, med_band)
+        np.testing.assert_allclose(lossm.center.grad.cpu().numpy(), gco.numpy(), rtol=0, atol=tol * float(gco.abs().max()))
+    for dt in ("bf16", "bf16c"):
+        with pytest.raises(_hip.AirError, match="fp32"):
+            m.set_compute_dtype(dt)(x.cuda())
+    with pytest.raises(NotImplementedError, match="ASP"):
+        Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, encoder_type="ASP")
+    with pytest.raises(ValueError, match="Undefined encoder"):
+        Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, encoder_type="XYZ")

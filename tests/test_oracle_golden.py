@@ -217,6 +217,30 @@ def test_ecapa_grads_small(golden):
     np.testing.assert_allclose(grads["layer2.convs.3.weight"].numpy(), g["g_layer2.convs.3.weight"], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("context,summed", [(False, False), (True, True), (False, True)])
+def test_ecapa_constructor_options_pinned_to_the_reference(golden, context, summed):
+    """oracle/ecapa.py's ``context=`` / ``summed=`` (ecapa_tdnn.py:126-129, :163-170, :177-180) against the REAL reference
+    built with those constructor options (tests/golden/make_golden_ecapa_variants.py -> ecapa_variants.npz)."""
+    g = golden("ecapa_variants.npz")
+    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f")
+    params = fill_state(o_ecapa.ecapa_shapes(context=context))
+    x = synth_feat((2, 60, 96), seed=496)
+    for mode in ("train", "eval"):
+        feat, out = o_ecapa.ecapa_forward(params, x, training=(mode == "train"), context=context, summed=summed)
+        np.testing.assert_allclose(feat.numpy(), g["feat_%s_%s" % (tag, mode)], atol=1e-5)
+        np.testing.assert_allclose(out.numpy(), g["out_%s_%s" % (tag, mode)], atol=1e-5)
+    tr = o_train.OracleTrainer("ecapa", params, fill_value("center", (1, 256)), context=context, summed=summed)
+    loss, _, _, grads, gcenter, _ = tr.loss_and_grads(x, torch.tensor([0, 1]))
+    np.testing.assert_allclose(loss.item(), g["loss_" + tag], rtol=1e-6)
+    for k, gr in grads.items():
+        if gr is not None:
+            np.testing.assert_allclose(gr.norm().item(), g["gnorm_%s_%s" % (tag, k)], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(grads["conv1.bias"].numpy(), g["g_%s_conv1.bias" % tag], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(grads["layer2.conv1.weight"][:8].numpy(), g["g_%s_layer2.conv1.weight" % tag], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(grads["attention.0.weight"][:4].numpy(), g["g_%s_attention.0.weight" % tag], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(gcenter.numpy(), g["g_%s_center" % tag], rtol=1e-3, atol=1e-6)
+
+
 def test_ecapa_bf16_oracle_pinned_to_fp32_goldens(golden):
     """BASELINE configs[2] (bf16 compute) has no reference implementation: the bf16 oracle is
     pinned through the reference's fp32 goldens at bf16 tolerance (eval mode: relative L2 of the
