@@ -1376,6 +1376,11 @@ __global__ __launch_bounds__(512) void c1b_gemm_ps_kernel(const NtGemm p, unsign
 // Workgroup tile: 64 output channels x 128 frames; wave w owns frames 32 w .. 32 w + 31.
 constexpr int TAP_MAXD = 4;
 constexpr int TAP_ROWS = BN + 2 * TAP_MAXD;  // 136 staged frames
+// TIMING-ONLY experiment builds of c1b_tap_kernel (results are garbage; build --variant ... -DTAP_X=<bits>): 1 = no
+// activation loads, 2 = no MFMAs, 4 = no output stores, 8 = no weight loads.  profiles/r06_res2_chain.md, section 3.
+#ifndef TAP_X
+#define TAP_X 0
+#endif
 
 struct C1bTap {
   const float* x;
@@ -1483,12 +1488,13 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
   unsigned rh[3][8];
 #define TAP_FETCH(k0)                                                                        \
   do {                                                                                       \
+    if (TAP_X & 8) { ra0 = ra1 = ra2 = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); } else { \
     ra0 = *reinterpret_cast<const uint4*>(ga[0] + (k0));                                     \
     ra1 = *reinterpret_cast<const uint4*>(ga[1] + (k0));                                     \
-    ra2 = *reinterpret_cast<const uint4*>(ga[2] + (k0));                                     \
+    ra2 = *reinterpret_cast<const uint4*>(ga[2] + (k0)); }                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                         \
         _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                   \
-          if (HIO) rh[i_][j_] = okb[i_] ? (unsigned)gh[i_][(size_t)((k0) + j_) * XP] : 0u;   \
+          if (HIO) rh[i_][j_] = (okb[i_] && !(TAP_X & 1)) ? (unsigned)gh[i_][(size_t)((k0) + j_) * XP] : 0u;   \
           else rb[i_][j_] = okb[i_] ? gb[i_][(size_t)((k0) + j_) * p.T] : 0.0f;              \
         }                                                                                    \
   } while (0)
@@ -1654,6 +1660,9 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
         for (int i = 0; i < 2; ++i) {
           const bf16x8 fa = *reinterpret_cast<const bf16x8*>(&sA[cur][(tap * 64 + i * 32 + r31) * LDK + kk * 16 + kgl * 8]);
           // HIO: operands swapped - the accumulators come out transposed (a lane = one channel, see the epilogue)
+          if (TAP_X & 2) {
+            acc[i][0] += (float)fa[0] + (float)fb[0];  // (keeps the operand reads alive)
+          } else
           acc[i] = HIO ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[i], 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
         }
@@ -1785,7 +1794,7 @@ __global__ __launch_bounds__(256) void c1b_tap_kernel(const C1bTap p) {
     for (int k = 0; k < 4; ++k) {
       const int c = tid + 256 * k;
       const int row = c >> 4, col = (c & 15) * 8;
-      if (t0 + col < p.Tp)
+      if (t0 + col < p.Tp && (!(TAP_X & 4) || tile[row * TPITCH + col] == 0x1234))
         *reinterpret_cast<uint4*>(yh + (size_t)(m0 + row) * p.Tp + t0 + col) =
             *reinterpret_cast<const uint4*>(&tile[row * TPITCH + col]);
     }
