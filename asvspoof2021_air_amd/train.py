@@ -189,7 +189,7 @@ class Trainer:
         self.loss_optimizer.zero_grad()
         feats, _ = self.model(feat)
         loss, neg_scores = self.loss(feats, labels)
-        (loss * self.weight_loss).backward()  # main_train.py:376, :406
+        (loss if self.weight_loss == 1.0 else loss * self.weight_loss).backward()  # main_train.py:376, :406
         scale = 1.0
         if self.world > 1:
             air_dist.allreduce_grads(self.model, self.loss)
@@ -348,7 +348,7 @@ class Trainer:
         feats, saved = model.forward_saved(self.features(pcm, None))
         leaf = feats.detach().requires_grad_(True)
         loss, neg = self.loss(leaf, labels)
-        (loss * self.weight_loss).backward()  # the OC-Softmax head only: d(loss) / d(feats) and the centre's gradient
+        (loss if self.weight_loss == 1.0 else loss * self.weight_loss).backward()  # the OC-Softmax head only: d(loss) / d(feats) and the centre's gradient
         grads = model.backward_saved(saved, leaf.grad)
         pairs = []
         for (n, p, _, _), gr in zip(model.arena().entries, grads):
@@ -370,9 +370,14 @@ class Trainer:
         state = {"g": None, "hi": arena.head_total}
         segments = []
 
+        # world > 1: other threads of the process (the process group's watchdog polling its events) make runtime calls
+        # while this thread captures; "thread_local" checks only the capturing thread's calls (the default, "global",
+        # turns any other thread's event query into a capture error)
+        mode = "thread_local" if self.world > 1 else "global"
+
         def begin():
             state["g"] = torch.cuda.CUDAGraph()
-            state["g"].capture_begin(pool=pool)
+            state["g"].capture_begin(pool=pool, capture_error_mode=mode)
 
         def cut(lo):
             """backward reports: everything that writes arena.grad[lo:] has been enqueued"""
@@ -417,10 +422,10 @@ class Trainer:
         self.loss_optimizer.zero_grad()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if self.world > 1 else "global"):
             feats, _ = self.model(self.features(s_pcm, None))
             loss, neg = self.loss(feats, s_labels)
-            (loss * self.weight_loss).backward()
+            (loss if self.weight_loss == 1.0 else loss * self.weight_loss).backward()
         # p.grad now ARE the tensors the captured kernels write (no zero_grad between replays - every gradient is
         # overwritten, none accumulated); kept here so _graphed_step can restore them after eager interludes
         grads = [(p, p.grad) for p in list(self.model.parameters()) + list(self.loss.parameters())
