@@ -176,10 +176,7 @@ class Res2Net2(nn.Module):
         self.encoder_type = encoder_type
         self.out_bn = out_bn
         super().__init__()
-        if encoder_type == "ASP":
-            raise NotImplementedError("encoder_type='ASP' (one attention weight per frame, ecapa_tdnn.py:133-134) is not "
-                                      "built: the trainer (main_train.py:167) and the reference's score files use 'ECA'")
-        if encoder_type != "ECA":
+        if encoder_type not in ("ECA", "ASP"):
             raise ValueError("Undefined encoder")  # ecapa_tdnn.py:135-136
         self.scale = model_scale
         self.conv1 = nn.Conv1d(self.n_mfcc, C, kernel_size=5, stride=1, padding=2)
@@ -193,7 +190,11 @@ class Res2Net2(nn.Module):
         # context=False / summed=True (round 6; the reference's own score files lfcc_ecapa512c{t,f}s{t,f}_* were made with
         # them): served by the fp32 path; the bf16 paths are built for the trainer's defaults (main_train.py:167)
         attn_input = 1536 * 3 if self.context else 1536  # :126-129
-        attn_output = 1536
+        # 'ASP' (:133-134): ONE attention weight per frame, shared by the 1536 channels.  Served (fp32 path) by the ECA
+        # kernels on the layer's weight row repeated 1536 times - every channel then carries the same logits, which is
+        # what the reference's broadcast of w (B, 1, T) over x (B, 1536, T) computes (:184-185); the gradient of the
+        # one row is the sum of the 1536 rows' gradients
+        attn_output = 1536 if encoder_type == "ECA" else 1
         self.attention = nn.Sequential(
             nn.Conv1d(attn_input, 128, kernel_size=1),
             nn.ReLU(),
@@ -340,9 +341,10 @@ class Res2Net2(nn.Module):
 
     def _forward_impl(self, x, save):
         bf = self.compute_dtype == "bf16c"
-        if (not self.context or self.summed) and self.compute_dtype != "fp32":
-            raise _hip.AirError("Res2Net2(context=%s, summed=%s): the non-default options run in compute_dtype 'fp32' "
-                                "(the bf16 paths are built for main_train.py:167's defaults)" % (self.context, self.summed))
+        if (not self.context or self.summed or self.encoder_type != "ECA") and self.compute_dtype != "fp32":
+            raise _hip.AirError("Res2Net2(context=%s, summed=%s, encoder_type=%r): the non-default options run in "
+                                "compute_dtype 'fp32' (the bf16 paths are built for main_train.py:167's defaults)" % (
+                                    self.context, self.summed, self.encoder_type))
         if self.compute_dtype == "bf16":
             if oh.tp(x.shape[2]) <= oh.max_tp():
                 return self._forward_h(x, save)
@@ -411,7 +413,11 @@ class Res2Net2(nn.Module):
         stA = _bn(a1, self.attention[2], training)
         a1n_bf = ops.bf16_rows(None, B, a1.shape[1], T, x.device) if (bf and save) else None
         a1n = ops.bn_apply(a1, stA[2], stA[3], y_bf=a1n_bf)
-        wts = ops.conv1d_fwd(a1n, det(a3.weight), det(a3.bias), bf16=bf)  # logits -> softmax weights below
+        w3, b3 = det(a3.weight), det(a3.bias)
+        if self.encoder_type == "ASP":  # the one row for every channel (weight-sized plumbing copies)
+            w3 = w3.expand(x4.shape[1], -1, -1).contiguous()
+            b3 = b3.expand(x4.shape[1]).contiguous()
+        wts = ops.conv1d_fwd(a1n, w3, b3, bf16=bf)  # logits -> softmax weights below
         pooled = ops.asp_fwd(x4, wts)  # :184-187 (mu | sg)
         st5 = _bn(pooled.view(B, -1, 1), self.bn5, training)
         p5 = ops.bn_apply(pooled.view(B, -1, 1), st5[2], st5[3]).view(B, -1)
@@ -428,7 +434,7 @@ class Res2Net2(nn.Module):
                 raise NotImplementedError("backward through eval-mode BatchNorm is not on the hot path")
             S = dict(bf16c=bf, x=x, r0=r0, st0=st0, h=h, h_bf=h_bf, a1n_bf=a1n_bf, cat123=cat123, cat_bf=cat_bf, blocks=blocks, x4=x4, x4_bf=x4_bf, mean=mean,
                      std=std,
-                     ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, pooled=pooled, st5=st5,
+                     ctx=ctx, w_x=w_x, w_c=w_c, a1=a1, stA=stA, a1n=a1n, wts=wts, w3=w3, pooled=pooled, st5=st5,
                      p5=p5, feat=feat, o7=o7, st7=st7)
         ops.bn_flush()
         return feat, out, S
@@ -566,10 +572,20 @@ class Res2Net2(nn.Module):
         ops.asp_bwd(x4, wts, S["pooled"], dpooled.view(B, -1), dx4, accumulate=False, rowsum=rows3,
                     dlogits_bf16=wide_bf)  # wts -> dlogits
         a0, a3 = self.attention[0], self.attention[3]
-        ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
-        on_side(lambda: ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf,
-                                         dy_bf=wide_bf, x_bf=S["a1n_bf"]), wts)
-        da1n = ops.conv1d_dgrad(wts, det(a3.weight), bf16=bf)
+        asp = self.encoder_type == "ASP"
+        if asp:  # the one row's gradients = the sums over the 1536 repeated rows'
+            ops.sum_rows(ops.sum_rows(rows3).view(-1, 1), out=G["attention.3.bias"])
+
+            def att3_wgrad():
+                dw = ops.conv1d_wgrad(S["a1n"], wts, tuple(S["w3"].shape))
+                ops.sum_rows(dw.view(dw.shape[0], -1), out=G["attention.3.weight"].view(-1))
+
+            on_side(att3_wgrad, wts)
+        else:
+            ops.sum_rows(rows3, out=G["attention.3.bias"])  # analytically zero (softmax over T): rounding noise
+            on_side(lambda: ops.conv1d_wgrad(S["a1n"], wts, a3.weight.shape, out=G["attention.3.weight"], bf16=bf,
+                                             dy_bf=wide_bf, x_bf=S["a1n_bf"]), wts)
+        da1n = ops.conv1d_dgrad(wts, S["w3"], bf16=bf)
         stA = S["stA"]
         da1_bf = ops.bf16_rows("ecapa.da1", B, 128, T, x4.device) if bf else None
         da1, _, _ = ops.bn_bwd(S["a1"], da1n, stA[0], stA[1], det(self.attention[2].weight),

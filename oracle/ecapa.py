@@ -125,7 +125,7 @@ def _conv_shapes(prefix, cout, cin, k, out):
     out[prefix + ".bias"] = (cout,)
 
 
-def ecapa_shapes(C=512, scale=8, nOut=2, n_mels=60, bottleneck=128, attn_ch=128, context=True):
+def ecapa_shapes(C=512, scale=8, nOut=2, n_mels=60, bottleneck=128, attn_ch=128, context=True, encoder_type="ECA"):
     s = OrderedDict()
     _conv_shapes("conv1", C, n_mels, 5, s)
     _bn_shapes("bn1", C, s)
@@ -146,7 +146,7 @@ def ecapa_shapes(C=512, scale=8, nOut=2, n_mels=60, bottleneck=128, attn_ch=128,
     _conv_shapes("layer4", 1536, 3 * C, 1, s)
     _conv_shapes("attention.0", attn_ch, 1536 * (3 if context else 1), 1, s)
     _bn_shapes("attention.2", attn_ch, s)
-    _conv_shapes("attention.3", 1536, attn_ch, 1, s)
+    _conv_shapes("attention.3", 1536 if encoder_type == "ECA" else 1, attn_ch, 1, s)  # :131-134 (ASP: one weight per frame)
     _bn_shapes("bn5", 3072, s)
     s["fc6.weight"] = (256, 3072)
     s["fc6.bias"] = (256,)

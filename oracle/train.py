@@ -60,8 +60,9 @@ class OracleTrainer:
     def forward(self, x, training=True, noise=None, updates=None, taps=None):
         if self.model == "resnet":
             return resnet_oracle.resnet18_forward(self.params, x, training, noise, updates, taps, relu=self.relu)
+        opts = {k: v for k, v in self.ecapa_options.items() if k != "encoder_type"}  # (ASP is the shape of attention.3)
         return ecapa_oracle.ecapa_forward(self.params, x, training=training, updates=updates, taps=taps,
-                                          bf16=self.bf16, **self.ecapa_options)
+                                          bf16=self.bf16, **opts)
 
     def loss_and_grads(self, x, labels, noise=None):
         names = self.trainable()

@@ -32,12 +32,14 @@ def main():
     B, T = 2, 96
     x = synth_feat((B, 60, T), seed=400 + T)
     labels = torch.tensor([0, 1])
-    for ctx, summed in ((False, False), (True, True), (False, True)):
-        tag = "c%ss%s" % ("t" if ctx else "f", "t" if summed else "f")
-        net = ref_ecapa.Res2Net2(ref_ecapa.Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, context=ctx, summed=summed)
+    for ctx, summed, enc in ((False, False, "ECA"), (True, True, "ECA"), (False, True, "ECA"), (True, False, "ASP"),
+                             (False, True, "ASP")):
+        tag = "c%ss%s" % ("t" if ctx else "f", "t" if summed else "f") + ("" if enc == "ECA" else "_asp")
+        net = ref_ecapa.Res2Net2(ref_ecapa.Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, context=ctx, summed=summed,
+                                 encoder_type=enc)
         fill_module_(net)
         ref_shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
-        assert ref_shapes == [(k, tuple(v)) for k, v in o_ecapa.ecapa_shapes(context=ctx).items()], tag
+        assert ref_shapes == [(k, tuple(v)) for k, v in o_ecapa.ecapa_shapes(context=ctx, encoder_type=enc).items()], tag
         params = {k: v.detach().clone() for k, v in net.state_dict().items()}
         for mode in ("train", "eval"):
             net.train(mode == "train")

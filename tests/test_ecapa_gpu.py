@@ -447,10 +447,12 @@ def test_bf16_resident_long_input_falls_back_to_bf16c():
     assert torch.equal(outs["bf16"][0], outs["bf16c"][0]) and torch.equal(outs["bf16"][1], outs["bf16c"][1])
 
 
-@pytest.mark.parametrize("context,summed", [(False, False), (True, True), (False, True)])
-def test_non_default_constructor_options_vs_the_reference(golden, context, summed):
+@pytest.mark.parametrize("context,summed,enc", [(False, False, "ECA"), (True, True, "ECA"), (False, True, "ECA"),
+                                                (True, False, "ASP"), (False, True, "ASP")])
+def test_non_default_constructor_options_vs_the_reference(golden, context, summed, enc):
     """VERDICT r5 missing 3: ``Res2Net2(context=False)`` (ecapa_tdnn.py:126-129, :177-180) and ``summed=True`` (:163-166)
-    - the variants the reference's own score files were made with (lfcc_ecapa512c{t,f}s{t,f}_*) - used to raise.  fp32
+    - the variants the reference's own score files were made with (lfcc_ecapa512c{t,f}s{t,f}_*) - and ``encoder_type='ASP'``
+    (:133-134: one attention weight per frame; served by the ECA kernels on the repeated weight row) used to raise.  fp32
     path against tests/golden/ecapa_variants.npz (the REAL reference, make_golden_ecapa_variants.py): the state_dict
     surface, train / eval forward, the OC-Softmax loss and every gradient - norms against the reference's, tensors
     against the fp64 oracle at the bounds of test_grads_vs_oracle_small (B = 2 is stiff: 5e-2; B = 8: 5e-3); the bf16
@@ -459,22 +461,41 @@ def test_non_default_constructor_options_vs_the_reference(golden, context, summe
     from asvspoof2021_air_amd.ecapa_tdnn import Bottle2neck, Res2Net2
     from asvspoof2021_air_amd.loss import AngularIsoLoss
     g = golden("ecapa_variants.npz")
-    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f")
-    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, context=context, summed=summed)
+    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f") + ("" if enc == "ECA" else "_asp")
+    m = Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, context=context, summed=summed, encoder_type=enc)
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [
-        (k, tuple(v)) for k, v in o_ecapa.ecapa_shapes(context=context).items()]
+        (k, tuple(v)) for k, v in o_ecapa.ecapa_shapes(context=context, encoder_type=enc).items()]
     fill_module_(m)
     m = m.cuda()
     x = synth_feat((2, 60, 96), seed=400 + 96)
+    sh = o_ecapa.ecapa_shapes(context=context, encoder_type=enc)
     for mode in ("train", "eval"):
         fill_module_(m)
         m.train(mode == "train")
         with torch.no_grad():
             feat, out = m(x.cuda())
-        np.testing.assert_allclose(feat.cpu().numpy(), g["feat_%s_%s" % (tag, mode)], atol=2e-4)
-        np.testing.assert_allclose(out.cpu().numpy(), g["out_%s_%s" % (tag, mode)], atol=5e-4)
+        # The golden is the fp32 reference.  Under 'ASP' with the filler weights the one attention row is nearly one-hot
+        # over time (largest weight 0.99999), so sg = sqrt(clamp(sum x^2 w - mu^2, 1e-4)) (:185) is a difference of two
+        # numbers of ~48 that agree to 1e-4: any two fp32 summation orders differ by 1e-4 .. 1e-3 there (the HIP mu sits
+        # 4e-5 from torch's on values of 7).  The bound is therefore the default test's constant or 4 x the distance of
+        # the ORACLE's own fp32 evaluation from its fp64 one, whichever is larger.
+        p32 = fill_state(sh)
+        p64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in p32.items()}
+        f32, o32 = o_ecapa.ecapa_forward(p32, x, training=(mode == "train"), context=context, summed=summed)
+        f64, o64 = o_ecapa.ecapa_forward(p64, x.double(), training=(mode == "train"), context=context, summed=summed)
+        bf, bo = float((f32.double() - f64).abs().max()), float((o32.double() - o64).abs().max())
+        np.testing.assert_allclose(feat.cpu().numpy(), g["feat_%s_%s" % (tag, mode)], atol=max(2e-4, 4 * bf))
+        np.testing.assert_allclose(out.cpu().numpy(), g["out_%s_%s" % (tag, mode)], atol=max(5e-4, 4 * bo))
+        np.testing.assert_allclose(feat.cpu().double().numpy(), f64.numpy(), atol=max(2e-4, 4 * bf))
+    # 'ASP' gradients: with the filler weights the single attention row is one-hot over time and sg sits on its clamp -
+    # the oracle's own fp32 evaluation is 9 % from its fp64 one there, which pins nothing.  The gradient part therefore
+    # runs on a TEMPERED attention (attention.3.weight x 0.02 in the model and in the oracle: weights spread over the
+    # frames); the golden comparison of loss / norms applies to the untempered variants only.
+    temper = 0.02 if enc == "ASP" else 1.0
     for B, T, tol in ((2, 96, 5e-2), (8, 64, 5e-3)):
         fill_module_(m)
+        with torch.no_grad():
+            m.attention[3].weight.mul_(temper)
         m.train()
         m.zero_grad(set_to_none=True)
         lossm = AngularIsoLoss(256, r_real=0.9, r_fake=0.2, alpha=20.0)
@@ -486,20 +507,22 @@ def test_non_default_constructor_options_vs_the_reference(golden, context, summe
         loss, _ = lossm(feat, labels.cuda())
         loss.backward()
         p64 = {k: (v.double() if v.dtype.is_floating_point else v)
-               for k, v in fill_state(o_ecapa.ecapa_shapes(context=context)).items()}
+               for k, v in fill_state(o_ecapa.ecapa_shapes(context=context, encoder_type=enc)).items()}
+        p64["attention.3.weight"] = p64["attention.3.weight"] * temper
         tr = o_train.OracleTrainer("ecapa", p64, fill_value("center", (1, 256)).double(), context=context, summed=summed)
         lo, _, _, go, gco, _ = tr.loss_and_grads(xx.double(), labels)
         # The summed variants are stiffer than the default graph: the ORACLE ITSELF, fp32 against fp64, moves gradients
         # by 3.7e-4 (context, summed) / 5.3e-3 (no context, summed) relative L2 at B = 8 where the default graph moves
         # 5e-6 (the block inputs x + x1 + x2 grow, more pre-activations sit within rounding of a ReLU): the bound on the
         # median tensor scales with the oracle's own fp32 distance, measured here.
-        p32 = fill_state(o_ecapa.ecapa_shapes(context=context))
+        p32 = fill_state(o_ecapa.ecapa_shapes(context=context, encoder_type=enc))
+        p32["attention.3.weight"] = p32["attention.3.weight"] * temper
         g32 = o_train.OracleTrainer("ecapa", p32, fill_value("center", (1, 256)), context=context,
                                     summed=summed).loss_and_grads(xx, labels)[3]
         band = {k: float(np.linalg.norm(g32[k].double().numpy() - go[k].numpy()) / (np.linalg.norm(go[k].numpy()) + 1e-30))
                 for k in go if go[k] is not None}
         np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-4)
-        if B == 2:
+        if B == 2 and temper == 1.0:
             np.testing.assert_allclose(loss.item(), g["loss_" + tag], rtol=1e-4)
         noise_floor = 1e-4 * float(go["attention.2.weight"].abs().max())
         errs = {}
@@ -519,7 +542,7 @@ def test_non_default_constructor_options_vs_the_reference(golden, context, summe
             # 2.8e-2, five more tensors of the same branch 0.7 - 1.8e-2, everything else at the median.  So: every
             # tensor inside the flip-tolerant 5e-2, and the MEDIAN tensor inside 10 x the oracle's own fp32 band.
             assert err < 5e-2, "%s %s (B = %d): relative L2 grad err %.3g (oracle fp32 band %.3g)" % (tag, k, B, err, band[k])
-            if B == 2:
+            if B == 2 and temper == 1.0:
                 np.testing.assert_allclose(p.grad.norm().item(), g["gnorm_%s_%s" % (tag, k)], rtol=5e-2)
         med, med_band = float(np.median(list(errs.values()))), float(np.median([band[k] for k in errs]))
         print("%s B = %d: median rel L2 %.3g (oracle fp32 band %.3g), worst %.3g" % (tag, B, med, med_band, max(errs.values())))
@@ -528,7 +551,5 @@ def test_non_default_constructor_options_vs_the_reference(golden, context, summe
     for dt in ("bf16", "bf16c"):
         with pytest.raises(_hip.AirError, match="fp32"):
             m.set_compute_dtype(dt)(x.cuda())
-    with pytest.raises(NotImplementedError, match="ASP"):
-        Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, encoder_type="ASP")
     with pytest.raises(ValueError, match="Undefined encoder"):
         Res2Net2(Bottle2neck, C=512, model_scale=8, nOut=2, n_mels=60, encoder_type="XYZ")

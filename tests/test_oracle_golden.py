@@ -217,13 +217,14 @@ def test_ecapa_grads_small(golden):
     np.testing.assert_allclose(grads["layer2.convs.3.weight"].numpy(), g["g_layer2.convs.3.weight"], rtol=1e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("context,summed", [(False, False), (True, True), (False, True)])
-def test_ecapa_constructor_options_pinned_to_the_reference(golden, context, summed):
+@pytest.mark.parametrize("context,summed,enc", [(False, False, "ECA"), (True, True, "ECA"), (False, True, "ECA"),
+                                                (True, False, "ASP"), (False, True, "ASP")])
+def test_ecapa_constructor_options_pinned_to_the_reference(golden, context, summed, enc):
     """oracle/ecapa.py's ``context=`` / ``summed=`` (ecapa_tdnn.py:126-129, :163-170, :177-180) against the REAL reference
     built with those constructor options (tests/golden/make_golden_ecapa_variants.py -> ecapa_variants.npz)."""
     g = golden("ecapa_variants.npz")
-    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f")
-    params = fill_state(o_ecapa.ecapa_shapes(context=context))
+    tag = "c%ss%s" % ("t" if context else "f", "t" if summed else "f") + ("" if enc == "ECA" else "_asp")
+    params = fill_state(o_ecapa.ecapa_shapes(context=context, encoder_type=enc))
     x = synth_feat((2, 60, 96), seed=496)
     for mode in ("train", "eval"):
         feat, out = o_ecapa.ecapa_forward(params, x, training=(mode == "train"), context=context, summed=summed)
