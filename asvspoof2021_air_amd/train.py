@@ -295,7 +295,9 @@ class Trainer:
             if self._graph_warm < 2:
                 self._graph_warm += 1
                 return None
-            g = self._capture(key, pcm, labels)
+            g = self._capture_or_fall_back(key, pcm, labels)
+            if g is None:
+                return None  # (every rank alike: the eager step takes over)
         if not self.model.training:  # an interleaved score() left eval mode behind
             self.model.train()
         # The captured kernels write the gradients into the tensors that were p.grad AT CAPTURE (arena views for the
@@ -340,6 +342,30 @@ class Trainer:
         self.feat_optimizer.step(grad_scale=scale)
         self.loss_optimizer.step(grad_scale=scale)
         return g["loss"].detach().clone(), g["neg"].clone()
+
+    def _capture_or_fall_back(self, key, pcm, labels):
+        """The capture, guarded for world > 1: were it to fail on ANY rank (a runtime that refuses a call inside a
+        capture, memory), EVERY rank drops the graph and goes on with the eager bucketed step - one rank replaying
+        while another launches its all-reduces from inside backward would pair the wrong collectives.  The agreement
+        costs one 4-byte all-reduce at capture time.  world 1: errors propagate as before."""
+        if self.world == 1:
+            return self._capture(key, pcm, labels)
+        err = None
+        try:
+            g = self._capture(key, pcm, labels)
+        except Exception as exc:  # noqa: BLE001
+            g, err = None, exc
+        dev = self.device if td.get_backend() == "nccl" else "cpu"
+        ok = torch.tensor([0 if g is None else 1], dtype=torch.int32, device=dev)
+        td.all_reduce(ok, op=td.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return g
+        import warnings
+        warnings.warn("hipGraph capture of the train step failed on %s (%s): every rank continues with the eager step" % (
+            "this rank" if err is not None else "another rank", repr(err)[:200] if err is not None else "-"))
+        self._drop_graph()
+        self.enable_graph(False)  # restores the side stream and the in-backward bucketer
+        return None
 
     def _fwd_bwd_direct(self, pcm, labels):
         """front-end + forward + loss + backward as plain calls in THIS thread (what model(x) -> loss.backward() does

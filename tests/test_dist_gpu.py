@@ -142,17 +142,24 @@ def _worker_steps(rank, world, port, out, kind, graph):
     if kind == "resnet":
         tr.model.noise_mode, tr.model._noise_seed = "device", 77 + rank  # per-rank attention noise, device-side offset
     if graph:
-        if graph == "segments":
+        if graph in ("segments", "fail_on_rank1"):
             tr.segment_bytes = 8 << 20
-        tr.enable_graph(segments=(graph == "segments"))
+        tr.enable_graph(segments=(graph != "chain"))
         assert tr.model._bucketer is None and tr.model.overlap_wgrad is False
+        if graph == "fail_on_rank1" and rank == 1:  # a capture that fails on ONE rank: every rank must fall back to eager
+            def boom(*a, **k):
+                raise RuntimeError("injected capture failure")
+            tr._capture = boom
     losses = []
     for i in range(5):
         pcm = synth_pcm(4, 16000, seed=900 + 10 * i + rank).cuda()
         labels = ((torch.arange(4) + i + rank) % 3 != 0).long().cuda()
         losses.append(tr.step(pcm, labels)[0].item())
     torch.cuda.synchronize()
-    assert (tr._graph is not None) == bool(graph)
+    if graph == "fail_on_rank1":
+        assert tr._graph is None and tr.use_graph is False and tr.model._bucketer is not None  # back on the eager path
+    else:
+        assert (tr._graph is not None) == bool(graph)
     if graph == "segments":  # several graphs, and their buckets went out between the replays
         assert len(tr._graph["segments"]) >= 3 and tr._seg_bucketer.total_launched >= 2 * 3, (
             len(tr._graph["segments"]), tr._seg_bucketer.total_launched)
@@ -171,7 +178,9 @@ def test_two_rank_graph_replay_equals_two_rank_eager(kind):
     ends = []
     # (round 6) "segments": the step captured as several hipGraphs cut at backward's bucket boundaries, each bucket's
     # all-reduce launched between two replays (replay's host time AND overlap) - same bits again
-    for graph in (False, "chain", "segments"):
+    # "fail_on_rank1": the capture raises on one rank only - both ranks agree (one 4-byte all-reduce) to drop the graph
+    # and finish the five steps eagerly: same bits again, no rank left replaying against a rank that buckets
+    for graph in (False, "chain", "segments") + (("fail_on_rank1",) if kind == "resnet" else ()):
         out = mgr.dict()
         mp.spawn(_worker_steps, args=(world, _free_port(), out, kind, graph), nprocs=world, join=True)
         (l0, w0, c0), (l1, w1, c1) = out[0], out[1]
