@@ -107,8 +107,10 @@ __global__ __launch_bounds__(256) void bf3_pack_kernel(const float* __restrict__
 
 // (timing-only experiment, BF3_EXP bit 4: what a BatchNorm + ReLU prologue on the lane-loaded activations would cost -
 // scale 1 / shift 0 from a table, so that results on non-negative inputs do not change: profiles/r06_bf3_prologue.md)
+#if BF3_EXP & 4
 __device__ float g_bf3_exp_scale[1024] = {[0 ... 1023] = 1.0f};
 __device__ float g_bf3_exp_shift[1024] = {};
+#endif
 
 struct Bf3Args {
   const float* x;
