@@ -535,54 +535,83 @@ class ASVspoof2021DFeval(ASVspoof2021LAeval):
 class DevicePrefetcher:
     """Iterates a DataLoader whose batches hold host tensors (``return_pcm='batch'``: pinned PCM + label tensors) and
     hands them over ON THE GPU: batch n + 1 is copied on a copy stream while the caller's stream runs step n (the
-    reference's loop does ``.to(device)`` on the compute stream, main_train.py:316-317).  Tensors go to ``device``
-    (pageable ones through a pinned staging copy), everything else (file names) passes through.  ``depth`` batches are
-    in flight; a batch's device buffers are reused only after the caller's stream has passed the next ``__next__``."""
+    reference's loop does ``.to(device)`` on the compute stream, main_train.py:316-317).  Everything that is not a tensor
+    (file names) passes through.  No allocation per batch on either side: the device tensors and the pinned staging
+    buffers of pageable inputs live in a ring of ``depth + 2`` slots per (position in the batch, shape, dtype) - a
+    fresh device tensor per batch costs a blocking allocation whenever the caching allocator has no block the caller's
+    stream is done with, and a copy from pageable memory blocks the host (tools/dbg_from_dataset.py).  A slot is
+    rewritten only behind an event the CALLER's stream records when it asks for the next batch, i.e. after it has
+    enqueued everything that reads the old one: a yielded batch is valid until ``depth + 1`` further batches were taken."""
 
     def __init__(self, loader, device="cuda", depth=2):
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._dev, self._staging = {}, {}
+        self._copied, self._consumed = {}, {}  # per slot: copy-stream event of its last fill / caller's-stream event of its last use
 
     def __len__(self):
         return len(self.loader)
 
-    def _to_device(self, item):
-        if torch.is_tensor(item):
-            if not item.is_pinned() and item.device.type == "cpu":
-                item = item.pin_memory()
-            return item.to(self.device, non_blocking=True), item  # (the pinned source stays alive with the batch)
-        return item, None
+    def _to_device(self, item, slot, k):
+        if not torch.is_tensor(item):
+            return item
+        key = (slot, k, tuple(item.shape), item.dtype)
+        if not item.is_pinned() and item.device.type == "cpu":
+            buf = self._staging.get(key)
+            if buf is None:
+                buf = self._staging[key] = torch.empty(item.shape, dtype=item.dtype, pin_memory=True)
+            buf.copy_(item)
+            item = buf
+        dst = self._dev.get(key)
+        if dst is None:
+            dst = self._dev[key] = torch.empty(item.shape, dtype=item.dtype, device=self.device)
+        dst.copy_(item, non_blocking=True)
+        return dst
 
     def __iter__(self):
         import collections
         queue = collections.deque()
         it = iter(self.loader)
         main = torch.cuda.current_stream(self.device)
+        nslot = self.depth + 2
+        count = [0]
 
         def fetch():
             try:
                 batch = next(it)
             except StopIteration:
                 return False
+            slot = count[0] % nslot
+            count[0] += 1
+            prev = self._copied.get(slot)
+            if prev is not None:
+                prev.synchronize()  # the staging buffers of this slot: their copies were issued depth + 2 batches ago
+            done = self._consumed.get(slot)
             with torch.cuda.stream(self.copy_stream):
-                moved = [self._to_device(x) for x in batch]
+                if done is not None:
+                    self.copy_stream.wait_event(done)  # (device side) the caller's stream is past the slot's old batch
+                moved = [self._to_device(x, slot, k) for k, x in enumerate(batch)]
                 ev = torch.cuda.Event()
                 ev.record(self.copy_stream)
+            self._copied[slot] = ev
             for x in batch:  # a ring-buffer batch (collate_fn, return_pcm='batch'): its slot is reusable after this copy
                 ring = getattr(x, "_air_ring", None) if torch.is_tensor(x) else None
                 if ring is not None:
                     ring[0]["events"][ring[1]] = ev
-            queue.append(([m[0] for m in moved], [m[1] for m in moved], ev))
+            queue.append((moved, ev, slot))
             return True
 
         for _ in range(self.depth):
             if not fetch():
                 break
+        last_slot = None
         while queue:
-            out, keep, ev = queue.popleft()
+            out, ev, slot = queue.popleft()
+            if last_slot is not None:  # the caller came back for more: what reads the previous batch is enqueued
+                done = torch.cuda.Event()
+                done.record(main)
+                self._consumed[last_slot] = done
             main.wait_event(ev)
-            for t in out:
-                if torch.is_tensor(t):
-                    t.record_stream(main)  # allocated on the copy stream, consumed on the caller's
             fetch()
+            last_slot = slot
             yield out

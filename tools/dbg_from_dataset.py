@@ -66,3 +66,71 @@ def host_only():
 
 
 run("loader on the host, resident tensors to the step", forever(host_only))
+
+# ---- where does `next` spend its time?  the prefetcher's pieces timed one by one
+import collections
+pf = air_ds.DevicePrefetcher(dl, dev, depth=2)
+T = collections.defaultdict(float)
+orig_to = pf._to_device
+
+
+def timed_to(item, slot, k):
+    a = time.perf_counter()
+    r = orig_to(item, slot, k)
+    T["to_device[%d]" % k] += time.perf_counter() - a
+    return r
+
+
+pf._to_device = timed_to
+orig_collate = ds.collate_fn
+
+
+def timed_collate(samples):
+    a = time.perf_counter()
+    r = orig_collate(samples)
+    T["collate"] += time.perf_counter() - a
+    return r
+
+
+dl2 = DataLoader(ds, batch_size=B, shuffle=True, drop_last=True, collate_fn=timed_collate, num_workers=0)
+pf.loader = dl2
+orig_getitem = type(ds).__getitem__
+n = 0
+t0 = time.perf_counter()
+for ep in range(8):
+    for b in pf:
+        a = time.perf_counter()
+        tr.step(b[0], b[3])
+        T["step"] += time.perf_counter() - a
+        n += 1
+torch.cuda.synchronize()
+tot = time.perf_counter() - t0
+print("per batch over %d batches: total %.2f ms |" % (n, 1e3 * tot / n), " ".join("%s %.2f" % (k, 1e3 * v / n) for k, v in sorted(T.items())))
+
+
+# which Event.synchronize blocks?  (dataset pinned ring vs prefetcher slot ring)
+orig_sync = torch.cuda.Event.synchronize
+acc = collections.defaultdict(lambda: [0, 0.0])
+import traceback
+
+
+def timed_sync(self):
+    a = time.perf_counter()
+    r = orig_sync(self)
+    d = time.perf_counter() - a
+    where = traceback.extract_stack(limit=2)[0]
+    k = "%s:%d" % (os.path.basename(where.filename), where.lineno)
+    acc[k][0] += 1
+    acc[k][1] += d
+    return r
+
+
+torch.cuda.Event.synchronize = timed_sync
+pf3 = air_ds.DevicePrefetcher(dl, dev, depth=2)
+for ep in range(8):
+    for b in pf3:
+        tr.step(b[0], b[3])
+torch.cuda.Event.synchronize = orig_sync
+torch.cuda.synchronize()
+for k, (n, t) in acc.items():
+    print("Event.synchronize at %s: %d calls, %.2f ms each" % (k, n, 1e3 * t / max(1, n)))
