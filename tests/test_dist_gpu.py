@@ -308,20 +308,25 @@ def test_bench_two_ranks_at_the_stated_per_gpu_size(kind):
         assert d["dtype"] == "bf16" and d["launch"].startswith("hipGraph")
 
 
-def test_bench_eight_ranks_on_one_gpu():
-    """`bench.py --gpus 8` exactly as the driver launches it (eight processes, LOCAL_RANK 0 - 7), configs[3]'s per-GPU
-    shape, all eight ranks time-slicing the one GPU of this box over gloo: rendezvous, bucketed all-reduce from inside
-    backward across EIGHT ranks, the barrier + max-over-ranks timing and the single JSON line.  (What RCCL over xGMI
-    adds on a real node is the transport; the call pattern is this one.)"""
+@pytest.mark.parametrize("kind", ["resnet_b64", "ecapa_bf16_b128_aug"])
+def test_bench_eight_ranks_on_one_gpu(kind):
+    """`bench.py --gpus 8` exactly as the driver launches it (eight processes, LOCAL_RANK 0 - 7) at BASELINE configs[3]'s
+    AND (round 6) configs[4]'s per-GPU shape - ResNet fp32 B = 64; ECAPA bf16 B = 128 + the IR augmentation - all eight
+    ranks time-slicing the one GPU of this box over gloo: rendezvous, the segmented replay with its buckets between the
+    replays across EIGHT ranks, the barrier + max-over-ranks timing and the single JSON line.  (What RCCL over xGMI adds
+    on a real node is the transport; the call pattern is this one.)"""
     out_json = os.path.join(tempfile.mkdtemp(prefix="air_bench_"), "line.json")
     env = dict(os.environ, AIR_DIST_BACKEND="gloo", PYTHONPATH=ROOT, AIR_BENCH_JSON_OUT=out_json)
+    extra = [] if kind == "resnet_b64" else ["--model", "ecapa", "--augment"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1",
-           "--warmup", "1", "--plain-timing", "--no-roofline", "--no-extra-configs"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+           "--warmup", "1", "--plain-timing", "--no-roofline", "--no-extra-configs"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _bench_line(r, out_json)
-    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp8"
+    per = 64 if kind == "resnet_b64" else 128
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 * per and d["config"]["parallelism"] == "dp8"
     assert d["ddp"]["world"] == 8 and d["ddp"]["ranks_seen"] == 8
+    assert d["launch"].startswith("hipGraph replay (") and "segments" in d["launch"] and d["ddp"]["buckets_between_replays"] > 0
     assert np.isfinite(d["final_loss"]) and d["value"] > 0
 
