@@ -86,22 +86,39 @@ __global__ __launch_bounds__(NT) void selfatt_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   // weighted mean and unbiased std over T (resnet.py:37-42)
+  // (round 6: the noise values of a channel are requested 32 frames at a time - every load of a chunk in flight before
+  // the first is consumed - instead of 8: the loop was one memory round trip per 8 frames, twice over; the sums keep
+  // their order, so the results are the same bits)
+  constexpr int NCH = 32;
   for (int c = threadIdx.x; c < C; c += NT) {
     float avg = 0.0f, zs = 0.0f;
-#pragma unroll 8
-    for (int t = 0; t < T; ++t) {
-      const float wv = xs[c * TP + t] * ws[t];
-      avg += wv;
-      zs += noise ? wv + noise[((size_t)b * T + t) * C + c] : wv;
+    const float* __restrict__ nc = noise ? noise + (size_t)b * T * C + c : nullptr;
+    for (int t0 = 0; t0 < T; t0 += NCH) {
+      float nz[NCH];
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) nz[u] = (nc && t0 + u < T) ? nc[(size_t)(t0 + u) * C] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NCH; ++u)
+        if (t0 + u < T) {
+          const float wv = xs[c * TP + t0 + u] * ws[t0 + u];
+          avg += wv;
+          zs += noise ? wv + nz[u] : wv;
+        }
     }
     const float zm = zs / (float)T;
     float ss = 0.0f;
-#pragma unroll 8
-    for (int t = 0; t < T; ++t) {
-      float z = xs[c * TP + t] * ws[t];
-      if (noise) z += noise[((size_t)b * T + t) * C + c];
-      const float d = z - zm;
-      ss = fmaf(d, d, ss);
+    for (int t0 = 0; t0 < T; t0 += NCH) {
+      float nz[NCH];
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) nz[u] = (nc && t0 + u < T) ? nc[(size_t)(t0 + u) * C] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NCH; ++u)
+        if (t0 + u < T) {
+          float z = xs[c * TP + t0 + u] * ws[t0 + u];
+          if (noise) z += nz[u];
+          const float d = z - zm;
+          ss = fmaf(d, d, ss);
+        }
     }
     out[(size_t)b * 2 * C + c] = avg;
     out[(size_t)b * 2 * C + C + c] = sqrtf(ss / (float)(T - 1));
@@ -149,13 +166,20 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   }
   for (int t = threadIdx.x; t < T; t += NT) al[t] = alpha[(size_t)b * T + t];
   __syncthreads();
+  constexpr int NCH = 32;  // noise values requested per chunk (see the forward kernel)
   for (int c = threadIdx.x; c < C; c += NT) {
     float zs = 0.0f;
-#pragma unroll 8
-    for (int t = 0; t < T; ++t) {
-      float z = xs[c * TP + t] * al[t];
-      if (nb) z += nb[(size_t)t * C + c];
-      zs += z;
+    for (int t0 = 0; t0 < T; t0 += NCH) {
+      float nz[NCH];
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) nz[u] = (nb && t0 + u < T) ? nb[(size_t)(t0 + u) * C + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NCH; ++u)
+        if (t0 + u < T) {
+          float z = xs[c * TP + t0 + u] * al[t0 + u];
+          if (nb) z += nz[u];
+          zs += z;
+        }
     }
     zm[c] = zs / (float)T;
     const float sd = out[(size_t)b * 2 * C + C + c];
@@ -165,23 +189,36 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   }
   __syncthreads();
   // a wave per frame, lanes over the channels: the noise rows (B, T, C) are read coalesced
-  for (int t = threadIdx.x >> 6; t < T; t += NT / 64) {
-    float acc = 0.0f, s = 0.0f;
-    const float a_t = al[t];
+  // (round 6: FOUR frames of a wave per trip - their noise rows requested together; each frame's sums keep their order)
+  constexpr int FPT = 4;
+  for (int tb = (threadIdx.x >> 6) * FPT; tb < T; tb += (NT / 64) * FPT) {
+    float acc[FPT], s[FPT];
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) acc[f] = s[f] = 0.0f;
     for (int c = threadIdx.x & 63; c < C; c += 64) {
-      const float xv = xs[c * TP + t];
-      float z = xv * a_t;
-      if (nb) z += nb[(size_t)t * C + c];
-      const float g = dav[c] + coef[c] * (z - zm[c]);
-      acc = fmaf(g, xv, acc);
-      s = fmaf(xv, att[c], s);
+      float nzv[FPT];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f) nzv[f] = (nb && tb + f < T) ? nb[(size_t)(tb + f) * C + c] : 0.0f;
+      const float dvc = dav[c], cfc = coef[c], zmc = zm[c], ac = att[c];
+#pragma unroll
+      for (int f = 0; f < FPT; ++f)
+        if (tb + f < T) {
+          const float xv = xs[c * TP + tb + f];
+          float z = xv * al[tb + f];
+          if (nb) z += nzv[f];
+          const float g = dvc + cfc * (z - zmc);
+          acc[f] = fmaf(g, xv, acc[f]);
+          s[f] = fmaf(xv, ac, s[f]);
+        }
     }
-    acc = air_wave_sum(acc);
-    s = air_wave_sum(s);
-    if ((threadIdx.x & 63) == 0) {
-      dal[t] = acc;
-      const float u = tanhf(s);
-      dw[t] = 1.0f - u * u;  // finished below once <alpha, dalpha> is known
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      const float a2 = air_wave_sum(acc[f]), s2 = air_wave_sum(s[f]);
+      if ((threadIdx.x & 63) == 0 && tb + f < T) {
+        dal[tb + f] = a2;
+        const float u = tanhf(s2);
+        dw[tb + f] = 1.0f - u * u;  // finished below once <alpha, dalpha> is known
+      }
     }
   }
   __syncthreads();
@@ -194,14 +231,21 @@ __global__ __launch_bounds__(NT) void selfatt_bwd_kernel(
   for (int c = threadIdx.x; c < C; c += NT) {
     const float ac = att[c], cf = coef[c], dv = dav[c], zmc = zm[c];
     float da = 0.0f;
-#pragma unroll 8
-    for (int t = 0; t < T; ++t) {
-      const float xv = xs[c * TP + t];
-      float z = xv * al[t];
-      if (nb) z += nb[(size_t)t * C + c];
-      const float g = dv + cf * (z - zmc);
-      dst[c * TP + t] = g * al[t] + dw[t] * ac;  // dx (staged: this thread is the only reader of its x row)
-      da = fmaf(dw[t], xv, da);
+    for (int t0 = 0; t0 < T; t0 += NCH) {
+      float nz[NCH];
+#pragma unroll
+      for (int u = 0; u < NCH; ++u) nz[u] = (nb && t0 + u < T) ? nb[(size_t)(t0 + u) * C + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < NCH; ++u)
+        if (t0 + u < T) {
+          const int t = t0 + u;
+          const float xv = xs[c * TP + t];
+          float z = xv * al[t];
+          if (nb) z += nz[u];
+          const float g = dv + cf * (z - zmc);
+          dst[c * TP + t] = g * al[t] + dw[t] * ac;  // dx (staged: this thread is the only reader of its x row)
+          da = fmaf(dw[t], xv, da);
+        }
     }
     datt_partial[(size_t)b * C + c] = da;
   }
