@@ -424,7 +424,14 @@ class Trainer:
         try:
             with torch.cuda.stream(cap):
                 begin()
-                loss, neg, grads = self._fwd_bwd_direct(s_pcm, s_labels)
+                try:
+                    loss, neg, grads = self._fwd_bwd_direct(s_pcm, s_labels)
+                except BaseException:
+                    try:  # leave the stream out of capture mode: the caller may go on eagerly (_capture_or_fall_back)
+                        state["g"].capture_end()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    raise
                 state["g"].capture_end()
                 segments.append((state["g"], None))  # the rest of the arena goes with the final all-reduce
         finally:
