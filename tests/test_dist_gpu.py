@@ -147,9 +147,11 @@ def _worker_steps(rank, world, port, out, kind, graph):
         tr.enable_graph(segments=(graph != "chain"))
         assert tr.model._bucketer is None and tr.model.overlap_wgrad is False
         if graph == "fail_on_rank1" and rank == 1:  # a capture that fails on ONE rank: every rank must fall back to eager
+            # ... in the MIDDLE of the capture (forward captured, backward raises): the stream has to come out of
+            # capture mode for the eager steps that follow
             def boom(*a, **k):
                 raise RuntimeError("injected capture failure")
-            tr._capture = boom
+            tr.model.backward_saved = boom
     losses = []
     for i in range(5):
         pcm = synth_pcm(4, 16000, seed=900 + 10 * i + rank).cuda()
@@ -158,6 +160,7 @@ def _worker_steps(rank, world, port, out, kind, graph):
     torch.cuda.synchronize()
     if graph == "fail_on_rank1":
         assert tr._graph is None and tr.use_graph is False and tr.model._bucketer is not None  # back on the eager path
+        assert not torch.cuda.is_current_stream_capturing()
     else:
         assert (tr._graph is not None) == bool(graph)
     if graph == "segments":  # several graphs, and their buckets went out between the replays
