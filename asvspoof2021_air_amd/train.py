@@ -248,7 +248,8 @@ class Trainer:
                 self._overlap_saved = (getattr(self.model, "overlap_wgrad", None), getattr(self.model, "_bucketer", None))
             batched = (isinstance(self.model, Res2Net2) and getattr(self.model, "compute_dtype", "fp32") == "bf16"
                        and os.environ.get("AIR_WGRAD_BATCHED", "0") == "1")
-            self.model.overlap_wgrad = batched
+            # (A/B, AIR_GRAPH_FORKS=1: keep the side stream under capture - a graph with a fork / join pair per weight gradient)
+            self.model.overlap_wgrad = batched or os.environ.get("AIR_GRAPH_FORKS", "0") == "1"
             if isinstance(self.model, Res2Net2):
                 self.model.wgrad_batched = batched
             if hasattr(self.model, "_bucketer"):
